@@ -1,0 +1,905 @@
+// =================================================================================================
+// TEST INFRASTRUCTURE ONLY.  CPU oracle for the CTDirect.jl collocation hot path.
+//
+// This file is a CPU restatement (C++17, single-threaded, no GPU code) of the reference algorithm in
+// /root/reference (CTDirect.jl v1.0.12, 100 % Julia).  It exists so the HIP engine in
+// ctdirect.jl_amd/csrc/ can be checked against an independent statement of the same arithmetic.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+// never links, imports or calls anything under oracle/.
+//
+// What each part follows (reference file:line):
+//   DOCP sizes / scheme structs     src/DOCP_data.jl:293-365, src/ode/trapeze.jl:14-42, midpoint.jl:17-39,
+//                                   irk.jl:138-160, irk_stagewise.jl:136-163 ; Butcher tables irk.jl:41-43,77-79,
+//                                   111-119, irk_stagewise.jl:61-64,103-109
+//   time grid                       src/DOCP_data.jl:176-214 (DOCPtime), :437-458 (get_time_grid)
+//   getters                         src/ode/common.jl:113-170, irk_stagewise.jl:173-224
+//   __constraints!, path, boundary  src/DOCP_functions.jl:80-140
+//   setWorkArray / step constraints trapeze.jl:50-71,118-142 ; midpoint.jl:47-72,124-156 ; irk.jl:167-172,236-308 ;
+//                                   irk_stagewise.jl:235-239,394-460
+//   __objective / integral          src/DOCP_functions.jl:23-54 ; trapeze.jl:78-110 ; midpoint.jl:79-116 ;
+//                                   irk.jl:179-228 ; irk_stagewise.jl:344-384
+//   bounds / initial guess          src/DOCP_functions.jl:163-191 ; src/DOCP_variables.jl:21-145 ; irk_stagewise.jl:250-335
+//   Jacobian / Hessian patterns     trapeze.jl:149-303 ; midpoint.jl:163-300 ; irk.jl:315-496 ; irk_stagewise.jl:468-638 ;
+//                                   add_nonzero_block! src/ode/common.jl:285-312
+//   Jacobian values                 third-party in the reference (ADNLPModels.SparseADJacobian, not under
+//                                   /root/reference): column-colour the pattern, one pass of c!(Dual) per colour,
+//                                   decompress into CSC order.  Restated here from the reference's own description
+//                                   (test/archives/AD_backend.md:3-5,18-19) and call site (src/collocation.jl:116-120).
+//
+// Pinning status: Julia is not installed here, so the reference cannot be executed.  The oracle is pinned by the
+// reference's own known-answer tests (tests/test_oracle_goldens.py): exact-feasible stagewise trajectory c == 0 and
+// objective 4/3 (test/ci/test_discretization_stagewise.jl:53-100,176-198), nnzj 6028 / nnzh 6519
+// (test/ci/test_modeler_solver.jl:37), zero-control dims 24 / 23 (test/ci/test_zero_control_allocations.jl:31,138),
+// goddard_all trapeze 4005/6007, 40005/60007 (test/archives/AD_backend.md:59-60), and by 50-digit mpmath fixtures
+// (tests/golden/).  Jacobian VALUES have no golden in the reference ("parity unpinned" for values; pinned by the
+// build's own mpmath derivative fixtures and finite differences).
+// =================================================================================================
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "dual.hpp"
+#include "problems.hpp"
+
+namespace orc {
+
+// Scheme ids (shared numbering with include/ctdirect_hip.h, restated here on purpose).
+enum Scheme {
+    TRAPEZE = 0,
+    MIDPOINT = 1,
+    GL1_CC = 2,   // :gauss_legendre_1 (test only in the reference), constant control
+    GL2_CC = 3,   // :gauss_legendre_2_constant_control
+    GL3_CC = 4,   // :gauss_legendre_3_constant_control
+    GL2_SW = 5,   // :gauss_legendre_2  (stagewise controls)
+    GL3_SW = 6,   // :gauss_legendre_3
+};
+
+struct Dims { int NLP_x, NLP_u, NLP_v, path_cons, boundary_cons; };               // DOCP_data.jl:88-94
+struct Flags { bool freet0, freetf, lagrange, mayer, max; };                      // DOCP_data.jl:24-30
+
+struct Disc {                                                                      // per-scheme struct fields
+    int scheme;
+    int stage = 0;
+    double a[3][3] = {{0}};
+    double b[3] = {0};
+    double c[3] = {0};
+    bool irk = false, stagewise = false;
+    int control_block = 0;            // stagewise only
+    int step_variables_block = 0;
+    int state_stage_eqs_block = 0;
+    int step_pathcons_block = 0;
+    bool final_control = false;
+};
+
+struct Docp {
+    int problem;
+    Dims dims;
+    Flags flags;
+    int steps;
+    std::vector<double> normalized_grid, fixed_grid;                              // DOCP_data.jl:147-152
+    Disc disc;
+    int64_t dim_NLP_variables = 0, dim_NLP_constraints = 0;
+    std::vector<double> var_l, var_u, con_l, con_u;
+    // pattern mode: 0 = REFERENCE_MANUAL (bug-compatible with DOCP_Jacobian_pattern), 1 = STRUCTURAL
+    // (= manual + the dynamics-row x v block that trapeze.jl:203 leaves out, hazard H1)
+    int pattern_mode = 0;
+    // cached pattern + colouring
+    bool have_pattern = false;
+    std::vector<int64_t> colptr, rowval;
+    std::vector<int> color;
+    int ncolors = 0;
+    std::string err;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scheme constructors = size formulas
+// ---------------------------------------------------------------------------------------------
+static void set_butcher(Disc& d, int s) {
+    d.stage = s;
+    if (s == 1) {                                  // irk.jl:41-43
+        d.a[0][0] = 0.5; d.b[0] = 1; d.c[0] = 0.5;
+    } else if (s == 2) {                           // irk.jl:77-79, irk_stagewise.jl:61-64
+        d.a[0][0] = 0.25;                   d.a[0][1] = (0.25 - std::sqrt(3.0) / 6);
+        d.a[1][0] = (0.25 + std::sqrt(3.0) / 6); d.a[1][1] = 0.25;
+        d.b[0] = 0.5; d.b[1] = 0.5;
+        d.c[0] = 0.5 - std::sqrt(3.0) / 6; d.c[1] = 0.5 + std::sqrt(3.0) / 6;
+    } else {                                       // irk.jl:111-119, irk_stagewise.jl:103-109
+        d.a[0][0] = (5.0 / 36.0);                      d.a[0][1] = (2.0 / 9 - std::sqrt(15.0) / 15);  d.a[0][2] = (5.0 / 36 - std::sqrt(15.0) / 30);
+        d.a[1][0] = (5.0 / 36.0 + std::sqrt(15.0) / 24); d.a[1][1] = (2.0 / 9.0);                      d.a[1][2] = (5.0 / 36.0 - std::sqrt(15.0) / 24);
+        d.a[2][0] = (5.0 / 36 + std::sqrt(15.0) / 30);   d.a[2][1] = (2.0 / 9 + std::sqrt(15.0) / 15);  d.a[2][2] = (5.0 / 36.0);
+        d.b[0] = 5.0 / 18.0; d.b[1] = 4.0 / 9.0; d.b[2] = 5.0 / 18.0;
+        d.c[0] = 0.5 - 0.1 * std::sqrt(15.0); d.c[1] = 0.5; d.c[2] = 0.5 + 0.1 * std::sqrt(15.0);
+    }
+}
+
+static void build_scheme(Docp& p, int scheme) {
+    Disc& d = p.disc;
+    const Dims& m = p.dims;
+    const int64_t N = p.steps;
+    d.scheme = scheme;
+    switch (scheme) {
+        case TRAPEZE:                                             // trapeze.jl:14-42
+            d.final_control = true;
+            d.step_variables_block = m.NLP_x + m.NLP_u;
+            d.state_stage_eqs_block = m.NLP_x;
+            d.step_pathcons_block = m.path_cons;
+            p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v + m.NLP_u;
+            break;
+        case MIDPOINT:                                            // midpoint.jl:17-39
+            d.step_variables_block = m.NLP_x + m.NLP_u;
+            d.state_stage_eqs_block = m.NLP_x;
+            d.step_pathcons_block = m.path_cons;
+            p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
+            break;
+        case GL1_CC: case GL2_CC: case GL3_CC: {                  // irk.jl:138-160
+            int s = scheme - GL1_CC + 1;
+            set_butcher(d, s);
+            d.irk = true;
+            d.step_variables_block = m.NLP_x + m.NLP_u + m.NLP_x * s;
+            d.state_stage_eqs_block = m.NLP_x * (1 + s);
+            d.step_pathcons_block = m.path_cons;
+            p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
+            break;
+        }
+        case GL2_SW: case GL3_SW: {                               // irk_stagewise.jl:136-163
+            int s = scheme - GL2_SW + 2;
+            set_butcher(d, s);
+            d.irk = true; d.stagewise = true;
+            d.control_block = m.NLP_u * s;
+            d.step_variables_block = m.NLP_x + d.control_block + s * m.NLP_x;
+            d.state_stage_eqs_block = m.NLP_x * (1 + s);
+            d.step_pathcons_block = m.path_cons;
+            p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
+            break;
+        }
+        default:
+            throw std::runtime_error("Unknown discretization method");   // DOCP_data.jl:342-349
+    }
+    p.dim_NLP_constraints = N * (d.state_stage_eqs_block + d.step_pathcons_block) + d.step_pathcons_block + m.boundary_cons;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getters (0-based offsets of the reference's 1-based views)
+// ---------------------------------------------------------------------------------------------
+// get_OCP_variable: common.jl:113-115
+template <class T> static const T* get_OCP_variable(const T* xu, const Docp& p) { return xu + (p.dim_NLP_variables - p.dims.NLP_v); }
+// get_OCP_state_at_time_step: common.jl:124-128  (i is 1-based as in the reference)
+template <class T> static const T* get_state(const T* xu, const Docp& p, int64_t i) { return xu + (i - 1) * p.disc.step_variables_block; }
+// get_OCP_control_at_time_step (generic): common.jl:140-155
+template <class T> static const T* get_control_generic(const T* xu, const Docp& p, int64_t i) {
+    if (!p.disc.final_control && i == p.steps + 1) i = p.steps;
+    return xu + (i - 1) * p.disc.step_variables_block + p.dims.NLP_x;
+}
+// get_stagecontrol_at_time_step: irk_stagewise.jl:173-188
+template <class T> static const T* get_stagecontrol(const T* xu, const Docp& p, int64_t i, int j) {
+    return xu + (i - 1) * p.disc.step_variables_block + p.dims.NLP_x + (j - 1) * p.dims.NLP_u;
+}
+// get_stagevars_at_time_step: common.jl:166-170 (constant control) / irk_stagewise.jl:212-224 (stagewise)
+template <class T> static const T* get_stagevars(const T* xu, const Docp& p, int64_t i, int j) {
+    int cb = p.disc.stagewise ? p.disc.control_block : p.dims.NLP_u;
+    return xu + (i - 1) * p.disc.step_variables_block + p.dims.NLP_x + cb + (j - 1) * p.dims.NLP_x;
+}
+// control used by path constraints / solution: generic view, or the b-weighted stage average
+// for stagewise schemes (irk_stagewise.jl:197-205; returns a new vector, hazard H5)
+template <class T> static void get_OCP_control(const T* xu, const Docp& p, int64_t i, T* ui) {
+    const int m = p.dims.NLP_u;
+    if (p.disc.stagewise) {
+        if (i == p.steps + 1) i = p.steps;
+        const T* u1 = get_stagecontrol(xu, p, i, 1);
+        for (int k = 0; k < m; ++k) ui[k] = p.disc.b[0] * u1[k];
+        for (int j = 2; j <= p.disc.stage; ++j) {
+            const T* uj = get_stagecontrol(xu, p, i, j);
+            for (int k = 0; k < m; ++k) ui[k] = ui[k] + p.disc.b[j - 1] * uj[k];
+        }
+    } else {
+        const T* u = get_control_generic(xu, p, i);
+        for (int k = 0; k < m; ++k) ui[k] = u[k];
+    }
+}
+
+// get_time_grid: DOCP_data.jl:437-458   grid = t0 + normalized_grid * (tf - t0)
+template <class P, class T> static void get_time_grid(const T* xu, const Docp& p, std::vector<T>& grid) {
+    grid.resize(p.steps + 1);
+    const T* v = get_OCP_variable(xu, p);
+    T t0 = P::template t0<T>(v);
+    T tf = P::template tf<T>(v);
+    for (int64_t i = 0; i <= p.steps; ++i) grid[i] = t0 + p.normalized_grid[i] * (tf - t0);
+}
+template <class P, class T> static void time_grid_for(const T* xu, const Docp& p, std::vector<T>& grid) {
+    if (p.flags.freet0 || p.flags.freetf) {
+        get_time_grid<P, T>(xu, p, grid);
+    } else {
+        grid.resize(p.steps + 1);
+        for (int64_t i = 0; i <= p.steps; ++i) grid[i] = T(p.fixed_grid[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// __constraints!  (src/DOCP_functions.jl:80-115)
+// ---------------------------------------------------------------------------------------------
+template <class P, class T> static void constraints(const Docp& p, const T* xu, T* c) {
+    const int n = p.dims.NLP_x, m = p.dims.NLP_u, np = p.dims.path_cons;
+    const int64_t N = p.steps;
+    const Disc& d = p.disc;
+    const int cblk = d.state_stage_eqs_block + d.step_pathcons_block;
+    std::vector<T> grid;
+    time_grid_for<P, T>(xu, p, grid);
+    const T* v = get_OCP_variable(xu, p);
+
+    // ---- setWorkArray
+    std::vector<T> work;
+    if (d.scheme == TRAPEZE) {                    // trapeze.jl:50-71: f at all N+1 nodes
+        work.resize((size_t)n * (N + 1));
+        for (int64_t i = 1; i <= N + 1; ++i) {
+            P::template dynamics<T>(&work[(i - 1) * n], grid[i - 1], get_state(xu, p, i), get_control_generic(xu, p, i), v);
+        }
+    } else if (d.scheme == MIDPOINT) {            // midpoint.jl:47-72: f at the N midpoints
+        work.resize((size_t)n * N);
+        std::vector<T> xs(n);
+        for (int64_t i = 1; i <= N; ++i) {
+            T ts = 0.5 * (grid[i - 1] + grid[i]);
+            const T* xi = get_state(xu, p, i);
+            const T* xip1 = get_state(xu, p, i + 1);
+            for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
+            P::template dynamics<T>(&work[(i - 1) * n], ts, xs.data(), get_control_generic(xu, p, i), v);
+        }
+    } else {                                      // irk.jl:167-172, irk_stagewise.jl:235-239: [x_ij ; sum_bk]
+        work.resize(2 * (size_t)n);
+    }
+
+    std::vector<T> ui(m > 0 ? m : 1);
+    // ---- main loop on time steps  (DOCP_functions.jl:92-98)
+    for (int64_t i = 1; i <= N; ++i) {
+        const int64_t offset = (i - 1) * cblk;
+        const T ti = grid[i - 1];
+        const T tip1 = grid[i];
+        const T* xi = get_state(xu, p, i);
+        const T* xip1 = get_state(xu, p, i + 1);
+        if (d.scheme == TRAPEZE) {                // trapeze.jl:118-142
+            T half_hi = 0.5 * (tip1 - ti);
+            const T* fi = &work[(i - 1) * n];
+            const T* fip1 = &work[i * n];
+            for (int k = 0; k < n; ++k) {
+                T x_next = xi[k] + half_hi * (fi[k] + fip1[k]);
+                c[offset + k] = xip1[k] - x_next;
+            }
+        } else if (d.scheme == MIDPOINT) {        // midpoint.jl:124-140 (control_steps == 1)
+            T hi = (tip1 - ti) / 1.0;
+            const T* fi = &work[(i - 1) * n];
+            for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * fi[k]);
+        } else {                                  // irk.jl:236-308 / irk_stagewise.jl:394-460
+            T hi = tip1 - ti;
+            T* work_xij = work.data();
+            T* work_sumbk = work.data() + n;
+            int offset_stage_eqs = n;
+            for (int j = 1; j <= d.stage; ++j) {
+                T tij = ti + d.c[j - 1] * hi;
+                const T* kij = get_stagevars(xu, p, i, j);
+                const T* uij = d.stagewise ? get_stagecontrol(xu, p, i, j) : get_control_generic(xu, p, i);
+                if (j == 1) {
+                    for (int k = 0; k < n; ++k) work_sumbk[k] = d.b[j - 1] * kij[k];
+                } else {
+                    for (int k = 0; k < n; ++k) work_sumbk[k] = work_sumbk[k] + d.b[j - 1] * kij[k];
+                }
+                for (int k = 0; k < n; ++k) work_xij[k] = xi[k];
+                for (int l = 1; l <= d.stage; ++l) {
+                    const T* kil = get_stagevars(xu, p, i, l);
+                    for (int k = 0; k < n; ++k) work_xij[k] = work_xij[k] + hi * d.a[j - 1][l - 1] * kil[k];
+                }
+                T* cs = c + offset + offset_stage_eqs;
+                P::template dynamics<T>(cs, tij, work_xij, uij, v);
+                for (int k = 0; k < n; ++k) cs[k] = kij[k] - cs[k];
+                offset_stage_eqs += n;
+            }
+            for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * work_sumbk[k]);
+        }
+        // path constraints  (stepPathConstraints!, DOCP_functions.jl:122-140)
+        if (np > 0) {
+            get_OCP_control(xu, p, i, ui.data());
+            P::template path<T>(c + offset + d.state_stage_eqs_block, ti, xi, ui.data(), v);
+        }
+    }
+    // path constraints at final time  (DOCP_functions.jl:100)
+    if (np > 0) {
+        const int64_t offset = N * cblk;
+        get_OCP_control(xu, p, N + 1, ui.data());
+        P::template path<T>(c + offset, grid[N], get_state(xu, p, N + 1), ui.data(), v);
+    }
+    // boundary constraints  (DOCP_functions.jl:103-111)
+    if (p.dims.boundary_cons > 0) {
+        const int64_t offset = p.dim_NLP_constraints - p.dims.boundary_cons;
+        P::template boundary<T>(c + offset, get_state(xu, p, 1), get_state(xu, p, N + 1), v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// __objective  (src/DOCP_functions.jl:23-54) with per-scheme integral()
+// ---------------------------------------------------------------------------------------------
+template <class P, class T> static T objective(const Docp& p, const T* xu) {
+    const int n = p.dims.NLP_x, m = p.dims.NLP_u;
+    const int64_t N = p.steps;
+    const Disc& d = p.disc;
+    std::vector<T> grid;
+    time_grid_for<P, T>(xu, p, grid);
+    const T* v = get_OCP_variable(xu, p);
+    T obj_mayer(0.0), obj_lagrange(0.0);
+    if (p.flags.mayer) obj_mayer = P::template mayer<T>(get_state(xu, p, 1), get_state(xu, p, N + 1), v);
+    if (p.flags.lagrange) {
+        T value(0.0);
+        if (d.scheme == TRAPEZE) {                // trapeze.jl:78-110
+            {
+                T hi = grid[1] - grid[0];
+                value = value + hi / 2.0 * P::template lagrange<T>(grid[0], get_state(xu, p, 1), get_control_generic(xu, p, 1), v);
+            }
+            for (int64_t i = 2; i <= N; ++i) {
+                T hi2 = grid[i] - grid[i - 2];
+                value = value + hi2 / 2.0 * P::template lagrange<T>(grid[i - 1], get_state(xu, p, i), get_control_generic(xu, p, i), v);
+            }
+            {
+                T hi = grid[N] - grid[N - 1];
+                value = value + hi / 2.0 * P::template lagrange<T>(grid[N], get_state(xu, p, N + 1), get_control_generic(xu, p, N + 1), v);
+            }
+        } else if (d.scheme == MIDPOINT) {        // midpoint.jl:79-97
+            std::vector<T> xs(n);
+            for (int64_t i = 1; i <= N; ++i) {
+                T hi = grid[i] - grid[i - 1];
+                T ts = 0.5 * (grid[i - 1] + grid[i]);
+                const T* xi = get_state(xu, p, i);
+                const T* xip1 = get_state(xu, p, i + 1);
+                for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
+                value = value + hi * P::template lagrange<T>(ts, xs.data(), get_control_generic(xu, p, i), v);
+            }
+        } else {                                  // irk.jl:179-228 / irk_stagewise.jl:344-384
+            std::vector<T> work_xij(n);
+            for (int64_t i = 1; i <= N; ++i) {
+                T ti = grid[i - 1];
+                const T* xi = get_state(xu, p, i);
+                T hi = grid[i] - ti;
+                T local_sum(0.0);
+                for (int j = 1; j <= d.stage; ++j) {
+                    T tij = ti + d.c[j - 1] * hi;
+                    const T* uij = d.stagewise ? get_stagecontrol(xu, p, i, j) : get_control_generic(xu, p, i);
+                    for (int k = 0; k < n; ++k) work_xij[k] = xi[k];
+                    for (int l = 1; l <= d.stage; ++l) {
+                        const T* kil = get_stagevars(xu, p, i, l);
+                        for (int k = 0; k < n; ++k) work_xij[k] = work_xij[k] + hi * d.a[j - 1][l - 1] * kil[k];
+                    }
+                    T term = d.b[j - 1] * P::template lagrange<T>(tij, work_xij.data(), uij, v);
+                    if (!d.stagewise && j == 1) local_sum = term;      // irk.jl:214-221 (assign on j==1)
+                    else local_sum = local_sum + term;                 // irk_stagewise.jl:376 (0.0 + ...)
+                }
+                value = value + hi * local_sum;
+            }
+        }
+        obj_lagrange = value;
+        (void)m;
+    }
+    return obj_mayer + obj_lagrange;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bounds  (src/DOCP_functions.jl:163-191, src/DOCP_variables.jl:21-98, irk_stagewise.jl:250-300)
+// ---------------------------------------------------------------------------------------------
+static void build_bounds_block(int dim, const std::vector<BoxEntry>& box, std::vector<double>& lb, std::vector<double>& ub) {
+    lb.assign(dim, -INF);
+    ub.assign(dim, INF);
+    for (const BoxEntry& e : box) { lb[e.index] = e.lb; ub[e.index] = e.ub; }
+}
+
+template <class P> static void variables_bounds(Docp& p) {
+    const int n = p.dims.NLP_x, m = p.dims.NLP_u, nv = p.dims.NLP_v;
+    const int64_t N = p.steps;
+    const Disc& d = p.disc;
+    p.var_l.assign(p.dim_NLP_variables, -INF);
+    p.var_u.assign(p.dim_NLP_variables, INF);
+    std::vector<double> x_lb, x_ub, u_lb, u_ub, v_lb, v_ub;
+    build_bounds_block(n, P::state_box(), x_lb, x_ub);
+    build_bounds_block(m, P::control_box(), u_lb, u_ub);
+    for (int64_t i = 1; i <= N + 1; ++i) {
+        int64_t off = (i - 1) * d.step_variables_block;          // set_state_at_time_step!
+        for (int k = 0; k < n; ++k) { p.var_l[off + k] = x_lb[k]; p.var_u[off + k] = x_ub[k]; }
+    }
+    if (m > 0) {
+        if (d.stagewise) {                                       // irk_stagewise.jl:275-286
+            for (int64_t i = 1; i <= N; ++i)
+                for (int j = 1; j <= d.stage; ++j) {
+                    int64_t off = (i - 1) * d.step_variables_block + n + (j - 1) * m;
+                    for (int k = 0; k < m; ++k) { p.var_l[off + k] = u_lb[k]; p.var_u[off + k] = u_ub[k]; }
+                }
+        } else {                                                 // DOCP_variables.jl:40-49 + setter common.jl:209-223
+            for (int64_t i = 1; i <= N + 1; ++i) {
+                if (i <= N || (d.final_control && i <= N + 1)) {
+                    int64_t off = (i - 1) * d.step_variables_block + n;
+                    for (int k = 0; k < m; ++k) { p.var_l[off + k] = u_lb[k]; p.var_u[off + k] = u_ub[k]; }
+                }
+            }
+        }
+    }
+    if (nv > 0) {
+        build_bounds_block(nv, P::variable_box(), v_lb, v_ub);
+        for (int k = 0; k < nv; ++k) {
+            p.var_l[p.dim_NLP_variables - nv + k] = v_lb[k];
+            p.var_u[p.dim_NLP_variables - nv + k] = v_ub[k];
+        }
+    }
+}
+
+template <class P> static void constraints_bounds(Docp& p) {
+    const int np = p.dims.path_cons, nb = p.dims.boundary_cons;
+    p.con_l.assign(p.dim_NLP_constraints, 0.0);
+    p.con_u.assign(p.dim_NLP_constraints, 0.0);
+    std::vector<double> plb(np > 0 ? np : 1), pub(np > 0 ? np : 1), blb(nb > 0 ? nb : 1), bub(nb > 0 ? nb : 1);
+    P::path_bounds(plb.data(), pub.data());
+    P::boundary_bounds(blb.data(), bub.data());
+    int64_t offset = 0;
+    for (int64_t i = 1; i <= p.steps + 1; ++i) {
+        if (i <= p.steps) offset += p.disc.state_stage_eqs_block;
+        if (np > 0) {
+            for (int k = 0; k < np; ++k) { p.con_l[offset + k] = plb[k]; p.con_u[offset + k] = pub[k]; }
+            offset += np;
+        }
+    }
+    if (nb > 0) {
+        for (int k = 0; k < nb; ++k) { p.con_l[offset + k] = blb[k]; p.con_u[offset + k] = bub[k]; }
+    }
+}
+
+// __initial_guess  (src/DOCP_variables.jl:122-145, irk_stagewise.jl:302-335).  use_problem_init selects the
+// problem file's own `init` tuple; otherwise the CTModels default (everything left at 0.1).
+template <class P> static void initial_guess(const Docp& p, bool use_problem_init, double* X) {
+    const int n = p.dims.NLP_x, m = p.dims.NLP_u, nv = p.dims.NLP_v;
+    const int64_t N = p.steps;
+    const Disc& d = p.disc;
+    for (int64_t k = 0; k < p.dim_NLP_variables; ++k) X[k] = 0.1;
+    if (!use_problem_init) return;
+    std::vector<double> tmp(std::max(std::max(n, m), std::max(nv, 1)));
+    if (nv > 0 && P::init_variable(tmp.data()))
+        for (int k = 0; k < nv; ++k) X[p.dim_NLP_variables - nv + k] = tmp[k];
+    std::vector<double> grid;
+    get_time_grid<P, double>(X, p, grid);
+    for (int64_t i = 1; i <= N + 1; ++i) {
+        double ti = grid[i - 1];
+        if (P::init_state(ti, tmp.data())) {
+            int64_t off = (i - 1) * d.step_variables_block;
+            for (int k = 0; k < n; ++k) X[off + k] = tmp[k];
+        }
+        if (m > 0 && !d.stagewise) {
+            if (i <= N || d.final_control) {
+                if (P::init_control(ti, tmp.data())) {
+                    int64_t off = (i - 1) * d.step_variables_block + n;
+                    for (int k = 0; k < m; ++k) X[off + k] = tmp[k];
+                }
+            }
+        }
+    }
+    if (m > 0 && d.stagewise) {
+        for (int64_t i = 1; i <= N; ++i) {
+            double ti = grid[i - 1];
+            double hi = grid[i] - ti;
+            for (int j = 1; j <= d.stage; ++j) {
+                double tij = ti + d.c[j - 1] * hi;
+                if (P::init_control(tij, tmp.data())) {
+                    int64_t off = (i - 1) * d.step_variables_block + n + (j - 1) * m;
+                    for (int k = 0; k < m; ++k) X[off + k] = tmp[k];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparsity patterns: literal (Is, Js) pushes + SparseArrays.sparse semantics
+// ---------------------------------------------------------------------------------------------
+struct IJ {
+    std::vector<int64_t> Is, Js;
+    // add_nonzero_block!(Is, Js, i_start, i_end, j_start, j_end; sym)   common.jl:297-306   (1-based, inclusive)
+    void block(int64_t i0, int64_t i1, int64_t j0, int64_t j1, bool sym = false) {
+        for (int64_t i = i0; i <= i1; ++i)
+            for (int64_t j = j0; j <= j1; ++j) {
+                Is.push_back(i); Js.push_back(j);
+                if (sym) { Is.push_back(j); Js.push_back(i); }
+            }
+    }
+    // add_nonzero_block!(Is, Js, i, j; sym)   common.jl:307-312
+    void single(int64_t i, int64_t j, bool sym = false) {
+        Is.push_back(i); Js.push_back(j);
+        if (sym) { Is.push_back(j); Js.push_back(i); }
+    }
+};
+
+// SparseArrays.sparse(Is, Js, ones(Bool), nrow, ncol): CSC, rows sorted within a column, duplicates merged.
+static void to_csc(const IJ& ij, int64_t ncol, std::vector<int64_t>& colptr, std::vector<int64_t>& rowval) {
+    const size_t nn = ij.Is.size();
+    std::vector<int64_t> cnt(ncol + 1, 0);
+    for (size_t k = 0; k < nn; ++k) cnt[ij.Js[k]]++;               // Js are 1-based -> bucket j
+    std::vector<int64_t> start(ncol + 2, 0);
+    for (int64_t j = 1; j <= ncol; ++j) start[j + 1] = start[j] + cnt[j];
+    std::vector<int64_t> rows(nn);
+    std::vector<int64_t> fill(start.begin(), start.end());
+    for (size_t k = 0; k < nn; ++k) rows[fill[ij.Js[k]]++] = ij.Is[k];
+    colptr.assign(ncol + 1, 0);
+    rowval.clear();
+    rowval.reserve(nn);
+    for (int64_t j = 1; j <= ncol; ++j) {
+        auto b = rows.begin() + start[j], e = rows.begin() + start[j + 1];
+        std::sort(b, e);
+        auto u = std::unique(b, e);
+        for (auto it = b; it != u; ++it) rowval.push_back(*it - 1);   // store 0-based
+        colptr[j] = (int64_t)rowval.size();
+    }
+}
+
+static void jacobian_pattern_ij(const Docp& p, IJ& ij) {
+    const Disc& d = p.disc;
+    const Dims& dm = p.dims;
+    const int64_t N = p.steps;
+    const int64_t v_start = p.dim_NLP_variables - dm.NLP_v + 1, v_end = p.dim_NLP_variables;
+    const int64_t c_block_step = d.state_stage_eqs_block + d.step_pathcons_block;
+    const int64_t blk = d.step_variables_block;
+    if (d.scheme == TRAPEZE) {                                         // trapeze.jl:149-233
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t c_offset = (i - 1) * c_block_step;
+            int64_t dyn_start = c_offset + 1, dyn_end = c_offset + dm.NLP_x;
+            int64_t path_start = c_offset + dm.NLP_x + 1, path_end = c_offset + c_block_step;
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1, xi_end = var_offset + dm.NLP_x;
+            int64_t ui_start = var_offset + dm.NLP_x + 1, ui_end = var_offset + dm.NLP_x + dm.NLP_u;
+            int64_t xip1_end = var_offset + dm.NLP_x + dm.NLP_u + dm.NLP_x;
+            int64_t uip1_start = var_offset + dm.NLP_x * 2 + dm.NLP_u + 1, uip1_end = var_offset + dm.NLP_x * 2 + dm.NLP_u * 2;
+            ij.block(dyn_start, dyn_end, xi_start, xi_end);
+            ij.block(dyn_start, dyn_end, ui_start, xip1_end);
+            ij.block(dyn_start, dyn_end, uip1_start, uip1_end);
+            ij.block(path_start, path_end, xi_start, xi_end);
+            ij.block(path_start, path_end, ui_start, ui_end);
+            ij.block(path_start, path_end, v_start, v_end);             // :203  (path rows only -- hazard H1)
+            if (p.pattern_mode == 1) ij.block(dyn_start, dyn_end, v_start, v_end);   // STRUCTURAL: what the comment at :202 intends
+        }
+        int64_t c_offset = N * c_block_step, c_block = d.step_pathcons_block;
+        int64_t var_offset = N * blk;
+        int64_t xf_start = var_offset + 1, xf_end = var_offset + dm.NLP_x;
+        int64_t uf_start = var_offset + dm.NLP_x + 1, uf_end = var_offset + dm.NLP_x + dm.NLP_u;
+        ij.block(c_offset + 1, c_offset + c_block, xf_start, xf_end);
+        ij.block(c_offset + 1, c_offset + c_block, uf_start, uf_end);
+        ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
+        c_offset = N * c_block_step + d.step_pathcons_block;
+        c_block = dm.boundary_cons;
+        ij.block(c_offset + 1, c_offset + c_block, 1, dm.NLP_x);
+        ij.block(c_offset + 1, c_offset + c_block, xf_start, xf_end);
+        ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
+        return;
+    }
+    if (d.scheme == MIDPOINT) {                                        // midpoint.jl:163-233
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t c_block = c_block_step, c_offset = (i - 1) * c_block;
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1;
+            int64_t ui_end = var_offset + dm.NLP_x + dm.NLP_u;
+            int64_t xip1_end = var_offset + blk + dm.NLP_x;
+            ij.block(c_offset + 1, c_offset + dm.NLP_x, xi_start, xip1_end);
+            ij.block(c_offset + dm.NLP_x + 1, c_offset + c_block, xi_start, ui_end);
+            ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
+        }
+    } else {                                                           // irk.jl:315-416 / irk_stagewise.jl:468-558
+        const int s = d.stage;
+        const int cu = d.stagewise ? dm.NLP_u * s : dm.NLP_u;
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t c_block = c_block_step, c_offset = (i - 1) * c_block;
+            int64_t dyn_start = c_offset + 1, dyn_end = c_offset + dm.NLP_x;
+            int64_t stage_start = c_offset + dm.NLP_x + 1, stage_end = c_offset + (s + 1) * dm.NLP_x;
+            int64_t path_start = c_offset + (s + 1) * dm.NLP_x + 1, path_end = c_offset + c_block;
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1, xi_end = var_offset + dm.NLP_x;
+            int64_t ui_end = var_offset + dm.NLP_x + cu;
+            int64_t ki_start = var_offset + dm.NLP_x + cu + 1, ki_end = var_offset + blk;
+            int64_t xip1_end = var_offset + blk + dm.NLP_x;
+            ij.block(dyn_start, dyn_end, xi_start, xi_end);
+            ij.block(dyn_start, dyn_end, ki_start, xip1_end);
+            ij.block(dyn_start, dyn_end, v_start, v_end);
+            ij.block(stage_start, stage_end, xi_start, ki_end);
+            ij.block(stage_start, stage_end, v_start, v_end);
+            ij.block(path_start, path_end, xi_start, ui_end);
+            ij.block(path_start, path_end, v_start, v_end);
+        }
+    }
+    // 2. final path constraints, 3. boundary constraints: identical text in midpoint.jl:206-227,
+    // irk.jl:383-402, irk_stagewise.jl:526-548 (u(tf) = U_N convention)
+    const int cu = d.stagewise ? dm.NLP_u * d.stage : dm.NLP_u;
+    int64_t c_offset = N * c_block_step, c_block = d.step_pathcons_block;
+    int64_t var_offset = N * blk;
+    int64_t xf_start = var_offset + 1, xf_end = var_offset + dm.NLP_x;
+    int64_t uf_start = var_offset - blk + dm.NLP_x + 1, uf_end = var_offset - blk + dm.NLP_x + cu;
+    ij.block(c_offset + 1, c_offset + c_block, xf_start, xf_end);
+    ij.block(c_offset + 1, c_offset + c_block, uf_start, uf_end);
+    ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
+    c_offset = N * c_block_step + d.step_pathcons_block;
+    c_block = dm.boundary_cons;
+    ij.block(c_offset + 1, c_offset + c_block, 1, dm.NLP_x);
+    ij.block(c_offset + 1, c_offset + c_block, xf_start, xf_end);
+    ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
+    if (d.stagewise && p.flags.lagrange)                               // irk_stagewise.jl:550-552 (hazard H2)
+        ij.single(p.dim_NLP_constraints, dm.NLP_x);
+}
+
+static void hessian_pattern_ij(const Docp& p, IJ& ij) {
+    const Disc& d = p.disc;
+    const Dims& dm = p.dims;
+    const int64_t N = p.steps;
+    const int64_t v_start = p.dim_NLP_variables - dm.NLP_v + 1, v_end = p.dim_NLP_variables;
+    const int64_t blk = d.step_variables_block;
+    ij.block(v_start, v_end, v_start, v_end);
+    if (d.scheme == TRAPEZE) {                                         // trapeze.jl:240-303
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t var_block = blk * 2, var_offset = (i - 1) * blk;
+            ij.block(var_offset + 1, var_offset + var_block, var_offset + 1, var_offset + var_block);
+            ij.block(var_offset + 1, var_offset + var_block, v_start, v_end, true);
+        }
+        if (p.flags.mayer || dm.boundary_cons > 0) {
+            int64_t var_offset = N * blk;
+            ij.block(1, dm.NLP_x, var_offset + 1, var_offset + dm.NLP_x, true);
+        }
+        return;
+    }
+    if (d.scheme == MIDPOINT) {                                        // midpoint.jl:240-300
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1, xip1_end = var_offset + blk + dm.NLP_x;
+            ij.block(xi_start, xip1_end, xi_start, xip1_end);
+            ij.block(xi_start, xip1_end, v_start, v_end, true);
+        }
+        int64_t var_offset = N * blk;
+        ij.block(1, dm.NLP_x, var_offset + 1, var_offset + dm.NLP_x, true);
+        return;
+    }
+    // irk.jl:423-496 / irk_stagewise.jl:565-638
+    const int cu = d.stagewise ? dm.NLP_u * d.stage : dm.NLP_u;
+    for (int64_t i = 1; i <= N; ++i) {
+        int64_t var_offset = (i - 1) * blk;
+        int64_t xi_start = var_offset + 1, ki_end = var_offset + blk;
+        ij.block(xi_start, ki_end, xi_start, ki_end);
+        ij.block(xi_start, ki_end, v_start, v_end, true);
+    }
+    int64_t var_offset = N * blk;
+    int64_t xf_start = var_offset + 1, xf_end = var_offset + dm.NLP_x;
+    int64_t uf_start = var_offset - blk + dm.NLP_x + 1, uf_end = var_offset - blk + dm.NLP_x + cu;
+    ij.block(xf_start, xf_end, xf_start, xf_end);
+    ij.block(uf_start, uf_end, uf_start, uf_end);
+    ij.block(xf_start, xf_end, uf_start, uf_end, true);
+    ij.block(xf_start, uf_end, v_start, v_end, true);                  // empty range (hazard H3)
+    ij.block(uf_start, uf_end, v_start, v_end, true);
+    ij.block(1, dm.NLP_x, xf_start, xf_end, true);
+}
+
+// Greedy distance-1 column colouring in natural order (stand-in for SparseMatrixColorings' column colouring
+// used by ADNLPModels.SparseADJacobian; any valid colouring decompresses to the same values).
+static void color_columns(Docp& p) {
+    const int64_t ncol = p.dim_NLP_variables, nrow = p.dim_NLP_constraints;
+    std::vector<std::vector<int>> rowcolors(nrow);
+    p.color.assign(ncol, -1);
+    p.ncolors = 0;
+    std::vector<char> forbidden;
+    for (int64_t j = 0; j < ncol; ++j) {
+        forbidden.assign(p.ncolors + 1, 0);
+        for (int64_t k = p.colptr[j]; k < p.colptr[j + 1]; ++k)
+            for (int cidx : rowcolors[p.rowval[k]]) forbidden[cidx] = 1;
+        int cidx = 0;
+        while (cidx < p.ncolors && forbidden[cidx]) ++cidx;
+        if (cidx == p.ncolors) ++p.ncolors;
+        p.color[j] = cidx;
+        for (int64_t k = p.colptr[j]; k < p.colptr[j + 1]; ++k) rowcolors[p.rowval[k]].push_back(cidx);
+    }
+}
+
+static void ensure_pattern(Docp& p) {
+    if (p.have_pattern) return;
+    IJ ij;
+    jacobian_pattern_ij(p, ij);
+    to_csc(ij, p.dim_NLP_variables, p.colptr, p.rowval);
+    color_columns(p);
+    p.have_pattern = true;
+}
+
+// jac_coord!: one pass of c!(Dual) per colour, decompressed into the pattern's CSC order
+template <class P> static void jacobian_colored(Docp& p, const double* xu, double* vals) {
+    ensure_pattern(p);
+    const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    std::vector<D1> z(nvar), cz(ncon);
+    for (int col = 0; col < p.ncolors; ++col) {
+        for (int64_t j = 0; j < nvar; ++j) z[j] = D1(xu[j], p.color[j] == col ? 1.0 : 0.0);
+        constraints<P, D1>(p, z.data(), cz.data());
+        for (int64_t j = 0; j < nvar; ++j)
+            if (p.color[j] == col)
+                for (int64_t k = p.colptr[j]; k < p.colptr[j + 1]; ++k) vals[k] = cz[p.rowval[k]].d;
+    }
+}
+
+// one full column of the dense Jacobian (independent of any pattern)
+template <class P> static void jacobian_column(const Docp& p, const double* xu, int64_t col, double* out) {
+    const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    std::vector<D1> z(nvar), cz(ncon);
+    for (int64_t j = 0; j < nvar; ++j) z[j] = D1(xu[j], j == col ? 1.0 : 0.0);
+    constraints<P, D1>(p, z.data(), cz.data());
+    for (int64_t r = 0; r < ncon; ++r) out[r] = cz[r].d;
+}
+
+template <class P> static void objective_gradient(const Docp& p, const double* xu, double* g) {
+    const int64_t nvar = p.dim_NLP_variables;
+    std::vector<D1> z(nvar);
+    for (int64_t j = 0; j < nvar; ++j) z[j] = D1(xu[j], 0.0);
+    for (int64_t j = 0; j < nvar; ++j) {
+        z[j].d = 1.0;
+        g[j] = objective<P, D1>(p, z.data()).d;
+        z[j].d = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// problem registry
+// ---------------------------------------------------------------------------------------------
+template <class P> struct Tag { using type = P; };
+template <class F> static void dispatch(int pid, F&& f) {
+    switch (pid) {
+        case 0: f(Tag<Goddard>{}); break;
+        case 1: f(Tag<GoddardAll>{}); break;
+        case 2: f(Tag<DoubleIntegratorPath>{}); break;
+        case 3: f(Tag<Quadrotor8>{}); break;
+        case 4: f(Tag<Quadrotor12>{}); break;
+        case 5: f(Tag<StagewiseScalar>{}); break;
+        case 6: f(Tag<EstimateInitialCondition>{}); break;
+        case 7: f(Tag<EstimateRotationRate>{}); break;
+        case 8: f(Tag<LeastSquaresConstraint>{}); break;
+        case 9: f(Tag<DoubleIntegratorFreeT0Tf>{}); break;
+        default: throw std::runtime_error("unknown problem id");
+    }
+}
+
+template <class P> static void make_docp(Docp& p, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len) {
+    p.dims = Dims{P::n, P::m, P::nv, P::p, P::bc};
+    p.flags = Flags{P::freet0, P::freetf, P::has_lagrange, P::has_mayer, P::maximize};
+    // DOCPtime  (DOCP_data.jl:176-214)
+    if (time_grid == nullptr) {
+        p.steps = (int)grid_size;
+        p.normalized_grid.resize(grid_size + 1);
+        // collect(LinRange(0, 1, N+1)): element i = (1 - t)*0 + t*1 with t = (i-1)/N
+        for (int64_t i = 0; i <= grid_size; ++i) {
+            double t = (double)i / (double)grid_size;
+            p.normalized_grid[i] = (1 - t) * 0.0 + t * 1.0;
+        }
+    } else {
+        for (int64_t i = 1; i < time_grid_len; ++i)
+            if (!(time_grid[i - 1] < time_grid[i])) throw std::invalid_argument("given time grid is not strictly increasing. Aborting...");
+        p.steps = (int)(time_grid_len - 1);
+        p.normalized_grid.assign(time_grid, time_grid + time_grid_len);
+        if (time_grid[0] != 0 || time_grid[time_grid_len - 1] != 1) {
+            double t0 = time_grid[0], tf = time_grid[time_grid_len - 1];
+            for (auto& t : p.normalized_grid) t = (t - t0) / (tf - t0);
+        }
+    }
+    p.fixed_grid.assign(p.steps + 1, 0.0);
+    if (!(P::freet0 || P::freetf)) {
+        double t0 = P::template t0<double>(nullptr), tf = P::template tf<double>(nullptr);
+        for (int64_t i = 0; i <= p.steps; ++i) p.fixed_grid[i] = t0 + (p.normalized_grid[i] * (tf - t0));
+    }
+    build_scheme(p, scheme);
+    variables_bounds<P>(p);
+    constraints_bounds<P>(p);
+}
+
+}  // namespace orc
+
+// =================================================================================================
+// C interface for the Python test harness (ctypes).  Status: 0 ok, nonzero = error (orc_last_error).
+// =================================================================================================
+using orc::Docp;
+static std::string g_err;
+
+extern "C" {
+
+int orc_create(int problem, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len, void** out) {
+    try {
+        auto p = std::make_unique<Docp>();
+        p->problem = problem;
+        orc::dispatch(problem, [&](auto tag) { orc::make_docp<typename decltype(tag)::type>(*p, scheme, grid_size, time_grid, time_grid_len); });
+        *out = p.release();
+        return 0;
+    } catch (const std::invalid_argument& e) { g_err = e.what(); return 2; }
+    catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+void orc_destroy(void* h) { delete (Docp*)h; }
+const char* orc_last_error() { return g_err.c_str(); }
+
+// out[0..11] = n, m, nv, path, boundary, steps, nvar, ncon, step_variables_block, state_stage_eqs_block, stage, final_control
+void orc_dims(void* h, int64_t* out) {
+    Docp& p = *(Docp*)h;
+    out[0] = p.dims.NLP_x; out[1] = p.dims.NLP_u; out[2] = p.dims.NLP_v; out[3] = p.dims.path_cons; out[4] = p.dims.boundary_cons;
+    out[5] = p.steps; out[6] = p.dim_NLP_variables; out[7] = p.dim_NLP_constraints;
+    out[8] = p.disc.step_variables_block; out[9] = p.disc.state_stage_eqs_block; out[10] = p.disc.stage; out[11] = p.disc.final_control;
+}
+// flags out[0..4] = freet0, freetf, lagrange, mayer, max
+void orc_flags(void* h, int32_t* out) {
+    Docp& p = *(Docp*)h;
+    out[0] = p.flags.freet0; out[1] = p.flags.freetf; out[2] = p.flags.lagrange; out[3] = p.flags.mayer; out[4] = p.flags.max;
+}
+void orc_butcher(void* h, double* a9, double* b3, double* c3) {
+    Docp& p = *(Docp*)h;
+    for (int i = 0; i < 3; ++i) { b3[i] = p.disc.b[i]; c3[i] = p.disc.c[i]; for (int j = 0; j < 3; ++j) a9[3 * i + j] = p.disc.a[i][j]; }
+}
+void orc_grids(void* h, double* normalized, double* fixed) {
+    Docp& p = *(Docp*)h;
+    std::memcpy(normalized, p.normalized_grid.data(), sizeof(double) * (p.steps + 1));
+    std::memcpy(fixed, p.fixed_grid.data(), sizeof(double) * (p.steps + 1));
+}
+void orc_bounds(void* h, double* lvar, double* uvar, double* lcon, double* ucon) {
+    Docp& p = *(Docp*)h;
+    std::memcpy(lvar, p.var_l.data(), sizeof(double) * p.dim_NLP_variables);
+    std::memcpy(uvar, p.var_u.data(), sizeof(double) * p.dim_NLP_variables);
+    std::memcpy(lcon, p.con_l.data(), sizeof(double) * p.dim_NLP_constraints);
+    std::memcpy(ucon, p.con_u.data(), sizeof(double) * p.dim_NLP_constraints);
+}
+void orc_initial_guess(void* h, int use_problem_init, double* x0) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::initial_guess<typename decltype(tag)::type>(p, use_problem_init != 0, x0); });
+}
+void orc_constraints(void* h, const double* xu, double* c) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::constraints<typename decltype(tag)::type, double>(p, xu, c); });
+}
+double orc_objective(void* h, const double* xu) {
+    Docp& p = *(Docp*)h;
+    double f = 0;
+    orc::dispatch(p.problem, [&](auto tag) { f = orc::objective<typename decltype(tag)::type, double>(p, xu); });
+    return f;
+}
+void orc_gradient(void* h, const double* xu, double* g) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::objective_gradient<typename decltype(tag)::type>(p, xu, g); });
+}
+void orc_set_pattern_mode(void* h, int mode) {
+    Docp& p = *(Docp*)h;
+    if (p.pattern_mode != mode) { p.pattern_mode = mode; p.have_pattern = false; }
+}
+int64_t orc_jac_nnz(void* h) {
+    Docp& p = *(Docp*)h;
+    orc::ensure_pattern(p);
+    return (int64_t)p.rowval.size();
+}
+int orc_jac_ncolors(void* h) {
+    Docp& p = *(Docp*)h;
+    orc::ensure_pattern(p);
+    return p.ncolors;
+}
+// 0-based CSC
+void orc_jac_pattern(void* h, int64_t* colptr, int64_t* rowval) {
+    Docp& p = *(Docp*)h;
+    orc::ensure_pattern(p);
+    std::memcpy(colptr, p.colptr.data(), sizeof(int64_t) * p.colptr.size());
+    std::memcpy(rowval, p.rowval.data(), sizeof(int64_t) * p.rowval.size());
+}
+void orc_jac_coord(void* h, const double* xu, double* vals) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::jacobian_colored<typename decltype(tag)::type>(p, xu, vals); });
+}
+void orc_jac_column(void* h, const double* xu, int64_t col, double* out) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::jacobian_column<typename decltype(tag)::type>(p, xu, col, out); });
+}
+// Hessian pattern: number of entries of the full symmetric pattern and of its lower triangle (nnzh as ADNLPModels reports it)
+void orc_hess_nnz(void* h, int64_t* full, int64_t* lower) {
+    Docp& p = *(Docp*)h;
+    orc::IJ ij;
+    orc::hessian_pattern_ij(p, ij);
+    std::vector<int64_t> colptr, rowval;
+    orc::to_csc(ij, p.dim_NLP_variables, colptr, rowval);
+    *full = (int64_t)rowval.size();
+    int64_t lo = 0;
+    for (int64_t j = 0; j < p.dim_NLP_variables; ++j)
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k)
+            if (rowval[k] >= j) ++lo;
+    *lower = lo;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+"""Shared helpers for the test-suite: golden-fixture loading and deterministic input fills."""
+import glob
+import json
+import math
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# parity tolerance (BASELINE.json north_star / SURVEY.md section 8d): max |a - b| / max(1, |b|) <= 1e-10
+TOL = 1e-10
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def fx(h):
+    return float.fromhex(h)
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+
+
+def load_golden(path):
+    with open(path) as f:
+        g = json.load(f)
+    out = dict(g)
+    out["time_grid"] = [fx(t) for t in g["time_grid"]] if g["time_grid"] else None
+    out["xu"] = np.array([fx(x) for x in g["xu"]])
+    out["c"] = np.array([fx(x) for x in g["c"]])
+    out["objective"] = fx(g["objective"])
+    nvar, ncon = g["dims"]["nvar"], g["dims"]["ncon"]
+    J = np.zeros((ncon, nvar))
+    for r, c, v in g["jac_nonzeros"]:
+        J[r, c] = fx(v)
+    out["J"] = J
+    grad = np.zeros(nvar)
+    for j, v in g["gradient"]:
+        grad[j] = fx(v)
+    out["gradient"] = grad
+    return out
+
+
+def csc_to_set(colptr, rowval):
+    s = set()
+    for j in range(len(colptr) - 1):
+        for k in range(colptr[j], colptr[j + 1]):
+            s.add((int(rowval[k]), j))
+    return s
+
+
+def dense_on_pattern(J, colptr, rowval):
+    vals = np.zeros(len(rowval))
+    for j in range(len(colptr) - 1):
+        for k in range(colptr[j], colptr[j + 1]):
+            vals[k] = J[rowval[k], j]
+    return vals
+
+
+# ---- xorshift64* (SURVEY.md section 8d seeded variant); bit-identical integer generator
+def xorshift64star(seed, count):
+    mask = (1 << 64) - 1
+    x = seed & mask
+    out = np.empty(count, dtype=np.float64)
+    for i in range(count):
+        x ^= x >> 12
+        x ^= (x << 25) & mask
+        x ^= x >> 27
+        r = (x * 0x2545F4914F6CDD1D) & mask
+        out[i] = ((r >> 11) / float(1 << 53)) * 2.0 - 1.0
+    return out
+
+
+def bench_inputs(d, perturb=0.0, seed=0x9E3779B97F4A7C15):
+    """Closed-form feasible-ish inputs for a DOCP-like object `d` (needs: problem name via d.problem_name,
+    n, m, nv, steps, step_variables_block, stage, stagewise, scheme_kind, dim_NLP_variables, butcher c).
+    Vectorised numpy version of the fills in SURVEY.md section 8(d); used for mid/large sizes where the
+    oracle (not mpmath) is the checker, so the exact fill formula only has to be the same on both sides."""
+    N, blk, n, m, nv = d.steps, d.step_variables_block, d.n, d.m, d.nv
+    nvar = d.dim_NLP_variables
+    xu = np.full(nvar, 0.1)
+    name = d.problem_name
+    tau = np.arange(N + 1) / N
+
+    def state(t):
+        if name.startswith("goddard"):
+            return [1 + 0.01 * t, 0.1 * np.sin(np.pi * t), 1 - 0.4 * t]
+        if name.startswith("double_integrator"):
+            return [t * t, 2 * t]
+        if name == "quadrotor":
+            return [0.01 * t, 5 * t, 2.5 + 0.01 * np.sin(5 * t), 0.1 * np.sin(2 * t), 5 + 0.1 * np.cos(t),
+                    0.02 * np.sin(4 * t), 0.1 * np.sin(6 * t), 0.15 * np.cos(5 * t)]
+        if name == "quadrotor12":
+            return [0.01 * t, 5 * t, 2.5 + 0.01 * np.sin(5 * t), 0.1 * np.sin(2 * t), 5 + 0.1 * np.cos(t),
+                    0.02 * np.sin(4 * t), 0.1 * np.sin(6 * t), 0.15 * np.cos(5 * t), 0.2 * np.sin(2 * t + 0.3),
+                    0.3 * np.sin(7 * t), 0.25 * np.cos(3 * t), 0.1 * np.sin(9 * t + 1)]
+        if name == "stagewise_scalar":
+            return [t * t]
+        return [np.cos(1.3 * t) + 0.1, np.sin(1.3 * t) - 0.05]
+
+    def control(t, j):
+        if name.startswith("goddard"):
+            return [0.5 + 0.5 * np.cos(7 * t + j)]
+        if name.startswith("double_integrator") or name == "stagewise_scalar":
+            return [2 * np.cos(3 * t + 0.1 * j)]
+        if name == "quadrotor":
+            return [10 + np.sin(4 * t + j), 0.3 * np.cos(3 * t + j), 0.2 * np.sin(5 * t + j), 0.05 * np.cos(2 * t + j)]
+        if name == "quadrotor12":
+            return [10 + np.sin(4 * t + j), 0.03 * np.cos(3 * t + j), 0.02 * np.sin(5 * t + j), 0.01 * np.cos(2 * t + j)]
+        return []
+
+    var = {"goddard": [0.2], "goddard_all": [0.2], "quadrotor": [1.0], "quadrotor12": [1.0],
+           "estimate_rotation_rate": [1.4], "estimate_initial_condition": [0.9, 0.1],
+           "least_squares_with_constraint": [0.8, 0.2], "double_integrator_freet0tf": [0.3, 2.1]}.get(name, [])
+    for k in range(nv):
+        xu[nvar - nv + k] = var[k]
+    st = state(tau)
+    for k in range(n):
+        xu[k:(N + 1) * blk:blk][:N + 1] = st[k] if np.ndim(st[k]) else np.full(N + 1, st[k])
+    kind = d.scheme_kind
+    if m > 0:
+        if kind == "irk" and d.stagewise:
+            s = d.stage
+            cj = d.butcher_c
+            for j in range(s):
+                tj = tau[:-1] + cj[j] * (tau[1:] - tau[:-1])
+                uj = control(tj, j + 1)
+                for k in range(m):
+                    xu[n + j * m + k:N * blk:blk] = uj[k]
+        else:
+            nodes = N + 1 if kind == "trapeze" else N
+            u0 = control(tau[:nodes], 0)
+            for k in range(m):
+                xu[n + k:nodes * blk:blk][:nodes] = u0[k]
+    if kind == "irk":
+        # stage variables: smooth, O(1) values near the local slope of the state fill (not exact dynamics:
+        # residuals are then O(1e-1), well conditioned, and identical on both sides by construction)
+        s = d.stage
+        cu = m * s if d.stagewise else m
+        for j in range(s):
+            for k in range(n):
+                xu[n + cu + j * n + k:N * blk:blk] = 0.3 * np.sin(3 * tau[:-1] + k + 0.5 * j) + 0.05 * (k + 1)
+    if perturb:
+        xu = xu + perturb * xorshift64star(seed, nvar)
+    return xu

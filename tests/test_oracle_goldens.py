@@ -1,0 +1,163 @@
+"""CPU tests: the oracle (oracle/ctd_oracle.cpp) against every known-answer value the reference's own tests hold
+for this path and against the 50-digit mpmath fixtures in tests/golden/."""
+import numpy as np
+import pytest
+
+from helpers import TOL, csc_to_set, dense_on_pattern, golden_files, load_golden, relerr
+
+
+def _exact_xu(d):
+    """x = t^2, u = 2t, K = 2 t_ij  (reference: test/ci/test_discretization_stagewise.jl:20-42)."""
+    _, T = d.grids()
+    _, _, c = d.butcher()
+    blk, s = d.step_variables_block, d.stage
+    xu = np.zeros(d.dim_NLP_variables)
+    for i in range(d.steps + 1):
+        xu[i * blk] = T[i] ** 2
+    for i in range(d.steps):
+        ti, hi = T[i], T[i + 1] - T[i]
+        for j in range(s):
+            tij = ti + c[j] * hi
+            xu[i * blk + 1 + j] = 2 * tij
+            xu[i * blk + 1 + s + j] = 2 * tij
+    return xu
+
+
+@pytest.mark.parametrize("scheme,stage,blk,eqs,nvar,ncon", [
+    ("gauss_legendre_2", 2, 5, 3, 16, 11),
+    ("gauss_legendre_3", 3, 7, 4, 22, 14),
+])
+def test_G1_stagewise_exact_feasible_trajectory(oracle_lib, scheme, stage, blk, eqs, nvar, ncon):
+    # reference: test/ci/test_discretization_stagewise.jl:53-100 and :176-198
+    grid = [0.0, 0.2, 0.6, 1.0]
+    d = oracle_lib.OracleDOCP("stagewise_scalar", scheme, time_grid=grid)
+    assert (d.n, d.m, d.nv, d.boundary_cons, d.path_cons) == (1, 1, 0, 2, 0)
+    assert d.stage == stage
+    assert d.step_variables_block == blk
+    assert d.state_stage_eqs_block == eqs
+    assert d.dim_NLP_variables == nvar
+    assert d.dim_NLP_constraints == ncon
+    _, fixed = d.grids()
+    assert np.allclose(fixed, grid)
+    lv, uv, lc, uc = d.bounds()
+    for j in range(stage):                       # bounds on stage controls :72-76
+        assert lv[1 + j] == 0.0 and uv[1 + j] == 2.0
+    xu = _exact_xu(d)
+    assert xu[1] != xu[stage]                    # u11 != u1s :87
+    c = d.constraints(xu)
+    assert np.max(np.abs(c - lc)) <= 1e-12      # :96-97
+    assert np.max(np.abs(c - uc)) <= 1e-12
+    assert abs(d.objective(xu) - 4.0 / 3.0) <= 1e-12   # :98
+
+
+def test_G2_goddard_midpoint_manual_nnz(oracle_lib):
+    # reference: test/ci/test_modeler_solver.jl:37  (default Collocation: midpoint, grid_size 250)
+    d = oracle_lib.OracleDOCP("goddard", "midpoint", 250)
+    assert d.jac_nnz() == 6028
+    full, lower = d.hess_nnz()
+    assert lower == 6519
+
+
+def test_G3_zero_control_dims(oracle_lib):
+    # reference: test/ci/test_zero_control_allocations.jl:31 and :138
+    d = oracle_lib.OracleDOCP("estimate_initial_condition", "midpoint", 10)
+    assert d.m == 0 and d.dim_NLP_variables == 10 * 2 + 2 + 2 and d.dim_NLP_constraints > 0
+    d = oracle_lib.OracleDOCP("estimate_rotation_rate", "midpoint", 10)
+    assert d.m == 0 and d.nv == 1 and d.dim_NLP_variables == 10 * 2 + 2 + 1
+    colptr, rowval = d.jac_pattern()
+    assert rowval.min() >= 0 and rowval.max() < d.dim_NLP_constraints      # :141-150
+
+
+@pytest.mark.parametrize("N,nvar,ncon,nnzh", [(1000, 4005, 6007, 30024), (10000, 40005, 60007, 300024)])
+def test_G4_goddard_all_trapeze_sizes(oracle_lib, N, nvar, ncon, nnzh):
+    # reference: test/archives/AD_backend.md:59-61 (sizes and manual Hessian nnz); the archived manual Jacobian
+    # nnz 42043 / 420043 (:63) is what STRUCTURAL mode gives; the current trapeze.jl:203 gives 39043 (hazard H1).
+    d = oracle_lib.OracleDOCP("goddard_all", "trapeze", N)
+    assert (d.dim_NLP_variables, d.dim_NLP_constraints) == (nvar, ncon)
+    assert d.hess_nnz()[1] == nnzh
+    assert d.jac_nnz() == 39 * N + 43
+    d.set_pattern_mode(1)
+    assert d.jac_nnz() == 42 * N + 43
+
+
+@pytest.mark.parametrize("sw,cc", [("gauss_legendre_2", "gauss_legendre_2_constant_control"),
+                                    ("gauss_legendre_3", "gauss_legendre_3_constant_control")])
+def test_G5_stagewise_vs_constant_control_dims(oracle_lib, sw, cc):
+    # reference: test/ci/test_discretization_stagewise.jl:131-139
+    grid = np.linspace(0.0, 1.0, 21)
+    a = oracle_lib.OracleDOCP("stagewise_scalar", cc, time_grid=grid)
+    b = oracle_lib.OracleDOCP("stagewise_scalar", sw, time_grid=grid)
+    assert a.dim_NLP_constraints == b.dim_NLP_constraints
+    assert b.dim_NLP_variables == a.dim_NLP_variables + b.steps * (b.stage - 1) * b.m
+
+
+def test_G6_default_initial_guess(oracle_lib):
+    # reference: src/DOCP_variables.jl:126, test/ci/test_initial_guess.jl:32-38
+    d = oracle_lib.OracleDOCP("double_integrator_path", "midpoint", 10)
+    assert np.all(d.initial_guess(use_problem_init=False) == 0.1)
+    g = oracle_lib.OracleDOCP("goddard", "gauss_legendre_2", 5)
+    x0 = g.initial_guess(use_problem_init=True)
+    blk = g.step_variables_block
+    assert np.allclose(x0[0:3], [1.01, 0.05, 0.8]) and np.allclose(x0[5 * blk:5 * blk + 3], [1.01, 0.05, 0.8])
+    assert np.all(x0[3:blk] == 0.1) and x0[-1] == 0.1
+
+
+def test_survey_table_sizes(oracle_lib):
+    # SURVEY.md section 8 head table (derived from the reference's size formulas)
+    rows = [("goddard", "trapeze", 100, 405, 304, 2428),
+            ("goddard_all", "trapeze", 100, 405, 607, 3943),
+            ("goddard", "gauss_legendre_2", 10000, 110004, 90004, 1110028),
+            ("double_integrator_path", "midpoint", 100000, 300002, 300005, 1300019)]
+    for prob, sch, N, nvar, ncon, nnzj in rows:
+        d = oracle_lib.OracleDOCP(prob, sch, N)
+        assert (d.dim_NLP_variables, d.dim_NLP_constraints, d.jac_nnz()) == (nvar, ncon, nnzj)
+    # formula-only rows (patterns too large to materialise in a unit test)
+    for prob, sch, N, nvar, ncon in [("goddard", "gauss_legendre_3", 80000, 1200004, 960004),
+                                     ("quadrotor12", "gauss_legendre_3", 20000, 1200013, 980024),
+                                     ("quadrotor", "gauss_legendre_3", 20000, 880009, 660015)]:
+        d = oracle_lib.OracleDOCP(prob, sch, N)
+        assert (d.dim_NLP_variables, d.dim_NLP_constraints) == (nvar, ncon)
+
+
+def test_time_grid_errors(oracle_lib):
+    # reference: src/DOCP_data.jl:186-189 (ArgumentError), :342-349 (unknown scheme)
+    with pytest.raises(ValueError):
+        oracle_lib.OracleDOCP("goddard", "midpoint", time_grid=[0.0, 0.5, 0.5, 1.0])
+    with pytest.raises(RuntimeError):
+        oracle_lib.OracleDOCP("goddard", 99, 10)
+    # non-normalised grids are normalised (:191-196)
+    d = oracle_lib.OracleDOCP("double_integrator_path", "midpoint", time_grid=[1.0, 2.0, 4.0, 5.0])
+    nrm, fixed = d.grids()
+    assert np.allclose(nrm, [0.0, 0.25, 0.75, 1.0]) and np.allclose(fixed, [0.0, 0.5, 1.5, 2.0])
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-5])
+def test_oracle_matches_mpmath_fixture(oracle_lib, path):
+    g = load_golden(path)
+    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
+    assert d.dim_NLP_variables == g["dims"]["nvar"] and d.dim_NLP_constraints == g["dims"]["ncon"]
+    assert d.step_variables_block == g["dims"]["step_variables_block"]
+    xu = g["xu"]
+    c = d.constraints(xu)
+    assert not np.any(c == 666.666)                       # every row written (sentinel, test/benchmark.jl:106,126)
+    assert relerr(c, g["c"]) <= TOL
+    assert abs(d.objective(xu) - g["objective"]) / max(1.0, abs(g["objective"])) <= TOL
+    assert relerr(d.gradient(xu), g["gradient"]) <= TOL
+    Jd = d.jac_dense(xu)
+    assert relerr(Jd, g["J"]) <= TOL
+    # STRUCTURAL pattern covers every true nonzero; coloured values on it equal the exact derivative
+    d.set_pattern_mode(1)
+    colptr, rowval = d.jac_pattern()
+    pat = csc_to_set(colptr, rowval)
+    true_nz = {(int(r), int(cc)) for r, cc, _ in g["jac_nonzeros"]}
+    assert true_nz <= pat
+    assert relerr(d.jac_coord(xu), dense_on_pattern(g["J"], colptr, rowval)) <= TOL
+    # REFERENCE_MANUAL pattern: only trapeze with free times drops true nonzeros (dyn rows x v, hazard H1)
+    d.set_pattern_mode(0)
+    colptr0, rowval0 = d.jac_pattern()
+    missing = true_nz - csc_to_set(colptr0, rowval0)
+    if g["scheme"] == "trapeze" and (d.freet0 or d.freetf or g["problem"] == "estimate_rotation_rate"):
+        nv0 = d.dim_NLP_variables - d.nv
+        assert all(cc >= nv0 for _, cc in missing)
+    else:
+        assert not missing
