@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- NLP-callback throughput of the MI355X collocation engine (BASELINE.json metric).
+
+One "step" = one fused evaluation (constraints c(x) + sparse Jacobian values, `ctd_cons_jac_dev_async`) of the workload
+on inputs already resident in HBM.  Workload at N GPUs: Goddard rocket, Gauss-Legendre 2 (stagewise), 10 000 time steps
+PER GPU -- BASELINE.json configs[1] at N = 1; at N > 1 the global grid has 10 000 x N steps, sharded by time step, and
+every step also stitches the constraint vector with an RCCL all-gather (weak scaling).  `value` = (shard evaluations
+all ranks completed) / (max-over-ranks wall time of the K timed steps).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PROBLEM, SCHEME, STEPS_PER_GPU = "goddard", "gauss_legendre_2", 10000
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+
+def cpu_baseline(x, budget_s=12.0):
+    """Reference-faithful CPU path on the host cores of this box: the oracle (a C++ restatement of the Julia reference,
+    kind = "port") evaluates cons! once and the Jacobian the way ADNLPModels does -- one pass of the constraints on
+    one-partial duals per colour of the pattern -- single-threaded, as the reference is."""
+    from oracle.oracle import OracleDOCP
+    o = OracleDOCP(PROBLEM, SCHEME, STEPS_PER_GPU)
+    o.jac_pattern()                      # build pattern + colouring outside the timed region (build-time in the reference)
+    o.constraints(x); o.jac_coord(x)     # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.constraints(x)
+        o.jac_coord(x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": n / el, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{n} fused evaluations (cons! + {o.jac_ncolors()}-colour forward-dual jac_coord!) of the same "
+                      f"{PROBLEM}/{SCHEME} N={STEPS_PER_GPU} workload in {el:.1f} s, oracle/ctd_oracle.cpp, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ctdirect_jl_amd as ct
+    from ctdirect_jl_amd import dist as ctdist
+    from helpers import bench_inputs, describe
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    N = STEPS_PER_GPU * world
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def make(steps=None):
+        return ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, steps=steps, stream=stream)
+
+    sh = ctdist.ShardedDOCP(make, N, world=world, rank=rank)
+    docp = sh.docp
+    x_host = bench_inputs(describe(docp, PROBLEM, SCHEME), perturb=1e-3)
+    x = torch.from_numpy(x_host).to(dev)
+    c = torch.zeros(docp.dim_NLP_constraints, dtype=torch.float64, device=dev)
+    vals = torch.zeros(docp.nnzj, dtype=torch.float64, device=dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sh.cons_jac(x, c, vals)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sh.cons_jac(x, c, vals)
+    sync_all()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+
+    # roofline of the dominant (only) kernel: per-dispatch HIP events on the stream it is launched on
+    kernel_ms = docp.time_cons_jac(x, c, vals, iters=200)
+    sh_nnz = docp.nnzj if world == 1 else None
+    # algorithmic bytes of one launch: read x, write c rows and Jacobian values of the shard
+    # B = 8 (nvar + ncon + nnzj) for the per-GPU 10 000-step problem
+    one = ct.DOCP(PROBLEM, STEPS_PER_GPU, SCHEME, device=-1)
+    alg_bytes = 8 * (one.dim_NLP_variables + one.dim_NLP_constraints + one.nnzj)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "NLP callback evals/s (constraints+sparse Jac), N-step Goddard, 1/2/4/8 GPU",
+            "value": args.steps * world / el,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{PROBLEM} / {SCHEME} (stagewise), {STEPS_PER_GPU} time steps per GPU "
+                            f"(global grid {N} steps, time-step sharded); fused cons!+jac_coord! on HBM-resident x; "
+                            + ("single GPU = BASELINE.json configs[1]" if world == 1 else
+                               "c stitched by in-place RCCL all-gather + tail broadcast every step; value counts one "
+                               "10000-step shard evaluation per GPU per step"),
+                "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,
+                "launch": docp.launch_info(),
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ctd::cons_jac_kernel<GoddardOCP, SC_IRK>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(x_host)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

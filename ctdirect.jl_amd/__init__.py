@@ -1,0 +1,16 @@
+"""MI355X-native collocation engine behind CTDirect.jl's NLP-callback boundary.
+
+The compute path is libctdirect_hip.so (hand-written HIP for gfx950, C ABI in include/ctdirect_hip.h); this package
+is the thin host-side mirror of the reference's DOCP interface plus the multi-GPU stitching helper.
+"""
+from . import _lib
+from .docp import (DOCP, PATTERN_MODES, PROBLEMS, SCHEMES, CTDirectError, DOCP_Jacobian_pattern, constraints,
+                   constraints_bounds, initial_guess, objective, variables_bounds)
+
+__all__ = ["DOCP", "PROBLEMS", "SCHEMES", "PATTERN_MODES", "CTDirectError", "DOCP_Jacobian_pattern", "constraints",
+           "constraints_bounds", "initial_guess", "objective", "variables_bounds", "build"]
+
+
+def build(jobs=8):
+    """Compile the HIP extension in-tree (gfx950)."""
+    return _lib.build(jobs)

@@ -1,0 +1,83 @@
+"""ctypes binding of libctdirect_hip.so -- the C ABI declared in include/ctdirect_hip.h.
+
+The library is the product: if it is missing or fails to load, importing the engine fails loudly.  There is no
+Python / NumPy / PyTorch compute fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctdirect_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# status codes (include/ctdirect_hip.h)
+CTD_OK, CTD_EINVAL, CTD_EGRID, CTD_ESCHEME, CTD_EPATTERN, CTD_EPROBLEM, CTD_ENODEVICE, CTD_EHIP, CTD_ENOMEM = range(9)
+
+
+class ctd_desc(C.Structure):
+    _fields_ = [("problem", C.c_int32), ("scheme", C.c_int32), ("pattern_mode", C.c_int32), ("device", C.c_int32),
+                ("grid_size", C.c_int64), ("time_grid", C.POINTER(C.c_double)), ("time_grid_len", C.c_int64),
+                ("step_begin", C.c_int64), ("step_end", C.c_int64), ("stream", C.c_void_p)]
+
+
+class ctd_init(C.Structure):
+    _fields_ = [("use_problem_default", C.c_int32), ("state", C.POINTER(C.c_double)),
+                ("control", C.POINTER(C.c_double)), ("variable", C.POINTER(C.c_double))]
+
+
+# every symbol include/ctdirect_hip.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+SYMBOLS = {
+    "ctd_create": (C.c_int32, [C.POINTER(ctd_desc), C.POINTER(_vp)]),
+    "ctd_destroy": (C.c_int32, [_vp]),
+    "ctd_last_error": (C.c_char_p, [_vp]),
+    "ctd_strerror": (C.c_char_p, [C.c_int32]),
+    "ctd_sizes": (C.c_int32, [_vp, _ip, _ip, _ip, _ip]),
+    "ctd_dims": (C.c_int32, [_vp, _ip]),
+    "ctd_time_grid": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_butcher": (C.c_int32, [_vp, _dp, _dp, _dp]),
+    "ctd_bounds": (C.c_int32, [_vp, _dp, _dp, _dp, _dp]),
+    "ctd_initial_guess": (C.c_int32, [_vp, _dp, C.POINTER(ctd_init)]),
+    "ctd_jac_structure": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_jac_csc": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_dropped_nonzeros": (C.c_int32, [_vp, _ip]),
+    "ctd_obj": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_cons": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_jac_coord": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_cons_jac": (C.c_int32, [_vp, _dp, _dp, _dp]),
+    "ctd_cons_jac_dev": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ctd_cons_jac_dev_async": (C.c_int32, [_vp, _vp, _vp, _vp]),
+    "ctd_obj_dev": (C.c_int32, [_vp, _vp, _dp]),
+    "ctd_sync": (C.c_int32, [_vp]),
+    "ctd_shard_info": (C.c_int32, [_vp, _ip]),
+    "ctd_time_cons_jac_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _dp]),
+    "ctd_launch_info": (C.c_int32, [_vp, _ip]),
+}
+
+
+def build(jobs=8):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC, "-s", f"-j{jobs}"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` or `make -C ctdirect.jl_amd/csrc`). There is no fallback path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)          # AttributeError if the library does not export the symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,435 @@
+// ctd_engine.hip -- handle, device buffers, launches and the extern "C" entry points of include/ctdirect_hip.h.
+//
+// There is no CPU compute path in this library: every hot-path entry point launches the HIP kernels of
+// ctd_kernels.hpp on the handle's device and fails with CTD_ENODEVICE when the handle has none.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ctdirect_hip.h"
+#include "ctd_host.hpp"
+#include "ctd_kernels.hpp"
+
+using namespace ctd;
+
+namespace ctd {
+// explicit specialisations live in the per-problem translation units
+#define CTD_DECLARE(P)                                                                                               \
+    template <> hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);    \
+    template <> hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
+CTD_DECLARE(GoddardOCP)
+CTD_DECLARE(GoddardAllOCP)
+CTD_DECLARE(DoubleIntegratorPathOCP)
+CTD_DECLARE(QuadrotorOCP)
+CTD_DECLARE(Quadrotor12OCP)
+CTD_DECLARE(StagewiseScalarOCP)
+CTD_DECLARE(EstimateInitialConditionOCP)
+CTD_DECLARE(EstimateRotationRateOCP)
+CTD_DECLARE(LeastSquaresConstraintOCP)
+CTD_DECLARE(DoubleIntegratorFreeT0TfOCP)
+#undef CTD_DECLARE
+}  // namespace ctd
+
+struct ctd_handle {
+    Model model;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t step_begin = 0, step_end = 0;
+    int tile = 0, block = 256;
+    KParams kp;                 // device pointers filled in, outputs set per call
+    size_t lds_bytes = 0;
+    int grid = 0;
+    // static device data
+    double* d_tau = nullptr;
+    uint32_t* d_tmpl = nullptr;
+    uint32_t* d_vtmpl = nullptr;
+    int64_t* d_edge_idx = nullptr;
+    uint32_t* d_edge_code = nullptr;
+    // staging for the host-pointer entry points
+    double* d_x = nullptr;
+    double* d_c = nullptr;
+    double* d_vals = nullptr;
+    // objective
+    double* d_partial = nullptr;
+    double* d_obj = nullptr;
+    int obj_blocks = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int32_t fail(ctd_handle* h, int32_t code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(h, CTD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+template <class T> static hipError_t upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    if (src.empty()) return hipSuccess;
+    hipError_t e = hipMalloc((void**)dst, src.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = std::getenv(name);
+    return (s && *s) ? std::atoi(s) : dflt;
+}
+
+static void free_device(ctd_handle* h) {
+    if (h->device < 0) return;
+    (void)hipSetDevice(h->device);
+    for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
+                    (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj})
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+extern "C" {
+
+const char* ctd_strerror(int32_t st) {
+    switch (st) {
+        case CTD_OK: return "ok";
+        case CTD_EINVAL: return "invalid argument";
+        case CTD_EGRID: return "given time grid is not strictly increasing";
+        case CTD_ESCHEME: return "unknown discretization method";
+        case CTD_EPATTERN: return "sparsity pattern not available";
+        case CTD_EPROBLEM: return "problem not in the compiled registry";
+        case CTD_ENODEVICE: return "no HIP device bound to this handle (there is no CPU fallback)";
+        case CTD_EHIP: return "HIP runtime error";
+        case CTD_ENOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* ctd_last_error(const ctd_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
+    if (!desc || !out) return fail(nullptr, CTD_EINVAL, "ctd_create: null argument");
+    *out = nullptr;
+    std::unique_ptr<ctd_handle> h(new (std::nothrow) ctd_handle());
+    if (!h) return fail(nullptr, CTD_ENOMEM, "ctd_create: out of memory");
+    HostDesc hd{desc->problem, desc->scheme, desc->pattern_mode, desc->grid_size, desc->time_grid, desc->time_grid_len};
+    std::string err;
+    int st;
+    try {
+        st = build_model(hd, h->model, err);
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, CTD_ENOMEM, "ctd_create: out of memory while building the model");
+    }
+    if (st) return fail(nullptr, st, err);
+    const Model& mo = h->model;
+    h->step_begin = desc->step_begin;
+    h->step_end = desc->step_end;
+    if (h->step_begin == 0 && h->step_end == 0) h->step_end = mo.L.N;
+    if (h->step_begin < 0 || h->step_end > mo.L.N || h->step_begin >= h->step_end)
+        return fail(nullptr, CTD_EINVAL, "ctd_create: shard [step_begin, step_end) is not inside [0, N)");
+    h->tile = env_int("CTD_TILE", 0);
+    if (h->tile <= 0) h->tile = default_tile(mo);
+    h->block = env_int("CTD_BLOCK", 256);
+    if (h->block < 64 || h->block > 256 || (h->block % 64)) h->block = 256;
+    mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
+    h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+    h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
+    h->device = desc->device;
+    if (h->device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || h->device >= ndev)
+            return fail(nullptr, CTD_ENODEVICE, "ctd_create: HIP device not available");
+        ctd_handle* hp = h.get();
+        if (h->lds_bytes > 160 * 1024) return fail(nullptr, CTD_EINVAL, "ctd_create: tile does not fit the 160 KiB LDS");
+        HIP_TRY(nullptr, hipSetDevice(hp->device));
+        if (desc->stream) { hp->stream = (hipStream_t)desc->stream; hp->own_stream = false; }
+        else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&hp->stream, hipStreamNonBlocking)); hp->own_stream = true; }
+        if (!mo.uniform) HIP_TRY(nullptr, upload(&hp->d_tau, mo.tau));
+        HIP_TRY(nullptr, upload(&hp->d_tmpl, mo.tmpl));
+        HIP_TRY(nullptr, upload(&hp->d_vtmpl, mo.vtmpl));
+        HIP_TRY(nullptr, upload(&hp->d_edge_idx, mo.edge_idx));
+        HIP_TRY(nullptr, upload(&hp->d_edge_code, mo.edge_code));
+        hp->kp.tau = hp->d_tau;
+        hp->kp.tmpl = hp->d_tmpl;
+        hp->kp.vtmpl = hp->d_vtmpl;
+        hp->kp.edge_idx = hp->d_edge_idx;
+        hp->kp.edge_code = hp->d_edge_code;
+        hp->obj_blocks = 256;
+        HIP_TRY(nullptr, hipMalloc((void**)&hp->d_partial, sizeof(double) * hp->obj_blocks));
+        HIP_TRY(nullptr, hipMalloc((void**)&hp->d_obj, sizeof(double)));
+        HIP_TRY(nullptr, hipEventCreate(&hp->ev0));
+        HIP_TRY(nullptr, hipEventCreate(&hp->ev1));
+    }
+    *out = h.release();
+    return CTD_OK;
+}
+
+int32_t ctd_destroy(ctd_handle* h) {
+    if (!h) return CTD_EINVAL;
+    free_device(h);
+    delete h;
+    return CTD_OK;
+}
+
+int32_t ctd_sizes(const ctd_handle* h, int64_t* nvar, int64_t* ncon, int64_t* nnzj, int64_t* nnzh) {
+    if (!h) return CTD_EINVAL;
+    if (nvar) *nvar = h->model.L.nvar;
+    if (ncon) *ncon = h->model.L.ncon;
+    if (nnzj) *nnzj = h->model.nnzj;
+    if (nnzh) *nnzh = -1;
+    return CTD_OK;
+}
+
+int32_t ctd_dims(const ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    const Layout& L = h->model.L;
+    const ProblemInfo& pi = h->model.info;
+    o[0] = L.n; o[1] = L.m; o[2] = L.nv; o[3] = L.p; o[4] = L.bc; o[5] = L.N;
+    o[6] = L.blk; o[7] = L.eqs; o[8] = L.p; o[9] = L.s; o[10] = L.final_control;
+    o[11] = pi.it0 >= 0; o[12] = pi.itf >= 0; o[13] = pi.lagrange; o[14] = pi.mayer; o[15] = pi.maximize;
+    return CTD_OK;
+}
+
+int32_t ctd_time_grid(const ctd_handle* h, double* normalized, double* fixed) {
+    if (!h) return CTD_EINVAL;
+    const Model& mo = h->model;
+    if (normalized) std::memcpy(normalized, mo.tau.data(), sizeof(double) * (mo.L.N + 1));
+    if (fixed) std::memcpy(fixed, mo.fixed_grid.data(), sizeof(double) * (mo.L.N + 1));
+    return CTD_OK;
+}
+
+int32_t ctd_butcher(const ctd_handle* h, double* a, double* b, double* c) {
+    if (!h) return CTD_EINVAL;
+    const Layout& L = h->model.L;
+    for (int i = 0; i < L.s; ++i) {
+        if (b) b[i] = L.b[i];
+        if (c) c[i] = L.c[i];
+        if (a) for (int j = 0; j < L.s; ++j) a[i * L.s + j] = L.a[3 * i + j];
+    }
+    return CTD_OK;
+}
+
+int32_t ctd_bounds(const ctd_handle* h, double* lvar, double* uvar, double* lcon, double* ucon) {
+    if (!h) return CTD_EINVAL;
+    const Model& mo = h->model;
+    if (lvar) std::memcpy(lvar, mo.var_l.data(), sizeof(double) * mo.L.nvar);
+    if (uvar) std::memcpy(uvar, mo.var_u.data(), sizeof(double) * mo.L.nvar);
+    if (lcon) std::memcpy(lcon, mo.con_l.data(), sizeof(double) * mo.L.ncon);
+    if (ucon) std::memcpy(ucon, mo.con_u.data(), sizeof(double) * mo.L.ncon);
+    return CTD_OK;
+}
+
+int32_t ctd_initial_guess(const ctd_handle* h, double* x0, const ctd_init* init) {
+    if (!h || !x0) return CTD_EINVAL;
+    if (init) model_initial_guess(h->model, x0, init->use_problem_default != 0, init->state, init->control, init->variable);
+    else model_initial_guess(h->model, x0, false, nullptr, nullptr, nullptr);
+    return CTD_OK;
+}
+
+int32_t ctd_jac_structure(const ctd_handle* h, int64_t* rows, int64_t* cols) {
+    if (!h || !rows || !cols) return CTD_EINVAL;
+    const Model& mo = h->model;
+    std::vector<int64_t> r;
+    int64_t nz = 0;
+    for (int64_t j = 0; j < mo.L.nvar; ++j) {
+        mo.gen_column(j, r);
+        for (int64_t row : r) { rows[nz] = row + 1; cols[nz] = j + 1; ++nz; }
+    }
+    return nz == mo.nnzj ? CTD_OK : CTD_EPATTERN;
+}
+
+int32_t ctd_jac_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval) {
+    if (!h || !colptr || !rowval) return CTD_EINVAL;
+    const Model& mo = h->model;
+    std::vector<int64_t> r;
+    int64_t nz = 0;
+    for (int64_t j = 0; j < mo.L.nvar; ++j) {
+        colptr[j] = nz;
+        mo.gen_column(j, r);
+        for (int64_t row : r) rowval[nz++] = row;
+    }
+    colptr[mo.L.nvar] = nz;
+    return nz == mo.nnzj ? CTD_OK : CTD_EPATTERN;
+}
+
+int32_t ctd_dropped_nonzeros(const ctd_handle* h, int64_t* count) {
+    if (!h || !count) return CTD_EINVAL;
+    *count = h->model.dropped;
+    return CTD_OK;
+}
+
+int32_t ctd_shard_info(const ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    const Model& mo = h->model;
+    const Layout& L = mo.L;
+    const bool first = h->step_begin == 0, last = h->step_end == L.N;
+    o[0] = h->step_begin; o[1] = h->step_end;
+    o[2] = h->step_begin * L.cb;
+    o[3] = last ? L.ncon : h->step_end * L.cb;
+    o[4] = mo.column_start(h->step_begin * L.blk);
+    o[5] = mo.column_start(h->step_end * L.blk);
+    o[6] = first; o[7] = last;
+    return CTD_OK;
+}
+
+int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    o[0] = h->grid; o[1] = h->block; o[2] = (int64_t)h->lds_bytes; o[3] = h->tile; o[4] = h->model.Lseg;
+    o[5] = (int64_t)h->model.edge_idx.size();
+    return CTD_OK;
+}
+
+// ---- hot path ------------------------------------------------------------------------------------------------
+
+static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, bool timed = false) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x_dev) return fail(h, CTD_EINVAL, "x is null");
+    HIP_TRY(h, hipSetDevice(h->device));
+    KParams kp = h->kp;
+    kp.c = c_dev;
+    kp.vals = vals_dev;
+    hipError_t e = hipErrorInvalidValue;
+    const int sc = h->model.L.sc;
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_cons_jac<P>(sc, kp, x_dev, h->grid, h->block, h->lds_bytes, h->stream, timed ? h->ev0 : nullptr,
+                               timed ? h->ev1 : nullptr);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return CTD_OK;
+}
+
+int32_t ctd_cons_jac_dev_async(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev) {
+    return enqueue_cons_jac(h, x_dev, c_dev, vals_dev);
+}
+
+int32_t ctd_sync(ctd_handle* h) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+int32_t ctd_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev) {
+    int32_t st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);
+    if (st) return st;
+    return ctd_sync(h);
+}
+
+static int32_t ensure_staging(ctd_handle* h, bool need_c, bool need_vals) {
+    const Model& mo = h->model;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->d_x) HIP_TRY(h, hipMalloc((void**)&h->d_x, sizeof(double) * mo.L.nvar));
+    if (need_c && !h->d_c) HIP_TRY(h, hipMalloc((void**)&h->d_c, sizeof(double) * mo.L.ncon));
+    if (need_vals && !h->d_vals) HIP_TRY(h, hipMalloc((void**)&h->d_vals, sizeof(double) * (mo.nnzj > 0 ? mo.nnzj : 1)));
+    return CTD_OK;
+}
+
+static int32_t host_cons_jac(ctd_handle* h, const double* x, double* c, double* vals) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x) return fail(h, CTD_EINVAL, "x is null");
+    const Model& mo = h->model;
+    int32_t st = ensure_staging(h, c != nullptr, vals != nullptr);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * mo.L.nvar, hipMemcpyHostToDevice, h->stream));
+    st = enqueue_cons_jac(h, h->d_x, c ? h->d_c : nullptr, vals ? h->d_vals : nullptr);
+    if (st) return st;
+    if (c) HIP_TRY(h, hipMemcpyAsync(c, h->d_c, sizeof(double) * mo.L.ncon, hipMemcpyDeviceToHost, h->stream));
+    if (vals) HIP_TRY(h, hipMemcpyAsync(vals, h->d_vals, sizeof(double) * mo.nnzj, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+int32_t ctd_cons(ctd_handle* h, const double* x, double* c) {
+    if (h && !c) return fail(h, CTD_EINVAL, "c is null");
+    return host_cons_jac(h, x, c, nullptr);
+}
+int32_t ctd_jac_coord(ctd_handle* h, const double* x, double* vals) {
+    if (h && !vals) return fail(h, CTD_EINVAL, "vals is null");
+    return host_cons_jac(h, x, nullptr, vals);
+}
+int32_t ctd_cons_jac(ctd_handle* h, const double* x, double* c, double* vals) {
+    if (h && (!c || !vals)) return fail(h, CTD_EINVAL, "c or vals is null");
+    return host_cons_jac(h, x, c, vals);
+}
+
+int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x_dev || !f_host) return fail(h, CTD_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Layout& L = h->model.L;
+    ObjParams op;
+    std::memset(&op, 0, sizeof(op));
+    op.L = L;
+    op.tau = h->d_tau;
+    const bool last = h->step_end == L.N;
+    // quadrature units: trapeze sums over nodes (node N belongs to the last shard), the others over steps
+    op.unit_begin = h->step_begin;
+    op.unit_end = (L.sc == SC_TRAPEZE && last) ? L.N + 1 : h->step_end;
+    op.add_mayer = last ? 1 : 0;
+    op.partial = h->d_partial;
+    op.out = h->d_obj;
+    const int64_t units = op.unit_end - op.unit_begin;
+    int blocks = (int)((units + 255) / 256);
+    if (blocks > h->obj_blocks) blocks = h->obj_blocks;
+    if (blocks < 1) blocks = 1;
+    op.nblocks = blocks;
+    hipError_t e = hipErrorInvalidValue;
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_obj<P>(L.sc, op, x_dev, blocks, 256, h->stream);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(f_host, h->d_obj, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+int32_t ctd_obj(ctd_handle* h, const double* x, double* f) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x || !f) return fail(h, CTD_EINVAL, "null argument");
+    int32_t st = ensure_staging(h, false, false);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * h->model.L.nvar, hipMemcpyHostToDevice, h->stream));
+    return ctd_obj_dev(h, h->d_x, f);
+}
+
+int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, int32_t iters, double* mean_ms) {
+    if (!h || !mean_ms || iters < 1) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    int32_t st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);   // warm
+    if (st) return st;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // per-dispatch events: the start/stop timestamps are taken by the dispatch of THIS kernel on the handle's stream
+    double total = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev, true);
+        if (st) return st;
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        total += (double)ms;
+    }
+    *mean_ms = total / iters;
+    return CTD_OK;
+}
+
+}  // extern "C"

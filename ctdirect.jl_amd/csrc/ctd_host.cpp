@@ -1,0 +1,658 @@
+// ctd_host.cpp -- host model: DOCP sizes, time grid, bounds, initial guess, Jacobian sparsity pattern (CSC) and the
+// emit tables of the kernels.  See ctd_host.hpp.
+#include "ctd_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+
+namespace ctd {
+
+// status codes (values as in include/ctdirect_hip.h)
+enum { ST_OK = 0, ST_EINVAL = 1, ST_EGRID = 2, ST_ESCHEME = 3, ST_EPATTERN = 4, ST_EPROBLEM = 5 };
+
+// ------------------------------------------------------------------------------------------------------
+// scheme structs: sizes and Butcher tables
+// ------------------------------------------------------------------------------------------------------
+static void set_butcher(Layout& L, int s) {
+    // Float64 expressions exactly as the reference's constructors write them:
+    // irk.jl:41-43 (s=1), irk.jl:77-79 / irk_stagewise.jl:61-64 (s=2), irk.jl:111-119 / irk_stagewise.jl:103-109 (s=3)
+    for (double& x : L.a) x = 0.0;
+    for (int i = 0; i < 3; ++i) L.b[i] = L.c[i] = 0.0;
+    const double r3 = std::sqrt(3.0), r15 = std::sqrt(15.0);
+    if (s == 1) {
+        L.a[0] = 0.5; L.b[0] = 1.0; L.c[0] = 0.5;
+    } else if (s == 2) {
+        L.a[0] = 0.25;            L.a[1] = 0.25 - r3 / 6;
+        L.a[3] = 0.25 + r3 / 6;   L.a[4] = 0.25;
+        L.b[0] = 0.5; L.b[1] = 0.5;
+        L.c[0] = 0.5 - r3 / 6; L.c[1] = 0.5 + r3 / 6;
+    } else {
+        L.a[0] = 5.0 / 36.0;            L.a[1] = 2.0 / 9 - r15 / 15;  L.a[2] = 5.0 / 36 - r15 / 30;
+        L.a[3] = 5.0 / 36.0 + r15 / 24; L.a[4] = 2.0 / 9.0;           L.a[5] = 5.0 / 36.0 - r15 / 24;
+        L.a[6] = 5.0 / 36 + r15 / 30;   L.a[7] = 2.0 / 9 + r15 / 15;  L.a[8] = 5.0 / 36.0;
+        L.b[0] = 5.0 / 18.0; L.b[1] = 4.0 / 9.0; L.b[2] = 5.0 / 18.0;
+        L.c[0] = 0.5 - 0.1 * r15; L.c[1] = 0.5; L.c[2] = 0.5 + 0.1 * r15;
+    }
+}
+
+static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
+    Layout& L = mo.L;
+    const ProblemInfo& pi = mo.info;
+    std::memset(&L, 0, sizeof(L));
+    L.scheme = scheme;
+    L.n = pi.n; L.m = pi.m; L.nv = pi.nv; L.p = pi.npath; L.bc = pi.nbc;
+    L.N = N;
+    L.it0 = pi.it0; L.itf = pi.itf; L.t0 = pi.t0; L.tf = pi.tf;
+    L.free_time = (pi.it0 >= 0 || pi.itf >= 0) ? 1 : 0;
+    switch (scheme) {
+        case 0:   // Trapeze: trapeze.jl:14-42
+            L.sc = SC_TRAPEZE; L.s = 0; L.cu = L.m; L.final_control = 1;
+            L.blk = L.n + L.m; L.eqs = L.n;
+            L.nvar = N * L.blk + L.n + L.nv + L.m;
+            break;
+        case 1:   // Midpoint: midpoint.jl:17-39
+            L.sc = SC_MIDPOINT; L.s = 0; L.cu = L.m;
+            L.blk = L.n + L.m; L.eqs = L.n;
+            L.nvar = N * L.blk + L.n + L.nv;
+            break;
+        case 2: case 3: case 4:   // Gauss_Legendre_{1,2,3}, constant control: irk.jl:138-160
+            L.sc = SC_IRK; L.s = scheme - 1; L.cu = L.m;
+            set_butcher(L, L.s);
+            L.blk = L.n + L.m + L.n * L.s; L.eqs = L.n * (1 + L.s);
+            L.nvar = N * L.blk + L.n + L.nv;
+            break;
+        case 5: case 6:           // Gauss_Legendre_{2,3}_Stagewise: irk_stagewise.jl:136-163
+            L.sc = SC_IRK; L.s = scheme - 3; L.stagewise = 1; L.cu = L.m * L.s;
+            set_butcher(L, L.s);
+            L.blk = L.n + L.cu + L.s * L.n; L.eqs = L.n * (1 + L.s);
+            L.nvar = N * L.blk + L.n + L.nv;
+            break;
+        default:
+            err = "Unknown discretization method (valid: trapeze, midpoint, gauss_legendre_1, gauss_legendre_2/3[_constant_control])";
+            return ST_ESCHEME;
+    }
+    L.cb = L.eqs + L.p;
+    L.ncon = N * L.cb + L.p + L.bc;
+    L.v_off = L.nvar - L.nv;
+    mo.R = make_rec_layout(L.n, L.m, L.nv, L.p, L.bc, L.s, L.cb);
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DOCPtime: src/DOCP_data.jl:176-214
+// ------------------------------------------------------------------------------------------------------
+static int build_time(Model& mo, const HostDesc& d, int64_t& N, std::string& err) {
+    if (d.time_grid == nullptr) {
+        if (d.grid_size < 1) { err = "grid_size must be >= 1"; return ST_EINVAL; }
+        N = d.grid_size;
+        mo.uniform = true;
+        mo.tau.resize(N + 1);
+        for (int64_t i = 0; i <= N; ++i) mo.tau[i] = (double)i / (double)N;      // collect(LinRange(0, 1, N+1))
+    } else {
+        if (d.time_grid_len < 2) { err = "time grid needs at least two points"; return ST_EINVAL; }
+        for (int64_t i = 1; i < d.time_grid_len; ++i)
+            if (!(d.time_grid[i - 1] < d.time_grid[i])) {
+                err = "given time grid is not strictly increasing. Aborting...";   // DOCP_data.jl:187
+                return ST_EGRID;
+            }
+        N = d.time_grid_len - 1;
+        mo.uniform = false;
+        mo.tau.assign(d.time_grid, d.time_grid + d.time_grid_len);
+        if (d.time_grid[0] != 0 || d.time_grid[N] != 1) {
+            const double t0 = d.time_grid[0], tf = d.time_grid[N];
+            for (double& t : mo.tau) t = (t - t0) / (tf - t0);
+        }
+    }
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bounds: __variables_bounds! (DOCP_variables.jl:21-63, irk_stagewise.jl:250-300), __constraints_bounds!
+// (DOCP_functions.jl:163-191)
+// ------------------------------------------------------------------------------------------------------
+static void bounds_block(int dim, const std::vector<BoxItem>& box, std::vector<double>& lb, std::vector<double>& ub) {
+    lb.assign(dim, -kInf);
+    ub.assign(dim, kInf);
+    for (const BoxItem& e : box) { lb[e.index] = e.lb; ub[e.index] = e.ub; }
+}
+
+static void build_bounds(Model& mo) {
+    const Layout& L = mo.L;
+    const ProblemInfo& pi = mo.info;
+    mo.var_l.assign(L.nvar, -kInf);
+    mo.var_u.assign(L.nvar, kInf);
+    std::vector<double> xl, xu, ul, uu, vl, vu;
+    bounds_block(L.n, pi.state_box, xl, xu);
+    bounds_block(L.m, pi.control_box, ul, uu);
+    for (int64_t i = 0; i <= L.N; ++i)
+        for (int k = 0; k < L.n; ++k) { mo.var_l[i * L.blk + k] = xl[k]; mo.var_u[i * L.blk + k] = xu[k]; }
+    if (L.m > 0) {
+        if (L.stagewise) {
+            for (int64_t i = 0; i < L.N; ++i)
+                for (int j = 0; j < L.s; ++j)
+                    for (int k = 0; k < L.m; ++k) {
+                        mo.var_l[i * L.blk + L.n + j * L.m + k] = ul[k];
+                        mo.var_u[i * L.blk + L.n + j * L.m + k] = uu[k];
+                    }
+        } else {
+            const int64_t last = L.final_control ? L.N : L.N - 1;     // set_control_at_time_step!, common.jl:209-223
+            for (int64_t i = 0; i <= last; ++i)
+                for (int k = 0; k < L.m; ++k) { mo.var_l[i * L.blk + L.n + k] = ul[k]; mo.var_u[i * L.blk + L.n + k] = uu[k]; }
+        }
+    }
+    if (L.nv > 0) {
+        bounds_block(L.nv, pi.variable_box, vl, vu);
+        for (int k = 0; k < L.nv; ++k) { mo.var_l[L.v_off + k] = vl[k]; mo.var_u[L.v_off + k] = vu[k]; }
+    }
+    mo.con_l.assign(L.ncon, 0.0);
+    mo.con_u.assign(L.ncon, 0.0);
+    int64_t off = 0;
+    for (int64_t i = 0; i <= L.N; ++i) {
+        if (i < L.N) off += L.eqs;
+        for (int k = 0; k < L.p; ++k) { mo.con_l[off + k] = pi.path_lb[k]; mo.con_u[off + k] = pi.path_ub[k]; }
+        off += L.p;
+    }
+    for (int k = 0; k < L.bc; ++k) { mo.con_l[off + k] = pi.bc_lb[k]; mo.con_u[off + k] = pi.bc_ub[k]; }
+}
+
+// __initial_guess: DOCP_variables.jl:122-145, irk_stagewise.jl:302-335
+void model_initial_guess(const Model& mo, double* X, bool use_default, const double* state, const double* control,
+                         const double* variable) {
+    const Layout& L = mo.L;
+    const ProblemInfo& pi = mo.info;
+    for (int64_t k = 0; k < L.nvar; ++k) X[k] = 0.1;
+    std::vector<double> tmp(std::max(std::max(L.n, L.m), std::max(L.nv, 1)));
+    // variable first (needed for the time grid when times are free)
+    if (L.nv > 0) {
+        if (variable) for (int k = 0; k < L.nv; ++k) X[L.v_off + k] = variable[k];
+        else if (use_default && pi.init_variable(tmp.data())) for (int k = 0; k < L.nv; ++k) X[L.v_off + k] = tmp[k];
+    }
+    const double t0 = L.it0 >= 0 ? X[L.v_off + L.it0] : L.t0;
+    const double tf = L.itf >= 0 ? X[L.v_off + L.itf] : L.tf;
+    auto grid = [&](int64_t i) { return t0 + mo.tau[i] * (tf - t0); };
+    auto get_state = [&](double t, double* out) -> bool {
+        if (state) { for (int k = 0; k < L.n; ++k) out[k] = state[k]; return true; }
+        return use_default && pi.init_state(t, out);
+    };
+    auto get_control = [&](double t, double* out) -> bool {
+        if (control) { for (int k = 0; k < L.m; ++k) out[k] = control[k]; return true; }
+        return use_default && pi.init_control(t, out);
+    };
+    for (int64_t i = 0; i <= L.N; ++i) {
+        const double ti = grid(i);
+        if (get_state(ti, tmp.data())) for (int k = 0; k < L.n; ++k) X[i * L.blk + k] = tmp[k];
+        if (L.m > 0 && !L.stagewise && (i < L.N || L.final_control))
+            if (get_control(ti, tmp.data())) for (int k = 0; k < L.m; ++k) X[i * L.blk + L.n + k] = tmp[k];
+    }
+    if (L.m > 0 && L.stagewise) {
+        for (int64_t i = 0; i < L.N; ++i) {
+            const double ti = grid(i), hi = grid(i + 1) - ti;
+            for (int j = 0; j < L.s; ++j) {
+                const double tij = ti + L.c[j] * hi;
+                if (get_control(tij, tmp.data()))
+                    for (int k = 0; k < L.m; ++k) X[i * L.blk + L.n + j * L.m + k] = tmp[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DOCP_Jacobian_pattern: the add_nonzero_block! calls of each scheme (0-based, half-open)
+// ------------------------------------------------------------------------------------------------------
+static inline void push_block(std::vector<Block>& out, int64_t r0, int64_t r1, int64_t c0, int64_t c1) {
+    if (r1 > r0 && c1 > c0) out.push_back(Block{r0, r1, c0, c1});
+}
+
+void Model::step_blocks(int64_t i, std::vector<Block>& out) const {
+    const int64_t n = L.n, m = L.m, cb = L.cb, blk = L.blk;
+    const int64_t co = i * cb, vo = i * blk, v0 = L.v_off, v1 = L.nvar;
+    if (L.sc == SC_TRAPEZE) {                                     // trapeze.jl:168-204
+        const int64_t dyn0 = co, dyn1 = co + n, path0 = co + n, path1 = co + cb;
+        push_block(out, dyn0, dyn1, vo, vo + n);                  // :191  x_i
+        push_block(out, dyn0, dyn1, vo + n, vo + n + m + n);      // :192  u_i, x_i+1
+        push_block(out, dyn0, dyn1, vo + 2 * n + m, vo + 2 * n + 2 * m);   // :193  u_i+1
+        push_block(out, path0, path1, vo, vo + n);                // :197
+        push_block(out, path0, path1, vo + n, vo + n + m);        // :198
+        push_block(out, path0, path1, v0, v1);                    // :203  (path rows only: hazard H1)
+        if (pattern_mode == 1) push_block(out, dyn0, dyn1, v0, v1);   // STRUCTURAL: the block the comment at :202 intends
+    } else if (L.sc == SC_MIDPOINT) {                             // midpoint.jl:175-204
+        push_block(out, co, co + n, vo, vo + blk + n);            // :192-194  x_i, u_i, x_i+1
+        push_block(out, co + n, co + cb, vo, vo + n + m);         // :197-199
+        push_block(out, co, co + cb, v0, v1);                     // :202
+    } else {                                                      // irk.jl:330-380 / irk_stagewise.jl:483-524
+        const int64_t s = L.s;
+        const int64_t dyn0 = co, dyn1 = co + n, st0 = co + n, st1 = co + (s + 1) * n, path0 = st1, path1 = co + cb;
+        const int64_t xi0 = vo, xi1 = vo + n, ui1 = vo + n + L.cu, ki0 = ui1, ki1 = vo + blk, xip1_1 = vo + blk + n;
+        push_block(out, dyn0, dyn1, xi0, xi1);
+        push_block(out, dyn0, dyn1, ki0, xip1_1);
+        push_block(out, dyn0, dyn1, v0, v1);
+        push_block(out, st0, st1, xi0, ki1);
+        push_block(out, st0, st1, v0, v1);
+        push_block(out, path0, path1, xi0, ui1);
+        push_block(out, path0, path1, v0, v1);
+    }
+}
+
+static void build_tail_blocks(Model& mo) {
+    const Layout& L = mo.L;
+    const int64_t N = L.N, n = L.n, m = L.m;
+    std::vector<Block>& out = mo.tail;
+    out.clear();
+    // 2. final path constraints (xf, uf, v): trapeze.jl:206-217, midpoint.jl:206-216, irk.jl:383-393, irk_stagewise.jl:526-537
+    const int64_t fp0 = N * L.cb, fp1 = fp0 + L.p;
+    const int64_t xf0 = N * L.blk, xf1 = xf0 + n;
+    push_block(out, fp0, fp1, xf0, xf1);
+    if (L.sc == SC_TRAPEZE) push_block(out, fp0, fp1, xf1, xf1 + m);
+    else push_block(out, fp0, fp1, (N - 1) * L.blk + n, (N - 1) * L.blk + n + L.cu);    // u(tf) = U_N convention
+    push_block(out, fp0, fp1, L.v_off, L.nvar);
+    // 3. boundary constraints (x0, xf, v)
+    const int64_t b0 = fp1, b1 = L.ncon;
+    push_block(out, b0, b1, 0, n);
+    push_block(out, b0, b1, xf0, xf1);
+    push_block(out, b0, b1, L.v_off, L.nvar);
+    // leftover "lagrange state" entry of the stagewise scheme: irk_stagewise.jl:550-552 (hazard H2)
+    if (L.stagewise && mo.info.lagrange && n > 0) push_block(out, L.ncon - 1, L.ncon, n - 1, n);
+}
+
+void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
+    rows.clear();
+    std::vector<Block> cand;
+    if (j >= L.v_off) {
+        for (int64_t i = 0; i < L.N; ++i) step_blocks(i, cand);
+    } else {
+        const int64_t sj = j / L.blk;
+        if (sj - 1 >= 0 && sj - 1 < L.N) step_blocks(sj - 1, cand);
+        if (sj < L.N) step_blocks(sj, cand);
+    }
+    for (const Block& b : tail) cand.push_back(b);
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    for (const Block& b : cand)
+        if (j >= b.c0 && j < b.c1) iv.emplace_back(b.r0, b.r1);
+    std::sort(iv.begin(), iv.end());
+    int64_t next = -1;
+    for (auto& p : iv) {
+        int64_t r = std::max(p.first, next);
+        for (; r < p.second; ++r) rows.push_back(r);
+        next = std::max(next, p.second);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// classification of a Jacobian position -> where its value comes from
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct Loc { int ci, di, beta; bool data_next; };
+const Loc kZero{C_ZERO, 0, 0, false};
+inline bool const_coef(int ci) { return ci == C_ZERO || ci == C_ONE || ci == C_NEG1 || (ci >= C_B && ci < C_B + 3); }
+}  // namespace
+
+// d(row lr of a step) / d(local variable q); q in [0,blk): own block, [blk, blk+n): X_{i+1}, then U_{i+1} (trapeze)
+static Loc local_entry(const Model& mo, int lr, int q) {
+    const Layout& L = mo.L;
+    const RecLayout& R = mo.R;
+    const int n = L.n, m = L.m;
+    auto F = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oF + r * n + c; };
+    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * m + c; };
+    const bool is_path = lr >= L.eqs;
+    if (L.sc == SC_IRK) {
+        // column kind
+        int kind, l = 0, c = 0;     // 0 x_i, 1 control, 2 K, 3 x_{i+1}, 4 none
+        if (q < n) { kind = 0; c = q; }
+        else if (q < n + L.cu) { kind = 1; if (L.stagewise) { l = (q - n) / m; c = (q - n) % m; } else c = q - n; }
+        else if (q < L.blk) { kind = 2; l = (q - n - L.cu) / n; c = (q - n - L.cu) % n; }
+        else if (q < L.blk + n) { kind = 3; c = q - L.blk; }
+        else kind = 4;
+        if (is_path) {
+            const int pq = lr - L.eqs;
+            if (kind == 0) return Loc{C_ONE, R.oPx + pq * n + c, 0, false};
+            if (kind == 1) return Loc{L.stagewise ? C_B + l : C_ONE, R.oPu + pq * m + c, 0, false};
+            return kZero;
+        }
+        if (lr < n) {   // state equation row
+            const int r = lr;
+            if (kind == 0) return r == c ? Loc{C_NEG1, 0, 0, false} : kZero;
+            if (kind == 2) return r == c ? Loc{C_HB + l, 0, 0, false} : kZero;
+            if (kind == 3) return r == c ? Loc{C_ONE, 0, 0, false} : kZero;
+            return kZero;
+        }
+        const int j = (lr - n) / n, r = (lr - n) % n;   // stage equation row
+        if (kind == 0) return Loc{C_NEG1, F(j, r, c), 0, false};
+        if (kind == 1) return (!L.stagewise || l == j) ? Loc{C_NEG1, G(j, r, c), 0, false} : kZero;
+        if (kind == 2) return Loc{C_HA + 3 * j + l, F(j, r, c), (j == l && r == c) ? 1 : 0, false};
+        return kZero;
+    }
+    // trapeze / midpoint
+    int kind, c = 0;   // 0 x_i, 1 u_i, 3 x_{i+1}, 5 u_{i+1}, 4 none
+    if (q < n) { kind = 0; c = q; }
+    else if (q < L.blk) { kind = 1; c = q - n; }
+    else if (q < L.blk + n) { kind = 3; c = q - L.blk; }
+    else if (q < L.blk + n + m) { kind = 5; c = q - L.blk - n; }
+    else kind = 4;
+    if (is_path) {
+        const int pq = lr - L.eqs;
+        if (kind == 0) return Loc{C_ONE, R.oPx + pq * n + c, 0, false};
+        if (kind == 1) return Loc{C_ONE, R.oPu + pq * m + c, 0, false};
+        return kZero;
+    }
+    const int r = lr;
+    if (L.sc == SC_MIDPOINT) {
+        if (kind == 0) return Loc{C_NHH, F(0, r, c), r == c ? 2 : 0, false};
+        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
+        if (kind == 3) return Loc{C_NHH, F(0, r, c), r == c ? 1 : 0, false};
+        return kZero;
+    }
+    if (kind == 0) return Loc{C_NHH, F(0, r, c), r == c ? 2 : 0, false};
+    if (kind == 1) return Loc{C_NHH, G(0, r, c), 0, false};
+    if (kind == 3) return Loc{C_NHH, F(0, r, c), r == c ? 1 : 0, true};
+    if (kind == 5) return Loc{C_NHH, G(0, r, c), 0, true};
+    return kZero;
+}
+
+// d(row lr of a step) / d v_k
+static Loc local_entry_v(const Model& mo, int lr, int k) {
+    const Layout& L = mo.L;
+    const RecLayout& R = mo.R;
+    const int n = L.n, nv = L.nv;
+    if (lr >= L.eqs) return Loc{C_ONE, R.oPv + (lr - L.eqs) * nv + k, 0, false};
+    if (lr < n) return Loc{C_ONE, R.oSv + lr * nv + k, 0, false};
+    const int j = (lr - n) / n, r = (lr - n) % n;
+    return Loc{C_NEG1, R.oEval + j * R.eval_sz + R.oW + r * nv + k, 0, false};
+}
+
+Model::Entry Model::classify(int64_t row, int64_t col) const {
+    const RecLayout& Rr = R;
+    const int64_t N = L.N;
+    const int n = L.n, m = L.m, nv = L.nv;
+    Entry e{0, 0, 0, C_ZERO, 0, 0, true};
+    auto set = [&](const Loc& lc, int64_t step) {
+        e.cstep = step;
+        e.dstep = lc.data_next ? step + 1 : step;
+        e.ci = lc.ci; e.di = lc.di; e.beta = lc.beta;
+        e.cconst = const_coef(lc.ci);
+    };
+    if (row < N * L.cb) {
+        const int64_t i = row / L.cb;
+        const int lr = (int)(row % L.cb);
+        e.kind = 0;
+        e.cstep = e.dstep = i;
+        if (col >= L.v_off) { set(local_entry_v(*this, lr, (int)(col - L.v_off)), i); return e; }
+        const int64_t q = col - i * L.blk;
+        if (q < 0 || q >= L.blk + n + m || col >= L.v_off) return e;   // not a local variable of this step: zero
+        set(local_entry(*this, lr, (int)q), i);
+        return e;
+    }
+    if (row < N * L.cb + L.p) {   // final path row
+        const int pq = (int)(row - N * L.cb);
+        e.kind = 1;
+        if (col >= L.v_off) { e.ci = C_ONE; e.di = Rr.oPv + pq * nv + (int)(col - L.v_off); return e; }
+        const int64_t xf0 = N * L.blk;
+        if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oPx + pq * n + (int)(col - xf0); return e; }
+        if (L.sc == SC_TRAPEZE) {
+            if (col >= xf0 + n && col < xf0 + n + m) { e.ci = C_ONE; e.di = Rr.oPu + pq * m + (int)(col - xf0 - n); }
+            return e;
+        }
+        const int64_t u0 = (N - 1) * L.blk + n;
+        if (col >= u0 && col < u0 + L.cu) {
+            const int o = (int)(col - u0);
+            if (L.stagewise) { e.ci = C_B + o / m; e.di = Rr.oPu + pq * m + o % m; }
+            else { e.ci = C_ONE; e.di = Rr.oPu + pq * m + o; }
+        }
+        return e;
+    }
+    // boundary row
+    const int r = (int)(row - N * L.cb - L.p);
+    e.kind = 2;
+    const int64_t xf0 = N * L.blk;
+    if (col >= L.v_off) { e.ci = C_ONE; e.di = Rr.oBv + r * nv + (int)(col - L.v_off); return e; }
+    if (col < n) { e.ci = C_ONE; e.di = Rr.oB0 + r * n + (int)col; return e; }
+    if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oBf + r * n + (int)(col - xf0); return e; }
+    return e;
+}
+
+int64_t Model::column_start(int64_t j) const {
+    const int64_t h = reg_first * L.blk, t = reg_last * L.blk;
+    if (j < h) return cp_head[j];
+    if (j < t) {
+        const int64_t i = j / L.blk;
+        return seg_base + (i - reg_first) * (int64_t)Lseg + cp_tmpl[j - i * L.blk];
+    }
+    return cp_tail[j - t];
+}
+
+// relative template codes of the step-periodic segment of step i
+static bool segment_codes(const Model& mo, int64_t i, std::vector<uint32_t>& codes, std::vector<int64_t>& cp,
+                          std::vector<int64_t>& relrows, int& need_prev) {
+    const Layout& L = mo.L;
+    codes.clear(); relrows.clear();
+    cp.assign(L.blk + 1, 0);
+    std::vector<int64_t> rows;
+    for (int lc = 0; lc < L.blk; ++lc) {
+        const int64_t col = i * L.blk + lc;
+        mo.gen_column(col, rows);
+        for (int64_t row : rows) {
+            Model::Entry e = mo.classify(row, col);
+            if (e.kind != 0) return false;
+            int64_t crel = i - e.cstep, drel = i - e.dstep;
+            if (e.cconst) crel = 0;
+            if (e.di == 0) drel = 0;
+            if (crel < 0 || crel > 1 || drel < 0 || drel > 1) return false;
+            if (crel == 1 || drel == 1) need_prev = 1;
+            codes.push_back(pack_code(e.di, e.ci, e.beta, (int)drel, (int)crel));
+            relrows.push_back(row - i * L.cb);
+        }
+        cp[lc + 1] = (int64_t)codes.size();
+    }
+    return true;
+}
+
+static int build_tables(Model& mo, std::string& err) {
+    const Layout& L = mo.L;
+    const int64_t N = L.N;
+    if (L.nv > kMaxNV) { err = "more than 4 optimisation variables are not supported by the emit tables"; return ST_EPATTERN; }
+    if (mo.R.stride >= 65536) { err = "per-step record too large for 16-bit data indices"; return ST_EPATTERN; }
+    // halo of a tile: trapeze reads the next node and the previous step's coefficients; midpoint the previous step
+    mo.HL = (L.sc == SC_IRK) ? 0 : 1;
+    mo.HH = (L.sc == SC_TRAPEZE) ? 1 : 0;
+
+    // ---- regular range --------------------------------------------------------------------------------
+    std::vector<uint32_t> c1, c2;
+    std::vector<int64_t> cp1, cp2, rr1, rr2;
+    int need_prev = 0;
+    mo.reg_first = mo.reg_last = N;    // all-edge mode by default (small N)
+    if (N >= 5) {
+        bool ok = segment_codes(mo, 1, c1, cp1, rr1, need_prev);
+        if (ok) {
+            for (int64_t chk : {(int64_t)2, N - 2}) {
+                int np2 = 0;
+                if (!segment_codes(mo, chk, c2, cp2, rr2, np2) || c2 != c1 || cp2 != cp1 || rr2 != rr1) { ok = false; break; }
+            }
+        }
+        if (!ok) { err = "Jacobian pattern is not step-periodic"; return ST_EPATTERN; }
+        if (need_prev && mo.HL == 0) { err = "internal: template needs the previous step but the tile has no halo"; return ST_EPATTERN; }
+        mo.reg_first = 1;
+        mo.reg_last = N - 1;
+        int np2 = 0;
+        if (segment_codes(mo, N - 1, c2, cp2, rr2, np2) && c2 == c1 && cp2 == cp1 && rr2 == rr1) mo.reg_last = N;
+        mo.tmpl = c1;
+        mo.cp_tmpl = cp1;
+        mo.Lseg = (int)c1.size();
+    } else {
+        mo.tmpl.clear(); mo.cp_tmpl.assign(L.blk + 1, 0); mo.Lseg = 0;
+    }
+
+    // ---- column starts ----------------------------------------------------------------------------------
+    std::vector<int64_t> rows;
+    const int64_t head_cols = mo.reg_first * L.blk;
+    mo.cp_head.assign(head_cols + 1, 0);
+    int64_t nz = 0;
+    for (int64_t j = 0; j < head_cols; ++j) { mo.cp_head[j] = nz; mo.gen_column(j, rows); nz += (int64_t)rows.size(); }
+    mo.cp_head[head_cols] = nz;
+    mo.seg_base = nz;
+    nz += (mo.reg_last - mo.reg_first) * (int64_t)mo.Lseg;
+    const int64_t tail0 = mo.reg_last * L.blk;
+    const int64_t tail_cols = L.nvar - tail0;
+    mo.cp_tail.assign(tail_cols + 1, 0);
+    std::vector<std::vector<int64_t>> vrows(L.nv);
+    for (int64_t jj = 0; jj < tail_cols; ++jj) {
+        const int64_t j = tail0 + jj;
+        mo.cp_tail[jj] = nz;
+        mo.gen_column(j, rows);
+        nz += (int64_t)rows.size();
+        if (j >= L.v_off) vrows[j - L.v_off] = rows;
+    }
+    mo.cp_tail[tail_cols] = nz;
+    mo.nnzj = nz;
+
+    // ---- V columns: per-step periodic part ----------------------------------------------------------------
+    mo.vr = 0;
+    mo.vtmpl.clear();
+    if (L.nv > 0) {
+        // local rows of step 0 present in V column 0
+        std::vector<int> lrows;
+        for (int64_t r : vrows[0]) { if (r < L.cb) lrows.push_back((int)r); else break; }
+        mo.vr = (int)lrows.size();
+        for (int k = 0; k < L.nv; ++k) {
+            const std::vector<int64_t>& vr_ = vrows[k];
+            int64_t cnt = 0;
+            for (int64_t r : vr_) if (r < N * L.cb) ++cnt;
+            if (cnt != N * (int64_t)mo.vr) { err = "V column is not step-periodic"; return ST_EPATTERN; }
+            for (int64_t i = 0; i < N; ++i)
+                for (int e = 0; e < mo.vr; ++e)
+                    if (vr_[i * mo.vr + e] != i * L.cb + lrows[e]) { err = "V column is not step-periodic"; return ST_EPATTERN; }
+            mo.vcol_base[k] = mo.column_start(L.v_off + k);
+            for (int e = 0; e < mo.vr; ++e) {
+                Loc lc = local_entry_v(mo, lrows[e], k);
+                mo.vtmpl.push_back(pack_code(lc.di, lc.ci, lc.beta, 0, 0));
+            }
+        }
+    }
+
+    // ---- edge entries -----------------------------------------------------------------------------------------
+    struct Raw { int64_t idx; Model::Entry e; };
+    std::vector<Raw> first, last;
+    std::set<int64_t> need;
+    need.insert(0);
+    need.insert(N - 1);
+    auto scan_col = [&](int64_t j, std::vector<Raw>& dst) {
+        mo.gen_column(j, rows);
+        const int64_t base = mo.column_start(j);
+        for (size_t t = 0; t < rows.size(); ++t) {
+            const int64_t row = rows[t];
+            if (j >= L.v_off && row < N * L.cb) continue;       // V-column step rows are emitted by the tiles
+            Model::Entry e = mo.classify(row, j);
+            if (e.kind == 0) {
+                if (!e.cconst) need.insert(e.cstep);
+                if (e.di != 0) need.insert(e.dstep);
+            }
+            dst.push_back(Raw{base + (int64_t)t, e});
+        }
+    };
+    for (int64_t j = 0; j < head_cols; ++j) scan_col(j, first);
+    for (int64_t j = tail0; j < L.nvar; ++j) scan_col(j, last);
+    if ((int)need.size() > kMaxEdgeSlots) { err = "internal: too many edge records"; return ST_EPATTERN; }
+    std::map<int64_t, int> slot_of;
+    mo.n_edge_slots = 0;
+    for (int64_t s : need) { slot_of[s] = mo.n_edge_slots; mo.edge_steps[mo.n_edge_slots++] = s; }
+    mo.edge_fp = mo.n_edge_slots;
+    mo.edge_b = mo.n_edge_slots + 1;
+    mo.edge_slot_first = slot_of[0];
+    mo.edge_slot_last = slot_of[N - 1];
+    mo.edge_idx.clear(); mo.edge_code.clear();
+    auto emit = [&](const std::vector<Raw>& src) {
+        for (const Raw& r : src) {
+            const Model::Entry& e = r.e;
+            int crec, drec;
+            if (e.kind == 0) {
+                drec = (e.di != 0) ? slot_of[e.dstep] : slot_of[0];
+                crec = (!e.cconst) ? slot_of[e.cstep] : drec;
+            } else {
+                crec = drec = (e.kind == 1) ? mo.edge_fp : mo.edge_b;
+            }
+            mo.edge_idx.push_back(r.idx);
+            mo.edge_code.push_back(pack_code(e.di, e.ci, e.beta, drec, crec));
+        }
+    };
+    emit(first);
+    mo.edge_split = (int)mo.edge_idx.size();
+    emit(last);
+    // tail of c: final path values and boundary values
+    for (int q = 0; q < L.p; ++q) {
+        mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + q));
+        mo.edge_code.push_back(pack_code(mo.R.oR + q, C_ONE, 0, mo.edge_fp, mo.edge_fp));
+    }
+    for (int r = 0; r < L.bc; ++r) {
+        mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + L.p + r));
+        mo.edge_code.push_back(pack_code(mo.R.oBval + r, C_ONE, 0, mo.edge_b, mo.edge_b));
+    }
+
+    // structural nonzeros the selected pattern leaves out (hazard H1)
+    mo.dropped = 0;
+    if (mo.pattern_mode == 0 && L.sc == SC_TRAPEZE && L.nv > 0 && (L.free_time || mo.dyn_v))
+        mo.dropped = N * (int64_t)L.n * L.nv;
+    return ST_OK;
+}
+
+int default_tile(const Model& mo) {
+    // steps per workgroup: keep the tile's LDS below ~40 KiB (>= 3 workgroups per CU) and leave enough tiles to fill
+    // 256 CUs several times over
+    const Layout& L = mo.L;
+    const int64_t per_step = (int64_t)(L.blk + mo.R.stride) * 8;
+    int64_t T = (40 * 1024) / per_step - mo.HL - mo.HH - 1;
+    if (T > 64) T = 64;
+    if (T < 1) T = 1;
+    while (T > 8 && (L.N + T - 1) / T < 1024) T /= 2;
+    return (int)T;
+}
+
+void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const {
+    std::memset(&kp, 0, sizeof(kp));
+    kp.L = L;
+    kp.R = R;
+    kp.T = tile;
+    kp.HL = HL; kp.HH = HH;
+    kp.step_begin = step_begin; kp.step_end = step_end;
+    kp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
+    kp.Lseg = Lseg; kp.vr = vr;
+    kp.seg_base = seg_base; kp.reg_first = reg_first; kp.reg_last = reg_last;
+    for (int k = 0; k < kMaxNV; ++k) kp.vcol_base[k] = vcol_base[k];
+    const bool owns_first = step_begin == 0, owns_last = step_end == L.N;
+    kp.edge_begin = owns_first ? 0 : edge_split;
+    kp.edge_end = owns_last ? (int)edge_idx.size() : edge_split;
+    if (kp.edge_end < kp.edge_begin) kp.edge_end = kp.edge_begin;
+    kp.has_edge = kp.edge_end > kp.edge_begin ? 1 : 0;
+    kp.n_edge_slots = n_edge_slots;
+    kp.edge_fp = edge_fp; kp.edge_b = edge_b;
+    kp.edge_slot_first = edge_slot_first; kp.edge_slot_last = edge_slot_last;
+    for (int k = 0; k < kMaxEdgeSlots; ++k) kp.edge_steps[k] = edge_steps[k];
+}
+
+int build_model(const HostDesc& d, Model& mo, std::string& err) {
+    mo.problem = d.problem;
+    mo.pattern_mode = d.pattern_mode;
+    if (d.pattern_mode != 0 && d.pattern_mode != 1) { err = "unknown pattern mode"; return ST_EPATTERN; }
+    bool found = for_problem(d.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        mo.info = P::info();
+        mo.dyn_t = P::DYN_T;
+        mo.dyn_v = P::DYN_V;
+    });
+    if (!found) { err = "problem id not in the compiled registry"; return ST_EPROBLEM; }
+    if (d.scheme < 0 || d.scheme > 6) { err = "Unknown discretization method"; return ST_ESCHEME; }
+    int64_t N = 0;
+    int st = build_time(mo, d, N, err);
+    if (st) return st;
+    st = build_layout(mo, d.scheme, N, err);
+    if (st) return st;
+    // fixed grid (DOCP_data.jl:201-211): only meaningful when no time is free
+    mo.fixed_grid.assign(N + 1, 0.0);
+    if (!mo.L.free_time)
+        for (int64_t i = 0; i <= N; ++i) mo.fixed_grid[i] = mo.L.t0 + (mo.tau[i] * (mo.L.tf - mo.L.t0));
+    build_bounds(mo);
+    build_tail_blocks(mo);
+    return build_tables(mo, err);
+}
+
+}  // namespace ctd

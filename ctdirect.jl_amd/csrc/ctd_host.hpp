@@ -1,0 +1,68 @@
+// ctd_host.hpp -- host-side model of a discretised OCP: sizes, grids, bounds, initial guess, sparsity pattern and
+// the emit tables the kernels consume.  Pure C++ (no HIP): everything here is build-time work in the reference too
+// (get_docp, src/collocation.jl:57-73).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ctd_layout.hpp"
+#include "ctd_problems.hpp"
+
+namespace ctd {
+
+struct HostDesc {
+    int problem, scheme, pattern_mode;
+    int64_t grid_size;
+    const double* time_grid;
+    int64_t time_grid_len;
+};
+
+struct Block { int64_t r0, r1, c0, c1; };   // rows [r0,r1) x cols [c0,c1), 0-based
+
+struct Model {
+    int problem = 0, pattern_mode = 0;
+    ProblemInfo info;
+    Layout L;
+    RecLayout R;
+    bool dyn_t = false, dyn_v = false;
+    // DOCPtime (src/DOCP_data.jl:147-152)
+    bool uniform = true;
+    std::vector<double> tau, fixed_grid;
+    // DOCPbounds (src/DOCP_data.jl:235-240)
+    std::vector<double> var_l, var_u, con_l, con_u;
+    // pattern
+    std::vector<Block> tail;
+    int64_t nnzj = 0;
+    int64_t dropped = 0;
+    // regular (step-periodic) part
+    std::vector<uint32_t> tmpl, vtmpl;
+    int Lseg = 0, vr = 0;
+    int64_t seg_base = 0, reg_first = 0, reg_last = 0;
+    int64_t vcol_base[kMaxNV] = {0, 0, 0, 0};
+    int HL = 0, HH = 0;
+    // edge part: entries [0, edge_split) belong to the shard that owns step 0, the rest to the owner of step N-1
+    std::vector<int64_t> edge_idx;
+    std::vector<uint32_t> edge_code;
+    int edge_split = 0;
+    int n_edge_slots = 0, edge_fp = 0, edge_b = 0, edge_slot_first = 0, edge_slot_last = 0;
+    int64_t edge_steps[kMaxEdgeSlots] = {0};
+    // CSC column starts without materialising the pattern: explicit for the head columns [0, reg_first*blk) and the
+    // tail columns [reg_last*blk, nvar); periodic in between (cp_tmpl is relative to the step's segment)
+    std::vector<int64_t> cp_head, cp_tmpl, cp_tail;
+
+    struct Entry { int kind; int64_t cstep, dstep; int ci, di, beta; bool cconst; };   // kind 0 step row, 1 final path, 2 boundary
+    Entry classify(int64_t row, int64_t col) const;
+    void step_blocks(int64_t i, std::vector<Block>& out) const;
+    void gen_column(int64_t j, std::vector<int64_t>& rows) const;
+    int64_t column_start(int64_t j) const;    // CSC colptr[j] without materialising the pattern
+    void fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const;
+};
+
+// status codes are those of include/ctdirect_hip.h; err receives a message on failure
+int build_model(const HostDesc& d, Model& m, std::string& err);
+void model_initial_guess(const Model& m, double* x0, bool use_problem_default, const double* state, const double* control,
+                         const double* variable);
+int default_tile(const Model& m);
+
+}  // namespace ctd

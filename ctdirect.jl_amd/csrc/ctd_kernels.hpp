@@ -1,0 +1,169 @@
+// ctd_kernels.hpp -- __global__ wrappers around the phase functions of ctd_kernel_body.hpp, plus the objective kernels.
+// Included by the per-problem translation units (ctd_kern_*.hip), which explicitly instantiate launch_* for one OCP
+// so the registry compiles in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "ctd_kernel_body.hpp"
+#include "ctd_problems.hpp"
+
+namespace ctd {
+
+// Fused constraints + sparse Jacobian values.  One workgroup = one tile of time steps (block 0 = edge block when
+// kp.has_edge).  Dynamic LDS = lds_doubles(kp) * 8 bytes.
+template <class P, int SC>
+__global__ void __launch_bounds__(256) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
+    extern __shared__ double ctd_lds[];
+    const BlockCtx cx = make_ctx(kp, (int)blockIdx.x, ctd_lds);
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    phase_load<P, SC>(kp, cx, xu, tid, nthr);
+    __syncthreads();
+    phase_eval<P, SC>(kp, cx, tid, nthr);
+    __syncthreads();
+    phase_fin<P, SC>(kp, cx, tid, nthr);
+    __syncthreads();
+    if (SC == SC_TRAPEZE) {
+        phase_fin2<P, SC>(kp, cx, tid, nthr);
+        __syncthreads();
+    }
+    phase_emit<P, SC>(kp, cx, tid, nthr);
+}
+
+// ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
+// One lane per quadrature unit (trapeze: node, otherwise: step) of the shard; per-workgroup partial sums are
+// reduced with wave shuffles and written to partial[blockIdx]; obj_finish_kernel adds them in index order
+// (deterministic) together with the Mayer term.
+struct ObjParams {
+    Layout L;
+    const double* tau;
+    int64_t unit_begin, unit_end;   // nodes (trapeze) or steps
+    int32_t add_mayer;
+    double* partial;
+    double* out;
+    int32_t nblocks;
+};
+
+template <class P> __device__ double obj_time(const ObjParams& op, const double* v, int64_t i) {
+    const double t0 = (P::IT0 >= 0) ? v[P::IT0 >= 0 ? P::IT0 : 0] : op.L.t0;
+    const double tf = (P::ITF >= 0) ? v[P::ITF >= 0 ? P::ITF : 0] : op.L.tf;
+    const double tau = op.tau ? op.tau[i] : (double)i / (double)op.L.N;
+    return t0 + tau * (tf - t0);
+}
+
+template <class P, int SC>
+__device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ xu, const double* v, int64_t i) {
+    constexpr int n = P::NX, m = P::NU;
+    const Layout& L = op.L;
+    const double* base = xu + i * (int64_t)L.blk;
+    double x[n > 0 ? n : 1], u[m > 0 ? m : 1];
+    if (SC == SC_TRAPEZE) {            // trapeze.jl:78-110: node weights h_1/2, (t_{i+1}-t_{i-1})/2, h_N/2
+        double w;
+        if (i == 0) w = (obj_time<P>(op, v, 1) - obj_time<P>(op, v, 0)) / 2.0;
+        else if (i == L.N) w = (obj_time<P>(op, v, L.N) - obj_time<P>(op, v, L.N - 1)) / 2.0;
+        else w = (obj_time<P>(op, v, i + 1) - obj_time<P>(op, v, i - 1)) / 2.0;
+        for (int c = 0; c < n; ++c) x[c] = base[c];
+        for (int c = 0; c < m; ++c) u[c] = base[n + c];
+        return w * P::template lagrange<double>(obj_time<P>(op, v, i), x, u, v);
+    }
+    const double ti = obj_time<P>(op, v, i), tip1 = obj_time<P>(op, v, i + 1);
+    const double h = tip1 - ti;
+    if (SC == SC_MIDPOINT) {           // midpoint.jl:87-97
+        for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+        for (int c = 0; c < m; ++c) u[c] = base[n + c];
+        return h * P::template lagrange<double>(0.5 * (ti + tip1), x, u, v);
+    }
+    // irk.jl:179-228 / irk_stagewise.jl:344-384
+    const double* K = base + n + L.cu;
+    double local = 0.0;
+    for (int j = 0; j < L.s; ++j) {
+        for (int c = 0; c < n; ++c) {
+            double xc = base[c];
+            for (int l = 0; l < L.s; ++l) xc = xc + h * L.a[3 * j + l] * K[l * n + c];
+            x[c] = xc;
+        }
+        const double* U = base + n + (L.stagewise ? j * m : 0);
+        for (int c = 0; c < m; ++c) u[c] = U[c];
+        const double term = L.b[j] * P::template lagrange<double>(ti + L.c[j] * h, x, u, v);
+        local = (j == 0) ? term : local + term;
+    }
+    return h * local;
+}
+
+template <class P, int SC>
+__global__ void __launch_bounds__(256) obj_partial_kernel(const ObjParams op, const double* __restrict__ xu) {
+    __shared__ double wsum[4];
+    double v[P::NV > 0 ? P::NV : 1];
+    for (int k = 0; k < P::NV; ++k) v[k] = xu[op.L.v_off + k];
+    double acc = 0.0;
+    if (P::HAS_LAGRANGE) {
+        for (int64_t i = op.unit_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < op.unit_end;
+             i += (int64_t)gridDim.x * blockDim.x)
+            acc += lagrange_unit<P, SC>(op, xu, v, i);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
+        op.partial[blockIdx.x] = s;
+    }
+}
+
+template <class P>
+__global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__ xu) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < op.nblocks; ++b) s += op.partial[b];
+    double mayer = 0.0;
+    if (P::HAS_MAYER && op.add_mayer) {
+        constexpr int n = P::NX, nv = P::NV;
+        double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1];
+        for (int c = 0; c < n; ++c) { x0[c] = xu[c]; xf[c] = xu[op.L.N * (int64_t)op.L.blk + c]; }
+        for (int k = 0; k < nv; ++k) v[k] = xu[op.L.v_off + k];
+        mayer = P::template mayer<double>(x0, xf, v);
+    }
+    op.out[0] = mayer + s;
+}
+
+// ---- launchers (explicitly instantiated per problem) ------------------------------------------------------------
+// e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel (hipExtLaunchKernelGGL),
+// so hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
+template <class P>
+hipError_t launch_cons_jac(int sc, const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
+                           hipEvent_t e0, hipEvent_t e1);
+template <class P>
+hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st);
+
+#define CTD_DEFINE_LAUNCHERS(P)                                                                                          \
+    template <> hipError_t launch_cons_jac<P>(int sc, const KParams& kp, const double* xu, int grid, int block,          \
+                                              size_t lds_bytes, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {          \
+        if (lds_bytes > 64 * 1024) {                                                                                     \
+            hipError_t e = hipSuccess;                                                                                   \
+            if (sc == SC_TRAPEZE) e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_TRAPEZE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            else if (sc == SC_MIDPOINT) e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_MIDPOINT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            else e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_IRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) return e;                                                                               \
+        }                                                                                                                \
+        if (e0 || e1) {                                                                                                  \
+            if (sc == SC_TRAPEZE) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_TRAPEZE>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
+            else if (sc == SC_MIDPOINT) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_MIDPOINT>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
+            else hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_IRK>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
+            return hipGetLastError();                                                                                    \
+        }                                                                                                                \
+        if (sc == SC_TRAPEZE) cons_jac_kernel<P, SC_TRAPEZE><<<grid, block, lds_bytes, st>>>(kp, xu);                    \
+        else if (sc == SC_MIDPOINT) cons_jac_kernel<P, SC_MIDPOINT><<<grid, block, lds_bytes, st>>>(kp, xu);             \
+        else cons_jac_kernel<P, SC_IRK><<<grid, block, lds_bytes, st>>>(kp, xu);                                         \
+        return hipGetLastError();                                                                                        \
+    }                                                                                                                    \
+    template <> hipError_t launch_obj<P>(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st) { \
+        if (sc == SC_TRAPEZE) obj_partial_kernel<P, SC_TRAPEZE><<<grid, block, 0, st>>>(op, xu);                         \
+        else if (sc == SC_MIDPOINT) obj_partial_kernel<P, SC_MIDPOINT><<<grid, block, 0, st>>>(op, xu);                  \
+        else obj_partial_kernel<P, SC_IRK><<<grid, block, 0, st>>>(op, xu);                                              \
+        obj_finish_kernel<P><<<1, 64, 0, st>>>(op, xu);                                                                  \
+        return hipGetLastError();                                                                                        \
+    }
+
+}  // namespace ctd

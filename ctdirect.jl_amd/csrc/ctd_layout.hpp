@@ -1,0 +1,134 @@
+// ctd_layout.hpp -- problem descriptor, LDS record layout and emit-code packing (host + device PODs).
+//
+// Restates the size/offset algebra of the reference's scheme structs:
+//   Trapeze   src/ode/trapeze.jl:14-42      [X_1,U_1, .., X_N+1,U_N+1, V]                (:1-4)
+//   Midpoint  src/ode/midpoint.jl:17-39     [X_1,U_1, .., X_N,U_N, X_N+1, V]             (:1-7)
+//   GL (cc)   src/ode/irk.jl:138-160        [X_i, U_i, K_i^1..K_i^s].., X_N+1, V         (:1-9)
+//   GL (sw)   src/ode/irk_stagewise.jl:136-163  [X_i, U_i^1..U_i^s, K_i^1..K_i^s].., X_N+1, V  (:6-11)
+// and the constraint layout [C_i^x, C_i^{k,1..s}, G_i].., G_N+1, B (irk_stagewise.jl:13-30).
+// All offsets here are 0-based.
+#pragma once
+#include "ctd_common.hpp"
+
+namespace ctd {
+
+enum SchemeClass { SC_TRAPEZE = 0, SC_MIDPOINT = 1, SC_IRK = 2 };
+
+constexpr int kMaxNV = 4;          // optimisation variables supported by the emit tables
+constexpr int kMaxEdgeSlots = 6;   // step/node records the edge block can hold
+
+struct Layout {
+    int32_t scheme;        // CTD_SCHEME_*
+    int32_t sc;            // SchemeClass
+    int32_t s;             // stages (0 for trapeze / midpoint)
+    int32_t stagewise;     // 1: one control per stage
+    int32_t n, m, nv, p, bc;
+    int32_t cu;            // control columns per step (m, or s*m stagewise)
+    int32_t blk;           // _step_variables_block
+    int32_t eqs;           // _state_stage_eqs_block
+    int32_t cb;            // eqs + _step_pathcons_block
+    int32_t final_control; // trapeze: U_{N+1} exists
+    int32_t it0, itf;      // index of t0/tf in v, -1 = fixed
+    int32_t free_time;     // it0 >= 0 || itf >= 0
+    int64_t N;             // time steps
+    int64_t nvar, ncon;
+    int64_t v_off;         // nvar - nv : first optimisation variable
+    double t0, tf;         // fixed values
+    double a[9], b[3], c[3];   // Butcher tables (row-major a), Float64 arithmetic as in irk_stagewise.jl:61-64,103-109
+};
+
+// ---- per-step LDS record (doubles) -------------------------------------------------------------------
+// [0] = 1.0
+// S eval blocks (S = max(s,1)), each: F[n*n] G[n*m] W[n*nv] f[n] ft[n]
+//     F = df/dx, G = df/du at the eval point, W = total d f/d v (explicit + through time and x_ij), f = value,
+//     ft = df/dt (scratch)
+// Sv[n*nv]   d(state-equation row)/dv
+// Px[p*n] Pu[p*m] Pv[p*nv] Pt[p]   path-constraint Jacobian at the node (Pv total, Pt scratch)
+// R[cb]      constraint values of the step (c rows)
+// C[kNC]     per-step coefficients the emit codes multiply with
+// The final-path record (FP) uses the P* fields and R[0..p); the boundary record (B) uses its own fields below.
+constexpr int kNC = 18;
+enum { C_ZERO = 0, C_ONE = 1, C_NEG1 = 2, C_HA = 3 /* -h a_jl at 3+3j+l */, C_HB = 12 /* -h b_j */, C_B = 15 /* b_j */,
+       C_NHH = 3 /* -h/2 (trapeze, midpoint) */, C_NH = 4 /* -h (midpoint) */ };
+
+struct RecLayout {
+    int32_t S, eval_sz;
+    int32_t oF, oG, oW, of, oft;          // inside an eval block
+    int32_t oEval;                        // first eval block
+    int32_t oSv, oPx, oPu, oPv, oPt, oR, oC;
+    int32_t oB0, oBf, oBv, oBval;         // boundary record
+    int32_t stride;
+};
+
+CTD_HD RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
+    RecLayout r;
+    r.S = s > 0 ? s : 1;
+    r.oF = 0; r.oG = n * n; r.oW = r.oG + n * m; r.of = r.oW + n * nv; r.oft = r.of + n;
+    r.eval_sz = r.oft + n;
+    r.oEval = 1;
+    r.oSv = r.oEval + r.S * r.eval_sz;
+    r.oPx = r.oSv + n * nv;
+    r.oPu = r.oPx + p * n;
+    r.oPv = r.oPu + p * m;
+    r.oPt = r.oPv + p * nv;
+    r.oR = r.oPt + p;
+    int end_step = r.oR + cb;
+    r.oB0 = 1; r.oBf = r.oB0 + bc * n; r.oBv = r.oBf + bc * n; r.oBval = r.oBv + bc * nv;
+    int end_b = r.oBval + bc;
+    int body = end_step > end_b ? end_step : end_b;
+    r.oC = body;
+    r.stride = body + kNC;
+    if ((r.stride & 1) == 0) r.stride += 1;     // odd stride: lanes that index consecutive records spread over LDS banks
+    return r;
+}
+
+// ---- 32-bit emit code ---------------------------------------------------------------------------------
+//   value = rec[crec][oC + ci] * rec[drec][di] + beta
+// bits  0-15 di, 16-21 ci, 22-23 beta (0: 0, 1: +1, 2: -1), 24-26 drec, 27-29 crec.
+// Inside tile templates drec/crec are relative (0 = the segment's own step, 1 = the previous step); inside the edge
+// list they are absolute record ids of the edge block.
+CTD_HD uint32_t pack_code(int di, int ci, int beta, int drec, int crec) {
+    return (uint32_t)di | ((uint32_t)ci << 16) | ((uint32_t)beta << 22) | ((uint32_t)drec << 24) | ((uint32_t)crec << 27);
+}
+CTD_HD int code_di(uint32_t c) { return (int)(c & 0xFFFFu); }
+CTD_HD int code_ci(uint32_t c) { return (int)((c >> 16) & 0x3Fu); }
+CTD_HD int code_beta(uint32_t c) { return (int)((c >> 22) & 0x3u); }
+CTD_HD int code_drec(uint32_t c) { return (int)((c >> 24) & 0x7u); }
+CTD_HD int code_crec(uint32_t c) { return (int)((c >> 27) & 0x7u); }
+
+constexpr int64_t kEdgeCBit = (int64_t)1 << 62;   // edge_idx flag: the entry goes to c[], not vals[]
+
+// ---- kernel parameters (passed by value) ---------------------------------------------------------------
+struct KParams {
+    Layout L;
+    RecLayout R;
+    const double* tau;          // normalized grid on device (N+1), or nullptr: uniform, tau_i = i / N
+    // tiling of the shard [step_begin, step_end)
+    int32_t T;                  // steps per tile
+    int32_t HL, HH;             // extra records a tile needs below / above its steps (midpoint: 1,0; trapeze: 0,1)
+    int32_t ntiles;
+    int32_t has_edge;           // block 0 is the edge block
+    int64_t step_begin, step_end;
+    // regular CSC segments: step i in [reg_first, reg_last) owns vals[seg_base + (i - reg_first) * Lseg, +Lseg)
+    const uint32_t* tmpl;
+    int32_t Lseg;
+    int32_t vr;                 // rows per step inside each V column
+    int64_t seg_base;
+    int64_t reg_first, reg_last;
+    // V columns: column k holds, for step i, vals[vcol_base[k] + i * vr, +vr) with codes vtmpl[k * vr ...]
+    const uint32_t* vtmpl;
+    int64_t vcol_base[kMaxNV];
+    // edge entries (first step, last step, final block, tails): explicit (index, code) list
+    const int64_t* edge_idx;
+    const uint32_t* edge_code;
+    int32_t edge_begin, edge_end;
+    int32_t n_edge_slots;
+    int32_t edge_fp, edge_b;            // record ids of the final-path and boundary records
+    int32_t edge_slot_first, edge_slot_last;   // slots holding step 0 and step N-1
+    int64_t edge_steps[kMaxEdgeSlots];
+    // outputs (global indexing); either may be null
+    double* c;
+    double* vals;
+};
+
+}  // namespace ctd

@@ -1,0 +1,80 @@
+"""Time-step sharding of one transcription across the GPUs of a node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference has no parallelism of any kind; what is partitioned here is its main loop
+`for i in 1:docp.time.steps` (src/DOCP_functions.jl:92-98): step i reads X_i, U_i, K_i, X_{i+1} and v, and writes only
+its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows.
+
+  * x is replicated (it is the solver's iterate; 1e6 doubles = 8 MB), so no halo exchange is needed;
+  * rank r evaluates the contiguous block of steps [r N/G, (r+1) N/G); the last rank also owns the final-time path rows
+    and the boundary rows, the first rank the irregular first-step columns;
+  * each rank writes its rows straight into a full-length c buffer at their global position, so the stitched
+    constraint vector is ONE in-place all-gather (+ a broadcast of the p+bc tail rows from the last rank);
+  * Jacobian values stay sharded: rank r holds one contiguous range of the global CSC value array (its step columns)
+    plus its slice of every V column -- what a distributed KKT consumer wants; `DOCP.shard` gives the ranges.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_steps(N, world, rank):
+    """Contiguous block of ceil/floor(N / world) steps for `rank` (equal blocks when world divides N)."""
+    base, rem = divmod(N, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def stitch_constraints(c, N, cb, world, rank, group=None):
+    """All-gather the per-rank row blocks of `c` in place.  `c` is the full-length constraint vector in which this
+    rank has already written rows [begin*cb, end*cb) (+ the tail rows on the last rank).  Returns c.
+
+    Equal blocks (world | N): one all_gather_into_tensor over c[:N*cb] with the rank's own block as the send buffer
+    (in place), then one broadcast of the tail rows.  Ragged blocks fall back to one broadcast per rank."""
+    if world == 1:
+        return c
+    tail = c[N * cb:]
+    if N % world == 0:
+        S = (N // world) * cb
+        body = c[:N * cb]
+        try:
+            dist.all_gather_into_tensor(body, body[rank * S:(rank + 1) * S], group=group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([body[r * S:(r + 1) * S] for r in range(world)], body[rank * S:(rank + 1) * S].clone(), group=group)
+    else:
+        for r in range(world):
+            b, e = shard_steps(N, world, r)
+            dist.broadcast(c[b * cb:e * cb], src=r, group=group)
+    if tail.numel() > 0:
+        dist.broadcast(tail, src=world - 1, group=group)
+    return c
+
+
+def reduce_objective(partial, group=None, device=None):
+    """Sum of the per-shard objective partials (Lagrange partial sums; the last shard adds the Mayer term)."""
+    t = torch.tensor([partial], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t[0])
+
+
+class ShardedDOCP:
+    """One rank's view of a grid-sharded transcription.  `make_docp(steps=(begin, end))` builds the engine handle
+    (ctdirect DOCP) for the rank's block of steps."""
+
+    def __init__(self, make_docp, N, world=None, rank=None, group=None):
+        self.world = dist.get_world_size(group) if world is None else world
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.group = group
+        self.N = N
+        self.steps = shard_steps(N, self.world, self.rank)
+        self.docp = make_docp(steps=self.steps)
+        disc = self.docp.discretization
+        self.cb = disc._state_stage_eqs_block + disc._step_pathcons_block
+
+    def cons_jac(self, x, c, vals):
+        """Evaluate this rank's rows into the full-length c / vals buffers, then stitch c across ranks."""
+        self.docp.cons_jac(x, c, vals, sync=False)
+        stitch_constraints(c, self.N, self.cb, self.world, self.rank, self.group)
+        return c, vals
+
+    def obj(self, x):
+        return reduce_objective(self.docp.obj(x), self.group, device=x.device if hasattr(x, "device") else None)

@@ -1,0 +1,344 @@
+"""Host-side mirror of the reference interface for the collocation hot path.
+
+Names, argument meaning and error behaviour follow CTDirect.jl (the reference is Julia; Julia is not available in
+this image, so the mirror above the C ABI is Python -- INTEGRATION.md holds the Julia `ccall` shim a maintainer
+would add).  What is mirrored:
+
+    CTDirect.DOCP(ocp, grid_size, control_steps, scheme, time_grid)          src/DOCP_data.jl:293-365
+    docp.dims / docp.flags / docp.time / docp.bounds / dim_NLP_*             src/DOCP_data.jl:24-30,88-94,147-152,235-240
+    CTDirect.__constraints!(c, xu, docp)                                     src/DOCP_functions.jl:80-115
+    CTDirect.__objective(xu, docp)                                           src/DOCP_functions.jl:23-54
+    CTDirect.__variables_bounds!(docp), __constraints_bounds!(docp)          src/DOCP_variables.jl:21-63, DOCP_functions.jl:163-191
+    CTDirect.__initial_guess(docp, init)                                     src/DOCP_variables.jl:122-145
+    CTDirect.DOCP_Jacobian_pattern(docp)                                     src/ode/{trapeze,midpoint,irk,irk_stagewise}.jl
+    NLPModels: obj, cons!, jac_structure!, jac_coord!                        served by ADNLPModels in the reference
+                                                                             (src/collocation.jl:137-149)
+
+All arithmetic happens in the HIP library; this module only moves pointers.  NumPy arrays go through the
+host-pointer entry points, torch CUDA(=HIP) tensors through the device-pointer ones.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+
+SCHEMES = {
+    "trapeze": 0,
+    "midpoint": 1,
+    "gauss_legendre_1": 2,
+    "gauss_legendre_2_constant_control": 3,
+    "gauss_legendre_3_constant_control": 4,
+    "gauss_legendre_2": 5,
+    "gauss_legendre_3": 6,
+}
+PROBLEMS = {
+    "goddard": 0,
+    "goddard_all": 1,
+    "double_integrator_path": 2,
+    "quadrotor": 3,
+    "quadrotor12": 4,
+    "stagewise_scalar": 5,
+    "estimate_initial_condition": 6,
+    "estimate_rotation_rate": 7,
+    "least_squares_with_constraint": 8,
+    "double_integrator_freet0tf": 9,
+}
+PATTERN_MODES = {"manual": 0, "reference_manual": 0, "structural": 1}
+
+
+class CTDirectError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"[ctd status {status}] {message}")
+        self.status = status
+
+
+def _raise(status, msg):
+    # same exception kinds as the reference: ArgumentError for the grid (src/DOCP_data.jl:186-189) -> ValueError
+    if status == _lib.CTD_EGRID:
+        raise ValueError(msg)
+    raise CTDirectError(status, msg)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _is_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class DOCP:
+    """Discretised OCP handle; mirrors `CTDirect.DOCP(ocp, grid_size, 1, scheme, time_grid)`.
+
+    `ocp` is the name (or id) of a problem of the compiled registry (include/ctdirect_hip.h) -- the reference takes
+    a CTModels.Model with Julia closures, which cannot cross the C ABI to the GPU.
+    `device` is the HIP device ordinal; -1 builds a host-only handle (sizes, bounds, patterns, initial guess).
+    `steps=(begin, end)` restricts the handle to a shard of the time grid (multi-GPU).
+    """
+
+    def __init__(self, ocp, grid_size=250, scheme="midpoint", time_grid=None, *, pattern="manual", device=0,
+                 steps=None, stream=None):
+        L = _lib.lib()
+        self.problem_name = ocp if isinstance(ocp, str) else {v: k for k, v in PROBLEMS.items()}.get(int(ocp), str(ocp))
+        pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
+        if isinstance(scheme, str):
+            if scheme not in SCHEMES:
+                _raise(_lib.CTD_ESCHEME, f"Unknown discretization method: {scheme}")    # src/DOCP_data.jl:342-349
+            sid = SCHEMES[scheme]
+        else:
+            sid = int(scheme)
+        self.scheme = scheme
+        d = _lib.ctd_desc()
+        d.problem, d.scheme = pid, sid
+        d.pattern_mode = PATTERN_MODES[pattern] if isinstance(pattern, str) else int(pattern)
+        d.device = int(device)
+        self._tg = None
+        if time_grid is not None:
+            self._tg = np.ascontiguousarray(time_grid, dtype=np.float64)
+            d.time_grid = _dp(self._tg)
+            d.time_grid_len = len(self._tg)
+            d.grid_size = len(self._tg) - 1
+        else:
+            d.time_grid = None
+            d.time_grid_len = 0
+            d.grid_size = int(grid_size)
+        if steps is not None:
+            d.step_begin, d.step_end = int(steps[0]), int(steps[1])
+        d.stream = C.c_void_p(stream) if stream else None
+        h = C.c_void_p()
+        st = L.ctd_create(C.byref(d), C.byref(h))
+        if st != _lib.CTD_OK:
+            _raise(st, L.ctd_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self._load_static()
+
+    # ---- static data ------------------------------------------------------------------------------------
+    def _load_static(self):
+        L = _lib.lib()
+        nvar, ncon, nnzj, nnzh = (C.c_int64() for _ in range(4))
+        self._ck(L.ctd_sizes(self._h, C.byref(nvar), C.byref(ncon), C.byref(nnzj), C.byref(nnzh)))
+        self.dim_NLP_variables, self.dim_NLP_constraints = nvar.value, ncon.value
+        self.nnzj, self.nnzh = nnzj.value, nnzh.value
+        o = np.zeros(16, dtype=np.int64)
+        self._ck(L.ctd_dims(self._h, _ip(o)))
+        self.dims = SimpleNamespace(NLP_x=int(o[0]), NLP_u=int(o[1]), NLP_v=int(o[2]), path_cons=int(o[3]),
+                                    boundary_cons=int(o[4]))
+        self.flags = SimpleNamespace(freet0=bool(o[11]), freetf=bool(o[12]), lagrange=bool(o[13]), mayer=bool(o[14]),
+                                     max=bool(o[15]))
+        stage = int(o[9])
+        self.discretization = SimpleNamespace(_step_variables_block=int(o[6]), _state_stage_eqs_block=int(o[7]),
+                                              _step_pathcons_block=int(o[8]), stage=stage, _final_control=bool(o[10]))
+        steps = int(o[5])
+        nrm = np.zeros(steps + 1)
+        fx = np.zeros(steps + 1)
+        self._ck(L.ctd_time_grid(self._h, _dp(nrm), _dp(fx)))
+        self.time = SimpleNamespace(steps=steps, control_steps=1, normalized_grid=nrm, fixed_grid=fx)
+        if stage > 0:
+            a = np.zeros(stage * stage); b = np.zeros(stage); c = np.zeros(stage)
+            self._ck(L.ctd_butcher(self._h, _dp(a), _dp(b), _dp(c)))
+            self.discretization.butcher_a = a.reshape(stage, stage)
+            self.discretization.butcher_b, self.discretization.butcher_c = b, c
+        sh = np.zeros(8, dtype=np.int64)
+        self._ck(L.ctd_shard_info(self._h, _ip(sh)))
+        self.shard = SimpleNamespace(step_begin=int(sh[0]), step_end=int(sh[1]), c_row_begin=int(sh[2]), c_row_end=int(sh[3]),
+                                     vals_main_begin=int(sh[4]), vals_main_end=int(sh[5]), owns_first=bool(sh[6]),
+                                     owns_last=bool(sh[7]))
+        self._bounds = None
+
+    def _ck(self, st):
+        if st != _lib.CTD_OK:
+            _raise(st, _lib.lib().ctd_last_error(self._h).decode() or _lib.lib().ctd_strerror(st).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ctd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bounds(self):
+        """docp.bounds with var_l, var_u, con_l, con_u (filled by __variables_bounds! / __constraints_bounds!)."""
+        if self._bounds is None:
+            lv = np.zeros(self.dim_NLP_variables); uv = np.zeros(self.dim_NLP_variables)
+            lc = np.zeros(self.dim_NLP_constraints); uc = np.zeros(self.dim_NLP_constraints)
+            self._ck(_lib.lib().ctd_bounds(self._h, _dp(lv), _dp(uv), _dp(lc), _dp(uc)))
+            self._bounds = SimpleNamespace(var_l=lv, var_u=uv, con_l=lc, con_u=uc)
+        return self._bounds
+
+    def launch_info(self):
+        o = np.zeros(6, dtype=np.int64)
+        self._ck(_lib.lib().ctd_launch_info(self._h, _ip(o)))
+        return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]),
+                    csc_period=int(o[4]), edge_entries=int(o[5]))
+
+    def dropped_nonzeros(self):
+        n = C.c_int64()
+        self._ck(_lib.lib().ctd_dropped_nonzeros(self._h, C.byref(n)))
+        return n.value
+
+    # ---- NLPModels-style callbacks --------------------------------------------------------------------------
+    def _check_x(self, x):
+        n = x.numel() if _is_tensor(x) else x.size
+        if n != self.dim_NLP_variables:
+            raise ValueError(f"x has {n} entries, expected dim_NLP_variables = {self.dim_NLP_variables}")
+
+    def _dev_ptr(self, t, n, name):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
+            raise ValueError(f"{name} must be a contiguous float64 tensor of {n} entries on the handle's GPU")
+        if t.device.index != self.device:
+            raise ValueError(f"{name} lives on cuda:{t.device.index}, handle is bound to device {self.device}")
+        return C.c_void_p(t.data_ptr())
+
+    def cons_jac(self, x, c=None, vals=None, sync=True):
+        """Fused cons!(nlp, x, c) + jac_coord!(nlp, x, vals): the benchmarked call.  Returns (c, vals)."""
+        L = _lib.lib()
+        self._check_x(x)
+        if _is_tensor(x):
+            import torch
+            if c is None:
+                c = torch.empty(self.dim_NLP_constraints, dtype=torch.float64, device=x.device)
+            if vals is None:
+                vals = torch.empty(self.nnzj, dtype=torch.float64, device=x.device)
+            fn = L.ctd_cons_jac_dev if sync else L.ctd_cons_jac_dev_async
+            self._ck(fn(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                        self._dev_ptr(c, self.dim_NLP_constraints, "c"), self._dev_ptr(vals, self.nnzj, "vals")))
+            return c, vals
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if c is None:
+            c = np.empty(self.dim_NLP_constraints)
+        if vals is None:
+            vals = np.empty(self.nnzj)
+        self._ck(L.ctd_cons_jac(self._h, _dp(x), _dp(c), _dp(vals)))
+        return c, vals
+
+    def cons(self, x, c=None):
+        """cons!(nlp, x, c) = __constraints!(c, x, docp); returns c (the reference's closure must return c too)."""
+        L = _lib.lib()
+        self._check_x(x)
+        if _is_tensor(x):
+            import torch
+            if c is None:
+                c = torch.empty(self.dim_NLP_constraints, dtype=torch.float64, device=x.device)
+            self._ck(L.ctd_cons_jac_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                        self._dev_ptr(c, self.dim_NLP_constraints, "c"), None))
+            return c
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if c is None:
+            c = np.empty(self.dim_NLP_constraints)
+        self._ck(L.ctd_cons(self._h, _dp(x), _dp(c)))
+        return c
+
+    def jac_coord(self, x, vals=None):
+        """jac_coord!(nlp, x, vals): Jacobian values in the CSC order of DOCP_Jacobian_pattern."""
+        L = _lib.lib()
+        self._check_x(x)
+        if _is_tensor(x):
+            import torch
+            if vals is None:
+                vals = torch.empty(self.nnzj, dtype=torch.float64, device=x.device)
+            self._ck(L.ctd_cons_jac_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), None,
+                                        self._dev_ptr(vals, self.nnzj, "vals")))
+            return vals
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if vals is None:
+            vals = np.empty(self.nnzj)
+        self._ck(L.ctd_jac_coord(self._h, _dp(x), _dp(vals)))
+        return vals
+
+    def obj(self, x):
+        """obj(nlp, x) = __objective(x, docp).  For a sharded handle: the shard's partial sum."""
+        L = _lib.lib()
+        self._check_x(x)
+        f = C.c_double()
+        if _is_tensor(x):
+            self._ck(L.ctd_obj_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), C.byref(f)))
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            self._ck(L.ctd_obj(self._h, _dp(x), C.byref(f)))
+        return f.value
+
+    def sync(self):
+        self._ck(_lib.lib().ctd_sync(self._h))
+
+    def time_cons_jac(self, x, c, vals, iters=20):
+        """Mean duration (ms) of one fused-kernel launch, from HIP events recorded by each dispatch on the handle's stream."""
+        ms = C.c_double()
+        self._ck(_lib.lib().ctd_time_cons_jac_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                                  self._dev_ptr(c, self.dim_NLP_constraints, "c"),
+                                                  self._dev_ptr(vals, self.nnzj, "vals"), int(iters), C.byref(ms)))
+        return ms.value
+
+    def jac_structure(self):
+        """jac_structure!(nlp, rows, cols): 1-based COO in CSC order."""
+        rows = np.zeros(self.nnzj, dtype=np.int64)
+        cols = np.zeros(self.nnzj, dtype=np.int64)
+        self._ck(_lib.lib().ctd_jac_structure(self._h, _ip(rows), _ip(cols)))
+        return rows, cols
+
+
+# ---- free functions named after the reference's --------------------------------------------------------------
+def constraints(c, xu, docp):
+    """`CTDirect.__constraints!(c, xu, docp)`; returns c."""
+    return docp.cons(xu, c)
+
+
+def objective(xu, docp):
+    """`CTDirect.__objective(xu, docp)`."""
+    return docp.obj(xu)
+
+
+def variables_bounds(docp):
+    """`CTDirect.__variables_bounds!(docp)` -> (var_l, var_u)."""
+    return docp.bounds.var_l, docp.bounds.var_u
+
+
+def constraints_bounds(docp):
+    """`CTDirect.__constraints_bounds!(docp)` -> (lb, ub)."""
+    return docp.bounds.con_l, docp.bounds.con_u
+
+
+def initial_guess(docp, init=None):
+    """`CTDirect.__initial_guess(docp, init)`.  init: None (everything 0.1), "problem" (the problem file's init
+    tuple) or a dict with optional constant `state`, `control`, `variable` entries."""
+    x0 = np.zeros(docp.dim_NLP_variables)
+    ci = _lib.ctd_init()
+    keep = []
+    if init == "problem":
+        ci.use_problem_default = 1
+    elif isinstance(init, dict):
+        for key in ("state", "control", "variable"):
+            if init.get(key) is not None:
+                a = np.ascontiguousarray(init[key], dtype=np.float64)
+                keep.append(a)
+                setattr(ci, key, _dp(a))
+    docp._ck(_lib.lib().ctd_initial_guess(docp._h, _dp(x0), C.byref(ci)))
+    return x0
+
+
+def DOCP_Jacobian_pattern(docp):
+    """`CTDirect.DOCP_Jacobian_pattern(docp)` as 0-based CSC arrays (colptr, rowval) of the Bool sparse matrix."""
+    colptr = np.zeros(docp.dim_NLP_variables + 1, dtype=np.int64)
+    rowval = np.zeros(docp.nnzj, dtype=np.int64)
+    docp._ck(_lib.lib().ctd_jac_csc(docp._h, _ip(colptr), _ip(rowval)))
+    return colptr, rowval
+
+
+def get_time_grid(xu, docp):
+    """`CTDirect.get_time_grid(xu, docp)` (src/DOCP_data.jl:437-458); cheap host-side helper for post-processing."""
+    # t0/tf live in v for free-time problems; ids follow the registry (0-based position inside v)
+    if not (docp.flags.freet0 or docp.flags.freetf):
+        return docp.time.fixed_grid.copy()
+    raise NotImplementedError("free-time grids are evaluated on the device inside the callbacks")

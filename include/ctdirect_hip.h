@@ -1,0 +1,180 @@
+/*
+ * ctdirect_hip.h -- C ABI of the MI355X-native collocation engine (libctdirect_hip.so).
+ *
+ * This is the drop-in boundary for CTDirect.jl's NLP-callback hot path.  In the reference the boundary is the call
+ *     ADNLPModels.ADNLPModel!(f, x0, lvar, uvar, c!, lcon, ucon; minimize, backends...)   src/collocation.jl:137-149
+ * inside build_adnlp_model (src/collocation.jl:90-153), after which ADNLPModels serves the NLPModels API
+ * (obj, cons!, jac_structure!, jac_coord!, ...) to Ipopt/MadNLP by calling the two Julia closures
+ *     f  = x -> CTDirect.__objective(x, docp)          src/collocation.jl:97,  src/DOCP_functions.jl:23-54
+ *     c! = (c, x) -> CTDirect.__constraints!(c, x, docp)  src/collocation.jl:98,  src/DOCP_functions.jl:80-115
+ * and differentiating c! with coloured ForwardDiff passes over DOCP_Jacobian_pattern(docp) (src/collocation.jl:116-120).
+ * A Julia shim subtypes NLPModels.AbstractNLPModel and forwards each NLPModels method to ONE entry
+ * point below through `ccall`; every entry point states the reference interface it replaces.
+ *
+ * Conventions
+ *   - all functions return an int32 status (CTD_OK == 0); no C++ exception crosses this boundary;
+ *   - the caller owns every buffer passed in; the engine owns its device buffers and staging inside the handle;
+ *   - host-pointer calls copy H2D / D2H and return when the result is in the caller's buffer;
+ *     `_dev` calls take device pointers (hipMalloc'ed, on the handle's device) and are synchronous;
+ *     `_dev_async` calls only enqueue on the handle's stream (ctd_sync waits);
+ *   - external layouts are the reference's: variables step-major [X_i, U_i.., K_i..]..., X_{N+1}, [U_{N+1}], V
+ *     (src/ode/trapeze.jl:1-4, midpoint.jl:1-7, irk.jl:1-9, irk_stagewise.jl:6-11); constraints
+ *     [C_i^x, C_i^{k,1..s}, G_i]..., G_{N+1}, B (src/ode/irk_stagewise.jl:13-30, src/DOCP_functions.jl:92-111);
+ *     Jacobian values in the CSC order of SparseArrays.sparse(Is, Js, ...) as DOCP_Jacobian_pattern returns it;
+ *   - all arithmetic is FP64; there is NO CPU fallback: compute entry points on a handle without a device fail
+ *     with CTD_ENODEVICE.
+ *   - a handle is not thread-safe; distinct handles are independent (one HIP stream each).
+ */
+#ifndef CTDIRECT_HIP_H
+#define CTDIRECT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctd_handle ctd_handle;
+
+/* status codes; the Julia shim rethrows CTD_EGRID as ArgumentError (src/DOCP_data.jl:186-189), CTD_ESCHEME as
+ * error("Unknown discretization method") (src/DOCP_data.jl:342-349), CTD_EPATTERN as the error of the
+ * DOCP_Jacobian_pattern stubs (src/ode/common.jl:252-272) */
+enum {
+    CTD_OK = 0,
+    CTD_EINVAL = 1,     /* null pointer / bad argument */
+    CTD_EGRID = 2,      /* time grid not strictly increasing */
+    CTD_ESCHEME = 3,    /* unknown discretization scheme */
+    CTD_EPATTERN = 4,   /* sparsity pattern not available / not step-periodic */
+    CTD_EPROBLEM = 5,   /* problem id not in the compiled registry */
+    CTD_ENODEVICE = 6,  /* compute call on a host-only handle, or no usable HIP device */
+    CTD_EHIP = 7,       /* a HIP runtime call failed (message in ctd_last_error) */
+    CTD_ENOMEM = 8
+};
+
+/* scheme symbols of the reference, src/DOCP_data.jl:307-349 */
+enum {
+    CTD_SCHEME_TRAPEZE = 0,                          /* :trapeze                              */
+    CTD_SCHEME_MIDPOINT = 1,                         /* :midpoint                             */
+    CTD_SCHEME_GAUSS_LEGENDRE_1 = 2,                 /* Gauss_Legendre_1 (test only, irk.jl:20) */
+    CTD_SCHEME_GAUSS_LEGENDRE_2_CONSTANT_CONTROL = 3,/* :gauss_legendre_2_constant_control    */
+    CTD_SCHEME_GAUSS_LEGENDRE_3_CONSTANT_CONTROL = 4,/* :gauss_legendre_3_constant_control    */
+    CTD_SCHEME_GAUSS_LEGENDRE_2 = 5,                 /* :gauss_legendre_2 (stagewise controls) */
+    CTD_SCHEME_GAUSS_LEGENDRE_3 = 6                  /* :gauss_legendre_3 (stagewise controls) */
+};
+
+/* compiled OCP registry (the reference takes arbitrary Julia closures from CTModels; a GPU engine behind a C ABI
+ * cannot -- see DESIGN.md "the unavoidable gap") */
+enum {
+    CTD_PROBLEM_GODDARD = 0,                    /* test/problems/goddard.jl:18-49                  */
+    CTD_PROBLEM_GODDARD_ALL = 1,                /* test/problems/goddard.jl:87-158                 */
+    CTD_PROBLEM_DOUBLE_INTEGRATOR_PATH = 2,     /* double_integrator.jl:42-58 + build-defined path */
+    CTD_PROBLEM_QUADROTOR = 3,                  /* test/problems/quadrotor.jl:7-105 (8 states)     */
+    CTD_PROBLEM_QUADROTOR12 = 4,                /* build-defined 12-state rigid body               */
+    CTD_PROBLEM_STAGEWISE_SCALAR = 5,           /* test/ci/test_discretization_stagewise.jl:1-14   */
+    CTD_PROBLEM_ESTIMATE_INITIAL_CONDITION = 6, /* test/problems/autonomous_system.jl:6-43         */
+    CTD_PROBLEM_ESTIMATE_ROTATION_RATE = 7,     /* test/problems/autonomous_system.jl:46-87        */
+    CTD_PROBLEM_LEAST_SQUARES_CONSTRAINT = 8,   /* test/problems/autonomous_system.jl:90-138       */
+    CTD_PROBLEM_DOUBLE_INTEGRATOR_FREET0TF = 9  /* test/problems/double_integrator.jl:79-99        */
+};
+
+enum {
+    CTD_PATTERN_REFERENCE_MANUAL = 0, /* DOCP_Jacobian_pattern exactly as written (bug-compatible, SURVEY hazards H1/H2) */
+    CTD_PATTERN_STRUCTURAL = 1        /* = manual + the dynamics-row x V block trapeze.jl:203 omits */
+};
+
+/* replaces the arguments of CTDirect.DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293-365,
+ * as selected by Collocation(; grid_size, scheme, time_grid), src/collocation.jl:16-48,57-73 */
+typedef struct ctd_desc {
+    int32_t problem;          /* CTD_PROBLEM_*                                                        */
+    int32_t scheme;           /* CTD_SCHEME_*                                                         */
+    int32_t pattern_mode;     /* CTD_PATTERN_*                                                        */
+    int32_t device;           /* HIP device ordinal; -1 = host-only handle (sizes, bounds, x0, patterns) */
+    int64_t grid_size;        /* N; used when time_grid == NULL (uniform grid, src/DOCP_data.jl:179-183) */
+    const double* time_grid;  /* optional strictly increasing grid of time_grid_len = N+1 points (:184-199) */
+    int64_t time_grid_len;
+    int64_t step_begin;       /* shard of the time grid this handle evaluates: steps [step_begin, step_end),  */
+    int64_t step_end;         /*   0-based; 0,0 = all N steps (single GPU)                                    */
+    void* stream;             /* optional hipStream_t to launch on; NULL = the handle creates its own         */
+} ctd_desc;
+
+/* replaces the `init` tuple handed to __initial_guess(docp, CTModels.build_initial_guess(ocp, init)),
+ * src/collocation.jl:101-102, src/DOCP_variables.jl:122-145, src/ode/irk_stagewise.jl:302-335.
+ * NULL pointers mean "not provided" (entries stay at the 0.1 default, src/DOCP_variables.jl:126). */
+typedef struct ctd_init {
+    int32_t use_problem_default; /* nonzero: use the init tuple of the problem file (e.g. goddard.jl:48)    */
+    const double* state;         /* constant state guess  [n]  or NULL                                      */
+    const double* control;       /* constant control guess [m] or NULL                                      */
+    const double* variable;      /* variable guess [nv] or NULL                                             */
+} ctd_init;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------ */
+/* get_docp: DOCP(...) + __variables_bounds! + __constraints_bounds!   (src/collocation.jl:57-73) */
+int32_t ctd_create(const ctd_desc* desc, ctd_handle** out);
+int32_t ctd_destroy(ctd_handle* h);
+const char* ctd_last_error(const ctd_handle* h);   /* h may be NULL: error of the last failed ctd_create */
+const char* ctd_strerror(int32_t status);
+
+/* ---- sizes and static data (host) ------------------------------------------------------------------------ */
+/* docp.dim_NLP_variables, docp.dim_NLP_constraints (src/DOCP_data.jl:285-286), nlp.meta.nnzj, nlp.meta.nnzh
+ * (nnzh = lower triangle of DOCP_Hessian_pattern; -1 while the Hessian row is not built) */
+int32_t ctd_sizes(const ctd_handle* h, int64_t* nvar, int64_t* ncon, int64_t* nnzj, int64_t* nnzh);
+/* out[0..15]: NLP_x, NLP_u, NLP_v, path_cons, boundary_cons (DOCPdims, src/DOCP_data.jl:88-94), steps,
+ * _step_variables_block, _state_stage_eqs_block, _step_pathcons_block, stage, _final_control, freet0, freetf,
+ * lagrange, mayer, max (DOCPFlags, :24-30) */
+int32_t ctd_dims(const ctd_handle* h, int64_t* out16);
+/* docp.time.normalized_grid / fixed_grid (src/DOCP_data.jl:147-152), each N+1 */
+int32_t ctd_time_grid(const ctd_handle* h, double* normalized, double* fixed);
+/* Butcher tables of the scheme struct (row-major a[stage*stage], b[stage], c[stage]), src/ode/irk_stagewise.jl:61-64,103-109 */
+int32_t ctd_butcher(const ctd_handle* h, double* a, double* b, double* c);
+/* docp.bounds.var_l/var_u/con_l/con_u : __variables_bounds! (src/DOCP_variables.jl:21-63, irk_stagewise.jl:250-300)
+ * and __constraints_bounds! (src/DOCP_functions.jl:163-191) */
+int32_t ctd_bounds(const ctd_handle* h, double* lvar, double* uvar, double* lcon, double* ucon);
+/* __initial_guess (src/DOCP_variables.jl:122-145, irk_stagewise.jl:302-335) */
+int32_t ctd_initial_guess(const ctd_handle* h, double* x0, const ctd_init* init);
+/* jac_structure!(nlp, rows, cols): 1-based (row, col) of every entry of DOCP_Jacobian_pattern(docp) in CSC order
+ * (src/ode/trapeze.jl:149-233, midpoint.jl:163-233, irk.jl:315-416, irk_stagewise.jl:468-558) */
+int32_t ctd_jac_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
+/* same pattern as 0-based CSC (colptr[nvar+1], rowval[nnzj]) */
+int32_t ctd_jac_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval);
+/* number of structurally nonzero Jacobian entries that the selected pattern does not hold (0 except
+ * REFERENCE_MANUAL + trapeze + a free time / v-dependent dynamics: hazard H1) */
+int32_t ctd_dropped_nonzeros(const ctd_handle* h, int64_t* count);
+
+/* ---- the hot path: host pointers -------------------------------------------------------------------------- */
+/* obj(nlp, x)       = __objective(x, docp)                       src/DOCP_functions.jl:23-54 */
+int32_t ctd_obj(ctd_handle* h, const double* x, double* f);
+/* cons!(nlp, x, c)  = __constraints!(c, x, docp)                 src/DOCP_functions.jl:80-115 */
+int32_t ctd_cons(ctd_handle* h, const double* x, double* c);
+/* jac_coord!(nlp, x, vals): values of dc/dx in the pattern's CSC order (ADNLPModels.SparseADJacobian,
+ * call site src/collocation.jl:116-120) */
+int32_t ctd_jac_coord(ctd_handle* h, const double* x, double* vals);
+/* fused cons! + jac_coord! at one x: the benchmarked call (BASELINE.json metric) */
+int32_t ctd_cons_jac(ctd_handle* h, const double* x, double* c, double* vals);
+
+/* ---- the hot path: device pointers (inputs and outputs stay in HBM) --------------------------------------- */
+/* c_dev has ncon entries and vals_dev nnzj entries (global indexing also for sharded handles: a shard writes only
+ * its rows / its CSC ranges, see ctd_shard_info).  Either of c_dev / vals_dev may be NULL to skip that output. */
+int32_t ctd_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev);
+int32_t ctd_cons_jac_dev_async(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev);
+int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host);
+int32_t ctd_sync(ctd_handle* h);
+
+/* ---- multi-GPU shards (time-step partition) ------------------------------------------ */
+/* out[0..7]: step_begin, step_end, c_row_begin, c_row_end (rows this shard writes, tail rows included on the last
+ * shard), vals_main_begin, vals_main_end (contiguous CSC range of the shard's step columns), owns_first, owns_last */
+int32_t ctd_shard_info(const ctd_handle* h, int64_t* out8);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+/* Launches the fused kernel `iters` times back-to-back on the handle's stream between two hipEvents (recorded on
+ * that same stream) and returns the mean duration of one launch in milliseconds.  Used by bench.py for the
+ * roofline figure; the outputs are the normal outputs of ctd_cons_jac_dev. */
+int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev,
+                              int32_t iters, double* mean_ms);
+/* kernel launch geometry: out[0..5] = grid blocks, block threads, dynamic LDS bytes, steps per tile, interior
+ * CSC period L (entries per regular step), number of edge entries */
+int32_t ctd_launch_info(const ctd_handle* h, int64_t* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTDIRECT_HIP_H */

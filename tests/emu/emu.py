@@ -1,0 +1,66 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes loader of the serial kernel-logic emulator (tests/emu/ctd_emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libctd_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        L = C.CDLL(_LIB)
+        L.emu_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _tg(time_grid):
+    if time_grid is None:
+        return None, 0
+    a = np.ascontiguousarray(time_grid, dtype=np.float64)
+    return a, len(a)
+
+
+def sizes(problem, scheme, mode, N, time_grid=None):
+    tg, n = _tg(time_grid)
+    out = np.zeros(4, dtype=np.int64)
+    st = lib().emu_sizes(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                         C.c_int64(n), out.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return [int(v) for v in out]
+
+
+def csc(problem, scheme, mode, N, time_grid=None):
+    nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
+    tg, n = _tg(time_grid)
+    colptr = np.zeros(nvar + 1, dtype=np.int64)
+    rowval = np.zeros(nnz, dtype=np.int64)
+    st = lib().emu_csc(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                       C.c_int64(n), colptr.ctypes.data_as(C.c_void_p), rowval.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return colptr, rowval
+
+
+def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_begin=0, step_end=0, c=None, vals=None):
+    nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
+    tg, n = _tg(time_grid)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert x.size == nvar
+    if c is None:
+        c = np.full(ncon, 666.666)
+    if vals is None:
+        vals = np.full(nnz, 666.666)
+    st = lib().emu_cons_jac(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                            C.c_int64(n), tile, nthr, C.c_int64(step_begin), C.c_int64(step_end),
+                            x.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return c, vals

@@ -150,3 +150,22 @@ def bench_inputs(d, perturb=0.0, seed=0x9E3779B97F4A7C15):
     if perturb:
         xu = xu + perturb * xorshift64star(seed, nvar)
     return xu
+
+
+def describe(d, problem, scheme):
+    """Adapter giving bench_inputs() the few attributes it needs, from an OracleDOCP or a ctdirect DOCP."""
+    from types import SimpleNamespace
+    if hasattr(d, "dims"):     # product DOCP
+        disc = d.discretization
+        return SimpleNamespace(problem_name=problem, n=d.dims.NLP_x, m=d.dims.NLP_u, nv=d.dims.NLP_v, steps=d.time.steps,
+                               step_variables_block=disc._step_variables_block, stage=disc.stage,
+                               stagewise=scheme in ("gauss_legendre_2", "gauss_legendre_3"),
+                               scheme_kind="trapeze" if scheme == "trapeze" else ("midpoint" if scheme == "midpoint" else "irk"),
+                               dim_NLP_variables=d.dim_NLP_variables,
+                               butcher_c=getattr(disc, "butcher_c", None))
+    return SimpleNamespace(problem_name=problem, n=d.n, m=d.m, nv=d.nv, steps=d.steps,
+                           step_variables_block=d.step_variables_block, stage=d.stage,
+                           stagewise=scheme in ("gauss_legendre_2", "gauss_legendre_3"),
+                           scheme_kind="trapeze" if scheme == "trapeze" else ("midpoint" if scheme == "midpoint" else "irk"),
+                           dim_NLP_variables=d.dim_NLP_variables,
+                           butcher_c=d.butcher()[2] if d.stage else None)

@@ -1,0 +1,137 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/ctdirect_hip.h declares, and its host logic
+(sizes, bounds, initial guess, sparsity patterns, error codes) matches the oracle and the reference's goldens.
+No compute entry point is called here (no GPU); we only check that compute on a host-only handle fails loudly."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ctdirect_jl_amd as ct
+from helpers import golden_files, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL = [(p, s) for p in ct.PROBLEMS for s in ct.SCHEMES]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ctdirect_hip.h")).read()
+    declared = set(re.findall(r"\b(ctd_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"ctd_handle", "ctd_desc", "ctd_init"}
+    assert declared == set(ct._lib.SYMBOLS), declared ^ set(ct._lib.SYMBOLS)
+    L = ct._lib.lib()
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_compute_on_host_only_handle_fails_loudly():
+    d = ct.DOCP("goddard", 10, "midpoint", device=-1)
+    x = np.full(d.dim_NLP_variables, 0.1)
+    for call in (d.cons, d.jac_coord, d.cons_jac, d.obj):
+        with pytest.raises(ct.CTDirectError) as e:
+            call(x)
+        assert e.value.status == ct._lib.CTD_ENODEVICE
+
+
+def test_reference_goldens_through_the_abi():
+    # nnzj 6028: test/ci/test_modeler_solver.jl:37 (default Collocation: midpoint, 250 steps)
+    d = ct.DOCP("goddard", device=-1)
+    assert (d.time.steps, d.scheme) == (250, "midpoint") and d.nnzj == 6028
+    # stagewise dims: test/ci/test_discretization_stagewise.jl:176-198
+    g = [0.0, 0.2, 0.6, 1.0]
+    for sch, blk, eqs, nvar, ncon in (("gauss_legendre_2", 5, 3, 16, 11), ("gauss_legendre_3", 7, 4, 22, 14)):
+        d = ct.DOCP("stagewise_scalar", scheme=sch, time_grid=g, device=-1)
+        assert (d.discretization._step_variables_block, d.discretization._state_stage_eqs_block) == (blk, eqs)
+        assert (d.dim_NLP_variables, d.dim_NLP_constraints) == (nvar, ncon)
+        assert np.allclose(d.time.fixed_grid, g) and d.time.control_steps == 1
+        lv, uv = ct.variables_bounds(d)
+        s = d.discretization.stage
+        assert np.all(lv[1:1 + s] == 0.0) and np.all(uv[1:1 + s] == 2.0)         # :72-76
+    # zero-control dims: test/ci/test_zero_control_allocations.jl:31,138
+    assert ct.DOCP("estimate_initial_condition", 10, "midpoint", device=-1).dim_NLP_variables == 24
+    assert ct.DOCP("estimate_rotation_rate", 10, "midpoint", device=-1).dim_NLP_variables == 23
+    # goddard_all trapeze sizes: test/archives/AD_backend.md:59-60,63
+    d = ct.DOCP("goddard_all", 1000, "trapeze", device=-1)
+    assert (d.dim_NLP_variables, d.dim_NLP_constraints, d.nnzj, d.dropped_nonzeros()) == (4005, 6007, 39043, 3000)
+    d = ct.DOCP("goddard_all", 1000, "trapeze", pattern="structural", device=-1)
+    assert (d.nnzj, d.dropped_nonzeros()) == (42043, 0)
+
+
+def test_survey_table_through_the_abi():
+    rows = [("goddard", "trapeze", 100, 405, 304, 2428), ("goddard_all", "trapeze", 100, 405, 607, 3943),
+            ("goddard", "gauss_legendre_2", 10000, 110004, 90004, 1110028),
+            ("double_integrator_path", "midpoint", 100000, 300002, 300005, 1300019),
+            ("goddard", "gauss_legendre_3", 80000, 1200004, 960004, 15360028),
+            ("quadrotor12", "gauss_legendre_3", 20000, 1200013, 980024, 59060600),
+            ("quadrotor", "gauss_legendre_3", 20000, 880009, 660015, 28580259)]
+    for prob, sch, N, nvar, ncon, nnzj in rows:
+        d = ct.DOCP(prob, N, sch, device=-1)
+        assert (d.dim_NLP_variables, d.dim_NLP_constraints, d.nnzj) == (nvar, ncon, nnzj)
+
+
+def test_error_codes():
+    with pytest.raises(ValueError):                                   # ArgumentError, src/DOCP_data.jl:186-189
+        ct.DOCP("goddard", scheme="midpoint", time_grid=[0.0, 0.5, 0.5, 1.0], device=-1)
+    with pytest.raises(ct.CTDirectError) as e:                        # error(...), src/DOCP_data.jl:342-349
+        ct.DOCP("goddard", 10, "euler", device=-1)
+    assert e.value.status == ct._lib.CTD_ESCHEME
+    with pytest.raises(ct.CTDirectError) as e:
+        ct.DOCP(99, 10, "midpoint", device=-1)
+    assert e.value.status == ct._lib.CTD_EPROBLEM
+    with pytest.raises(ct.CTDirectError) as e:
+        ct.DOCP("goddard", 10, "midpoint", steps=(5, 20), device=-1)
+    assert e.value.status == ct._lib.CTD_EINVAL
+
+
+@pytest.mark.parametrize("prob,sch", ALL, ids=[f"{p}-{s}" for p, s in ALL])
+def test_host_logic_matches_oracle(oracle_lib, prob, sch):
+    rng = np.random.default_rng(1)
+    for N, tg in ((1, None), (2, None), (4, None), (5, None), (23, None), (9, np.cumsum(rng.uniform(0.5, 1.5, 10)))):
+        o = oracle_lib.OracleDOCP(prob, sch, N, time_grid=tg)
+        d = ct.DOCP(prob, N, sch, time_grid=tg, device=-1)
+        assert (d.dim_NLP_variables, d.dim_NLP_constraints) == (o.dim_NLP_variables, o.dim_NLP_constraints)
+        assert (d.dims.NLP_x, d.dims.NLP_u, d.dims.NLP_v, d.dims.path_cons, d.dims.boundary_cons) == \
+               (o.n, o.m, o.nv, o.path_cons, o.boundary_cons)
+        assert (d.flags.freet0, d.flags.freetf, d.flags.lagrange, d.flags.mayer, d.flags.max) == \
+               (o.freet0, o.freetf, o.lagrange, o.mayer, o.max)
+        nrm, fixed = o.grids()
+        assert np.array_equal(d.time.normalized_grid, nrm) and np.array_equal(d.time.fixed_grid, fixed)
+        if o.stage:
+            a, b, c = o.butcher()
+            assert np.array_equal(d.discretization.butcher_a, a) and np.array_equal(d.discretization.butcher_b, b)
+            assert np.array_equal(d.discretization.butcher_c, c)
+        lv, uv, lc, uc = o.bounds()
+        assert np.array_equal(d.bounds.var_l, lv) and np.array_equal(d.bounds.var_u, uv)
+        assert np.array_equal(d.bounds.con_l, lc) and np.array_equal(d.bounds.con_u, uc)
+        assert np.array_equal(ct.initial_guess(d), o.initial_guess(False))
+        assert np.array_equal(ct.initial_guess(d, "problem"), o.initial_guess(True))
+        for mode, name in ((0, "manual"), (1, "structural")):
+            o.set_pattern_mode(mode)
+            dm = d if mode == 0 else ct.DOCP(prob, N, sch, time_grid=tg, pattern=name, device=-1)
+            cp, rv = o.jac_pattern()
+            cp2, rv2 = ct.DOCP_Jacobian_pattern(dm)
+            assert dm.nnzj == o.jac_nnz()
+            assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2)       # bit-exact sparsity pattern
+            rows, cols = dm.jac_structure()
+            assert np.array_equal(rows, rv + 1)
+            assert np.array_equal(cols, np.repeat(np.arange(1, len(cp)), np.diff(cp)))
+
+
+def test_initial_guess_constant_overrides():
+    d = ct.DOCP("goddard", 6, "trapeze", device=-1)
+    x0 = ct.initial_guess(d, {"state": [1.0, 0.2, 0.9], "control": [0.5], "variable": [0.3]})
+    blk = d.discretization._step_variables_block
+    assert np.allclose(x0[:blk], [1.0, 0.2, 0.9, 0.5]) and np.allclose(x0[6 * blk:6 * blk + 4], [1.0, 0.2, 0.9, 0.5])
+    assert x0[-1] == 0.3
+
+
+def test_shard_info():
+    N = 40
+    full = ct.DOCP("goddard_all", N, "gauss_legendre_2", device=-1)
+    a = ct.DOCP("goddard_all", N, "gauss_legendre_2", steps=(0, 20), device=-1)
+    b = ct.DOCP("goddard_all", N, "gauss_legendre_2", steps=(20, 40), device=-1)
+    cb = full.discretization._state_stage_eqs_block + full.discretization._step_pathcons_block
+    assert (a.shard.c_row_begin, a.shard.c_row_end) == (0, 20 * cb)
+    assert (b.shard.c_row_begin, b.shard.c_row_end) == (20 * cb, full.dim_NLP_constraints)
+    assert a.shard.vals_main_end == b.shard.vals_main_begin
+    assert a.shard.owns_first and not a.shard.owns_last and b.shard.owns_last and not b.shard.owns_first

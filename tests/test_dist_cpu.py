@@ -1,0 +1,80 @@
+"""CPU tests of the multi-GPU plumbing (world_size 2, gloo): shard ranges and the in-place stitching of the constraint
+vector.  The per-shard values come from the oracle here (there is no GPU and the engine has no CPU path); on the GPU
+box the same plumbing is driven by bench.py with the HIP engine."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ctdirect_jl_amd as ct
+from ctdirect_jl_amd import dist as ctdist
+
+
+def test_shard_steps_partition():
+    for N in (1, 7, 10, 100, 10001):
+        for world in (1, 2, 3, 8):
+            if world > N:
+                continue
+            blocks = [ctdist.shard_steps(N, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == N
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, prob, sch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        sys.path.insert(0, os.path.dirname(here))
+        from helpers import bench_inputs, describe
+        from oracle.oracle import OracleDOCP
+        o = OracleDOCP(prob, sch, N)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        full = o.constraints(x)
+        d = ct.DOCP(prob, N, sch, steps=ctdist.shard_steps(N, world, rank), device=-1)
+        cb = d.discretization._state_stage_eqs_block + d.discretization._step_pathcons_block
+        # this rank "computes" only its rows (taken from the oracle), everything else is a sentinel
+        c = torch.full((d.dim_NLP_constraints,), 666.666, dtype=torch.float64)
+        a, b = d.shard.c_row_begin, d.shard.c_row_end
+        c[a:b] = torch.from_numpy(full[a:b])
+        ctdist.stitch_constraints(c, N, cb, world, rank)
+        ok = bool(np.array_equal(c.numpy(), full))
+        tot = ctdist.reduce_objective(float(rank + 1))
+        q.put((rank, ok, tot))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,prob,sch", [(10, "goddard_all", "gauss_legendre_2"), (7, "goddard", "trapeze"),
+                                        (64, "double_integrator_path", "midpoint")])
+def test_stitch_constraints_world2_gloo(N, prob, sch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, prob, sch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(tot == 3.0 for _, _, tot in res)

@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI of libctdirect_hip.so; the
+checker is the CPU oracle (oracle/) and the 50-digit mpmath fixtures (tests/golden/).
+
+Tolerance (BASELINE.json north_star):  max |gpu - ref| / max(1, |ref|) <= 1e-10 for constraint
+values, Jacobian values and the objective; sparsity patterns bit-exact (checked on CPU in test_abi_cpu.py, re-checked
+here for the handles used).
+"""
+import numpy as np
+import pytest
+
+import ctdirect_jl_amd as ct
+from helpers import TOL, bench_inputs, dense_on_pattern, describe, golden_files, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+SENT = 666.666   # unwritten-output sentinel, idea from the reference's test/benchmark.jl:106,126
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _rel(a, b):
+    return abs(a - b) / max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-5])
+def test_fixture_parity_host_pointers(path):
+    """Every golden fixture through the host-pointer entry points (ctd_cons, ctd_jac_coord, ctd_cons_jac, ctd_obj)."""
+    g = load_golden(path)
+    for pattern in ("manual", "structural"):
+        d = ct.DOCP(g["problem"], g["grid_size"], g["scheme"], time_grid=g["time_grid"], pattern=pattern, device=0)
+        cp, rv = ct.DOCP_Jacobian_pattern(d)
+        ref = dense_on_pattern(g["J"], cp, rv)
+        c = np.full(d.dim_NLP_constraints, SENT)
+        vals = np.full(d.nnzj, SENT)
+        d.cons_jac(g["xu"], c, vals)
+        assert not np.any(c == SENT) and not np.any(vals == SENT)
+        assert relerr(c, g["c"]) <= TOL
+        assert relerr(vals, ref) <= TOL
+        assert relerr(d.cons(g["xu"]), g["c"]) <= TOL
+        assert relerr(d.jac_coord(g["xu"]), ref) <= TOL
+        assert _rel(d.obj(g["xu"]), g["objective"]) <= TOL
+        d.close()
+
+
+def test_reference_known_answer_on_gpu():
+    """The reference's own known-answer test (test/ci/test_discretization_stagewise.jl:79-100): on the exact feasible
+    trajectory x = t^2, u = 2t, K = 2 t_ij the constraints vanish (atol 1e-12) and the objective is 4/3 (atol 1e-12)."""
+    grid = [0.0, 0.2, 0.6, 1.0]
+    for sch in ("gauss_legendre_2", "gauss_legendre_3"):
+        d = ct.DOCP("stagewise_scalar", scheme=sch, time_grid=grid, device=0)
+        blk, s = d.discretization._step_variables_block, d.discretization.stage
+        T, cc = d.time.fixed_grid, d.discretization.butcher_c
+        xu = np.zeros(d.dim_NLP_variables)
+        for i in range(4):
+            xu[i * blk] = T[i] ** 2
+        for i in range(3):
+            for j in range(s):
+                tij = T[i] + cc[j] * (T[i + 1] - T[i])
+                xu[i * blk + 1 + j] = 2 * tij
+                xu[i * blk + 1 + s + j] = 2 * tij
+        c = d.cons(xu)
+        assert np.max(np.abs(c - d.bounds.con_l)) <= 1e-12 and np.max(np.abs(c - d.bounds.con_u)) <= 1e-12
+        assert abs(d.obj(xu) - 4.0 / 3.0) <= 1e-12
+
+
+PAIRS = [(p, s) for p in ct.PROBLEMS for s in ct.SCHEMES]
+
+
+@pytest.mark.parametrize("prob,sch", PAIRS, ids=[f"{p}-{s}" for p, s in PAIRS])
+def test_oracle_parity_midsize(oracle_lib, torch_cuda, prob, sch):
+    """All registry problems x all schemes at sizes that exercise edge-only (N < 5), single-tile and multi-tile
+    launches, uniform and ragged (non-uniform) grids, device-pointer entry points."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    for N, tg in ((1, None), (3, None), (5, None), (64, None), (257, None), (1000, None),
+                  (101, np.cumsum(rng.uniform(0.2, 1.8, 102)))):
+        o = oracle_lib.OracleDOCP(prob, sch, N, time_grid=tg)
+        o.set_pattern_mode(1)
+        d = ct.DOCP(prob, N, sch, time_grid=tg, pattern="structural", device=0)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        xd = torch.from_numpy(x).cuda()
+        c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
+        d.cons_jac(xd, c, v)
+        c, v = c.cpu().numpy(), v.cpu().numpy()
+        assert not np.any(c == SENT) and not np.any(v == SENT)
+        assert relerr(c, o.constraints(x)) <= TOL
+        assert relerr(v, o.jac_coord(x)) <= TOL
+        assert _rel(d.obj(xd), o.objective(x)) <= TOL
+        # REFERENCE_MANUAL pattern: same values on the (possibly smaller) pattern
+        dm = ct.DOCP(prob, N, sch, time_grid=tg, pattern="manual", device=0)
+        if dm.nnzj == d.nnzj:
+            assert np.array_equal(dm.jac_coord(xd).cpu().numpy(), v)
+        else:
+            import scipy.sparse as sp
+            cps, rvs = ct.DOCP_Jacobian_pattern(d)
+            cpm, rvm = ct.DOCP_Jacobian_pattern(dm)
+            Js = sp.csc_matrix((v, rvs, cps), shape=(d.dim_NLP_constraints, d.dim_NLP_variables))
+            Jm = sp.csc_matrix((dm.jac_coord(xd).cpu().numpy(), rvm, cpm), shape=Js.shape)
+            mask = sp.csc_matrix((np.ones(len(rvm)), rvm, cpm), shape=Js.shape)
+            assert abs(Js.multiply(mask) - Jm).max() == 0.0
+            assert dm.dropped_nonzeros() == d.nnzj - dm.nnzj
+        d.close()
+        dm.close()
+
+
+@pytest.mark.parametrize("tile,block", [(1, 64), (3, 128), (16, 256), (64, 256)])
+def test_tile_and_block_shapes(oracle_lib, torch_cuda, monkeypatch, tile, block):
+    """Results do not depend on the launch geometry (steps per workgroup, workgroup size)."""
+    torch = torch_cuda
+    monkeypatch.setenv("CTD_TILE", str(tile))
+    monkeypatch.setenv("CTD_BLOCK", str(block))
+    for prob, sch, N in (("goddard", "gauss_legendre_2", 333), ("goddard_all", "trapeze", 200),
+                         ("quadrotor", "midpoint", 150), ("quadrotor12", "gauss_legendre_3", 40)):
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        o.set_pattern_mode(1)
+        d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
+        assert d.launch_info()["steps_per_tile"] == tile and d.launch_info()["block"] == block
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        c, v = d.cons_jac(torch.from_numpy(x).cuda())
+        assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL
+        assert relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+        d.close()
+
+
+def test_shards_compose_on_gpu(torch_cuda):
+    """Time-step shards (multi-GPU partition) write disjoint rows / CSC ranges and together
+    reproduce the unsharded evaluation bit for bit."""
+    torch = torch_cuda
+    for prob, sch, N in (("goddard", "gauss_legendre_3", 1000), ("goddard_all", "trapeze", 777),
+                         ("double_integrator_path", "midpoint", 1203)):
+        full = ct.DOCP(prob, N, sch, device=0)
+        x = torch.from_numpy(bench_inputs(describe(full, prob, sch), perturb=1e-3)).cuda()
+        cf, vf = full.cons_jac(x)
+        c = torch.full_like(cf, SENT)
+        v = torch.full_like(vf, SENT)
+        cuts = [0, N // 3, N // 2 + 1, N]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sh = ct.DOCP(prob, N, sch, steps=(a, b), device=0)
+            c2 = torch.full_like(cf, SENT)
+            v2 = torch.full_like(vf, SENT)
+            sh.cons_jac(x, c2, v2)
+            assert not bool(((c != SENT) & (c2 != SENT)).any()) and not bool(((v != SENT) & (v2 != SENT)).any())
+            rows = torch.nonzero(c2 != SENT).flatten()
+            assert int(rows.min()) == sh.shard.c_row_begin and int(rows.max()) == sh.shard.c_row_end - 1
+            c = torch.where(c2 != SENT, c2, c)
+            v = torch.where(v2 != SENT, v2, v)
+            sh.close()
+        assert torch.equal(c, cf) and torch.equal(v, vf)
+        full.close()
+
+
+def test_idempotent_and_async(torch_cuda):
+    """Repeated and asynchronous launches give bit-identical outputs (no atomics, one writer per output)."""
+    torch = torch_cuda
+    d = ct.DOCP("goddard", 5000, "gauss_legendre_2", device=0)
+    x = torch.from_numpy(bench_inputs(describe(d, "goddard", "gauss_legendre_2"), perturb=1e-3)).cuda()
+    c0, v0 = d.cons_jac(x)
+    c1 = torch.empty_like(c0)
+    v1 = torch.empty_like(v0)
+    for _ in range(5):
+        d.cons_jac(x, c1, v1, sync=False)
+    d.sync()
+    assert torch.equal(c0, c1) and torch.equal(v0, v1)
+    assert d.time_cons_jac(x, c1, v1, iters=3) > 0.0
+
+
+# ---- BASELINE.json configurations at full size ------------------------------------------------------------------------
+FULL = [("goddard", "trapeze", 100), ("goddard_all", "trapeze", 100),                 # config 1 / 1'
+        ("goddard", "gauss_legendre_2", 10000),                                       # config 2 (bench workload)
+        ("double_integrator_path", "midpoint", 100000)]                               # config 3
+
+
+@pytest.mark.parametrize("prob,sch,N", FULL, ids=[f"{p}-{s}-{n}" for p, s, n in FULL])
+def test_baseline_configs_full_parity(oracle_lib, torch_cuda, prob, sch, N):
+    torch = torch_cuda
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    o.set_pattern_mode(1)
+    d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+    xd = torch.from_numpy(x).cuda()
+    c, v = d.cons_jac(xd)
+    assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL
+    assert relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+    assert _rel(d.obj(xd), o.objective(x)) <= TOL
+
+
+BIG = [("goddard", "gauss_legendre_3", 80000),      # config 4 (15.36 M Jacobian entries)
+       ("quadrotor", "gauss_legendre_3", 20000),    # config 5' (reference's quadrotor, 28.6 M entries)
+       ("quadrotor12", "gauss_legendre_3", 20000)]  # config 5  (59.06 M entries)
+
+
+@pytest.mark.parametrize("prob,sch,N", BIG, ids=[f"{p}-{s}-{n}" for p, s, n in BIG])
+def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch, N):
+    """At the largest sizes the oracle's coloured Jacobian is too slow / large for a unit test, so:
+       (1) c(x) against the oracle at full size (cheap: O(N));
+       (2) every output written (sentinel), outputs finite;
+       (3) the Jacobian is the derivative of the constraints: J d == (c(x + e d) - c(x - e d)) / 2e along a random
+           direction d, with J applied from (rows, cols, vals) -- a size-independent property;
+       (4) windows of steps against the oracle run on the same window (non-uniform sub-grid, tf scaled by the window
+           width): c rows and all non-V Jacobian entries of those steps."""
+    torch = torch_cuda
+    d = ct.DOCP(prob, N, sch, device=0)
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+    xd = torch.from_numpy(x).cuda()
+    c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
+    v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
+    d.cons_jac(xd, c, v)
+    assert not bool((c == SENT).any()) and not bool((v == SENT).any())
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(v).all())
+    assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL                              # (1)
+    assert _rel(d.obj(xd), o.objective(x)) <= TOL
+    # (3) directional derivative, all on the device
+    rows, cols = d.jac_structure()
+    rows_t = torch.from_numpy(rows - 1).cuda()
+    cols_t = torch.from_numpy(cols - 1).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    dirv = torch.rand(d.dim_NLP_variables, dtype=torch.float64, device="cuda", generator=gen) - 0.5
+    Jd = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
+    Jd.index_add_(0, rows_t, v * dirv[cols_t])
+    eps = 1e-6
+    fd = (d.cons(xd + eps * dirv) - d.cons(xd - eps * dirv)) / (2 * eps)
+    err = float(((Jd - fd).abs() / torch.clamp(fd.abs(), min=1.0)).max())
+    assert err <= 1e-6, err
+    del rows_t, cols_t
+    # (4) windows against the oracle
+    blk = d.discretization._step_variables_block
+    cb = d.discretization._state_stage_eqs_block + d.discretization._step_pathcons_block
+    nv = d.dims.NLP_v
+    cp = None
+    W = 6
+    vh = v.cpu().numpy()
+    ch = c.cpu().numpy()
+    tau = d.time.normalized_grid
+    for s0 in (1, N // 2, N - W - 1):
+        sub = tau[s0:s0 + W + 1]
+        ow = oracle_lib.OracleDOCP(prob, sch, time_grid=sub)
+        xw = np.concatenate([x[s0 * blk:(s0 + W) * blk + d.dims.NLP_x], x[len(x) - nv:]])
+        assert xw.size == ow.dim_NLP_variables
+        width = sub[-1] - sub[0]
+        xw[-1] = x[-1] * width if nv else 0.0          # tf' = tf * window width keeps every h_i (autonomous dynamics)
+        cw = ow.constraints(xw)
+        assert relerr(ch[s0 * cb:(s0 + W) * cb], cw[:W * cb]) <= 1e-9
+        cpw, rvw = ow.jac_pattern()
+        vw = ow.jac_coord(xw)
+        if cp is None:
+            cp = np.zeros(d.dim_NLP_variables + 1, dtype=np.int64)
+            np.cumsum(np.bincount(cols - 1, minlength=d.dim_NLP_variables), out=cp[1:])
+        for jl in range(blk, (W - 1) * blk):           # interior columns of the window (skip its first/last step)
+            jg = s0 * blk + jl
+            seg_g = vh[cp[jg]:cp[jg + 1]]
+            seg_w = vw[cpw[jl]:cpw[jl + 1]]
+            assert np.array_equal(rows[cp[jg]:cp[jg + 1]] - 1 - s0 * cb, rvw[cpw[jl]:cpw[jl + 1]])
+            assert relerr(seg_g, seg_w) <= 1e-9
+    d.close()

@@ -1,0 +1,75 @@
+"""CPU tests of the KERNEL LOGIC: the engine's phase functions (ctdirect.jl_amd/csrc/ctd_kernel_body.hpp) are compiled
+with g++ and stepped serially (tests/emu/, test infrastructure only) and must reproduce the mpmath fixtures and the
+oracle.  This exercises the emit tables, tile/edge indexing and the chain-rule algebra without a GPU; the HIP build of
+the same code is checked on hardware by tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import ctdirect_jl_amd as ct
+from emu import emu
+from helpers import TOL, bench_inputs, dense_on_pattern, golden_files, load_golden, relerr, describe
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-5])
+def test_emulated_kernel_matches_fixture(oracle_lib, path):
+    g = load_golden(path)
+    pid, sid = ct.PROBLEMS[g["problem"]], ct.SCHEMES[g["scheme"]]
+    o = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
+    for mode in (0, 1):
+        o.set_pattern_mode(mode)
+        cp, rv = o.jac_pattern()
+        cp2, rv2 = emu.csc(pid, sid, mode, g["grid_size"], g["time_grid"])
+        assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2)
+        ref = dense_on_pattern(g["J"], cp, rv)
+        for tile, nthr in ((0, 64), (1, 3), (3, 17)):
+            c, vals = emu.cons_jac(pid, sid, mode, g["grid_size"], g["xu"], g["time_grid"], tile=tile, nthr=nthr)
+            assert relerr(c, g["c"]) <= TOL
+            assert relerr(vals, ref) <= TOL
+
+
+PAIRS = [(p, s) for p in ct.PROBLEMS for s in ct.SCHEMES]
+
+
+@pytest.mark.parametrize("prob,sch", PAIRS, ids=[f"{p}-{s}" for p, s in PAIRS])
+def test_emulated_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
+    rng = np.random.default_rng(3)
+    for N, tg in ((5, None), (6, None), (37, None), (13, np.cumsum(rng.uniform(0.5, 1.5, 14)))):
+        o = oracle_lib.OracleDOCP(prob, sch, N, time_grid=tg)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        cref = o.constraints(x)
+        Jd = o.jac_dense(x) if N <= 13 else None
+        for mode in (0, 1):
+            o.set_pattern_mode(mode)
+            cp, rv = o.jac_pattern()
+            if Jd is not None:
+                vref = dense_on_pattern(Jd, cp, rv)
+            elif mode == 1:
+                vref = o.jac_coord(x)
+            else:
+                continue
+            for tile, nthr in ((0, 64), (1, 5), (4, 33), (7, 256)):
+                c, vals = emu.cons_jac(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, N, x, tg, tile=tile, nthr=nthr)
+                assert not np.any(c == 666.666) and not np.any(vals == 666.666)      # every output written
+                assert relerr(c, cref) <= TOL and relerr(vals, vref) <= TOL
+
+
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "quadrotor", "double_integrator_freet0tf"])
+def test_emulated_shards_compose_exactly(prob):
+    N = 23
+    for sch in ct.SCHEMES:
+        d = ct.DOCP(prob, N, sch, device=-1)
+        x = bench_inputs(describe(d, prob, sch), perturb=1e-3)
+        pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+        cf, vf = emu.cons_jac(pid, sid, 0, N, x, tile=4, nthr=64)
+        for cuts in ([0, 11, 23], [0, 1, 22, 23]):
+            c = np.full_like(cf, 666.666)
+            v = np.full_like(vf, 666.666)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                c2 = np.full_like(cf, 666.666)
+                v2 = np.full_like(vf, 666.666)
+                emu.cons_jac(pid, sid, 0, N, x, tile=3, nthr=32, step_begin=a, step_end=b, c=c2, vals=v2)
+                assert not np.any((c != 666.666) & (c2 != 666.666))      # shards write disjoint rows / CSC ranges
+                assert not np.any((v != 666.666) & (v2 != 666.666))
+                c = np.where(c2 != 666.666, c2, c)
+                v = np.where(v2 != 666.666, v2, v)
+            assert np.array_equal(c, cf) and np.array_equal(v, vf)
