@@ -74,10 +74,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     N = STEPS_PER_GPU * world
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def make(steps=None):
-        return ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, steps=steps, stream=stream)
+    def make(steps=None):      # the handle launches on torch's current stream: ordered with the RCCL collectives
+        return ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, steps=steps, stream="torch")
 
     sh = ctdist.ShardedDOCP(make, N, world=world, rank=rank)
     docp = sh.docp

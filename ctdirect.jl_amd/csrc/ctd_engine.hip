@@ -147,6 +147,11 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     if (h->block < 64 || h->block > 256 || (h->block % 64)) h->block = 256;
     mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
     h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+    while (h->lds_bytes > 64 * 1024 && h->tile > 1) {      // a requested tile that does not fit is shrunk, not rejected
+        h->tile = (h->tile + 1) / 2;
+        mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
+        h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+    }
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
     h->device = desc->device;
     if (h->device >= 0) {
@@ -156,7 +161,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         ctd_handle* hp = h.get();
         if (h->lds_bytes > 160 * 1024) return fail(nullptr, CTD_EINVAL, "ctd_create: tile does not fit the 160 KiB LDS");
         HIP_TRY(nullptr, hipSetDevice(hp->device));
-        if (desc->stream) { hp->stream = (hipStream_t)desc->stream; hp->own_stream = false; }
+        if (desc->stream_mode == CTD_STREAM_GIVEN) { hp->stream = (hipStream_t)desc->stream; hp->own_stream = false; }
         else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&hp->stream, hipStreamNonBlocking)); hp->own_stream = true; }
         if (!mo.uniform) HIP_TRY(nullptr, upload(&hp->d_tau, mo.tau));
         HIP_TRY(nullptr, upload(&hp->d_tmpl, mo.tmpl));

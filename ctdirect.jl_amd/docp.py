@@ -80,10 +80,13 @@ class DOCP:
     a CTModels.Model with Julia closures, which cannot cross the C ABI to the GPU.
     `device` is the HIP device ordinal; -1 builds a host-only handle (sizes, bounds, patterns, initial guess).
     `steps=(begin, end)` restricts the handle to a shard of the time grid (multi-GPU).
+    `stream`: "torch" (default) launches on torch's current stream of `device` when torch sees that GPU, so the
+    callbacks are ordered with the caller's tensor work; "own" gives the handle a private stream; an integer is a raw
+    hipStream_t.
     """
 
     def __init__(self, ocp, grid_size=250, scheme="midpoint", time_grid=None, *, pattern="manual", device=0,
-                 steps=None, stream=None):
+                 steps=None, stream="torch"):
         L = _lib.lib()
         self.problem_name = ocp if isinstance(ocp, str) else {v: k for k, v in PROBLEMS.items()}.get(int(ocp), str(ocp))
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
@@ -110,7 +113,18 @@ class DOCP:
             d.grid_size = int(grid_size)
         if steps is not None:
             d.step_begin, d.step_end = int(steps[0]), int(steps[1])
-        d.stream = C.c_void_p(stream) if stream else None
+        d.stream, d.stream_mode = None, 0
+        if int(device) >= 0 and stream != "own":
+            if stream == "torch":
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        d.stream = C.c_void_p(torch.cuda.current_stream(int(device)).cuda_stream)
+                        d.stream_mode = 1
+                except ImportError:
+                    pass
+            elif stream is not None:
+                d.stream, d.stream_mode = C.c_void_p(int(stream)), 1
         h = C.c_void_p()
         st = L.ctd_create(C.byref(d), C.byref(h))
         if st != _lib.CTD_OK:

@@ -94,8 +94,13 @@ typedef struct ctd_desc {
     int64_t time_grid_len;
     int64_t step_begin;       /* shard of the time grid this handle evaluates: steps [step_begin, step_end),  */
     int64_t step_end;         /*   0-based; 0,0 = all N steps (single GPU)                                    */
-    void* stream;             /* optional hipStream_t to launch on; NULL = the handle creates its own         */
+    void* stream;             /* hipStream_t to launch on when stream_mode == CTD_STREAM_GIVEN                */
+    int32_t stream_mode;      /* CTD_STREAM_OWN: the handle creates a private non-blocking stream (default);  */
+    int32_t reserved;         /* CTD_STREAM_GIVEN: launch on `stream` (NULL = the device's default stream),   */
+                              /* so launches are ordered with the caller's other work on that stream          */
 } ctd_desc;
+
+enum { CTD_STREAM_OWN = 0, CTD_STREAM_GIVEN = 1 };
 
 /* replaces the `init` tuple handed to __initial_guess(docp, CTModels.build_initial_guess(ocp, init)),
  * src/collocation.jl:101-102, src/DOCP_variables.jl:122-145, src/ode/irk_stagewise.jl:302-335.

@@ -104,7 +104,15 @@ def test_oracle_parity_midsize(oracle_lib, torch_cuda, prob, sch):
             Jm = sp.csc_matrix((dm.jac_coord(xd).cpu().numpy(), rvm, cpm), shape=Js.shape)
             mask = sp.csc_matrix((np.ones(len(rvm)), rvm, cpm), shape=Js.shape)
             assert abs(Js.multiply(mask) - Jm).max() == 0.0
-            assert dm.dropped_nonzeros() == d.nnzj - dm.nnzj
+            # entries only the STRUCTURAL pattern holds (trapeze dynamics rows x V, hazard H1): either they are true
+            # nonzeros the manual pattern drops (free times / v-dependent dynamics) and the handle reports them, or
+            # the problem does not depend on v there and their values are exactly zero
+            extra = Js - Js.multiply(mask)
+            assert dm.dropped_nonzeros() in (0, d.nnzj - dm.nnzj)
+            if dm.dropped_nonzeros() == 0:
+                assert abs(extra).max() == 0.0
+            else:
+                assert abs(extra).max() > 0.0
         d.close()
         dm.close()
 
@@ -120,7 +128,8 @@ def test_tile_and_block_shapes(oracle_lib, torch_cuda, monkeypatch, tile, block)
         o = oracle_lib.OracleDOCP(prob, sch, N)
         o.set_pattern_mode(1)
         d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
-        assert d.launch_info()["steps_per_tile"] == tile and d.launch_info()["block"] == block
+        assert d.launch_info()["steps_per_tile"] <= tile and d.launch_info()["block"] == block
+        assert d.launch_info()["lds_bytes"] <= 64 * 1024          # a tile that does not fit is shrunk
         x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
         c, v = d.cons_jac(torch.from_numpy(x).cuda())
         assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL
@@ -216,26 +225,30 @@ def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch
     assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(v).all())
     assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL                              # (1)
     assert _rel(d.obj(xd), o.objective(x)) <= TOL
-    # (3) directional derivative, all on the device
+    if d.nnzj <= 16_000_000:          # config 4: the oracle's coloured Jacobian is still affordable -> direct parity
+        assert relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+    # (3) directional derivative: J d (scipy, from the pattern + GPU values) vs central differences of the GPU's c(x)
+    import scipy.sparse as sp
     rows, cols = d.jac_structure()
-    rows_t = torch.from_numpy(rows - 1).cuda()
-    cols_t = torch.from_numpy(cols - 1).cuda()
-    gen = torch.Generator(device="cuda").manual_seed(5)
-    dirv = torch.rand(d.dim_NLP_variables, dtype=torch.float64, device="cuda", generator=gen) - 0.5
-    Jd = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
-    Jd.index_add_(0, rows_t, v * dirv[cols_t])
+    cp = np.zeros(d.dim_NLP_variables + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols - 1, minlength=d.dim_NLP_variables), out=cp[1:])
+    vh = v.cpu().numpy()
+    J = sp.csc_matrix((vh, rows - 1, cp), shape=(d.dim_NLP_constraints, d.dim_NLP_variables))
+    rng = np.random.default_rng(5)
+    dirv = rng.uniform(-0.5, 0.5, d.dim_NLP_variables)
+    Jd = J @ dirv
     eps = 1e-6
-    fd = (d.cons(xd + eps * dirv) - d.cons(xd - eps * dirv)) / (2 * eps)
-    err = float(((Jd - fd).abs() / torch.clamp(fd.abs(), min=1.0)).max())
-    assert err <= 1e-6, err
-    del rows_t, cols_t
+    xp = torch.from_numpy(x + eps * dirv).cuda()
+    xm = torch.from_numpy(x - eps * dirv).cuda()
+    fd = ((d.cons(xp) - d.cons(xm)) / (2 * eps)).cpu().numpy()
+    err = float(np.max(np.abs(Jd - fd) / np.maximum(1.0, np.abs(fd))))
+    assert err <= 2e-5, err          # truncation error of the difference quotient (third derivatives ~ 500^3 for Goddard)
+    del J
     # (4) windows against the oracle
     blk = d.discretization._step_variables_block
     cb = d.discretization._state_stage_eqs_block + d.discretization._step_pathcons_block
     nv = d.dims.NLP_v
-    cp = None
     W = 6
-    vh = v.cpu().numpy()
     ch = c.cpu().numpy()
     tau = d.time.normalized_grid
     for s0 in (1, N // 2, N - W - 1):
@@ -249,9 +262,6 @@ def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch
         assert relerr(ch[s0 * cb:(s0 + W) * cb], cw[:W * cb]) <= 1e-9
         cpw, rvw = ow.jac_pattern()
         vw = ow.jac_coord(xw)
-        if cp is None:
-            cp = np.zeros(d.dim_NLP_variables + 1, dtype=np.int64)
-            np.cumsum(np.bincount(cols - 1, minlength=d.dim_NLP_variables), out=cp[1:])
         for jl in range(blk, (W - 1) * blk):           # interior columns of the window (skip its first/last step)
             jg = s0 * blk + jl
             seg_g = vh[cp[jg]:cp[jg + 1]]
