@@ -56,6 +56,7 @@ SYMBOLS = {
     "ctd_shard_info": (C.c_int32, [_vp, _ip]),
     "ctd_time_cons_jac_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _dp]),
     "ctd_launch_info": (C.c_int32, [_vp, _ip]),
+    "ctd_debug_stamps": (C.c_int32, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_int64]),
 }
 
 

@@ -2,15 +2,19 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstddef>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CTD_HD __host__ __device__ __forceinline__
+// one 16-byte store of two consecutive doubles (p is 16-byte aligned)
+#define CTD_STORE2(p, a, b) (*reinterpret_cast<double2*>(p) = make_double2((a), (b)))
 #else
 // The kernel bodies are plain C++ templates so that the test-suite can compile them with g++ and step them
 // serially with bounds checking (tests/emu/, test infrastructure only).  The shipped library always builds
 // them with hipcc for gfx950 and the C ABI only ever launches the HIP kernels.
 #define CTD_HD inline
+#define CTD_STORE2(p, a, b) do { (p)[0] = (a); (p)[1] = (b); } while (0)
 #endif
 
 namespace ctd {
@@ -55,10 +59,11 @@ template <int K> CTD_HD Dual<K> operator*(const Dual<K>& a, const Dual<K>& b) {
     for (int i = 0; i < K; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
     return r;
 }
+// quotient: the value is the exact IEEE quotient; the partials use one reciprocal instead of K divisions
 template <int K> CTD_HD Dual<K> operator/(const Dual<K>& a, const Dual<K>& b) {
-    Dual<K> r; const double q = a.v / b.v; r.v = q;
+    Dual<K> r; const double q = a.v / b.v; const double inv = 1.0 / b.v; r.v = q;
 #pragma unroll
-    for (int i = 0; i < K; ++i) r.d[i] = (a.d[i] - q * b.d[i]) / b.v;
+    for (int i = 0; i < K; ++i) r.d[i] = (a.d[i] - q * b.d[i]) * inv;
     return r;
 }
 template <int K> CTD_HD Dual<K> operator+(const Dual<K>& a, double b) { Dual<K> r = a; r.v = a.v + b; return r; }
@@ -78,15 +83,15 @@ template <int K> CTD_HD Dual<K> operator*(const Dual<K>& a, double b) {
 }
 template <int K> CTD_HD Dual<K> operator*(double a, const Dual<K>& b) { return b * a; }
 template <int K> CTD_HD Dual<K> operator/(const Dual<K>& a, double b) {
-    Dual<K> r; r.v = a.v / b;
+    Dual<K> r; r.v = a.v / b; const double inv = 1.0 / b;
 #pragma unroll
-    for (int i = 0; i < K; ++i) r.d[i] = a.d[i] / b;
+    for (int i = 0; i < K; ++i) r.d[i] = a.d[i] * inv;
     return r;
 }
 template <int K> CTD_HD Dual<K> operator/(double a, const Dual<K>& b) {
-    Dual<K> r; const double q = a / b.v; r.v = q;
+    Dual<K> r; const double q = a / b.v; const double w = -q * (1.0 / b.v); r.v = q;
 #pragma unroll
-    for (int i = 0; i < K; ++i) r.d[i] = -q * b.d[i] / b.v;
+    for (int i = 0; i < K; ++i) r.d[i] = w * b.d[i];
     return r;
 }
 

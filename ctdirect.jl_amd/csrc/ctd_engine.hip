@@ -19,21 +19,17 @@
 using namespace ctd;
 
 namespace ctd {
-// explicit specialisations live in the per-problem translation units
-#define CTD_DECLARE(P)                                                                                               \
-    template <> hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, hipEvent_t);    \
-    template <> hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
-CTD_DECLARE(GoddardOCP)
-CTD_DECLARE(GoddardAllOCP)
-CTD_DECLARE(DoubleIntegratorPathOCP)
-CTD_DECLARE(QuadrotorOCP)
-CTD_DECLARE(Quadrotor12OCP)
-CTD_DECLARE(StagewiseScalarOCP)
-CTD_DECLARE(EstimateInitialConditionOCP)
-CTD_DECLARE(EstimateRotationRateOCP)
-CTD_DECLARE(LeastSquaresConstraintOCP)
-CTD_DECLARE(DoubleIntegratorFreeT0TfOCP)
-#undef CTD_DECLARE
+// the instantiations live in the per-problem translation units
+CTD_EXTERN_LAUNCHERS(GoddardOCP)
+CTD_EXTERN_LAUNCHERS(GoddardAllOCP)
+CTD_EXTERN_LAUNCHERS(DoubleIntegratorPathOCP)
+CTD_EXTERN_LAUNCHERS(QuadrotorOCP)
+CTD_EXTERN_LAUNCHERS(Quadrotor12OCP)
+CTD_EXTERN_LAUNCHERS(StagewiseScalarOCP)
+CTD_EXTERN_LAUNCHERS(EstimateInitialConditionOCP)
+CTD_EXTERN_LAUNCHERS(EstimateRotationRateOCP)
+CTD_EXTERN_LAUNCHERS(LeastSquaresConstraintOCP)
+CTD_EXTERN_LAUNCHERS(DoubleIntegratorFreeT0TfOCP)
 }  // namespace ctd
 
 struct ctd_handle {
@@ -147,12 +143,14 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     if (h->block < 64 || h->block > 256 || (h->block % 64)) h->block = 256;
     mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
     h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+    const int debug_stop = env_int("CTD_DEBUG_STOP", 0);
     while (h->lds_bytes > 64 * 1024 && h->tile > 1) {      // a requested tile that does not fit is shrunk, not rejected
         h->tile = (h->tile + 1) / 2;
         mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
         h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
     }
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
+    h->kp.debug_stop = debug_stop;
     h->device = desc->device;
     if (h->device >= 0) {
         int ndev = 0;
@@ -415,6 +413,30 @@ int32_t ctd_obj(ctd_handle* h, const double* x, double* f) {
     if (st) return st;
     HIP_TRY(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * h->model.L.nvar, hipMemcpyHostToDevice, h->stream));
     return ctd_obj_dev(h, h->d_x, f);
+}
+
+int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, uint64_t* out, int64_t cap) {
+    if (!h || !out) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    const int64_t words = (int64_t)h->grid * 12;
+    if (cap < words) return fail(h, CTD_EINVAL, "stamp buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long* d_st = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_st, sizeof(unsigned long long) * words));
+    HIP_TRY(h, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * words, h->stream));
+    int32_t st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);     // warm, no stamps
+    if (st == CTD_OK) {
+        h->kp.stamps = d_st;
+        st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);
+        h->kp.stamps = nullptr;
+    }
+    if (st == CTD_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_st, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) st = fail(h, CTD_EHIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_st);
+    return st;
 }
 
 int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, int32_t iters, double* mean_ms) {

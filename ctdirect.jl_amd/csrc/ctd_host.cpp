@@ -596,14 +596,16 @@ static int build_tables(Model& mo, std::string& err) {
 }
 
 int default_tile(const Model& mo) {
-    // steps per workgroup: keep the tile's LDS below ~40 KiB (>= 3 workgroups per CU) and leave enough tiles to fill
-    // 256 CUs several times over
+    // steps per 256-lane workgroup, from the MI355X tuning sweeps (profiles/): the largest power of two whose tile fits
+    // ~60 KiB of LDS (two workgroups per CU stay resident), at most 32 for the Gauss-Legendre schemes and 64 for
+    // trapeze / midpoint (small records), and fewer when the grid would otherwise not cover the 256 CUs
     const Layout& L = mo.L;
-    const int64_t per_step = (int64_t)(L.blk + mo.R.stride) * 8;
-    int64_t T = (40 * 1024) / per_step - mo.HL - mo.HH - 1;
-    if (T > 64) T = 64;
-    if (T < 1) T = 1;
-    while (T > 8 && (L.N + T - 1) / T < 1024) T /= 2;
+    const int64_t per_step = (int64_t)(L.blk + mo.R.stride + 1) * 8;
+    const int64_t fit = (60 * 1024) / per_step - mo.HL - mo.HH;
+    const int64_t cap = (L.sc == SC_IRK) ? 32 : 64;
+    int64_t T = 1;
+    while (T * 2 <= fit && T * 2 <= cap) T *= 2;
+    while (T > 4 && (L.N + T - 1) / T < 256) T /= 2;
     return (int)T;
 }
 

@@ -1,5 +1,5 @@
 // Kernel instantiations of the collocation engine for one registry entry (DoubleIntegratorFreeT0TfOCP); see ctd_kernels.hpp.
 #include "ctd_kernels.hpp"
 namespace ctd {
-CTD_DEFINE_LAUNCHERS(DoubleIntegratorFreeT0TfOCP)
+CTD_INSTANTIATE_LAUNCHERS(DoubleIntegratorFreeT0TfOCP)
 }

@@ -1,5 +1,5 @@
 // Kernel instantiations of the collocation engine for one registry entry (DoubleIntegratorPathOCP); see ctd_kernels.hpp.
 #include "ctd_kernels.hpp"
 namespace ctd {
-CTD_DEFINE_LAUNCHERS(DoubleIntegratorPathOCP)
+CTD_INSTANTIATE_LAUNCHERS(DoubleIntegratorPathOCP)
 }

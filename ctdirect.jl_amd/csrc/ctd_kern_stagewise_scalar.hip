@@ -1,5 +1,5 @@
 // Kernel instantiations of the collocation engine for one registry entry (StagewiseScalarOCP); see ctd_kernels.hpp.
 #include "ctd_kernels.hpp"
 namespace ctd {
-CTD_DEFINE_LAUNCHERS(StagewiseScalarOCP)
+CTD_INSTANTIATE_LAUNCHERS(StagewiseScalarOCP)
 }

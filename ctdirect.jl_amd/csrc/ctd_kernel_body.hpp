@@ -1,17 +1,20 @@
 // ctd_kernel_body.hpp -- the fused constraints + sparse-Jacobian evaluation, written as phase functions.
 //
 // One workgroup evaluates a TILE of consecutive time steps of the collocation grid (reference loop:
-// `for i in 1:docp.time.steps`, src/DOCP_functions.jl:92-98), in four phases separated by workgroup barriers:
+// `for i in 1:docp.time.steps`, src/DOCP_functions.jl:92-98), in phases separated by workgroup barriers:
 //
 //   load   the tile's slice of the NLP vector xu (step-major, external layout) is copied once into LDS with
-//          coalesced loads; every later read of X_i, U_i^j, K_i^j, X_{i+1} comes from LDS
+//          coalesced loads, together with the normalized times tau_i of its grid points; every later read of
+//          X_i, U_i^j, K_i^j, X_{i+1} comes from LDS
 //   eval   one lane per (step, eval point, direction chunk): the OCP dynamics (and path constraints) are evaluated
 //          on forward duals in registers -> df/dx, df/du, df/dt, df/dv and the values land in the step's LDS record
 //          (replaces setWorkArray + stepStateConstraints! + stepPathConstraints! AND the ncolors Dual passes of
 //          ADNLPModels: trapeze.jl:50-71,118-142, midpoint.jl:47-72,124-140, irk.jl:236-308,
-//          irk_stagewise.jl:394-460, DOCP_functions.jl:122-140)
-//   fin    one lane per step: scheme chain rule pieces that need a whole step (residual rows, d/dv through the
-//          free time grid of get_time_grid, DOCP_data.jl:437-458, per-step coefficients -h a_jl, -h b_j, ...)
+//          irk_stagewise.jl:394-460, DOCP_functions.jl:122-140).  When all directions of a function fit one chunk the
+//          same lane also finishes its part of the scheme's chain rule (no extra phase);
+//   fin    only for OCPs whose directions need several chunks: one lane per (step, stage) combines the chunks
+//          (d/dv through the free time grid of get_time_grid, DOCP_data.jl:437-458, residual rows, coefficients)
+//   fin2   trapeze only: the step residual needs the dynamics of two nodes
 //   emit   all lanes stream the outputs in their final external order with coalesced 8-byte stores:
 //          c rows of the tile, the tile's contiguous range of CSC values (one 32-bit code per entry of the
 //          step-periodic pattern: value = coef * record[di] + beta), and the tile's slice of every V column
@@ -20,11 +23,17 @@
 // the final time (:100) and the few CSC entries whose layout is not step-periodic (first and last step columns,
 // final-state columns, tails of the V columns), driven by an explicit (index, code) list.
 //
-// The phase functions are plain templates over (OCP functor, scheme class); `tid`/`nthr` are the lane id and
-// workgroup size.  ctd_kernels.hip wraps them in the __global__ kernel; tests/emu/ steps them serially on the CPU
+// The phase functions are plain templates over (OCP functor, scheme class, stage count); `tid`/`nthr` are the lane id
+// and workgroup size.  ctd_kernels.hpp wraps them in the __global__ kernel; tests/emu/ steps them serially on the CPU
 // (test infrastructure only -- the C ABI never takes that path).
 #pragma once
 #include "ctd_layout.hpp"
+
+// emit variant: 0 = one 8-byte store per lane and entry (default, measured faster on MI355X for this kernel),
+// 1 = 16-byte stores of entry pairs (emit_stream)
+#ifndef CTD_EMIT_PAIRS
+#define CTD_EMIT_PAIRS 0
+#endif
 
 namespace ctd {
 
@@ -36,6 +45,7 @@ struct BlockCtx {
     int64_t lo;        // step / node index of slot 0 (tile)
     double* in;        // staged slice of xu
     double* v;         // optimisation variables
+    double* tau;       // normalized times: tile: tau[k] = tau_{lo+k}, k <= nslots+1; edge: tau[2k], tau[2k+1], tau[2 ns] = tau_N
     double* rec;       // records
 };
 
@@ -52,10 +62,12 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.in_stride = L.blk + L.n + L.m;
         cx.a = cx.b = cx.lo = 0;
         cx.in = lds;
-        cx.v = cx.in + (int64_t)cx.nslots * cx.in_stride;
-        cx.rec = cx.v + kMaxNV;
+        cx.v = cx.in + cx.nslots * cx.in_stride;
+        cx.tau = cx.v + kMaxNV;
+        cx.rec = cx.tau + 2 * kMaxEdgeSlots + 2;
     } else {
         const int tile = block - (kp.has_edge ? 1 : 0);
+        const int cap = kp.T + kp.HL + kp.HH;
         cx.is_edge = 0;
         cx.a = kp.step_begin + (int64_t)tile * kp.T;
         cx.b = cx.a + kp.T < kp.step_end ? cx.a + kp.T : kp.step_end;
@@ -63,8 +75,9 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.nslots = (int)(cx.b - cx.a) + kp.HL + kp.HH;
         cx.in_stride = L.blk;
         cx.in = lds;
-        cx.v = cx.in + (int64_t)(kp.T + kp.HL + kp.HH + 1) * L.blk + L.n + L.m;
-        cx.rec = cx.v + kMaxNV;
+        cx.v = cx.in + (cap + 1) * L.blk + L.n + L.m;
+        cx.tau = cx.v + kMaxNV;
+        cx.rec = cx.tau + cap + 2;
     }
     return cx;
 }
@@ -72,38 +85,53 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
 // LDS doubles a block needs (host uses this to size the launch)
 inline int64_t lds_doubles(const KParams& kp) {
     const Layout& L = kp.L;
-    int64_t tile = (int64_t)(kp.T + kp.HL + kp.HH + 1) * L.blk + L.n + L.m + kMaxNV + (int64_t)(kp.T + kp.HL + kp.HH) * kp.R.stride;
-    int64_t edge = (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
+    const int64_t cap = kp.T + kp.HL + kp.HH;
+    int64_t tile = (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
+    int64_t edge = (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
+                   (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
     return tile > edge ? tile : edge;
 }
 
 // normalized time of grid point i: collect(LinRange(0, 1, N+1))[i+1] = i / N (src/DOCP_data.jl:179-183), or the
-// user grid normalised on the host (:191-199)
-CTD_HD double tau_at(const KParams& kp, int64_t i) {
+// user grid normalised on the host (:191-199).  Evaluated once per slot in phase_load (one FP64 division per slot).
+CTD_HD double tau_global(const KParams& kp, int64_t i) {
+    if (i < 0) i = 0;
+    if (i > kp.L.N) i = kp.L.N;
     return kp.tau ? kp.tau[i] : (double)i / (double)kp.L.N;
 }
+CTD_HD double slot_tau(const BlockCtx& cx, int k, int d) { return cx.is_edge ? cx.tau[2 * k + d] : cx.tau[k + d]; }
+CTD_HD double final_tau(const BlockCtx& cx) { return cx.tau[2 * cx.nslots]; }   // edge block only
 
 // get_time_grid (src/DOCP_data.jl:437-458): t_i = t0 + tau_i (tf - t0), t0/tf fixed or components of v
-template <class P> CTD_HD void time_ends(const KParams& kp, const double* v, double& t0, double& tf) {
-    t0 = (P::IT0 >= 0) ? v[P::IT0 >= 0 ? P::IT0 : 0] : kp.L.t0;
-    tf = (P::ITF >= 0) ? v[P::ITF >= 0 ? P::ITF : 0] : kp.L.tf;
+template <class P> CTD_HD double time_of(const KParams& kp, const double* v, double tau) {
+    const double t0 = (P::IT0 >= 0) ? v[P::IT0 >= 0 ? P::IT0 : 0] : kp.L.t0;
+    const double tf = (P::ITF >= 0) ? v[P::ITF >= 0 ? P::ITF : 0] : kp.L.tf;
+    return t0 + tau * (tf - t0);
 }
-template <class P> CTD_HD double time_at(const KParams& kp, const double* v, int64_t i) {
-    double t0, tf;
-    time_ends<P>(kp, v, t0, tf);
-    return t0 + tau_at(kp, i) * (tf - t0);
-}
-// d t_i / d v_k, following the dual arithmetic of the same expression
-template <class P> CTD_HD double dtime_at(const KParams& kp, int64_t i, int k) {
+// d t / d v_k, following the dual arithmetic of the same expression
+template <class P> CTD_HD double dtime_of(double tau, int k) {
     const double dt0 = (P::IT0 == k) ? 1.0 : 0.0;
     const double dtf = (P::ITF == k) ? 1.0 : 0.0;
-    return dt0 + tau_at(kp, i) * (dtf - dt0);
+    return dt0 + tau * (dtf - dt0);
 }
+
+template <class P> struct Dirs {
+    static constexpr int DYN = P::NX + P::NU + (P::DYN_T ? 1 : 0) + (P::DYN_V ? P::NV : 0);
+    static constexpr int PATH = P::NX + P::NU + (P::PATH_T ? 1 : 0) + (P::PATH_V ? P::NV : 0);
+    static constexpr int BND = 2 * P::NX + P::NV;
+    static constexpr int DC = P::DC;
+    static constexpr int NCH_DYN = (DYN + DC - 1) / DC;
+    static constexpr int NCH_PATH = (PATH + DC - 1) / DC;
+    static constexpr int NCH_BND = (BND + DC - 1) / DC;
+    // every function of the OCP is differentiated in a single pass: the evaluating lane finishes the chain rule
+    static constexpr bool FUSED = (NCH_DYN == 1) && (P::NPATH == 0 || NCH_PATH == 1);
+    static constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
+};
 
 // ------------------------------------------------------------------------------------------------------
 // phase: load
 // ------------------------------------------------------------------------------------------------------
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __restrict__ xu, int tid, int nthr) {
     const Layout& L = kp.L;
     if (cx.is_edge) {
@@ -113,44 +141,212 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
             const int64_t g = kp.edge_steps[k] * L.blk + o;
             cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
         }
+        for (int e = tid; e <= 2 * cx.nslots; e += nthr)
+            cx.tau[e] = (e == 2 * cx.nslots) ? tau_global(kp, L.N) : tau_global(kp, kp.edge_steps[e >> 1] + (e & 1));
     } else {
         const int64_t g0 = (cx.lo < 0 ? 0 : cx.lo) * (int64_t)L.blk;
         int64_t g1 = (cx.lo + cx.nslots) * (int64_t)L.blk + L.n + L.m;
         if (g1 > L.v_off) g1 = L.v_off;
         const int64_t shift = cx.lo * (int64_t)L.blk;
         for (int64_t g = g0 + tid; g < g1; g += nthr) cx.in[g - shift] = xu[g];
+        for (int e = tid; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
     }
     if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
+// finishing pieces (called from the eval lanes when Dirs<P>::FUSED, from phase_fin otherwise)
+// ------------------------------------------------------------------------------------------------------
+template <class P> CTD_HD void fill_const_coefs(const KParams& kp, double* C) {
+#pragma unroll
+    for (int e = 0; e < kNC; ++e) C[e] = 0.0;
+    C[C_ONE] = 1.0; C[C_NEG1] = -1.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[C_B + j] = kp.L.b[j];
+}
+
+// per-record coefficients + (IRK) the state-equation rows, which depend on the inputs only
+template <class P, int SC, int S>
+CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
+    constexpr int n = P::NX, nv = P::NV;
+    const Layout& L = kp.L;
+    const RecLayout& R = kp.R;
+    const int64_t i = slot_index(kp, cx, k);
+    double* rec = cx.rec + k * R.stride;
+    double* C = rec + R.oC;
+    fill_const_coefs<P>(kp, C);
+    if (i < 0 || i >= L.N) return;
+    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double h = time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0);
+    if (SC == SC_IRK) {
+        const double* base = cx.in + k * cx.in_stride;
+        const double* K = base + n + L.cu;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+#pragma unroll
+            for (int l = 0; l < S; ++l) C[C_HA + 3 * j + l] = -(h * L.a[3 * j + l]);
+            C[C_HB + j] = -(h * L.b[j]);
+        }
+        // state rows: X_{i+1} - (X_i + h sum_j b_j K^j)   (irk_stagewise.jl:456-457, irk.jl:304-306)
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            double sumbk = L.b[0] * K[r];
+#pragma unroll
+            for (int j = 1; j < S; ++j) sumbk = sumbk + L.b[j] * K[j * n + r];
+            rec[R.oR + r] = base[L.blk + r] - (base[r] + h * sumbk);
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk) : 0.0;
+                rec[R.oSv + r * nv + kk] = -(dh * sumbk);
+            }
+        }
+    } else if (SC == SC_MIDPOINT) {
+        C[C_NHH] = -(0.5 * (h / 1.0));
+        C[C_NH] = -(h / 1.0);
+    } else {
+        C[C_NHH] = -(0.5 * h);
+    }
+}
+
+// the part of the chain rule that needs all partials of one eval point
+template <class P, int SC, int S>
+CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
+    constexpr int n = P::NX, nv = P::NV;
+    constexpr bool FREE = Dirs<P>::FREE;
+    const Layout& L = kp.L;
+    const RecLayout& R = kp.R;
+    const int64_t i = slot_index(kp, cx, k);
+    if (i < 0) return;
+    if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
+    double* rec = cx.rec + k * R.stride;
+    double* ev = rec + R.oEval + j * R.eval_sz;
+    const double* base = cx.in + k * cx.in_stride;
+    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    double dti[nv > 0 ? nv : 1], dh[nv > 0 ? nv : 1];
+#pragma unroll
+    for (int kk = 0; kk < nv; ++kk) {
+        dti[kk] = FREE ? dtime_of<P>(tau0, kk) : 0.0;
+        dh[kk] = FREE ? dtime_of<P>(tau1, kk) - dti[kk] : 0.0;
+    }
+    if (SC == SC_IRK) {
+        const double* K = base + n + L.cu;
+        // stage rows: K_i^j - f(...)   (irk_stagewise.jl:448-451)
+#pragma unroll
+        for (int r = 0; r < n; ++r) rec[R.oR + n + j * n + r] = K[j * n + r] - ev[R.of + r];
+#pragma unroll
+        for (int kk = 0; kk < nv; ++kk) {
+            // d x_ij / d v_kk = dh * sum_l a_jl K^l  (x_i itself does not depend on v)
+            double dx[n > 0 ? n : 1];
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < S; ++l) acc = acc + (dh[kk] * L.a[3 * j + l]) * K[l * n + c];
+                dx[c] = acc;
+            }
+            const double dtij = dti[kk] + L.c[j] * dh[kk];
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
+                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dtij;
+                if (FREE) {
+#pragma unroll
+                    for (int c = 0; c < n; ++c) w = w + ev[R.oF + r * n + c] * dx[c];
+                }
+                ev[R.oW + r * nv + kk] = w;
+            }
+        }
+    } else if (SC == SC_MIDPOINT) {
+        const double h = (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0)) / 1.0;
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            const double f = ev[R.of + r];
+            rec[R.oR + r] = base[L.blk + r] - (base[r] + h * f);    // midpoint.jl:139
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
+                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (0.5 * (dti[kk] + (dti[kk] + dh[kk])));
+                ev[R.oW + r * nv + kk] = w;
+                rec[R.oSv + r * nv + kk] = -(dh[kk] * f + h * w);
+            }
+        }
+    } else {  // SC_TRAPEZE: node-level total d f / d v; the step residual needs the next node (fin_trapeze_step)
+#pragma unroll
+        for (int r = 0; r < n; ++r)
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
+                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dti[kk];
+                ev[R.oW + r * nv + kk] = w;
+            }
+    }
+}
+
+// path rows: total d/dv = explicit + dg/dt * dt/dv
+template <class P>
+CTD_HD void fin_path(const KParams& kp, double* rec, double tau) {
+    constexpr int nv = P::NV, np = P::NPATH;
+    const RecLayout& R = kp.R;
+#pragma unroll
+    for (int r = 0; r < np; ++r)
+#pragma unroll
+        for (int kk = 0; kk < nv; ++kk) {
+            double pv = P::PATH_V ? rec[R.oPv + r * nv + kk] : 0.0;
+            if (P::PATH_T && Dirs<P>::FREE) pv = pv + rec[R.oPt + r] * dtime_of<P>(tau, kk);
+            rec[R.oPv + r * nv + kk] = pv;
+        }
+}
+
+// trapeze: X_{i+1} - (X_i + h/2 (f_i + f_{i+1}))  (trapeze.jl:128-140); needs the record of node i+1
+template <class P>
+CTD_HD void fin_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
+    constexpr int n = P::NX, nv = P::NV;
+    const Layout& L = kp.L;
+    const RecLayout& R = kp.R;
+    const int64_t i = slot_index(kp, cx, k);
+    if (i < 0 || i >= L.N || k + 1 >= cx.nslots) return;
+    if (slot_index(kp, cx, k + 1) != i + 1) return;
+    double* rec = cx.rec + k * R.stride;
+    const double* nxt = rec + R.stride;
+    const double* base = cx.in + k * cx.in_stride;
+    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double half_h = 0.5 * (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0));
+    const double* e0 = rec + R.oEval;
+    const double* e1 = nxt + R.oEval;
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+        const double fs = e0[R.of + r] + e1[R.of + r];
+        rec[R.oR + r] = base[L.blk + r] - (base[r] + half_h * fs);
+#pragma unroll
+        for (int kk = 0; kk < nv; ++kk) {
+            const double dhalf = Dirs<P>::FREE ? 0.5 * (dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk)) : 0.0;
+            rec[R.oSv + r * nv + kk] = -(dhalf * fs + half_h * (e0[R.oW + r * nv + kk] + e1[R.oW + r * nv + kk]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // phase: eval (dual evaluation of the OCP functions)
 // ------------------------------------------------------------------------------------------------------
-template <class P> struct Dirs {
-    static constexpr int DYN = P::NX + P::NU + (P::DYN_T ? 1 : 0) + (P::DYN_V ? P::NV : 0);
-    static constexpr int PATH = P::NX + P::NU + (P::PATH_T ? 1 : 0) + (P::PATH_V ? P::NV : 0);
-    static constexpr int BND = 2 * P::NX + P::NV;
-    static constexpr int DC = P::DC;
-    static constexpr int NCH_DYN = (DYN + DC - 1) / DC;
-    static constexpr int NCH_PATH = (PATH + DC - 1) / DC;
-    static constexpr int NCH_BND = (BND + DC - 1) / DC;
-};
-
 // the control seen by path constraints: U_i, or for stagewise schemes the b-weighted stage average
 // (get_OCP_control_at_time_step, src/ode/common.jl:140-155 / irk_stagewise.jl:197-205)
-template <class P> CTD_HD void node_control(const KParams& kp, const double* base, double* u) {
+template <class P, int S> CTD_HD void node_control(const KParams& kp, const double* base, double* u) {
     const Layout& L = kp.L;
     if (L.stagewise) {
+#pragma unroll
         for (int c = 0; c < P::NU; ++c) u[c] = L.b[0] * base[P::NX + c];
-        for (int j = 1; j < L.s; ++j)
+#pragma unroll
+        for (int j = 1; j < S; ++j)
+#pragma unroll
             for (int c = 0; c < P::NU; ++c) u[c] = u[c] + L.b[j] * base[P::NX + j * P::NU + c];
     } else {
+#pragma unroll
         for (int c = 0; c < P::NU; ++c) u[c] = base[P::NX + c];
     }
 }
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
     using D = Dual<DC>;
@@ -159,28 +355,35 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0) return;
     if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
-    const double* base = cx.in + (int64_t)k * cx.in_stride;
+    const double* base = cx.in + k * cx.in_stride;
+    const double ti = time_of<P>(kp, cx.v, slot_tau(cx, k, 0));
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
     double t;
     if (SC == SC_TRAPEZE) {                       // f(t_i, X_i, U_i, v): trapeze.jl:60-69
-        t = time_at<P>(kp, cx.v, i);
+        t = ti;
+#pragma unroll
         for (int c = 0; c < n; ++c) xv[c] = base[c];
+#pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
-        t = 0.5 * (time_at<P>(kp, cx.v, i) + time_at<P>(kp, cx.v, i + 1));
+        t = 0.5 * (ti + time_of<P>(kp, cx.v, slot_tau(cx, k, 1)));
+#pragma unroll
         for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + base[L.blk + c]);
+#pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
-        const double ti = time_at<P>(kp, cx.v, i);
-        const double h = time_at<P>(kp, cx.v, i + 1) - ti;
+        const double h = time_of<P>(kp, cx.v, slot_tau(cx, k, 1)) - ti;
         t = ti + L.c[j] * h;
         const double* K = base + n + L.cu;
+#pragma unroll
         for (int c = 0; c < n; ++c) {
             double x = base[c];
-            for (int l = 0; l < L.s; ++l) x = x + h * L.a[3 * j + l] * K[l * n + c];
+#pragma unroll
+            for (int l = 0; l < S; ++l) x = x + h * L.a[3 * j + l] * K[l * n + c];
             xv[c] = x;
         }
         const double* U = base + n + (L.stagewise ? j * m : 0);
+#pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = U[c];
     }
     // seed directions [x | u | t | v] of this chunk
@@ -210,19 +413,29 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int d = 0; d < DC; ++d) V[c].d[d] = (P::DYN_V && g0 + d == gV + c) ? 1.0 : 0.0;
     }
     P::template dynamics<D>(out, Tt, X, U, V);
-    double* ev = cx.rec + (int64_t)k * R.stride + R.oEval + j * R.eval_sz;
+    double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
 #pragma unroll
     for (int d = 0; d < DC; ++d) {
         const int g = g0 + d;
-        if (g < n) { for (int r = 0; r < n; ++r) ev[R.oF + r * n + g] = out[r].d[d]; }
-        else if (g < n + m) { for (int r = 0; r < n; ++r) ev[R.oG + r * m + (g - n)] = out[r].d[d]; }
-        else if (P::DYN_T && g == n + m) { for (int r = 0; r < n; ++r) ev[R.oft + r] = out[r].d[d]; }
-        else if (P::DYN_V && g < Dirs<P>::DYN) {
+        if (g < n) {
+#pragma unroll
+            for (int r = 0; r < n; ++r) ev[R.oF + r * n + g] = out[r].d[d];
+        } else if (g < n + m) {
+#pragma unroll
+            for (int r = 0; r < n; ++r) ev[R.oG + r * m + (g - n)] = out[r].d[d];
+        } else if (P::DYN_T && g == n + m) {
+#pragma unroll
+            for (int r = 0; r < n; ++r) ev[R.oft + r] = out[r].d[d];
+        } else if (P::DYN_V && g < Dirs<P>::DYN) {
             const int kk = g - n - m - (P::DYN_T ? 1 : 0);
+#pragma unroll
             for (int r = 0; r < n; ++r) ev[R.oW + r * nv + kk] = out[r].d[d];
         }
     }
-    if (q == 0) for (int r = 0; r < n; ++r) ev[R.of + r] = out[r].v;
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) ev[R.of + r] = out[r].v;
+    }
 }
 
 // path constraints g(t, x, u, v) on duals into record `rec`: stepPathConstraints!, DOCP_functions.jl:122-140
@@ -260,42 +473,62 @@ CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv
 #pragma unroll
     for (int d = 0; d < DC; ++d) {
         const int g = g0 + d;
-        if (g < n) { for (int r = 0; r < np; ++r) rec[R.oPx + r * n + g] = out[r].d[d]; }
-        else if (g < n + m) { for (int r = 0; r < np; ++r) rec[R.oPu + r * m + (g - n)] = out[r].d[d]; }
-        else if (P::PATH_T && g == n + m) { for (int r = 0; r < np; ++r) rec[R.oPt + r] = out[r].d[d]; }
-        else if (P::PATH_V && g < Dirs<P>::PATH) {
+        if (g < n) {
+#pragma unroll
+            for (int r = 0; r < np; ++r) rec[R.oPx + r * n + g] = out[r].d[d];
+        } else if (g < n + m) {
+#pragma unroll
+            for (int r = 0; r < np; ++r) rec[R.oPu + r * m + (g - n)] = out[r].d[d];
+        } else if (P::PATH_T && g == n + m) {
+#pragma unroll
+            for (int r = 0; r < np; ++r) rec[R.oPt + r] = out[r].d[d];
+        } else if (P::PATH_V && g < Dirs<P>::PATH) {
             const int kk = g - n - m - (P::PATH_T ? 1 : 0);
+#pragma unroll
             for (int r = 0; r < np; ++r) rec[R.oPv + r * nv + kk] = out[r].d[d];
         }
     }
-    if (q == 0) for (int r = 0; r < np; ++r) rec[value_off + r] = out[r].v;
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < np; ++r) rec[value_off + r] = out[r].v;
+    }
 }
 
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void eval_step_path(const KParams& kp, const BlockCtx& cx, int k, int q) {
     constexpr int n = P::NX, m = P::NU;
     const Layout& L = kp.L;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0 || i >= L.N) return;
-    const double* base = cx.in + (int64_t)k * cx.in_stride;
+    const double* base = cx.in + k * cx.in_stride;
     double uv[m > 0 ? m : 1];
-    node_control<P>(kp, base, uv);
+    node_control<P, S>(kp, base, uv);
     double xv[n > 0 ? n : 1];
+#pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[c];
-    eval_path<P>(kp, cx.rec + (int64_t)k * kp.R.stride, time_at<P>(kp, cx.v, i), xv, uv, cx.v, q, kp.R.oR + L.eqs);
+    double* rec = cx.rec + k * kp.R.stride;
+    const double tau = slot_tau(cx, k, 0);
+    eval_path<P>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, kp.R.oR + L.eqs);
+    if (Dirs<P>::FUSED) fin_path<P>(kp, rec, tau);
 }
 
 // path constraints at the final time (DOCP_functions.jl:100) with the convention u(tf) = U_N unless U_{N+1} exists
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
     constexpr int n = P::NX, m = P::NU;
     const Layout& L = kp.L;
-    const double* base = cx.in + (int64_t)kp.edge_slot_last * cx.in_stride;
+    const double* base = cx.in + kp.edge_slot_last * cx.in_stride;
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
+#pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[L.blk + c];
-    if (SC == SC_TRAPEZE) { for (int c = 0; c < m; ++c) uv[c] = base[L.blk + n + c]; }
-    else node_control<P>(kp, base, uv);
-    eval_path<P>(kp, cx.rec + (int64_t)kp.edge_fp * kp.R.stride, time_at<P>(kp, cx.v, L.N), xv, uv, cx.v, q, kp.R.oR);
+    if (SC == SC_TRAPEZE) {
+#pragma unroll
+        for (int c = 0; c < m; ++c) uv[c] = base[L.blk + n + c];
+    } else node_control<P, S>(kp, base, uv);
+    double* rec = cx.rec + kp.edge_fp * kp.R.stride;
+    const double tau = final_tau(cx);
+    eval_path<P>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, kp.R.oR);
+    if (Dirs<P>::FUSED) fin_path<P>(kp, rec, tau);
 }
 
 // boundary constraints phi(x0, xf, v) on duals: DOCP_functions.jl:103-111
@@ -305,8 +538,8 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
     using D = Dual<DC>;
     const Layout& L = kp.L;
     const RecLayout& R = kp.R;
-    const double* b0 = cx.in + (int64_t)kp.edge_slot_first * cx.in_stride;
-    const double* bf = cx.in + (int64_t)kp.edge_slot_last * cx.in_stride + L.blk;
+    const double* b0 = cx.in + kp.edge_slot_first * cx.in_stride;
+    const double* bf = cx.in + kp.edge_slot_last * cx.in_stride + L.blk;
     D X0[n > 0 ? n : 1], XF[n > 0 ? n : 1], V[nv > 0 ? nv : 1], out[nb > 0 ? nb : 1];
     const int g0 = q * DC;
 #pragma unroll
@@ -326,209 +559,96 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
         for (int d = 0; d < DC; ++d) V[c].d[d] = (g0 + d == 2 * n + c) ? 1.0 : 0.0;
     }
     P::template boundary<D>(out, X0, XF, V);
-    double* rec = cx.rec + (int64_t)kp.edge_b * R.stride;
+    double* rec = cx.rec + kp.edge_b * R.stride;
 #pragma unroll
     for (int d = 0; d < DC; ++d) {
         const int g = g0 + d;
-        if (g < n) { for (int r = 0; r < nb; ++r) rec[R.oB0 + r * n + g] = out[r].d[d]; }
-        else if (g < 2 * n) { for (int r = 0; r < nb; ++r) rec[R.oBf + r * n + (g - n)] = out[r].d[d]; }
-        else if (g < 2 * n + nv) { for (int r = 0; r < nb; ++r) rec[R.oBv + r * nv + (g - 2 * n)] = out[r].d[d]; }
+        if (g < n) {
+#pragma unroll
+            for (int r = 0; r < nb; ++r) rec[R.oB0 + r * n + g] = out[r].d[d];
+        } else if (g < 2 * n) {
+#pragma unroll
+            for (int r = 0; r < nb; ++r) rec[R.oBf + r * n + (g - n)] = out[r].d[d];
+        } else if (g < 2 * n + nv) {
+#pragma unroll
+            for (int r = 0; r < nb; ++r) rec[R.oBv + r * nv + (g - 2 * n)] = out[r].d[d];
+        }
     }
-    if (q == 0) for (int r = 0; r < nb; ++r) rec[R.oBval + r] = out[r].v;
+    if (q == 0) {
+#pragma unroll
+        for (int r = 0; r < nb; ++r) rec[R.oBval + r] = out[r].v;
+    }
 }
 
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+    constexpr bool FUSED = Dirs<P>::FUSED;
     const RecLayout& R = kp.R;
     const int ns = cx.nslots;
-    const int n_dyn = R.S * Dirs<P>::NCH_DYN * ns;
+    const int n_dyn = S * Dirs<P>::NCH_DYN * ns;
     const int n_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH * ns : 0;
-    int n_fp = 0, n_b = 0;
+    const int n_lead = FUSED ? ns : 0;               // coefficient / state-row lanes (fused mode)
+    int n_fp = 0, n_b = 0, n_aux = 0;
     if (cx.is_edge) {
         n_fp = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
         n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
+        n_aux = 2;                                   // coefficients of the final-path and boundary records
     }
-    const int total = n_dyn + n_path + n_fp + n_b;
+    const int total = n_dyn + n_path + n_lead + n_fp + n_b + n_aux;
     for (int task = tid; task < total; task += nthr) {
-        if (task < n_dyn) {
+        int t = task;
+        if (t < n_dyn) {
             // slot fastest: neighbouring lanes run the same (eval point, chunk) on neighbouring steps
-            const int k = task % ns, jq = task / ns;
-            eval_dynamics<P, SC>(kp, cx, k, jq / Dirs<P>::NCH_DYN, jq % Dirs<P>::NCH_DYN);
-        } else if (task < n_dyn + n_path) {
-            const int t2 = task - n_dyn;
-            eval_step_path<P, SC>(kp, cx, t2 % ns, t2 / ns);
-        } else if (task < n_dyn + n_path + n_fp) {
-            eval_final_path<P, SC>(kp, cx, task - n_dyn - n_path);
-        } else {
-            eval_boundary<P>(kp, cx, task - n_dyn - n_path - n_fp);
+            const int k = t % ns, jq = t / ns;
+            const int j = jq / Dirs<P>::NCH_DYN, q = jq % Dirs<P>::NCH_DYN;
+            eval_dynamics<P, SC, S>(kp, cx, k, j, q);
+            if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j);
+            continue;
         }
+        t -= n_dyn;
+        if (t < n_path) { eval_step_path<P, SC, S>(kp, cx, t % ns, t / ns); continue; }
+        t -= n_path;
+        if (t < n_lead) { fin_lead<P, SC, S>(kp, cx, t); continue; }
+        t -= n_lead;
+        if (t < n_fp) { eval_final_path<P, SC, S>(kp, cx, t); continue; }
+        t -= n_fp;
+        if (t < n_b) { eval_boundary<P>(kp, cx, t); continue; }
+        t -= n_b;
+        fill_const_coefs<P>(kp, cx.rec + (t == 0 ? kp.edge_fp : kp.edge_b) * R.stride + R.oC);
     }
     // record header: [0] = 1.0 (every record of the block, used by constant entries of the pattern)
     const int nrec = cx.is_edge ? ns + 2 : ns;
-    for (int k = tid; k < nrec; k += nthr) cx.rec[(int64_t)k * R.stride] = 1.0;
+    for (int k = tid; k < nrec; k += nthr) cx.rec[k * R.stride] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
-// phase: fin (one lane per record)
+// phase: fin (only when the OCP needs several direction chunks) and fin2 (trapeze)
 // ------------------------------------------------------------------------------------------------------
-template <class P> CTD_HD void fill_const_coefs(const KParams& kp, double* C) {
-    for (int e = 0; e < kNC; ++e) C[e] = 0.0;
-    C[C_ZERO] = 0.0; C[C_ONE] = 1.0; C[C_NEG1] = -1.0;
-    for (int j = 0; j < 3; ++j) C[C_B + j] = kp.L.b[j];
-}
-
-template <class P, int SC>
-CTD_HD void finalize_step(const KParams& kp, const BlockCtx& cx, int k) {
-    constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH;
-    constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
-    const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
-    const int64_t i = slot_index(kp, cx, k);
-    double* rec = cx.rec + (int64_t)k * R.stride;
-    double* C = rec + R.oC;
-    fill_const_coefs<P>(kp, C);
-    if (i < 0 || i > L.N) return;
-    const bool is_step = i < L.N;
-    const double* base = cx.in + (int64_t)k * cx.in_stride;
-    const double ti = time_at<P>(kp, cx.v, i);
-    const double tip1 = is_step ? time_at<P>(kp, cx.v, i + 1) : ti;
-    double dti[nv > 0 ? nv : 1], dti1[nv > 0 ? nv : 1], dh[nv > 0 ? nv : 1];
-    for (int kk = 0; kk < nv; ++kk) {
-        dti[kk] = FREE ? dtime_at<P>(kp, i, kk) : 0.0;
-        dti1[kk] = (FREE && is_step) ? dtime_at<P>(kp, i + 1, kk) : dti[kk];
-        dh[kk] = dti1[kk] - dti[kk];
-    }
-    // path rows: total d/dv = explicit + dg/dt * dt_i/dv
-    if (np > 0 && is_step) {
-        for (int r = 0; r < np; ++r)
-            for (int kk = 0; kk < nv; ++kk) {
-                double pv = P::PATH_V ? rec[R.oPv + r * nv + kk] : 0.0;
-                if (P::PATH_T && FREE) pv = pv + rec[R.oPt + r] * dti[kk];
-                rec[R.oPv + r * nv + kk] = pv;
-            }
-    }
-    if (SC == SC_IRK) {
-        if (!is_step) return;
-        const double h = tip1 - ti;
-        for (int j = 0; j < L.s; ++j) {
-            for (int l = 0; l < L.s; ++l) C[C_HA + 3 * j + l] = -(h * L.a[3 * j + l]);
-            C[C_HB + j] = -(h * L.b[j]);
-        }
-        const double* K = base + n + L.cu;
-        double* Rr = rec + R.oR;
-        for (int j = 0; j < L.s; ++j) {
-            double* ev = rec + R.oEval + j * R.eval_sz;
-            // stage rows: K_i^j - f(...)   (irk_stagewise.jl:448-451)
-            for (int r = 0; r < n; ++r) Rr[n + j * n + r] = K[j * n + r] - ev[R.of + r];
-            if (nv > 0) {
-                for (int kk = 0; kk < nv; ++kk) {
-                    // d x_ij / d v_kk = dh * sum_l a_jl K^l  (x_i itself does not depend on v)
-                    double dx[n > 0 ? n : 1];
-                    for (int c = 0; c < n; ++c) {
-                        double acc = 0.0;
-                        for (int l = 0; l < L.s; ++l) acc = acc + (dh[kk] * L.a[3 * j + l]) * K[l * n + c];
-                        dx[c] = acc;
-                    }
-                    const double dtij = dti[kk] + L.c[j] * dh[kk];
-                    for (int r = 0; r < n; ++r) {
-                        double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
-                        if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dtij;
-                        if (FREE) for (int c = 0; c < n; ++c) w = w + ev[R.oF + r * n + c] * dx[c];
-                        ev[R.oW + r * nv + kk] = w;
-                    }
-                }
-            }
-        }
-        // state rows: X_{i+1} - (X_i + h sum_j b_j K^j)   (irk_stagewise.jl:456-457)
-        for (int r = 0; r < n; ++r) {
-            double sumbk = L.b[0] * K[r];
-            for (int j = 1; j < L.s; ++j) sumbk = sumbk + L.b[j] * K[j * n + r];
-            Rr[r] = base[L.blk + r] - (base[r] + h * sumbk);
-            for (int kk = 0; kk < nv; ++kk) rec[R.oSv + r * nv + kk] = -(dh[kk] * sumbk);
-        }
-    } else if (SC == SC_MIDPOINT) {
-        if (!is_step) return;
-        const double h = (tip1 - ti) / 1.0;
-        C[C_NHH] = -(0.5 * h);
-        C[C_NH] = -h;
-        double* ev = rec + R.oEval;
-        double* Rr = rec + R.oR;
-        for (int r = 0; r < n; ++r) {
-            Rr[r] = base[L.blk + r] - (base[r] + h * ev[R.of + r]);    // midpoint.jl:139
-            for (int kk = 0; kk < nv; ++kk) {
-                double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
-                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (0.5 * (dti[kk] + dti1[kk]));
-                ev[R.oW + r * nv + kk] = w;
-                rec[R.oSv + r * nv + kk] = -(dh[kk] * ev[R.of + r] + h * w);
-            }
-        }
-    } else {  // SC_TRAPEZE: node-level part; the step-level part needs the next node (finalize_trapeze_step)
-        double* ev = rec + R.oEval;
-        for (int r = 0; r < n; ++r)
-            for (int kk = 0; kk < nv; ++kk) {
-                double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
-                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dti[kk];
-                ev[R.oW + r * nv + kk] = w;
-            }
-        if (is_step) C[C_NHH] = -(0.5 * (tip1 - ti));
-    }
-    (void)m;
-}
-
-// trapeze: X_{i+1} - (X_i + h/2 (f_i + f_{i+1}))  (trapeze.jl:128-140); needs the record of node i+1
-template <class P>
-CTD_HD void finalize_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
-    constexpr int n = P::NX, nv = P::NV;
-    constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
-    const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
-    const int64_t i = slot_index(kp, cx, k);
-    if (i < 0 || i >= L.N || k + 1 >= cx.nslots) return;
-    if (slot_index(kp, cx, k + 1) != i + 1) return;
-    double* rec = cx.rec + (int64_t)k * R.stride;
-    const double* nxt = cx.rec + (int64_t)(k + 1) * R.stride;
-    const double* base = cx.in + (int64_t)k * cx.in_stride;
-    const double ti = time_at<P>(kp, cx.v, i), tip1 = time_at<P>(kp, cx.v, i + 1);
-    const double half_h = 0.5 * (tip1 - ti);
-    const double* e0 = rec + R.oEval;
-    const double* e1 = nxt + R.oEval;
-    for (int r = 0; r < n; ++r) {
-        const double fs = e0[R.of + r] + e1[R.of + r];
-        rec[R.oR + r] = base[L.blk + r] - (base[r] + half_h * fs);
-        for (int kk = 0; kk < nv; ++kk) {
-            const double dhalf = FREE ? 0.5 * (dtime_at<P>(kp, i + 1, kk) - dtime_at<P>(kp, i, kk)) : 0.0;
-            rec[R.oSv + r * nv + kk] = -(dhalf * fs + half_h * (e0[R.oW + r * nv + kk] + e1[R.oW + r * nv + kk]));
-        }
-    }
-}
-
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
-    constexpr int nv = P::NV, np = P::NPATH;
-    constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
-    const RecLayout& R = kp.R;
-    for (int k = tid; k < cx.nslots; k += nthr) finalize_step<P, SC>(kp, cx, k);
-    if (cx.is_edge) {
-        // final-path record and boundary record: coefficients, and total d/dv of the final path rows
-        for (int e = tid; e < 2; e += nthr) {
-            double* rec = cx.rec + (int64_t)(e == 0 ? kp.edge_fp : kp.edge_b) * R.stride;
-            fill_const_coefs<P>(kp, rec + R.oC);
-            if (e == 0 && np > 0) {
-                for (int r = 0; r < np; ++r)
-                    for (int kk = 0; kk < nv; ++kk) {
-                        double pv = P::PATH_V ? rec[R.oPv + r * nv + kk] : 0.0;
-                        if (P::PATH_T && FREE) pv = pv + rec[R.oPt + r] * dtime_at<P>(kp, kp.L.N, kk);
-                        rec[R.oPv + r * nv + kk] = pv;
-                    }
-            }
+    if (Dirs<P>::FUSED) return;
+    const int ns = cx.nslots;
+    const int n_stage = S * ns, n_lead = ns, n_path = (P::NPATH > 0) ? ns : 0;
+    const int n_fp = (cx.is_edge && P::NPATH > 0) ? 1 : 0;
+    for (int task = tid; task < n_stage + n_lead + n_path + n_fp; task += nthr) {
+        int t = task;
+        if (t < n_stage) { fin_stage<P, SC, S>(kp, cx, t % ns, t / ns); continue; }
+        t -= n_stage;
+        if (t < n_lead) { fin_lead<P, SC, S>(kp, cx, t); continue; }
+        t -= n_lead;
+        if (t < n_path) {
+            const int64_t i = slot_index(kp, cx, t);
+            if (i >= 0 && i < kp.L.N) fin_path<P>(kp, cx.rec + t * kp.R.stride, slot_tau(cx, t, 0));
+            continue;
         }
+        fin_path<P>(kp, cx.rec + kp.edge_fp * kp.R.stride, final_tau(cx));
     }
 }
 
-template <class P, int SC>
+template <class P, int SC, int S>
 CTD_HD void phase_fin2(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     if (SC == SC_TRAPEZE && !cx.is_edge)
-        for (int k = tid; k < cx.nslots; k += nthr) finalize_trapeze_step<P>(kp, cx, k);
+        for (int k = tid; k < cx.nslots; k += nthr) fin_trapeze_step<P>(kp, cx, k);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -542,7 +662,91 @@ CTD_HD double eval_code(const KParams& kp, const double* rec_c, const double* re
     return coef * data + beta;
 }
 
-template <class P, int SC>
+// Streams E = nsteps * period step-periodic outputs to out[0 .. E) with 16-byte stores (two consecutive entries per
+// lane: 8-byte-per-lane stores are issue-bound at about half the chip's write bandwidth).  Entry e = s * period + k comes
+// from the record of slot (slot0 + s) through code(k).  A lane owns a fixed PAIR position inside the pair period
+// (period entries when period is even, 2 * period when odd), so its two codes are decoded once into registers and the
+// loop over steps only does 4 LDS reads, 2 multiply-adds and one store.  An odd 8-byte element in front of / behind the
+// 16-byte aligned body is written by lane 0 / the owner of the last pair.
+template <class CodeFn>
+CTD_HD void emit_stream(const KParams& kp, const BlockCtx& cx, double* out, int E, int period, int slot0, CodeFn code,
+                        int tid, int nthr) {
+    if (E <= 0) return;
+    const RecLayout& R = kp.R;
+    const int stride = R.stride;
+    auto value = [&](uint32_t c, int slot) -> double {
+        const double* rc = cx.rec + (slot - code_crec(c)) * stride;
+        const double* rd = cx.rec + (slot - code_drec(c)) * stride;
+        const int bt = code_beta(c);
+        return rc[R.oC + code_ci(c)] * rd[code_di(c)] + (bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0));
+    };
+    const int off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 1);   // 1: out[0] is not 16-byte aligned
+    if (off && tid == 0) out[0] = value(code(0), slot0);
+    const int npairs = (E - off) >> 1;
+    const bool tail = ((E - off) & 1) != 0;
+    const int pd = (period & 1) ? 2 * period : period;     // entries after which the (k0, k1) pattern of a pair repeats
+    const int pp = pd >> 1;                                // pairs per pattern period
+    const int sp = pd / period;                            // steps per pattern period (1 or 2)
+    const int par = nthr / pp;                             // pattern periods in flight
+    if (par >= 1) {
+        if (tid < par * pp) {
+            const int g = tid / pp, j = tid - g * pp;
+            const int e0 = off + 2 * j;                    // first entry of the lane's pair inside a period
+            const int s0 = e0 / period, k0 = e0 - s0 * period;
+            const int e1 = e0 + 1;
+            const int s1 = e1 / period, k1 = e1 - s1 * period;
+            const uint32_t c0 = code(k0), c1 = code(k1);
+            const int bt0 = code_beta(c0), bt1 = code_beta(c1);
+            const double beta0 = bt0 == 0 ? 0.0 : (bt0 == 1 ? 1.0 : -1.0);
+            const double beta1 = bt1 == 0 ? 0.0 : (bt1 == 1 ? 1.0 : -1.0);
+            const int base = slot0 + g * sp;
+            const double* pc0 = cx.rec + (base + s0 - code_crec(c0)) * stride + R.oC + code_ci(c0);
+            const double* pd0 = cx.rec + (base + s0 - code_drec(c0)) * stride + code_di(c0);
+            const double* pc1 = cx.rec + (base + s1 - code_crec(c1)) * stride + R.oC + code_ci(c1);
+            const double* pd1 = cx.rec + (base + s1 - code_drec(c1)) * stride + code_di(c1);
+            const int adv = par * sp * stride;
+            double* o = out + e0 + g * pd;
+            const int oadv = par * pd;
+            int p = j + g * pp;                            // global pair index
+#pragma unroll 4
+            for (; p < npairs; p += par * pp, pc0 += adv, pd0 += adv, pc1 += adv, pd1 += adv, o += oadv) {
+                const double v0 = (*pc0) * (*pd0) + beta0;
+                const double v1 = (*pc1) * (*pd1) + beta1;
+                CTD_STORE2(o, v0, v1);
+            }
+            if (tail && p == npairs) *o = (*pc0) * (*pd0) + beta0;      // last, unpaired entry of the stream
+        }
+    } else {
+        // long periods (more pairs than lanes): a lane owns pair positions j, j + nthr, ... and walks the periods
+        const int nper = (npairs + pp - 1) / pp;
+        for (int j = tid; j < pp; j += nthr) {
+            const int e0 = off + 2 * j;
+            const int s0 = e0 / period, k0 = e0 - s0 * period;
+            const int e1 = e0 + 1;
+            const int s1 = e1 / period, k1 = e1 - s1 * period;
+            const uint32_t c0 = code(k0), c1 = code(k1);
+            const int bt0 = code_beta(c0), bt1 = code_beta(c1);
+            const double beta0 = bt0 == 0 ? 0.0 : (bt0 == 1 ? 1.0 : -1.0);
+            const double beta1 = bt1 == 0 ? 0.0 : (bt1 == 1 ? 1.0 : -1.0);
+            const double* pc0 = cx.rec + (slot0 + s0 - code_crec(c0)) * stride + R.oC + code_ci(c0);
+            const double* pd0 = cx.rec + (slot0 + s0 - code_drec(c0)) * stride + code_di(c0);
+            const double* pc1 = cx.rec + (slot0 + s1 - code_crec(c1)) * stride + R.oC + code_ci(c1);
+            const double* pd1 = cx.rec + (slot0 + s1 - code_drec(c1)) * stride + code_di(c1);
+            const int adv = sp * stride;
+            double* o = out + e0;
+            int p = j;
+#pragma unroll 4
+            for (int q = 0; q < nper && p < npairs; ++q, p += pp, pc0 += adv, pd0 += adv, pc1 += adv, pd1 += adv, o += pd) {
+                const double v0 = (*pc0) * (*pd0) + beta0;
+                const double v1 = (*pc1) * (*pd1) + beta1;
+                CTD_STORE2(o, v0, v1);
+            }
+            if (tail && p == npairs) *o = (*pc0) * (*pd0) + beta0;
+        }
+    }
+}
+
+template <class P, int SC, int S>
 CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     const Layout& L = kp.L;
     const RecLayout& R = kp.R;
@@ -550,8 +754,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
         for (int e = kp.edge_begin + tid; e < kp.edge_end; e += nthr) {
             const uint32_t code = kp.edge_code[e];
             const int64_t idx = kp.edge_idx[e];
-            const double val = eval_code(kp, cx.rec + (int64_t)code_crec(code) * R.stride,
-                                         cx.rec + (int64_t)code_drec(code) * R.stride, code);
+            const double val = eval_code(kp, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);
             if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
             else if (kp.vals) kp.vals[idx] = val;
         }
@@ -559,16 +762,54 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     }
     const int nsteps = (int)(cx.b - cx.a);
     const int slot0 = (int)(cx.a - cx.lo);
+#if CTD_EMIT_PAIRS
+    // (A) constraint rows of the tile: c[a*cb .. b*cb): entry (s, r) = record(s).R[r]
+    if (kp.c) {
+        const int oR = R.oR;
+        emit_stream(kp, cx, kp.c + cx.a * (int64_t)L.cb, nsteps * L.cb, L.cb, slot0,
+                    [oR](int k) { return pack_code(oR + k, C_ONE, 0, 0, 0); }, tid, nthr);
+    }
+    if (!kp.vals) return;
+    // (B) step-periodic CSC segments of the regular steps of the tile
+    {
+        const int64_t ra = cx.a > kp.reg_first ? cx.a : kp.reg_first;
+        const int64_t rb = cx.b < kp.reg_last ? cx.b : kp.reg_last;
+        if (rb > ra) {
+            const uint32_t* tmpl = kp.tmpl;
+            emit_stream(kp, cx, kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)kp.Lseg, (int)(rb - ra) * kp.Lseg,
+                        kp.Lseg, (int)(ra - cx.lo), [tmpl](int k) { return tmpl[k]; }, tid, nthr);
+        }
+    }
+    // (C) the tile's slice of every V column
+    if (kp.vr > 0) {
+        for (int kk = 0; kk < P::NV; ++kk) {
+            const uint32_t* codes = kp.vtmpl + kk * kp.vr;
+            emit_stream(kp, cx, kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr, nsteps * kp.vr, kp.vr, slot0,
+                        [codes](int k) { return codes[k]; }, tid, nthr);
+        }
+    }
+#else
+    const int stride = R.stride;
+    // Every output stream of the tile is step-periodic with a small period (cb rows, Lseg CSC entries, vr entries of a
+    // V column).  A lane owns ONE position k of the period (its code is decoded once, into registers) and walks the
+    // steps; with period <= nthr, floor(nthr / period) steps are in flight at a time and lane -> address is the identity
+    // inside each pass (fully coalesced 8-byte stores); with period > nthr a lane owns positions k, k + nthr, ...
     // (A) constraint rows of the tile: c[a*cb .. b*cb)
     if (kp.c) {
-        const int total = nsteps * L.cb;
-        double* out = kp.c + cx.a * (int64_t)L.cb;
-        int s = tid / L.cb, r = tid - s * L.cb;
-        const int ds = nthr / L.cb, dr = nthr - ds * L.cb;
-        for (int e = tid; e < total; e += nthr) {
-            out[e] = cx.rec[(int64_t)(slot0 + s) * R.stride + R.oR + r];
-            s += ds; r += dr;
-            if (r >= L.cb) { r -= L.cb; s += 1; }
+        const int cb = L.cb;
+        double* out = kp.c + cx.a * (int64_t)cb;
+        const int par = nthr / cb;
+        if (par >= 1) {
+            if (tid < par * cb) {
+                const int g = tid / cb, r = tid - g * cb;
+                const double* src = cx.rec + (slot0 + g) * stride + R.oR + r;
+                for (int s = g; s < nsteps; s += par, src += par * stride) out[s * cb + r] = *src;
+            }
+        } else {
+            for (int r = tid; r < cb; r += nthr) {
+                const double* src = cx.rec + slot0 * stride + R.oR + r;
+                for (int s = 0; s < nsteps; ++s, src += stride) out[s * cb + r] = *src;
+            }
         }
     }
     if (!kp.vals) return;
@@ -578,38 +819,92 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
         const int64_t rb = cx.b < kp.reg_last ? cx.b : kp.reg_last;
         if (rb > ra) {
             const int Ls = kp.Lseg;
-            const int total = (int)(rb - ra) * Ls;
+            const int nreg = (int)(rb - ra);
             double* out = kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)Ls;
             const int sl0 = (int)(ra - cx.lo);
-            int s = tid / Ls, k = tid - s * Ls;
-            const int ds = nthr / Ls, dk = nthr - ds * Ls;
-            for (int e = tid; e < total; e += nthr) {
-                const uint32_t code = kp.tmpl[k];
-                const double* rc = cx.rec + (int64_t)(sl0 + s - code_crec(code)) * R.stride;
-                const double* rd = cx.rec + (int64_t)(sl0 + s - code_drec(code)) * R.stride;
-                out[e] = eval_code(kp, rc, rd, code);
-                s += ds; k += dk;
-                if (k >= Ls) { k -= Ls; s += 1; }
+            const int par = nthr / Ls;
+            // inner loops: uniform trip count and batches of 4 steps, so the 8 LDS reads of a batch are independent
+            // and in flight together (reads past the last step are clamped, only the store is predicated)
+            if (par >= 1) {
+                if (tid < par * Ls) {
+                    const int g = tid / Ls, k = tid - g * Ls;
+                    const uint32_t code = kp.tmpl[k];
+                    const int bt = code_beta(code);
+                    const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
+                    const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
+                    const double* pd = cx.rec + (sl0 - code_drec(code)) * stride + code_di(code);
+                    const int last = nreg - 1;
+                    for (int s0 = g; s0 < nreg; s0 += 4 * par) {
+                        double a[4], b[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int s = s0 + u * par < last ? s0 + u * par : last;
+                            a[u] = pc[s * stride];
+                            b[u] = pd[s * stride];
+                        }
+                        if (kp.debug_stop == 5) {          // ablation: LDS reads + arithmetic, no stores
+                            if (a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] == 1.2345e300) out[k] = beta;
+                            continue;
+                        }
+                        if (kp.debug_stop == 6) { a[0] = a[1] = a[2] = a[3] = 1.0; b[0] = b[1] = b[2] = b[3] = 2.0; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int s = s0 + u * par;
+                            if (s < nreg) out[s * Ls + k] = a[u] * b[u] + beta;
+                        }
+                    }
+                }
+            } else {
+                for (int k = tid; k < Ls; k += nthr) {
+                    const uint32_t code = kp.tmpl[k];
+                    const int bt = code_beta(code);
+                    const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
+                    const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
+                    const double* pd = cx.rec + (sl0 - code_drec(code)) * stride + code_di(code);
+                    const int last = nreg - 1;
+                    for (int s0 = 0; s0 < nreg; s0 += 4) {
+                        double a[4], b[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int s = s0 + u < last ? s0 + u : last;
+                            a[u] = pc[s * stride];
+                            b[u] = pd[s * stride];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (s0 + u < nreg) out[(s0 + u) * Ls + k] = a[u] * b[u] + beta;
+                    }
+                }
             }
         }
     }
     // (C) the tile's slice of every V column
     if (kp.vr > 0) {
         const int vr = kp.vr;
-        const int total = nsteps * vr;
+        const int par = nthr / vr;
         for (int kk = 0; kk < P::NV; ++kk) {
             double* out = kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)vr;
             const uint32_t* codes = kp.vtmpl + kk * vr;
-            int s = tid / vr, k = tid - s * vr;
-            const int ds = nthr / vr, dk = nthr - ds * vr;
-            for (int e = tid; e < total; e += nthr) {
-                const double* rr = cx.rec + (int64_t)(slot0 + s) * R.stride;
-                out[e] = eval_code(kp, rr, rr, codes[k]);
-                s += ds; k += dk;
-                if (k >= vr) { k -= vr; s += 1; }
+            if (par >= 1) {
+                if (tid < par * vr) {
+                    const int g = tid / vr, k = tid - g * vr;
+                    const uint32_t code = codes[k];
+                    const double* pc = cx.rec + (slot0 + g) * stride + R.oC + code_ci(code);
+                    const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);
+                    const int adv = par * stride;
+                    for (int s = g; s < nsteps; s += par, pc += adv, pd += adv) out[s * vr + k] = (*pc) * (*pd);
+                }
+            } else {
+                for (int k = tid; k < vr; k += nthr) {
+                    const uint32_t code = codes[k];
+                    const double* pc = cx.rec + slot0 * stride + R.oC + code_ci(code);
+                    const double* pd = cx.rec + slot0 * stride + code_di(code);
+                    for (int s = 0; s < nsteps; ++s, pc += stride, pd += stride) out[s * vr + k] = (*pc) * (*pd);
+                }
             }
         }
     }
+#endif
 }
 
 }  // namespace ctd

@@ -12,22 +12,46 @@ namespace ctd {
 
 // Fused constraints + sparse Jacobian values.  One workgroup = one tile of time steps (block 0 = edge block when
 // kp.has_edge).  Dynamic LDS = lds_doubles(kp) * 8 bytes.
-template <class P, int SC>
+__device__ __forceinline__ void ctd_stamp(const KParams& kp, int slot) {
+    if (kp.stamps && threadIdx.x == 0) {
+        unsigned long long* p = kp.stamps + ((size_t)blockIdx.x * 6 + slot) * 2;
+        p[0] = wall_clock64();   // constant 100 MHz counter, comparable across workgroups
+        p[1] = clock64();        // shader cycles
+    }
+}
+
+template <class P, int SC, int S>
 __global__ void __launch_bounds__(256) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
     extern __shared__ double ctd_lds[];
+    ctd_stamp(kp, 0);
+    if (kp.debug_stop == 1) return;
     const BlockCtx cx = make_ctx(kp, (int)blockIdx.x, ctd_lds);
     const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
-    phase_load<P, SC>(kp, cx, xu, tid, nthr);
+    phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
     __syncthreads();
-    phase_eval<P, SC>(kp, cx, tid, nthr);
+    ctd_stamp(kp, 1);
+    if (kp.debug_stop == 2) return;
+    phase_eval<P, SC, S>(kp, cx, tid, nthr);
     __syncthreads();
-    phase_fin<P, SC>(kp, cx, tid, nthr);
-    __syncthreads();
-    if (SC == SC_TRAPEZE) {
-        phase_fin2<P, SC>(kp, cx, tid, nthr);
+    ctd_stamp(kp, 2);
+    if (kp.debug_stop == 3) return;
+    if (!Dirs<P>::FUSED) {
+        phase_fin<P, SC, S>(kp, cx, tid, nthr);
         __syncthreads();
     }
-    phase_emit<P, SC>(kp, cx, tid, nthr);
+    if (SC == SC_TRAPEZE) {
+        phase_fin2<P, SC, S>(kp, cx, tid, nthr);
+        __syncthreads();
+    }
+    ctd_stamp(kp, 3);
+    if (kp.debug_stop == 4) return;
+    phase_emit<P, SC, S>(kp, cx, tid, nthr);
+    ctd_stamp(kp, 4);
+    if (kp.stamps) {             // diagnostics: time until this workgroup's stores have left the CU
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        ctd_stamp(kp, 5);
+    }
 }
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
@@ -128,42 +152,52 @@ __global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__
     op.out[0] = mayer + s;
 }
 
-// ---- launchers (explicitly instantiated per problem) ------------------------------------------------------------
-// e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel (hipExtLaunchKernelGGL),
-// so hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
+// ---- launchers ---------------------------------------------------------------------------------------------------
+// Defined here as templates; each per-problem translation unit (ctd_kern_*.hip) explicitly instantiates them for one
+// OCP so the registry compiles in parallel, and ctd_engine.hip only sees `extern template` declarations.
+// Five kernel variants per OCP: (trapeze), (midpoint), (Gauss-Legendre s = 1, 2, 3); the stage count is a template
+// parameter so every loop over stages unrolls.
+template <class P, int SC, int S>
+hipError_t launch_variant(const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
+                          hipEvent_t e0, hipEvent_t e1) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    // e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel, so
+    // hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
+    if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
+    else cons_jac_kernel<P, SC, S><<<grid, block, lds_bytes, st>>>(kp, xu);
+    return hipGetLastError();
+}
+
 template <class P>
 hipError_t launch_cons_jac(int sc, const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
-                           hipEvent_t e0, hipEvent_t e1);
-template <class P>
-hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st);
+                           hipEvent_t e0, hipEvent_t e1) {
+    if (sc == SC_TRAPEZE) return launch_variant<P, SC_TRAPEZE, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    if (sc == SC_MIDPOINT) return launch_variant<P, SC_MIDPOINT, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    if (kp.L.s == 1) return launch_variant<P, SC_IRK, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    if (kp.L.s == 2) return launch_variant<P, SC_IRK, 2>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    return launch_variant<P, SC_IRK, 3>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+}
 
-#define CTD_DEFINE_LAUNCHERS(P)                                                                                          \
-    template <> hipError_t launch_cons_jac<P>(int sc, const KParams& kp, const double* xu, int grid, int block,          \
-                                              size_t lds_bytes, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {          \
-        if (lds_bytes > 64 * 1024) {                                                                                     \
-            hipError_t e = hipSuccess;                                                                                   \
-            if (sc == SC_TRAPEZE) e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_TRAPEZE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            else if (sc == SC_MIDPOINT) e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_MIDPOINT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            else e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC_IRK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            if (e != hipSuccess) return e;                                                                               \
-        }                                                                                                                \
-        if (e0 || e1) {                                                                                                  \
-            if (sc == SC_TRAPEZE) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_TRAPEZE>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
-            else if (sc == SC_MIDPOINT) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_MIDPOINT>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
-            else hipExtLaunchKernelGGL((cons_jac_kernel<P, SC_IRK>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu); \
-            return hipGetLastError();                                                                                    \
-        }                                                                                                                \
-        if (sc == SC_TRAPEZE) cons_jac_kernel<P, SC_TRAPEZE><<<grid, block, lds_bytes, st>>>(kp, xu);                    \
-        else if (sc == SC_MIDPOINT) cons_jac_kernel<P, SC_MIDPOINT><<<grid, block, lds_bytes, st>>>(kp, xu);             \
-        else cons_jac_kernel<P, SC_IRK><<<grid, block, lds_bytes, st>>>(kp, xu);                                         \
-        return hipGetLastError();                                                                                        \
-    }                                                                                                                    \
-    template <> hipError_t launch_obj<P>(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st) { \
-        if (sc == SC_TRAPEZE) obj_partial_kernel<P, SC_TRAPEZE><<<grid, block, 0, st>>>(op, xu);                         \
-        else if (sc == SC_MIDPOINT) obj_partial_kernel<P, SC_MIDPOINT><<<grid, block, 0, st>>>(op, xu);                  \
-        else obj_partial_kernel<P, SC_IRK><<<grid, block, 0, st>>>(op, xu);                                              \
-        obj_finish_kernel<P><<<1, 64, 0, st>>>(op, xu);                                                                  \
-        return hipGetLastError();                                                                                        \
-    }
+template <class P>
+hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st) {
+    if (sc == SC_TRAPEZE) obj_partial_kernel<P, SC_TRAPEZE><<<grid, block, 0, st>>>(op, xu);
+    else if (sc == SC_MIDPOINT) obj_partial_kernel<P, SC_MIDPOINT><<<grid, block, 0, st>>>(op, xu);
+    else obj_partial_kernel<P, SC_IRK><<<grid, block, 0, st>>>(op, xu);
+    obj_finish_kernel<P><<<1, 64, 0, st>>>(op, xu);
+    return hipGetLastError();
+}
+
+#define CTD_INSTANTIATE_LAUNCHERS(P)                                                                                       \
+    template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, \
+                                           hipEvent_t);                                                                    \
+    template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
+#define CTD_EXTERN_LAUNCHERS(P)                                                                                            \
+    extern template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t,      \
+                                                  hipEvent_t, hipEvent_t);                                                 \
+    extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
 
 }  // namespace ctd

@@ -129,6 +129,12 @@ struct KParams {
     // outputs (global indexing); either may be null
     double* c;
     double* vals;
+    // diagnostics only (ctd_debug_stamps): when non-null, lane 0 of every workgroup stores 6 x {realtime, cycle}
+    // stamps at the phase boundaries; null in every normal launch
+    unsigned long long* stamps;
+    // diagnostics only (env CTD_DEBUG_STOP): 0 = normal; k > 0: every workgroup returns after phase k (1 nothing, 2 load,
+    // 3 eval, 4 fin) -- ablation timing, outputs are then incomplete
+    int32_t debug_stop;
 };
 
 }  // namespace ctd

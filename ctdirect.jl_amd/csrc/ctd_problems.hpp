@@ -17,6 +17,13 @@
 #include <vector>
 #include "ctd_common.hpp"
 
+// dual directions evaluated per pass by one lane (per-problem default; -DCTD_DC_OVERRIDE=k for tuning experiments)
+#ifdef CTD_DC_OVERRIDE
+#define CTD_DC(dflt) (CTD_DC_OVERRIDE)
+#else
+#define CTD_DC(dflt) (dflt)
+#endif
+
 namespace ctd {
 
 struct BoxItem { int index; double lb, ub; };   // (lb, index, ub) triplets, src/DOCP_variables.jl:88-98
@@ -48,7 +55,7 @@ struct GoddardOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 4;                     // dual directions per pass
+    static constexpr int DC = CTD_DC(4);                     // dual directions per pass
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     // xdot = F0(x) + u F1(x)   (goddard.jl:7-16, :44)
@@ -84,7 +91,7 @@ struct GoddardAllOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = true;
-    static constexpr int DC = 4;
+    static constexpr int DC = CTD_DC(4);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // f! :127-132
@@ -123,7 +130,7 @@ struct DoubleIntegratorPathOCP {
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 3;
+    static constexpr int DC = CTD_DC(3);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 2.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -154,7 +161,7 @@ struct QuadrotorOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 4;
+    static constexpr int DC = CTD_DC(4);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // :20-40
@@ -210,7 +217,7 @@ struct Quadrotor12OCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 4;
+    static constexpr int DC = CTD_DC(4);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -271,7 +278,7 @@ struct StagewiseScalarOCP {
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 2;
+    static constexpr int DC = CTD_DC(2);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T*, const T* u, const T*) { dx[0] = u[0]; }
@@ -294,7 +301,7 @@ struct EstimateInitialConditionOCP {                                            
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 2;
+    static constexpr int DC = CTD_DC(2);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 3.14159265358979323846 / 2; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -314,7 +321,7 @@ struct EstimateRotationRateOCP {                                                
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = true, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 3;
+    static constexpr int DC = CTD_DC(3);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T* v) {
@@ -339,7 +346,7 @@ struct LeastSquaresConstraintOCP {                                              
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 2;
+    static constexpr int DC = CTD_DC(2);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -365,7 +372,7 @@ struct DoubleIntegratorFreeT0TfOCP {
     static constexpr int IT0 = 0, ITF = 1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
-    static constexpr int DC = 3;
+    static constexpr int DC = CTD_DC(3);
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) { dx[0] = x[1]; dx[1] = u[0]; }

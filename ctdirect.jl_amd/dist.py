@@ -76,5 +76,17 @@ class ShardedDOCP:
         stitch_constraints(c, self.N, self.cb, self.world, self.rank, self.group)
         return c, vals
 
+    def bind_cons_jac(self, x, c, vals):
+        """Zero-argument callable: enqueue this rank's evaluation, then stitch c (same as cons_jac, pointers pre-bound)."""
+        launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
+        if self.world == 1:
+            return launch
+        N, cb, world, rank, group = self.N, self.cb, self.world, self.rank, self.group
+
+        def call():
+            launch()
+            stitch_constraints(c, N, cb, world, rank, group)
+        return call
+
     def obj(self, x):
         return reduce_objective(self.docp.obj(x), self.group, device=x.device if hasattr(x, "device") else None)

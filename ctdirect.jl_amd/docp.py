@@ -238,6 +238,23 @@ class DOCP:
         self._ck(L.ctd_cons_jac(self._h, _dp(x), _dp(c), _dp(vals)))
         return c, vals
 
+    def bind_cons_jac(self, x, c, vals, sync=False):
+        """Pre-binds the device pointers of (x, c, vals) and returns a zero-argument callable that enqueues one fused
+        evaluation -- the per-iteration path of a GPU-resident solver loop, without the Python argument checks."""
+        L = _lib.lib()
+        fn = L.ctd_cons_jac_dev if sync else L.ctd_cons_jac_dev_async
+        h = self._h
+        px = self._dev_ptr(x, self.dim_NLP_variables, "x")
+        pc = self._dev_ptr(c, self.dim_NLP_constraints, "c")
+        pv = self._dev_ptr(vals, self.nnzj, "vals")
+        ck = self._ck
+
+        def call():
+            st = fn(h, px, pc, pv)
+            if st:
+                ck(st)
+        return call
+
     def cons(self, x, c=None):
         """cons!(nlp, x, c) = __constraints!(c, x, docp); returns c (the reference's closure must return c too)."""
         L = _lib.lib()
@@ -294,6 +311,16 @@ class DOCP:
                                                   self._dev_ptr(c, self.dim_NLP_constraints, "c"),
                                                   self._dev_ptr(vals, self.nnzj, "vals"), int(iters), C.byref(ms)))
         return ms.value
+
+    def debug_stamps(self, x, c, vals):
+        """Diagnostics: per-workgroup phase stamps of one launch, array [grid, 6, 2] (realtime 100 MHz, shader cycles)."""
+        grid = self.launch_info()["grid"]
+        out = np.zeros(grid * 12, dtype=np.uint64)
+        self._ck(_lib.lib().ctd_debug_stamps(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                             self._dev_ptr(c, self.dim_NLP_constraints, "c"),
+                                             self._dev_ptr(vals, self.nnzj, "vals"),
+                                             out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        return out.reshape(grid, 6, 2)
 
     def jac_structure(self):
         """jac_structure!(nlp, rows, cols): 1-based COO in CSC order."""

@@ -17,18 +17,18 @@
 
 using namespace ctd;
 
-template <class P, int SC>
+template <class P, int SC, int S>
 static void run_blocks(const KParams& kp, const double* xu, int nthr) {
     const int nblocks = kp.ntiles + (kp.has_edge ? 1 : 0);
     const int64_t nlds = lds_doubles(kp);
     for (int b = 0; b < nblocks; ++b) {
         std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
         BlockCtx cx = make_ctx(kp, b, lds.data());
-        for (int t = 0; t < nthr; ++t) phase_load<P, SC>(kp, cx, xu, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_eval<P, SC>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_fin<P, SC>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_fin2<P, SC>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_emit<P, SC>(kp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_load<P, SC, S>(kp, cx, xu, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_fin2<P, SC, S>(kp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr);
     }
 }
 
@@ -86,9 +86,13 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {
-            case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE>(kp, x, nthr); break;
-            case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT>(kp, x, nthr); break;
-            default: run_blocks<P, SC_IRK>(kp, x, nthr); break;
+            case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE, 1>(kp, x, nthr); break;
+            case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT, 1>(kp, x, nthr); break;
+            default:
+                if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, x, nthr);
+                else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, x, nthr);
+                else run_blocks<P, SC_IRK, 3>(kp, x, nthr);
+                break;
         }
     });
     return ok ? 0 : 5;
