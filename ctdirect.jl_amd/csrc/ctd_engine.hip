@@ -39,6 +39,7 @@ struct ctd_handle {
     bool own_stream = false;
     int64_t step_begin = 0, step_end = 0;
     int tile = 0, block = 256;
+    int pipe_mode = -1, pipe_occ = 0;
     KParams kp;                 // device pointers filled in, outputs set per call
     size_t lds_bytes = 0;
     int grid = 0;
@@ -139,12 +140,15 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         return fail(nullptr, CTD_EINVAL, "ctd_create: shard [step_begin, step_end) is not inside [0, N)");
     h->tile = env_int("CTD_TILE", 0);
     if (h->tile <= 0) h->tile = default_tile(mo);
+    int maxb = 256;
+    for_problem(mo.problem, [&](auto tag) { maxb = decltype(tag)::type::MAXB; });
     h->block = env_int("CTD_BLOCK", 256);
-    if (h->block < 64 || h->block > 256 || (h->block % 64)) h->block = 256;
+    if (h->block < 64 || (h->block % 64)) h->block = 256;
+    if (h->block > maxb) h->block = maxb;
     mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
     h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
     const int debug_stop = env_int("CTD_DEBUG_STOP", 0);
-    while (h->lds_bytes > 64 * 1024 && h->tile > 1) {      // a requested tile that does not fit is shrunk, not rejected
+    while (h->lds_bytes > 80 * 1024 && h->tile > 1) {      // a requested tile that does not fit (2 workgroups / CU) is shrunk, not rejected
         h->tile = (h->tile + 1) / 2;
         mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
         h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
@@ -152,6 +156,9 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
     h->kp.debug_stop = debug_stop;
     h->device = desc->device;
+    // 0 classic driver (default: on MI355X the pipelined driver measured within 1 us of it, profiles/r01_pipeline.md),
+    // 1 pipelined driver, -1 automatic choice (pipelined for Gauss-Legendre grids with >= 3 sub-tiles per workgroup)
+    h->pipe_mode = env_int("CTD_PIPE", 0);
     if (h->device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || h->device >= ndev)
@@ -176,6 +183,33 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         HIP_TRY(nullptr, hipMalloc((void**)&hp->d_obj, sizeof(double)));
         HIP_TRY(nullptr, hipEventCreate(&hp->ev0));
         HIP_TRY(nullptr, hipEventCreate(&hp->ev1));
+        // pipelined driver: sub-tiles of Ts steps, as many chunks as workgroups are resident at once
+        if (hp->pipe_mode != 0 && hp->block >= 128) {
+            KParams pk = hp->kp;
+            pk.pipe_Ts = env_int("CTD_PIPE_TS", 0);
+            if (pk.pipe_Ts <= 0) pk.pipe_Ts = default_pipe_tile(mo);
+            const size_t plds = (size_t)pipe_lds_doubles(pk) * sizeof(double);
+            int occ = 0, ncu = 0;
+            for_problem(mo.problem, [&](auto tag) { occ = pipe_occupancy<typename decltype(tag)::type>(mo.L.sc, mo.L.s, hp->block, plds); });
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, hp->device) == hipSuccess) ncu = prop.multiProcessorCount;
+            const int64_t nsteps = hp->step_end - hp->step_begin;
+            const int64_t nsub = (nsteps + pk.pipe_Ts - 1) / pk.pipe_Ts;
+            int64_t capacity = (int64_t)occ * ncu;
+            if (capacity < 1) capacity = 1;
+            const int64_t nchunks0 = nsub < capacity ? nsub : capacity;
+            const int64_t subs_per_chunk = (nsub + nchunks0 - 1) / nchunks0;
+            pk.pipe_chunk = (int32_t)(subs_per_chunk * pk.pipe_Ts);
+            const int64_t nchunks = (nsteps + pk.pipe_chunk - 1) / pk.pipe_chunk;
+            const bool want = hp->pipe_mode == 1 || (hp->pipe_mode < 0 && mo.L.sc == SC_IRK && subs_per_chunk >= 3);
+            if (want && plds <= 160 * 1024 && occ > 0) {
+                hp->kp.pipe_Ts = pk.pipe_Ts;
+                hp->kp.pipe_chunk = pk.pipe_chunk;
+                hp->lds_bytes = plds;
+                hp->grid = (int)nchunks + (hp->kp.has_edge ? 1 : 0);
+                hp->pipe_occ = occ;
+            }
+        }
     }
     *out = h.release();
     return CTD_OK;
@@ -293,6 +327,7 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
     if (!h || !o) return CTD_EINVAL;
     o[0] = h->grid; o[1] = h->block; o[2] = (int64_t)h->lds_bytes; o[3] = h->tile; o[4] = h->model.Lseg;
     o[5] = (int64_t)h->model.edge_idx.size();
+    o[6] = h->kp.pipe_Ts; o[7] = h->kp.pipe_chunk;
     return CTD_OK;
 }
 

@@ -1,6 +1,7 @@
 // ctd_host.cpp -- host model: DOCP sizes, time grid, bounds, initial guess, Jacobian sparsity pattern (CSC) and the
 // emit tables of the kernels.  See ctd_host.hpp.
 #include "ctd_host.hpp"
+#include "ctd_kernel_body.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -609,6 +610,20 @@ int default_tile(const Model& mo) {
     return (int)T;
 }
 
+int default_pipe_tile(const Model& mo) {
+    const Layout& L = mo.L;
+    const int S = L.s > 0 ? L.s : 1;
+    const int lanes_per_step = S * mo.nch_dyn + mo.nch_path + (mo.fused ? 1 : 0);
+    int Ts = 1;
+    while (Ts * 2 <= 16 && (Ts * 2 + mo.HL + mo.HH) * lanes_per_step <= 64) Ts *= 2;
+    auto lds = [&](int t) {
+        const int64_t cap = t + mo.HL + mo.HH;
+        return (int64_t)8 * (kMaxNV + 3 * ((cap + 1) * L.blk + L.n + L.m) + 3 * (cap + 2) + 2 * cap * mo.R.stride);
+    };
+    while (Ts > 1 && lds(Ts) > 60 * 1024) Ts /= 2;
+    return Ts;
+}
+
 void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const {
     std::memset(&kp, 0, sizeof(kp));
     kp.L = L;
@@ -618,6 +633,9 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.step_begin = step_begin; kp.step_end = step_end;
     kp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
     kp.Lseg = Lseg; kp.vr = vr;
+    kp.div_cb = make_fastdiv((uint32_t)L.cb);
+    kp.div_Lseg = make_fastdiv((uint32_t)(Lseg > 0 ? Lseg : 1));
+    kp.div_vr = make_fastdiv((uint32_t)(vr > 0 ? vr : 1));
     kp.seg_base = seg_base; kp.reg_first = reg_first; kp.reg_last = reg_last;
     for (int k = 0; k < kMaxNV; ++k) kp.vcol_base[k] = vcol_base[k];
     const bool owns_first = step_begin == 0, owns_last = step_end == L.N;
@@ -640,6 +658,9 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.info = P::info();
         mo.dyn_t = P::DYN_T;
         mo.dyn_v = P::DYN_V;
+        mo.nch_dyn = Dirs<P>::NCH_DYN;
+        mo.nch_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+        mo.fused = Dirs<P>::FUSED;
     });
     if (!found) { err = "problem id not in the compiled registry"; return ST_EPROBLEM; }
     if (d.scheme < 0 || d.scheme > 6) { err = "Unknown discretization method"; return ST_ESCHEME; }

@@ -26,6 +26,9 @@ struct Model {
     Layout L;
     RecLayout R;
     bool dyn_t = false, dyn_v = false;
+    // lanes one step needs in the eval phase: dynamics passes per stage, path passes, fused lead lane (ctd_kernel_body.hpp Dirs<P>)
+    int nch_dyn = 1, nch_path = 0;
+    bool fused = true;
     // DOCPtime (src/DOCP_data.jl:147-152)
     bool uniform = true;
     std::vector<double> tau, fixed_grid;
@@ -64,5 +67,8 @@ int build_model(const HostDesc& d, Model& m, std::string& err);
 void model_initial_guess(const Model& m, double* x0, bool use_problem_default, const double* state, const double* control,
                          const double* variable);
 int default_tile(const Model& m);
+// sub-tile length of the pipelined driver: the producer is ONE wave, so Ts * (lanes per step) <= 64, and the three input
+// + two record buffers must fit ~60 KiB of LDS
+int default_pipe_tile(const Model& m);
 
 }  // namespace ctd

@@ -47,7 +47,15 @@ struct BlockCtx {
     double* v;         // optimisation variables
     double* tau;       // normalized times: tile: tau[k] = tau_{lo+k}, k <= nslots+1; edge: tau[2k], tau[2k+1], tau[2 ns] = tau_N
     double* rec;       // records
+    const uint32_t* codes;   // emit template of the step segment (Lseg codes): LDS copy when small, else the global table
+    const uint32_t* vcodes;  // V-column templates (nv * vr codes)
 };
+
+// doubles reserved at the start of the LDS for the emit templates (staged once per workgroup by load_codes)
+// (only small templates are staged: copying thousands of codes per workgroup costs more than the latency it hides)
+constexpr int kMaxStagedCodes = 1024;
+CTD_HD bool codes_staged(const KParams& kp) { return kp.Lseg + kp.L.nv * kp.vr <= kMaxStagedCodes; }
+CTD_HD int code_doubles(const KParams& kp) { return codes_staged(kp) ? (kp.Lseg + kp.L.nv * kp.vr + 1) / 2 : 0; }
 
 CTD_HD int64_t slot_index(const KParams& kp, const BlockCtx& cx, int k) {
     return cx.is_edge ? kp.edge_steps[k] : cx.lo + k;
@@ -56,6 +64,9 @@ CTD_HD int64_t slot_index(const KParams& kp, const BlockCtx& cx, int k) {
 CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     BlockCtx cx;
     const Layout& L = kp.L;
+    cx.codes = codes_staged(kp) ? reinterpret_cast<const uint32_t*>(lds) : kp.tmpl;
+    cx.vcodes = codes_staged(kp) ? cx.codes + kp.Lseg : kp.vtmpl;
+    lds += code_doubles(kp);
     if (kp.has_edge && block == 0) {
         cx.is_edge = 1;
         cx.nslots = kp.n_edge_slots;
@@ -82,12 +93,50 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     return cx;
 }
 
+// ---- pipelined driver: LDS = v | 3 input buffers | 3 tau buffers | 2 record buffers --------------------------------
+struct PipeGeom { int cap, in_sz, tau_sz, rec_sz; };
+CTD_HD PipeGeom pipe_geom(const KParams& kp) {
+    PipeGeom g;
+    g.cap = kp.pipe_Ts + kp.HL + kp.HH;
+    g.in_sz = (g.cap + 1) * kp.L.blk + kp.L.n + kp.L.m;
+    g.tau_sz = g.cap + 2;
+    g.rec_sz = g.cap * kp.R.stride;
+    return g;
+}
+// sub-tile q of the chunk [A, B): steps [A + q Ts, min(A + (q+1) Ts, B)), input buffer q % 3, record buffer q % 2
+CTD_HD BlockCtx make_sub_ctx(const KParams& kp, double* lds, int64_t A, int64_t B, int q) {
+    const PipeGeom g = pipe_geom(kp);
+    BlockCtx cx;
+    cx.codes = codes_staged(kp) ? reinterpret_cast<const uint32_t*>(lds) : kp.tmpl;
+    cx.vcodes = codes_staged(kp) ? cx.codes + kp.Lseg : kp.vtmpl;
+    lds += code_doubles(kp);
+    cx.is_edge = 0;
+    cx.a = A + (int64_t)q * kp.pipe_Ts;
+    cx.b = cx.a + kp.pipe_Ts < B ? cx.a + kp.pipe_Ts : B;
+    cx.lo = cx.a - kp.HL;
+    cx.nslots = (int)(cx.b - cx.a) + kp.HL + kp.HH;
+    cx.in_stride = kp.L.blk;
+    cx.v = lds;
+    cx.in = lds + kMaxNV + (q % 3) * g.in_sz;
+    cx.tau = lds + kMaxNV + 3 * g.in_sz + (q % 3) * g.tau_sz;
+    cx.rec = lds + kMaxNV + 3 * g.in_sz + 3 * g.tau_sz + (q & 1) * g.rec_sz;
+    return cx;
+}
+inline int64_t pipe_lds_doubles(const KParams& kp) {
+    const PipeGeom g = pipe_geom(kp);
+    const Layout& L = kp.L;
+    int64_t pipe = code_doubles(kp) + kMaxNV + 3 * (int64_t)g.in_sz + 3 * g.tau_sz + 2 * (int64_t)g.rec_sz;
+    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
+                   (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
+    return pipe > edge ? pipe : edge;
+}
+
 // LDS doubles a block needs (host uses this to size the launch)
 inline int64_t lds_doubles(const KParams& kp) {
     const Layout& L = kp.L;
     const int64_t cap = kp.T + kp.HL + kp.HH;
-    int64_t tile = (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
-    int64_t edge = (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
+    int64_t tile = code_doubles(kp) + (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
+    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
                    (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
     return tile > edge ? tile : edge;
 }
@@ -115,6 +164,13 @@ template <class P> CTD_HD double dtime_of(double tau, int k) {
     return dt0 + tau * (dtf - dt0);
 }
 
+// record layout of (OCP, scheme class, stages): a compile-time constant, so every LDS access of the kernels uses an
+// immediate offset (the host builds its emit codes from the same function, ctd_host.cpp)
+template <class P, int SC, int S> struct RL {
+    static constexpr int cb = (SC == SC_IRK ? P::NX * (1 + S) : P::NX) + P::NPATH;
+    static constexpr RecLayout R = make_rec_layout(P::NX, P::NU, P::NV, P::NPATH, P::NBC, SC == SC_IRK ? S : 0, cb);
+};
+
 template <class P> struct Dirs {
     static constexpr int DYN = P::NX + P::NU + (P::DYN_T ? 1 : 0) + (P::DYN_V ? P::NV : 0);
     static constexpr int PATH = P::NX + P::NU + (P::PATH_T ? 1 : 0) + (P::PATH_V ? P::NV : 0);
@@ -131,7 +187,17 @@ template <class P> struct Dirs {
 // ------------------------------------------------------------------------------------------------------
 // phase: load
 // ------------------------------------------------------------------------------------------------------
-template <class P, int SC, int S>
+// stage the emit templates in LDS (once per workgroup): the emit loops then start from an LDS read instead of a
+// dependent global load
+CTD_HD void load_codes(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+    if (!codes_staged(kp)) return;
+    uint32_t* dst = const_cast<uint32_t*>(cx.codes);
+    for (int e = tid; e < kp.Lseg; e += nthr) dst[e] = kp.tmpl[e];
+    const int nvc = kp.L.nv * kp.vr;
+    for (int e = tid; e < nvc; e += nthr) dst[kp.Lseg + e] = kp.vtmpl[e];
+}
+
+template <class P, int SC, int S, bool LOAD_V = true>
 CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __restrict__ xu, int tid, int nthr) {
     const Layout& L = kp.L;
     if (cx.is_edge) {
@@ -147,11 +213,15 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const int64_t g0 = (cx.lo < 0 ? 0 : cx.lo) * (int64_t)L.blk;
         int64_t g1 = (cx.lo + cx.nslots) * (int64_t)L.blk + L.n + L.m;
         if (g1 > L.v_off) g1 = L.v_off;
-        const int64_t shift = cx.lo * (int64_t)L.blk;
-        for (int64_t g = g0 + tid; g < g1; g += nthr) cx.in[g - shift] = xu[g];
+        // 32-bit lane-relative indices: the 64-bit part of the addresses is wave-uniform
+        const double* __restrict__ src = xu + g0;
+        double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
+        const int cnt = (int)(g1 - g0);
+        for (int e = tid; e < cnt; e += nthr) dst[e] = src[e];
         for (int e = tid; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
     }
-    if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
+    if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
+    if (LOAD_V && !cx.is_edge) load_codes(kp, cx, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -170,7 +240,7 @@ template <class P, int SC, int S>
 CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
     constexpr int n = P::NX, nv = P::NV;
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const int64_t i = slot_index(kp, cx, k);
     double* rec = cx.rec + k * R.stride;
     double* C = rec + R.oC;
@@ -214,7 +284,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
     constexpr int n = P::NX, nv = P::NV;
     constexpr bool FREE = Dirs<P>::FREE;
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0) return;
     if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
@@ -282,11 +352,45 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
     }
 }
 
+// One ROW r of fin_stage for Gauss-Legendre schemes, r a runtime lane parameter (LDS addresses only, no per-row code):
+// wide-state OCPs spread the n rows of a stage over n lanes instead of walking them serially.
+template <class P, int S>
+CTD_HD void fin_stage_row(const KParams& kp, const BlockCtx& cx, int k, int j, int r) {
+    constexpr int n = P::NX, nv = P::NV;
+    constexpr bool FREE = Dirs<P>::FREE;
+    constexpr RecLayout R = RL<P, SC_IRK, S>::R;
+    const Layout& L = kp.L;
+    const int64_t i = slot_index(kp, cx, k);
+    if (i < 0 || i >= L.N) return;
+    double* rec = cx.rec + k * R.stride;
+    double* ev = rec + R.oEval + j * R.eval_sz;
+    const double* K = cx.in + k * cx.in_stride + n + L.cu;
+    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    rec[R.oR + n + j * n + r] = K[j * n + r] - ev[R.of + r];
+#pragma unroll
+    for (int kk = 0; kk < nv; ++kk) {
+        const double dti = FREE ? dtime_of<P>(tau0, kk) : 0.0;
+        const double dh = FREE ? dtime_of<P>(tau1, kk) - dti : 0.0;
+        double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
+        if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (dti + L.c[j] * dh);
+        if (FREE) {
+#pragma unroll
+            for (int c = 0; c < n; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < S; ++l) acc = acc + (dh * L.a[3 * j + l]) * K[l * n + c];
+                w = w + ev[R.oF + r * n + c] * acc;
+            }
+        }
+        ev[R.oW + r * nv + kk] = w;
+    }
+}
+
 // path rows: total d/dv = explicit + dg/dt * dt/dv
-template <class P>
+template <class P, int SC, int S>
 CTD_HD void fin_path(const KParams& kp, double* rec, double tau) {
     constexpr int nv = P::NV, np = P::NPATH;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
 #pragma unroll
     for (int r = 0; r < np; ++r)
 #pragma unroll
@@ -302,7 +406,7 @@ template <class P>
 CTD_HD void fin_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
     constexpr int n = P::NX, nv = P::NV;
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC_TRAPEZE, 1>::R;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0 || i >= L.N || k + 1 >= cx.nslots) return;
     if (slot_index(kp, cx, k + 1) != i + 1) return;
@@ -351,7 +455,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
     using D = Dual<DC>;
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0) return;
     if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
@@ -439,12 +543,12 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
 }
 
 // path constraints g(t, x, u, v) on duals into record `rec`: stepPathConstraints!, DOCP_functions.jl:122-140
-template <class P>
+template <class P, int SC, int S>
 CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv, const double* uv, const double* vv, int q,
                       int value_off) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, DC = P::DC;
     using D = Dual<DC>;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     D X[n > 0 ? n : 1], U[m > 0 ? m : 1], V[nv > 0 ? nv : 1], Tt, out[np > 0 ? np : 1];
     const int g0 = q * DC;
     constexpr int gT = n + m, gV = n + m + (P::PATH_T ? 1 : 0);
@@ -497,6 +601,7 @@ CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv
 template <class P, int SC, int S>
 CTD_HD void eval_step_path(const KParams& kp, const BlockCtx& cx, int k, int q) {
     constexpr int n = P::NX, m = P::NU;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const Layout& L = kp.L;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0 || i >= L.N) return;
@@ -506,16 +611,17 @@ CTD_HD void eval_step_path(const KParams& kp, const BlockCtx& cx, int k, int q) 
     double xv[n > 0 ? n : 1];
 #pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[c];
-    double* rec = cx.rec + k * kp.R.stride;
+    double* rec = cx.rec + k * R.stride;
     const double tau = slot_tau(cx, k, 0);
-    eval_path<P>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, kp.R.oR + L.eqs);
-    if (Dirs<P>::FUSED) fin_path<P>(kp, rec, tau);
+    eval_path<P, SC, S>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR + L.eqs);
+    if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, rec, tau);
 }
 
 // path constraints at the final time (DOCP_functions.jl:100) with the convention u(tf) = U_N unless U_{N+1} exists
 template <class P, int SC, int S>
 CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
     constexpr int n = P::NX, m = P::NU;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const Layout& L = kp.L;
     const double* base = cx.in + kp.edge_slot_last * cx.in_stride;
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
@@ -525,19 +631,19 @@ CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[L.blk + n + c];
     } else node_control<P, S>(kp, base, uv);
-    double* rec = cx.rec + kp.edge_fp * kp.R.stride;
+    double* rec = cx.rec + kp.edge_fp * R.stride;
     const double tau = final_tau(cx);
-    eval_path<P>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, kp.R.oR);
-    if (Dirs<P>::FUSED) fin_path<P>(kp, rec, tau);
+    eval_path<P, SC, S>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR);
+    if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, rec, tau);
 }
 
 // boundary constraints phi(x0, xf, v) on duals: DOCP_functions.jl:103-111
-template <class P>
+template <class P, int SC, int S>
 CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
     constexpr int n = P::NX, nv = P::NV, nb = P::NBC, DC = P::DC;
     using D = Dual<DC>;
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const double* b0 = cx.in + kp.edge_slot_first * cx.in_stride;
     const double* bf = cx.in + kp.edge_slot_last * cx.in_stride + L.blk;
     D X0[n > 0 ? n : 1], XF[n > 0 ? n : 1], V[nv > 0 ? nv : 1], out[nb > 0 ? nb : 1];
@@ -583,36 +689,44 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
 template <class P, int SC, int S>
 CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     constexpr bool FUSED = Dirs<P>::FUSED;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
-    const int n_dyn = S * Dirs<P>::NCH_DYN * ns;
-    const int n_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH * ns : 0;
-    const int n_lead = FUSED ? ns : 0;               // coefficient / state-row lanes (fused mode)
+    // task = (role << lg) | slot with the slot count rounded up to a power of two: decoding is a shift and a mask, and
+    // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
+    // passes, one lead role (coefficients + state rows, fused mode); the edge block appends its few special tasks.
+    int lg = 0;
+    while ((1 << lg) < ns) ++lg;
+    const int mask = (1 << lg) - 1;
+    constexpr int r_dyn = S * Dirs<P>::NCH_DYN;
+    constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+    constexpr int r_lead = FUSED ? 1 : 0;
+    const int n_slot_tasks = (r_dyn + r_path + r_lead) << lg;
     int n_fp = 0, n_b = 0, n_aux = 0;
     if (cx.is_edge) {
         n_fp = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
         n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
         n_aux = 2;                                   // coefficients of the final-path and boundary records
     }
-    const int total = n_dyn + n_path + n_lead + n_fp + n_b + n_aux;
+    const int total = n_slot_tasks + n_fp + n_b + n_aux;
     for (int task = tid; task < total; task += nthr) {
-        int t = task;
-        if (t < n_dyn) {
-            // slot fastest: neighbouring lanes run the same (eval point, chunk) on neighbouring steps
-            const int k = t % ns, jq = t / ns;
-            const int j = jq / Dirs<P>::NCH_DYN, q = jq % Dirs<P>::NCH_DYN;
-            eval_dynamics<P, SC, S>(kp, cx, k, j, q);
-            if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j);
+        if (task < n_slot_tasks) {
+            const int k = task & mask, role = task >> lg;
+            if (k >= ns) continue;
+            if (role < r_dyn) {
+                const int j = role / Dirs<P>::NCH_DYN, q = role % Dirs<P>::NCH_DYN;
+                eval_dynamics<P, SC, S>(kp, cx, k, j, q);
+                if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j);
+            } else if (role < r_dyn + r_path) {
+                eval_step_path<P, SC, S>(kp, cx, k, role - r_dyn);
+            } else {
+                fin_lead<P, SC, S>(kp, cx, k);
+            }
             continue;
         }
-        t -= n_dyn;
-        if (t < n_path) { eval_step_path<P, SC, S>(kp, cx, t % ns, t / ns); continue; }
-        t -= n_path;
-        if (t < n_lead) { fin_lead<P, SC, S>(kp, cx, t); continue; }
-        t -= n_lead;
+        int t = task - n_slot_tasks;
         if (t < n_fp) { eval_final_path<P, SC, S>(kp, cx, t); continue; }
         t -= n_fp;
-        if (t < n_b) { eval_boundary<P>(kp, cx, t); continue; }
+        if (t < n_b) { eval_boundary<P, SC, S>(kp, cx, t); continue; }
         t -= n_b;
         fill_const_coefs<P>(kp, cx.rec + (t == 0 ? kp.edge_fp : kp.edge_b) * R.stride + R.oC);
     }
@@ -627,21 +741,28 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
 template <class P, int SC, int S>
 CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     if (Dirs<P>::FUSED) return;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
-    const int n_stage = S * ns, n_lead = ns, n_path = (P::NPATH > 0) ? ns : 0;
+    constexpr int rows = (SC == SC_IRK && P::NX > 4) ? P::NX : 1;    // rows of a stage per lane: 1 row each for wide states
+    const int n_stage = S * ns * rows, n_lead = ns, n_path = (P::NPATH > 0) ? ns : 0;
     const int n_fp = (cx.is_edge && P::NPATH > 0) ? 1 : 0;
     for (int task = tid; task < n_stage + n_lead + n_path + n_fp; task += nthr) {
         int t = task;
-        if (t < n_stage) { fin_stage<P, SC, S>(kp, cx, t % ns, t / ns); continue; }
+        if (t < n_stage) {
+            const int k = t % ns, jr = t / ns;
+            if (rows > 1) fin_stage_row<P, S>(kp, cx, k, jr / rows, jr % rows);
+            else fin_stage<P, SC, S>(kp, cx, k, jr);
+            continue;
+        }
         t -= n_stage;
         if (t < n_lead) { fin_lead<P, SC, S>(kp, cx, t); continue; }
         t -= n_lead;
         if (t < n_path) {
             const int64_t i = slot_index(kp, cx, t);
-            if (i >= 0 && i < kp.L.N) fin_path<P>(kp, cx.rec + t * kp.R.stride, slot_tau(cx, t, 0));
+            if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + t * R.stride, slot_tau(cx, t, 0));
             continue;
         }
-        fin_path<P>(kp, cx.rec + kp.edge_fp * kp.R.stride, final_tau(cx));
+        fin_path<P, SC, S>(kp, cx.rec + kp.edge_fp * R.stride, final_tau(cx));
     }
 }
 
@@ -654,8 +775,8 @@ CTD_HD void phase_fin2(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
 // ------------------------------------------------------------------------------------------------------
 // phase: emit
 // ------------------------------------------------------------------------------------------------------
-CTD_HD double eval_code(const KParams& kp, const double* rec_c, const double* rec_d, uint32_t code) {
-    const double coef = rec_c[kp.R.oC + code_ci(code)];
+CTD_HD double eval_code(int oC, const double* rec_c, const double* rec_d, uint32_t code) {
+    const double coef = rec_c[oC + code_ci(code)];
     const double data = rec_d[code_di(code)];
     const int bt = code_beta(code);
     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
@@ -669,10 +790,9 @@ CTD_HD double eval_code(const KParams& kp, const double* rec_c, const double* re
 // loop over steps only does 4 LDS reads, 2 multiply-adds and one store.  An odd 8-byte element in front of / behind the
 // 16-byte aligned body is written by lane 0 / the owner of the last pair.
 template <class CodeFn>
-CTD_HD void emit_stream(const KParams& kp, const BlockCtx& cx, double* out, int E, int period, int slot0, CodeFn code,
+CTD_HD void emit_stream(const RecLayout R, const BlockCtx& cx, double* out, int E, int period, int slot0, CodeFn code,
                         int tid, int nthr) {
     if (E <= 0) return;
-    const RecLayout& R = kp.R;
     const int stride = R.stride;
     auto value = [&](uint32_t c, int slot) -> double {
         const double* rc = cx.rec + (slot - code_crec(c)) * stride;
@@ -749,12 +869,12 @@ CTD_HD void emit_stream(const KParams& kp, const BlockCtx& cx, double* out, int 
 template <class P, int SC, int S>
 CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     const Layout& L = kp.L;
-    const RecLayout& R = kp.R;
+    constexpr RecLayout R = RL<P, SC, S>::R;
     if (cx.is_edge) {
         for (int e = kp.edge_begin + tid; e < kp.edge_end; e += nthr) {
             const uint32_t code = kp.edge_code[e];
             const int64_t idx = kp.edge_idx[e];
-            const double val = eval_code(kp, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);
+            const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);
             if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
             else if (kp.vals) kp.vals[idx] = val;
         }
@@ -766,7 +886,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     // (A) constraint rows of the tile: c[a*cb .. b*cb): entry (s, r) = record(s).R[r]
     if (kp.c) {
         const int oR = R.oR;
-        emit_stream(kp, cx, kp.c + cx.a * (int64_t)L.cb, nsteps * L.cb, L.cb, slot0,
+        emit_stream(R, cx, kp.c + cx.a * (int64_t)L.cb, nsteps * L.cb, L.cb, slot0,
                     [oR](int k) { return pack_code(oR + k, C_ONE, 0, 0, 0); }, tid, nthr);
     }
     if (!kp.vals) return;
@@ -775,16 +895,16 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
         const int64_t ra = cx.a > kp.reg_first ? cx.a : kp.reg_first;
         const int64_t rb = cx.b < kp.reg_last ? cx.b : kp.reg_last;
         if (rb > ra) {
-            const uint32_t* tmpl = kp.tmpl;
-            emit_stream(kp, cx, kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)kp.Lseg, (int)(rb - ra) * kp.Lseg,
+            const uint32_t* tmpl = cx.codes;
+            emit_stream(R, cx, kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)kp.Lseg, (int)(rb - ra) * kp.Lseg,
                         kp.Lseg, (int)(ra - cx.lo), [tmpl](int k) { return tmpl[k]; }, tid, nthr);
         }
     }
     // (C) the tile's slice of every V column
     if (kp.vr > 0) {
         for (int kk = 0; kk < P::NV; ++kk) {
-            const uint32_t* codes = kp.vtmpl + kk * kp.vr;
-            emit_stream(kp, cx, kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr, nsteps * kp.vr, kp.vr, slot0,
+            const uint32_t* codes = cx.vcodes + kk * kp.vr;
+            emit_stream(R, cx, kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr, nsteps * kp.vr, kp.vr, slot0,
                         [codes](int k) { return codes[k]; }, tid, nthr);
         }
     }
@@ -798,10 +918,10 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     if (kp.c) {
         const int cb = L.cb;
         double* out = kp.c + cx.a * (int64_t)cb;
-        const int par = nthr / cb;
+        const int par = (int)fast_div((uint32_t)nthr, kp.div_cb);
         if (par >= 1) {
             if (tid < par * cb) {
-                const int g = tid / cb, r = tid - g * cb;
+                const int g = (int)fast_div((uint32_t)tid, kp.div_cb), r = tid - g * cb;
                 const double* src = cx.rec + (slot0 + g) * stride + R.oR + r;
                 for (int s = g; s < nsteps; s += par, src += par * stride) out[s * cb + r] = *src;
             }
@@ -822,13 +942,13 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
             const int nreg = (int)(rb - ra);
             double* out = kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)Ls;
             const int sl0 = (int)(ra - cx.lo);
-            const int par = nthr / Ls;
+            const int par = (int)fast_div((uint32_t)nthr, kp.div_Lseg);
             // inner loops: uniform trip count and batches of 4 steps, so the 8 LDS reads of a batch are independent
             // and in flight together (reads past the last step are clamped, only the store is predicated)
             if (par >= 1) {
                 if (tid < par * Ls) {
-                    const int g = tid / Ls, k = tid - g * Ls;
-                    const uint32_t code = kp.tmpl[k];
+                    const int g = (int)fast_div((uint32_t)tid, kp.div_Lseg), k = tid - g * Ls;
+                    const uint32_t code = cx.codes[k];
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
@@ -856,7 +976,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
                 }
             } else {
                 for (int k = tid; k < Ls; k += nthr) {
-                    const uint32_t code = kp.tmpl[k];
+                    const uint32_t code = cx.codes[k];
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
@@ -881,13 +1001,13 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     // (C) the tile's slice of every V column
     if (kp.vr > 0) {
         const int vr = kp.vr;
-        const int par = nthr / vr;
+        const int par = (int)fast_div((uint32_t)nthr, kp.div_vr);
         for (int kk = 0; kk < P::NV; ++kk) {
             double* out = kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)vr;
-            const uint32_t* codes = kp.vtmpl + kk * vr;
+            const uint32_t* codes = cx.vcodes + kk * vr;
             if (par >= 1) {
                 if (tid < par * vr) {
-                    const int g = tid / vr, k = tid - g * vr;
+                    const int g = (int)fast_div((uint32_t)tid, kp.div_vr), k = tid - g * vr;
                     const uint32_t code = codes[k];
                     const double* pc = cx.rec + (slot0 + g) * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);

@@ -21,7 +21,7 @@ __device__ __forceinline__ void ctd_stamp(const KParams& kp, int slot) {
 }
 
 template <class P, int SC, int S>
-__global__ void __launch_bounds__(256) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
+__global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
     extern __shared__ double ctd_lds[];
     ctd_stamp(kp, 0);
     if (kp.debug_stop == 1) return;
@@ -52,6 +52,91 @@ __global__ void __launch_bounds__(256) cons_jac_kernel(const KParams kp, const d
         __syncthreads();
         ctd_stamp(kp, 5);
     }
+}
+
+// ---- pipelined driver -------------------------------------------------------------------------------------------
+// Co-resident workgroups of the classic driver run in lock-step (all evaluate, then all store), so HBM idles during
+// every load/eval phase.  Here a workgroup owns a chunk of consecutive steps and software-pipelines it in sub-tiles:
+// in iteration q wave 0 (producer) evaluates sub-tile q+1 into the other record buffer while waves 1.. (consumers)
+// prefetch the inputs of sub-tile q+2 and stream sub-tile q out; one workgroup barrier per iteration.  The grid is sized
+// to what is resident at once, so the store stream only waits for the prologue.
+__device__ __forceinline__ void ctd_wave_sync() {
+    // LDS results of this wave's earlier instructions become visible to all its lanes (program order + drained counters)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <class P, int SC, int S>
+__device__ __forceinline__ void ctd_produce(const KParams& kp, const BlockCtx& cx, int lane) {
+    // the producer's dependent FP64 chain is the pole of every iteration: let it win issue arbitration against the
+    // co-resident consumer waves (whose stores are in flight anyway)
+    __builtin_amdgcn_s_setprio(3);
+    phase_eval<P, SC, S>(kp, cx, lane, 64);
+    if (!Dirs<P>::FUSED) {
+        ctd_wave_sync();
+        phase_fin<P, SC, S>(kp, cx, lane, 64);
+    }
+    if (SC == SC_TRAPEZE) {
+        ctd_wave_sync();
+        phase_fin2<P, SC, S>(kp, cx, lane, 64);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <class P, int SC, int S>
+__global__ void __launch_bounds__(P::MAXB) cons_jac_pipe_kernel(const KParams kp, const double* __restrict__ xu) {
+    extern __shared__ double ctd_lds[];
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    if (kp.has_edge && blockIdx.x == 0) {          // edge block: same phases as the classic driver
+        const BlockCtx cx = make_ctx(kp, 0, ctd_lds);
+        phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
+        __syncthreads();
+        phase_eval<P, SC, S>(kp, cx, tid, nthr);
+        __syncthreads();
+        if (!Dirs<P>::FUSED) {
+            phase_fin<P, SC, S>(kp, cx, tid, nthr);
+            __syncthreads();
+        }
+        phase_emit<P, SC, S>(kp, cx, tid, nthr);
+        return;
+    }
+    const int chunk = (int)blockIdx.x - (kp.has_edge ? 1 : 0);
+    const int64_t A = kp.step_begin + (int64_t)chunk * kp.pipe_chunk;
+    const int64_t B = A + kp.pipe_chunk < kp.step_end ? A + kp.pipe_chunk : kp.step_end;
+    if (A >= B) return;
+    const int Q = (int)((B - A + kp.pipe_Ts - 1) / kp.pipe_Ts);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int ctid = tid - 64, cthr = nthr - 64;       // consumer lane id / count
+    ctd_stamp(kp, 0);
+    // prologue: inputs of sub-tiles 0 and 1, records of sub-tile 0
+    {
+        const BlockCtx c0 = make_sub_ctx(kp, ctd_lds, A, B, 0);
+        phase_load<P, SC, S, true>(kp, c0, xu, tid, nthr);
+        if (Q > 1) {
+            const BlockCtx c1 = make_sub_ctx(kp, ctd_lds, A, B, 1);
+            phase_load<P, SC, S, false>(kp, c1, xu, tid, nthr);
+        }
+        __syncthreads();
+        ctd_stamp(kp, 1);
+        if (wave == 0) ctd_produce<P, SC, S>(kp, c0, lane);
+        __syncthreads();
+        ctd_stamp(kp, 2);
+    }
+    for (int q = 0; q < Q; ++q) {
+        if (q == 1) ctd_stamp(kp, 3);          // diagnostics: end of iteration 0
+        if (q == Q - 1) ctd_stamp(kp, 4);      // start of the last iteration
+        if (wave == 0) {
+            if (q + 1 < Q) ctd_produce<P, SC, S>(kp, make_sub_ctx(kp, ctd_lds, A, B, q + 1), lane);
+        } else {
+            // emit first (its stores are fire-and-forget), then fetch the inputs of sub-tile q+2: the load latency then
+            // overlaps the producer's evaluation instead of delaying this iteration's stores
+            phase_emit<P, SC, S>(kp, make_sub_ctx(kp, ctd_lds, A, B, q), ctid, cthr);
+            if (q + 2 < Q) phase_load<P, SC, S, false>(kp, make_sub_ctx(kp, ctd_lds, A, B, q + 2), xu, ctid, cthr);
+        }
+        __syncthreads();
+    }
+    ctd_stamp(kp, 5);
 }
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
@@ -160,6 +245,16 @@ __global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__
 template <class P, int SC, int S>
 hipError_t launch_variant(const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
                           hipEvent_t e0, hipEvent_t e1) {
+    if (kp.pipe_Ts > 0) {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)cons_jac_pipe_kernel<P, SC, S>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_pipe_kernel<P, SC, S>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
+        else cons_jac_pipe_kernel<P, SC, S><<<grid, block, lds_bytes, st>>>(kp, xu);
+        return hipGetLastError();
+    }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
@@ -170,6 +265,24 @@ hipError_t launch_variant(const KParams& kp, const double* xu, int grid, int blo
     if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
     else cons_jac_kernel<P, SC, S><<<grid, block, lds_bytes, st>>>(kp, xu);
     return hipGetLastError();
+}
+
+// resident workgroups per CU of the pipelined kernel for this geometry (occupancy API; advisory)
+template <class P, int SC, int S>
+int pipe_blocks_per_cu(int block, size_t lds_bytes) {
+    int nb = 0;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)cons_jac_pipe_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cons_jac_pipe_kernel<P, SC, S>, block, lds_bytes) != hipSuccess) return 0;
+    return nb;
+}
+template <class P>
+int pipe_occupancy(int sc, int s, int block, size_t lds_bytes) {
+    if (sc == SC_TRAPEZE) return pipe_blocks_per_cu<P, SC_TRAPEZE, 1>(block, lds_bytes);
+    if (sc == SC_MIDPOINT) return pipe_blocks_per_cu<P, SC_MIDPOINT, 1>(block, lds_bytes);
+    if (s == 1) return pipe_blocks_per_cu<P, SC_IRK, 1>(block, lds_bytes);
+    if (s == 2) return pipe_blocks_per_cu<P, SC_IRK, 2>(block, lds_bytes);
+    return pipe_blocks_per_cu<P, SC_IRK, 3>(block, lds_bytes);
 }
 
 template <class P>
@@ -194,10 +307,12 @@ hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, i
 #define CTD_INSTANTIATE_LAUNCHERS(P)                                                                                       \
     template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, \
                                            hipEvent_t);                                                                    \
-    template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
+    template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);                       \
+    template int pipe_occupancy<P>(int, int, int, size_t);
 #define CTD_EXTERN_LAUNCHERS(P)                                                                                            \
     extern template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t,      \
                                                   hipEvent_t, hipEvent_t);                                                 \
-    extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);
+    extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);               \
+    extern template int pipe_occupancy<P>(int, int, int, size_t);
 
 }  // namespace ctd

@@ -60,8 +60,8 @@ struct RecLayout {
     int32_t stride;
 };
 
-CTD_HD RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
-    RecLayout r;
+constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
+    RecLayout r{};
     r.S = s > 0 ? s : 1;
     r.oF = 0; r.oG = n * n; r.oW = r.oG + n * m; r.of = r.oW + n * nv; r.oft = r.of + n;
     r.eval_sz = r.oft + n;
@@ -96,6 +96,11 @@ CTD_HD int code_beta(uint32_t c) { return (int)((c >> 22) & 0x3u); }
 CTD_HD int code_drec(uint32_t c) { return (int)((c >> 24) & 0x7u); }
 CTD_HD int code_crec(uint32_t c) { return (int)((c >> 27) & 0x7u); }
 
+// exact x / d for the small operands of the emit loops (x * d < 2^32): q = umulhi(x, M), M = floor(2^32 / d) + 1 (d > 1)
+struct FastDiv { uint32_t d, M; };
+inline FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, d > 1 ? (uint32_t)(((uint64_t)1 << 32) / d + 1) : 0u}; }
+CTD_HD uint32_t fast_div(uint32_t x, FastDiv f) { return f.d > 1 ? (uint32_t)(((uint64_t)x * f.M) >> 32) : x; }
+
 constexpr int64_t kEdgeCBit = (int64_t)1 << 62;   // edge_idx flag: the entry goes to c[], not vals[]
 
 // ---- kernel parameters (passed by value) ---------------------------------------------------------------
@@ -113,6 +118,7 @@ struct KParams {
     const uint32_t* tmpl;
     int32_t Lseg;
     int32_t vr;                 // rows per step inside each V column
+    FastDiv div_cb, div_Lseg, div_vr;
     int64_t seg_base;
     int64_t reg_first, reg_last;
     // V columns: column k holds, for step i, vals[vcol_base[k] + i * vr, +vr) with codes vtmpl[k * vr ...]
@@ -126,6 +132,10 @@ struct KParams {
     int32_t edge_fp, edge_b;            // record ids of the final-path and boundary records
     int32_t edge_slot_first, edge_slot_last;   // slots holding step 0 and step N-1
     int64_t edge_steps[kMaxEdgeSlots];
+    // pipelined driver (cons_jac_pipe_kernel): each workgroup owns pipe_chunk consecutive steps and walks them in
+    // sub-tiles of pipe_Ts steps; 0 = classic one-tile-per-workgroup driver
+    int32_t pipe_Ts;
+    int32_t pipe_chunk;
     // outputs (global indexing); either may be null
     double* c;
     double* vals;

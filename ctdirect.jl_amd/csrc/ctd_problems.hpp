@@ -56,6 +56,7 @@ struct GoddardOCP {
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(4);                     // dual directions per pass
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     // xdot = F0(x) + u F1(x)   (goddard.jl:7-16, :44)
@@ -92,6 +93,7 @@ struct GoddardAllOCP {
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = true;
     static constexpr int DC = CTD_DC(4);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // f! :127-132
@@ -131,6 +133,7 @@ struct DoubleIntegratorPathOCP {
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(3);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 2.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -162,6 +165,7 @@ struct QuadrotorOCP {
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(4);
+    static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // :20-40
@@ -218,6 +222,7 @@ struct Quadrotor12OCP {
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(4);
+    static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -279,6 +284,7 @@ struct StagewiseScalarOCP {
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(2);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T*, const T* u, const T*) { dx[0] = u[0]; }
@@ -302,6 +308,7 @@ struct EstimateInitialConditionOCP {                                            
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(2);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 3.14159265358979323846 / 2; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -322,6 +329,7 @@ struct EstimateRotationRateOCP {                                                
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = true, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(3);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T* v) {
@@ -347,6 +355,7 @@ struct LeastSquaresConstraintOCP {                                              
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(2);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -373,6 +382,7 @@ struct DoubleIntegratorFreeT0TfOCP {
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr int DC = CTD_DC(3);
+    static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) { dx[0] = x[1]; dx[1] = u[0]; }

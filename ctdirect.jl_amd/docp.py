@@ -192,10 +192,10 @@ class DOCP:
         return self._bounds
 
     def launch_info(self):
-        o = np.zeros(6, dtype=np.int64)
+        o = np.zeros(8, dtype=np.int64)
         self._ck(_lib.lib().ctd_launch_info(self._h, _ip(o)))
         return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]),
-                    csc_period=int(o[4]), edge_entries=int(o[5]))
+                    csc_period=int(o[4]), edge_entries=int(o[5]), pipe_subtile=int(o[6]), pipe_chunk=int(o[7]))
 
     def dropped_nonzeros(self):
         n = C.c_int64()

@@ -129,7 +129,7 @@ def test_tile_and_block_shapes(oracle_lib, torch_cuda, monkeypatch, tile, block)
         o.set_pattern_mode(1)
         d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
         assert d.launch_info()["steps_per_tile"] <= tile and d.launch_info()["block"] == block
-        assert d.launch_info()["lds_bytes"] <= 64 * 1024          # a tile that does not fit is shrunk
+        assert d.launch_info()["lds_bytes"] <= 80 * 1024          # a tile that does not fit is shrunk
         x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
         c, v = d.cons_jac(torch.from_numpy(x).cuda())
         assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL
