@@ -46,6 +46,8 @@ SYMBOLS = {
     "ctd_jac_csc": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_dropped_nonzeros": (C.c_int32, [_vp, _ip]),
     "ctd_obj": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_grad": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_grad_dev": (C.c_int32, [_vp, _vp, _vp]),
     "ctd_cons": (C.c_int32, [_vp, _dp, _dp]),
     "ctd_jac_coord": (C.c_int32, [_vp, _dp, _dp]),
     "ctd_cons_jac": (C.c_int32, [_vp, _dp, _dp, _dp]),

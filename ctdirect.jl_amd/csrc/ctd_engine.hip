@@ -56,6 +56,9 @@ struct ctd_handle {
     // objective
     double* d_partial = nullptr;
     double* d_obj = nullptr;
+    double* d_g = nullptr;          // staging for ctd_grad (host pointers)
+    double* d_gpartial = nullptr;   // per-workgroup partial sums of dg/dv
+    int gblocks = 0;
     int obj_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
@@ -92,7 +95,8 @@ static void free_device(ctd_handle* h) {
     if (h->device < 0) return;
     (void)hipSetDevice(h->device);
     for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
-                    (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj})
+                    (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
+                    (void*)h->d_gpartial})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -121,7 +125,8 @@ const char* ctd_last_error(const ctd_handle* h) { return h ? h->err.c_str() : g_
 int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     if (!desc || !out) return fail(nullptr, CTD_EINVAL, "ctd_create: null argument");
     *out = nullptr;
-    std::unique_ptr<ctd_handle> h(new (std::nothrow) ctd_handle());
+    struct Del { void operator()(ctd_handle* p) const { if (p) { free_device(p); delete p; } } };
+    std::unique_ptr<ctd_handle, Del> h(new (std::nothrow) ctd_handle());
     if (!h) return fail(nullptr, CTD_ENOMEM, "ctd_create: out of memory");
     HostDesc hd{desc->problem, desc->scheme, desc->pattern_mode, desc->grid_size, desc->time_grid, desc->time_grid_len};
     std::string err;
@@ -437,6 +442,53 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIP_TRY(h, hipMemcpyAsync(f_host, h->d_obj, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Layout& L = h->model.L;
+    const int64_t units = (L.sc == SC_IRK) ? L.N : L.N + 1;
+    const int blocks = (int)((units + 255) / 256);
+    if (!h->d_gpartial || h->gblocks < blocks) {
+        if (h->d_gpartial) (void)hipFree(h->d_gpartial);
+        h->d_gpartial = nullptr;
+        HIP_TRY(h, hipMalloc((void**)&h->d_gpartial, sizeof(double) * (size_t)blocks * kMaxNV));
+        h->gblocks = blocks;
+    }
+    GradParams gp;
+    std::memset(&gp, 0, sizeof(gp));
+    gp.L = L;
+    gp.tau = h->d_tau;
+    gp.g = g_dev;
+    gp.partial = h->d_gpartial;
+    gp.nblocks = blocks;
+    HIP_TRY(h, hipMemsetAsync(g_dev, 0, sizeof(double) * L.nvar, h->stream));
+    hipError_t e = hipErrorInvalidValue;
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_grad<P>(L.sc, L.s, gp, x_dev, blocks, h->stream);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+int32_t ctd_grad(ctd_handle* h, const double* x, double* g) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x || !g) return fail(h, CTD_EINVAL, "null argument");
+    int32_t st = ensure_staging(h, false, false);
+    if (st) return st;
+    const int64_t nvar = h->model.L.nvar;
+    if (!h->d_g) HIP_TRY(h, hipMalloc((void**)&h->d_g, sizeof(double) * nvar));
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * nvar, hipMemcpyHostToDevice, h->stream));
+    st = ctd_grad_dev(h, h->d_x, h->d_g);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpy(g, h->d_g, sizeof(double) * nvar, hipMemcpyDeviceToHost));
     return CTD_OK;
 }
 

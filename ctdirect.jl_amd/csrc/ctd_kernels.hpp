@@ -237,6 +237,264 @@ __global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__
     op.out[0] = mayer + s;
 }
 
+// ---- objective gradient: grad!(nlp, x, g) -----------------------------------------------------------------------------
+// In the reference the gradient is ReverseDiff over __objective (gradient_backend = ReverseDiffADGradient,
+// src/collocation.jl:127).  Here: forward duals over the Lagrange / Mayer functions + the quadrature's chain rule.
+// Owner-computes, no atomics: one lane per quadrature unit writes the gradient entries of its own variables (trapeze:
+// node; midpoint: node, gathering the two adjacent steps; Gauss-Legendre: step); the partials with respect to v are
+// reduced per workgroup and summed in index order by grad_finish_kernel, which also adds the Mayer term.
+struct GradParams {
+    Layout L;
+    const double* tau;
+    double* g;          // nvar, zero-filled before the launch
+    double* partial;    // nblocks * kMaxNV
+    int32_t nblocks;
+};
+
+template <class P> struct LagDirs {
+    static constexpr int N = P::NX + P::NU + (P::LAG_T ? 1 : 0) + (P::LAG_V ? P::NV : 0);
+    static constexpr int NCH = (N + P::DC - 1) / P::DC;
+    static constexpr int NMAY = 2 * P::NX + P::NV;
+    static constexpr int NCH_MAY = (NMAY + P::DC - 1) / P::DC;
+};
+
+// d lagrange / d (x, u, t, v) at one point, DC directions per pass, chunk index compile-time (no runtime-indexed arrays)
+template <class P, int Q>
+__device__ __forceinline__ void lagrange_partials(double t, const double* x, const double* u, const double* v, double& val,
+                                                  double* lx, double* lu, double& lt, double* lv) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
+    using D = Dual<DC>;
+    constexpr int g0 = Q * DC, gT = n + m, gV = n + m + (P::LAG_T ? 1 : 0);
+    D X[n > 0 ? n : 1], U[m > 0 ? m : 1], V[nv > 0 ? nv : 1], Tt;
+#pragma unroll
+    for (int c = 0; c < n; ++c) {
+        X[c].v = x[c];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) X[c].d[d] = (g0 + d == c) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < m; ++c) {
+        U[c].v = u[c];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) U[c].d[d] = (g0 + d == n + c) ? 1.0 : 0.0;
+    }
+    Tt.v = t;
+#pragma unroll
+    for (int d = 0; d < DC; ++d) Tt.d[d] = (P::LAG_T && g0 + d == gT) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < nv; ++c) {
+        V[c].v = v[c];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) V[c].d[d] = (P::LAG_V && g0 + d == gV + c) ? 1.0 : 0.0;
+    }
+    const D r = P::template lagrange<D>(Tt, X, U, V);
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        constexpr int dummy = 0; (void)dummy;
+        const int g = g0 + d;
+        if (g < n) lx[g] = r.d[d];
+        else if (g < n + m) lu[g - n] = r.d[d];
+        else if (P::LAG_T && g == gT) lt = r.d[d];
+        else if (P::LAG_V && g < LagDirs<P>::N) lv[g - gV] = r.d[d];
+    }
+    if (Q == 0) val = r.v;
+    if constexpr (Q + 1 < LagDirs<P>::NCH) lagrange_partials<P, Q + 1>(t, x, u, v, val, lx, lu, lt, lv);
+}
+
+template <class P, int Q>
+__device__ __forceinline__ void mayer_partials(const double* x0, const double* xf, const double* v, double* g0x, double* gfx, double* gv) {
+    constexpr int n = P::NX, nv = P::NV, DC = P::DC;
+    using D = Dual<DC>;
+    constexpr int g0 = Q * DC;
+    D X0[n > 0 ? n : 1], XF[n > 0 ? n : 1], V[nv > 0 ? nv : 1];
+#pragma unroll
+    for (int c = 0; c < n; ++c) {
+        X0[c].v = x0[c]; XF[c].v = xf[c];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) { X0[c].d[d] = (g0 + d == c) ? 1.0 : 0.0; XF[c].d[d] = (g0 + d == n + c) ? 1.0 : 0.0; }
+    }
+#pragma unroll
+    for (int c = 0; c < nv; ++c) {
+        V[c].v = v[c];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) V[c].d[d] = (g0 + d == 2 * n + c) ? 1.0 : 0.0;
+    }
+    const D r = P::template mayer<D>(X0, XF, V);
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        const int g = g0 + d;
+        if (g < n) g0x[g] = r.d[d];
+        else if (g < 2 * n) gfx[g - n] = r.d[d];
+        else if (g < 2 * n + nv) gv[g - 2 * n] = r.d[d];
+    }
+    if constexpr (Q + 1 < LagDirs<P>::NCH_MAY) mayer_partials<P, Q + 1>(x0, xf, v, g0x, gfx, gv);
+}
+
+template <class P> __device__ __forceinline__ double grad_tau(const GradParams& gp, int64_t i) {
+    return gp.tau ? gp.tau[i] : (double)i / (double)gp.L.N;
+}
+template <class P> __device__ __forceinline__ double grad_time(const GradParams& gp, const double* v, double tau) {
+    const double t0 = (P::IT0 >= 0) ? v[P::IT0 >= 0 ? P::IT0 : 0] : gp.L.t0;
+    const double tf = (P::ITF >= 0) ? v[P::ITF >= 0 ? P::ITF : 0] : gp.L.tf;
+    return t0 + tau * (tf - t0);
+}
+
+template <class P, int SC, int S>
+__global__ void __launch_bounds__(256) grad_units_kernel(const GradParams gp, const double* __restrict__ xu) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV;
+    constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
+    __shared__ double wsum[4][kMaxNV];
+    const Layout& L = gp.L;
+    double v[nv > 0 ? nv : 1], gv[nv > 0 ? nv : 1];
+    for (int k = 0; k < nv; ++k) { v[k] = xu[L.v_off + k]; gv[k] = 0.0; }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t units = (SC == SC_IRK) ? L.N : L.N + 1;      // steps, or nodes for trapeze / midpoint
+    if (P::HAS_LAGRANGE && i < units) {
+        double* g = gp.g;
+        const double* base = xu + i * (int64_t)L.blk;
+        double x[n > 0 ? n : 1], u[m > 0 ? m : 1], lx[n > 0 ? n : 1], lu[m > 0 ? m : 1], lv[nv > 0 ? nv : 1];
+        double lt = 0.0, val = 0.0;
+        for (int k = 0; k < nv; ++k) lv[k] = 0.0;
+        if (SC == SC_TRAPEZE) {
+            // node weight w_i = h_1/2, (t_{i+1}-t_{i-1})/2, h_N/2   (trapeze.jl:78-110)
+            const int64_t ia = i == 0 ? 0 : i - 1, ib = i == L.N ? L.N : i + 1;
+            const double ta = grad_tau<P>(gp, ia), tb = grad_tau<P>(gp, ib), ti = grad_tau<P>(gp, i);
+            const double w = (grad_time<P>(gp, v, tb) - grad_time<P>(gp, v, ta)) / 2.0;
+            for (int c = 0; c < n; ++c) x[c] = base[c];
+            for (int c = 0; c < m; ++c) u[c] = base[n + c];
+            lagrange_partials<P, 0>(grad_time<P>(gp, v, ti), x, u, v, val, lx, lu, lt, lv);
+            for (int c = 0; c < n; ++c) g[i * L.blk + c] = w * lx[c];
+            for (int c = 0; c < m; ++c) g[i * L.blk + n + c] = w * lu[c];
+            for (int k = 0; k < nv; ++k) {
+                const double dw = FREE ? (dtime_of<P>(tb, k) - dtime_of<P>(ta, k)) / 2.0 : 0.0;
+                gv[k] = dw * val + w * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * dtime_of<P>(ti, k) : 0.0));
+            }
+        } else if (SC == SC_MIDPOINT) {
+            // node i gathers step i (x_i, u_i, v) and step i-1 (x_i): h * l(0.5(t_i+t_{i+1}), 0.5(x_i+x_{i+1}), u_i, v)   (midpoint.jl:87-97)
+            double gx[n > 0 ? n : 1];
+            for (int c = 0; c < n; ++c) gx[c] = 0.0;
+            if (i < L.N) {
+                const double t0 = grad_tau<P>(gp, i), t1 = grad_tau<P>(gp, i + 1);
+                const double ta = grad_time<P>(gp, v, t0), tb = grad_time<P>(gp, v, t1), h = tb - ta;
+                for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+                for (int c = 0; c < m; ++c) u[c] = base[n + c];
+                lagrange_partials<P, 0>(0.5 * (ta + tb), x, u, v, val, lx, lu, lt, lv);
+                for (int c = 0; c < n; ++c) gx[c] = h * (0.5 * lx[c]);
+                for (int c = 0; c < m; ++c) g[i * L.blk + n + c] = h * lu[c];
+                for (int k = 0; k < nv; ++k) {
+                    const double d0 = FREE ? dtime_of<P>(t0, k) : 0.0, d1 = FREE ? dtime_of<P>(t1, k) : 0.0;
+                    gv[k] = (d1 - d0) * val + h * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * (0.5 * (d0 + d1)) : 0.0));
+                }
+            }
+            if (i >= 1) {
+                const double* pb = base - L.blk;
+                const double ta = grad_time<P>(gp, v, grad_tau<P>(gp, i - 1)), tb = grad_time<P>(gp, v, grad_tau<P>(gp, i));
+                const double h = tb - ta;
+                for (int c = 0; c < n; ++c) x[c] = 0.5 * (pb[c] + pb[L.blk + c]);
+                for (int c = 0; c < m; ++c) u[c] = pb[n + c];
+                double val2 = 0.0, lt2 = 0.0, lu2[m > 0 ? m : 1], lv2[nv > 0 ? nv : 1];
+                lagrange_partials<P, 0>(0.5 * (ta + tb), x, u, v, val2, lx, lu2, lt2, lv2);
+                for (int c = 0; c < n; ++c) gx[c] = gx[c] + h * (0.5 * lx[c]);
+            }
+            for (int c = 0; c < n; ++c) g[i * L.blk + c] = gx[c];
+        } else {
+            // step i: h sum_j b_j l(t_ij, x_ij, u_ij, v)   (irk.jl:179-228, irk_stagewise.jl:344-384)
+            const double t0 = grad_tau<P>(gp, i), t1 = grad_tau<P>(gp, i + 1);
+            const double ti = grad_time<P>(gp, v, t0), h = grad_time<P>(gp, v, t1) - ti;
+            const double* K = base + n + L.cu;
+            double gx[n > 0 ? n : 1], gK[S][n > 0 ? n : 1], gu[m > 0 ? m : 1];
+            for (int c = 0; c < n; ++c) { gx[c] = 0.0; for (int l = 0; l < S; ++l) gK[l][c] = 0.0; }
+            for (int c = 0; c < m; ++c) gu[c] = 0.0;
+            double sum_bl = 0.0;
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                double sa[n > 0 ? n : 1];              // sum_l a_jl K^l (for d x_ij / d v)
+                for (int c = 0; c < n; ++c) {
+                    double xc = base[c], acc = 0.0;
+#pragma unroll
+                    for (int l = 0; l < S; ++l) { xc = xc + h * L.a[3 * j + l] * K[l * n + c]; acc = acc + L.a[3 * j + l] * K[l * n + c]; }
+                    x[c] = xc; sa[c] = acc;
+                }
+                const double* U = base + n + (L.stagewise ? j * m : 0);
+                for (int c = 0; c < m; ++c) u[c] = U[c];
+                lagrange_partials<P, 0>(ti + L.c[j] * h, x, u, v, val, lx, lu, lt, lv);
+                const double hb = h * L.b[j];
+                for (int c = 0; c < n; ++c) {
+                    gx[c] = gx[c] + hb * lx[c];
+#pragma unroll
+                    for (int l = 0; l < S; ++l) gK[l][c] = gK[l][c] + hb * (h * L.a[3 * j + l]) * lx[c];
+                }
+                if (L.stagewise) { for (int c = 0; c < m; ++c) g[i * L.blk + n + j * m + c] = hb * lu[c]; }
+                else { for (int c = 0; c < m; ++c) gu[c] = gu[c] + hb * lu[c]; }
+                sum_bl = sum_bl + L.b[j] * val;
+                for (int k = 0; k < nv; ++k) {
+                    const double d0 = FREE ? dtime_of<P>(t0, k) : 0.0, dh = FREE ? dtime_of<P>(t1, k) - d0 : 0.0;
+                    double e = P::LAG_V ? lv[k] : 0.0;
+                    if (P::LAG_T && FREE) e = e + lt * (d0 + L.c[j] * dh);
+                    if (FREE) for (int c = 0; c < n; ++c) e = e + lx[c] * (dh * sa[c]);
+                    gv[k] = gv[k] + hb * e;
+                }
+            }
+            for (int k = 0; k < nv; ++k) {
+                const double dh = FREE ? dtime_of<P>(t1, k) - dtime_of<P>(t0, k) : 0.0;
+                gv[k] = gv[k] + dh * sum_bl;
+            }
+            for (int c = 0; c < n; ++c) g[i * L.blk + c] = gx[c];
+            if (!L.stagewise) for (int c = 0; c < m; ++c) g[i * L.blk + n + c] = gu[c];
+#pragma unroll
+            for (int l = 0; l < S; ++l)
+                for (int c = 0; c < n; ++c) g[i * L.blk + n + L.cu + l * n + c] = gK[l][c];
+        }
+    }
+    // deterministic reduction of the v-partials: wave shuffles, then one value per workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < nv; ++k) {
+        double a = gv[k];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) wsum[wave][k] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < nv; ++k) {
+            double sacc = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sacc += wsum[w][k];
+            gp.partial[(size_t)blockIdx.x * kMaxNV + k] = sacc;
+        }
+}
+
+template <class P>
+__global__ void grad_finish_kernel(const GradParams gp, const double* __restrict__ xu) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int n = P::NX, nv = P::NV;
+    const Layout& L = gp.L;
+    double gvs[nv > 0 ? nv : 1];
+    for (int k = 0; k < nv; ++k) {
+        double sacc = 0.0;
+        for (int b = 0; b < gp.nblocks; ++b) sacc += gp.partial[(size_t)b * kMaxNV + k];
+        gvs[k] = sacc;
+    }
+    if (P::HAS_MAYER) {
+        double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1], g0x[n > 0 ? n : 1], gfx[n > 0 ? n : 1], gmv[nv > 0 ? nv : 1];
+        for (int c = 0; c < n; ++c) { x0[c] = xu[c]; xf[c] = xu[L.N * (int64_t)L.blk + c]; g0x[c] = 0.0; gfx[c] = 0.0; }
+        for (int k = 0; k < nv; ++k) { v[k] = xu[L.v_off + k]; gmv[k] = 0.0; }
+        mayer_partials<P, 0>(x0, xf, v, g0x, gfx, gmv);
+        for (int c = 0; c < n; ++c) { gp.g[c] += g0x[c]; gp.g[L.N * (int64_t)L.blk + c] += gfx[c]; }
+        for (int k = 0; k < nv; ++k) gvs[k] += gmv[k];
+    }
+    for (int k = 0; k < nv; ++k) gp.g[L.v_off + k] = gvs[k];
+}
+
+template <class P>
+hipError_t launch_grad(int sc, int s, const GradParams& gp, const double* xu, int grid, hipStream_t st) {
+    if (sc == SC_TRAPEZE) grad_units_kernel<P, SC_TRAPEZE, 1><<<grid, 256, 0, st>>>(gp, xu);
+    else if (sc == SC_MIDPOINT) grad_units_kernel<P, SC_MIDPOINT, 1><<<grid, 256, 0, st>>>(gp, xu);
+    else if (s == 1) grad_units_kernel<P, SC_IRK, 1><<<grid, 256, 0, st>>>(gp, xu);
+    else if (s == 2) grad_units_kernel<P, SC_IRK, 2><<<grid, 256, 0, st>>>(gp, xu);
+    else grad_units_kernel<P, SC_IRK, 3><<<grid, 256, 0, st>>>(gp, xu);
+    grad_finish_kernel<P><<<1, 64, 0, st>>>(gp, xu);
+    return hipGetLastError();
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // Defined here as templates; each per-problem translation unit (ctd_kern_*.hip) explicitly instantiates them for one
 // OCP so the registry compiles in parallel, and ctd_engine.hip only sees `extern template` declarations.
@@ -308,11 +566,13 @@ hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, i
     template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, \
                                            hipEvent_t);                                                                    \
     template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);                       \
-    template int pipe_occupancy<P>(int, int, int, size_t);
+    template int pipe_occupancy<P>(int, int, int, size_t);                                                                \
+    template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 #define CTD_EXTERN_LAUNCHERS(P)                                                                                            \
     extern template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t,      \
                                                   hipEvent_t, hipEvent_t);                                                 \
     extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);               \
-    extern template int pipe_occupancy<P>(int, int, int, size_t);
+    extern template int pipe_occupancy<P>(int, int, int, size_t);                                                         \
+    extern template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 
 }  // namespace ctd

@@ -55,6 +55,7 @@ struct GoddardOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);                     // dual directions per pass
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -92,6 +93,7 @@ struct GoddardAllOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = true;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -132,6 +134,7 @@ struct DoubleIntegratorPathOCP {
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -164,6 +167,7 @@ struct QuadrotorOCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -221,6 +225,7 @@ struct Quadrotor12OCP {
     static constexpr int IT0 = -1, ITF = 0;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -283,6 +288,7 @@ struct StagewiseScalarOCP {
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = false;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -307,6 +313,7 @@ struct EstimateInitialConditionOCP {                                            
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -328,6 +335,7 @@ struct EstimateRotationRateOCP {                                                
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = true, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -354,6 +362,7 @@ struct LeastSquaresConstraintOCP {                                              
     static constexpr int IT0 = -1, ITF = -1;
     static constexpr bool HAS_LAGRANGE = true, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = true, LAG_V = false;       // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }
@@ -381,6 +390,7 @@ struct DoubleIntegratorFreeT0TfOCP {
     static constexpr int IT0 = 0, ITF = 1;
     static constexpr bool HAS_LAGRANGE = false, HAS_MAYER = true;
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
+    static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr double t0_fixed() { return 0.0; }

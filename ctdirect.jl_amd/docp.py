@@ -301,6 +301,23 @@ class DOCP:
             self._ck(L.ctd_obj(self._h, _dp(x), C.byref(f)))
         return f.value
 
+    def grad(self, x, g=None):
+        """grad!(nlp, x, g): gradient of __objective (ReverseDiff over the closure in the reference, src/collocation.jl:127)."""
+        L = _lib.lib()
+        self._check_x(x)
+        if _is_tensor(x):
+            import torch
+            if g is None:
+                g = torch.empty(self.dim_NLP_variables, dtype=torch.float64, device=x.device)
+            self._ck(L.ctd_grad_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                    self._dev_ptr(g, self.dim_NLP_variables, "g")))
+            return g
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if g is None:
+            g = np.empty(self.dim_NLP_variables)
+        self._ck(L.ctd_grad(self._h, _dp(x), _dp(g)))
+        return g
+
     def sync(self):
         self._ck(_lib.lib().ctd_sync(self._h))
 
@@ -339,6 +356,11 @@ def constraints(c, xu, docp):
 def objective(xu, docp):
     """`CTDirect.__objective(xu, docp)`."""
     return docp.obj(xu)
+
+
+def gradient(xu, docp, g=None):
+    """Gradient of `CTDirect.__objective(xu, docp)` (NLPModels `grad!`)."""
+    return docp.grad(xu, g)
 
 
 def variables_bounds(docp):

@@ -148,6 +148,10 @@ int32_t ctd_dropped_nonzeros(const ctd_handle* h, int64_t* count);
 /* ---- the hot path: host pointers -------------------------------------------------------------------------- */
 /* obj(nlp, x)       = __objective(x, docp)                       src/DOCP_functions.jl:23-54 */
 int32_t ctd_obj(ctd_handle* h, const double* x, double* f);
+/* grad!(nlp, x, g): gradient of __objective with respect to the nvar NLP variables (the reference obtains it with
+ * ReverseDiff over the objective closure: gradient_backend = ReverseDiffADGradient, src/collocation.jl:127).
+ * Always the gradient of the whole objective, also on a sharded handle (it is O(nvar) work). */
+int32_t ctd_grad(ctd_handle* h, const double* x, double* g);
 /* cons!(nlp, x, c)  = __constraints!(c, x, docp)                 src/DOCP_functions.jl:80-115 */
 int32_t ctd_cons(ctd_handle* h, const double* x, double* c);
 /* jac_coord!(nlp, x, vals): values of dc/dx in the pattern's CSC order (ADNLPModels.SparseADJacobian,
@@ -162,6 +166,7 @@ int32_t ctd_cons_jac(ctd_handle* h, const double* x, double* c, double* vals);
 int32_t ctd_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev);
 int32_t ctd_cons_jac_dev_async(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev);
 int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host);
+int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_sync(ctd_handle* h);
 
 /* ---- multi-GPU shards (time-step partition) ------------------------------------------ */

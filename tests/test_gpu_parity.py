@@ -44,6 +44,7 @@ def test_fixture_parity_host_pointers(path):
         assert relerr(d.cons(g["xu"]), g["c"]) <= TOL
         assert relerr(d.jac_coord(g["xu"]), ref) <= TOL
         assert _rel(d.obj(g["xu"]), g["objective"]) <= TOL
+        assert relerr(d.grad(g["xu"]), g["gradient"]) <= TOL          # grad! against the mpmath gradient
         d.close()
 
 
@@ -92,6 +93,8 @@ def test_oracle_parity_midsize(oracle_lib, torch_cuda, prob, sch):
         assert relerr(c, o.constraints(x)) <= TOL
         assert relerr(v, o.jac_coord(x)) <= TOL
         assert _rel(d.obj(xd), o.objective(x)) <= TOL
+        if N <= 257:          # the oracle's gradient is one dual pass per variable: keep it to the smaller grids
+            assert relerr(d.grad(xd).cpu().numpy(), o.gradient(x)) <= TOL
         # REFERENCE_MANUAL pattern: same values on the (possibly smaller) pattern
         dm = ct.DOCP(prob, N, sch, time_grid=tg, pattern="manual", device=0)
         if dm.nnzj == d.nnzj:
@@ -162,6 +165,45 @@ def test_shards_compose_on_gpu(torch_cuda):
             sh.close()
         assert torch.equal(c, cf) and torch.equal(v, vf)
         full.close()
+
+
+def test_pipelined_driver_on_gpu(oracle_lib, torch_cuda, monkeypatch):
+    """The optional pipelined driver (CTD_PIPE=1: producer / consumer waves over sub-tiles) gives the same results."""
+    torch = torch_cuda
+    monkeypatch.setenv("CTD_PIPE", "1")
+    for prob, sch, N in (("goddard", "gauss_legendre_3", 2000), ("goddard_all", "gauss_legendre_2", 777),
+                         ("quadrotor", "gauss_legendre_2_constant_control", 300), ("double_integrator_path", "midpoint", 1500),
+                         ("goddard_all", "trapeze", 501)):
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        o.set_pattern_mode(1)
+        d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
+        assert d.launch_info()["pipe_subtile"] > 0
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
+        d.cons_jac(torch.from_numpy(x).cuda(), c, v)
+        c, v = c.cpu().numpy(), v.cpu().numpy()
+        assert not np.any(c == SENT) and not np.any(v == SENT)
+        assert relerr(c, o.constraints(x)) <= TOL and relerr(v, o.jac_coord(x)) <= TOL
+        d.close()
+
+
+def test_gradient_full_size_directional(oracle_lib, torch_cuda):
+    """grad! at the bench size: g . d against central differences of the GPU objective and, cheaply, against the oracle's
+    directional derivative (one dual pass is O(N), unlike its full gradient)."""
+    torch = torch_cuda
+    for prob, sch, N in (("quadrotor", "gauss_legendre_3", 20000), ("double_integrator_path", "midpoint", 100000),
+                         ("least_squares_with_constraint", "trapeze", 50000)):
+        d = ct.DOCP(prob, N, sch, device=0)
+        x = bench_inputs(describe(d, prob, sch), perturb=1e-3)
+        g = d.grad(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.all(np.isfinite(g))
+        rng = np.random.default_rng(3)
+        dirv = rng.uniform(-0.5, 0.5, x.size)
+        eps = 1e-6
+        fd = (d.obj(x + eps * dirv) - d.obj(x - eps * dirv)) / (2 * eps)
+        assert abs(g @ dirv - fd) / max(1.0, abs(fd)) <= 1e-6
+        d.close()
 
 
 def test_idempotent_and_async(torch_cuda):
