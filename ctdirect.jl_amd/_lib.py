@@ -78,6 +78,13 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built (run `python -c 'import "
                 "__graft_entry__ as g; g.build()'` or `make -C ctdirect.jl_amd/csrc`). There is no fallback path.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same soname as /opt/rocm's).  If torch is
+        # going to be used in this process it must be loaded first so that this library binds to the same runtime
+        # (two runtimes in one process do not see each other's devices, streams or allocations).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)          # AttributeError if the library does not export the symbol
