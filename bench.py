@@ -67,11 +67,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU path"
+    # rehearsal knobs (one-GPU box): CTD_BENCH_DEVICE pins every rank to one device, CTD_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device).  The driver's multi-GPU run uses neither: one rank per GPU over RCCL/xGMI.
+    if os.environ.get("CTD_BENCH_DEVICE"):
+        local_rank = int(os.environ["CTD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CTD_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     N = STEPS_PER_GPU * world
     def make(steps=None):      # the handle launches on torch's current stream: ordered with the RCCL collectives

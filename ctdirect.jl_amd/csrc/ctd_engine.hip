@@ -321,7 +321,7 @@ int32_t ctd_shard_info(const ctd_handle* h, int64_t* o) {
     const bool first = h->step_begin == 0, last = h->step_end == L.N;
     o[0] = h->step_begin; o[1] = h->step_end;
     o[2] = h->step_begin * L.cb;
-    o[3] = last ? L.ncon : h->step_end * L.cb;
+    o[3] = h->step_end * L.cb;      // (+ the p + bc tail rows [N*cb, ncon), which every shard writes)
     o[4] = mo.column_start(h->step_begin * L.blk);
     o[5] = mo.column_start(h->step_end * L.blk);
     o[6] = first; o[7] = last;

@@ -578,8 +578,7 @@ static int build_tables(Model& mo, std::string& err) {
     };
     emit(first);
     mo.edge_split = (int)mo.edge_idx.size();
-    emit(last);
-    // tail of c: final path values and boundary values
+    // tail of c: final path values and boundary values (computed by every shard)
     for (int q = 0; q < L.p; ++q) {
         mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + q));
         mo.edge_code.push_back(pack_code(mo.R.oR + q, C_ONE, 0, mo.edge_fp, mo.edge_fp));
@@ -588,6 +587,8 @@ static int build_tables(Model& mo, std::string& err) {
         mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + L.p + r));
         mo.edge_code.push_back(pack_code(mo.R.oBval + r, C_ONE, 0, mo.edge_b, mo.edge_b));
     }
+    mo.edge_split2 = (int)mo.edge_idx.size();
+    emit(last);
 
     // structural nonzeros the selected pattern leaves out (hazard H1)
     mo.dropped = 0;
@@ -640,7 +641,7 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     for (int k = 0; k < kMaxNV; ++k) kp.vcol_base[k] = vcol_base[k];
     const bool owns_first = step_begin == 0, owns_last = step_end == L.N;
     kp.edge_begin = owns_first ? 0 : edge_split;
-    kp.edge_end = owns_last ? (int)edge_idx.size() : edge_split;
+    kp.edge_end = owns_last ? (int)edge_idx.size() : edge_split2;
     if (kp.edge_end < kp.edge_begin) kp.edge_end = kp.edge_begin;
     kp.has_edge = kp.edge_end > kp.edge_begin ? 1 : 0;
     kp.n_edge_slots = n_edge_slots;

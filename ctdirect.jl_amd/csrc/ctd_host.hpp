@@ -44,10 +44,12 @@ struct Model {
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     int64_t vcol_base[kMaxNV] = {0, 0, 0, 0};
     int HL = 0, HH = 0;
-    // edge part: entries [0, edge_split) belong to the shard that owns step 0, the rest to the owner of step N-1
+    // edge part: entries [0, edge_split) belong to the shard that owns step 0, [edge_split, edge_split2) are the tail rows
+    // of c (final-time path + boundary values: every shard computes them, x is replicated), the rest belongs to the owner
+    // of step N-1
     std::vector<int64_t> edge_idx;
     std::vector<uint32_t> edge_code;
-    int edge_split = 0;
+    int edge_split = 0, edge_split2 = 0;
     int n_edge_slots = 0, edge_fp = 0, edge_b = 0, edge_slot_first = 0, edge_slot_last = 0;
     int64_t edge_steps[kMaxEdgeSlots] = {0};
     // CSC column starts without materialising the pattern: explicit for the head columns [0, reg_first*blk) and the

@@ -8,8 +8,9 @@ its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows
   * x is replicated (it is the solver's iterate; 1e6 doubles = 8 MB), so no halo exchange is needed;
   * rank r evaluates the contiguous block of steps [r N/G, (r+1) N/G); the last rank also owns the final-time path rows
     and the boundary rows, the first rank the irregular first-step columns;
-  * each rank writes its rows straight into a full-length c buffer at their global position, so the stitched
-    constraint vector is ONE in-place all-gather (+ a broadcast of the p+bc tail rows from the last rank);
+  * each rank writes its rows straight into a full-length c buffer at their global position, and every rank computes the
+    p+bc tail rows (final-time path and boundary constraints) itself, so the stitched constraint vector is ONE in-place
+    all-gather per evaluation;
   * Jacobian values stay sharded: rank r holds one contiguous range of the global CSC value array (its step columns)
     plus its slice of every V column -- what a distributed KKT consumer wants; `DOCP.shard` gives the ranges.
 """
@@ -26,13 +27,13 @@ def shard_steps(N, world, rank):
 
 def stitch_constraints(c, N, cb, world, rank, group=None):
     """All-gather the per-rank row blocks of `c` in place.  `c` is the full-length constraint vector in which this
-    rank has already written rows [begin*cb, end*cb) (+ the tail rows on the last rank).  Returns c.
+    rank has already written its step rows [begin*cb, end*cb) and the tail rows [N*cb, ncon) (every rank computes
+    those).  Returns c.
 
-    Equal blocks (world | N): one all_gather_into_tensor over c[:N*cb] with the rank's own block as the send buffer
-    (in place), then one broadcast of the tail rows.  Ragged blocks fall back to one broadcast per rank."""
+    Equal blocks (world | N): ONE all_gather_into_tensor over c[:N*cb] with the rank's own block as the send buffer
+    (in place).  Ragged blocks fall back to one broadcast per rank."""
     if world == 1:
         return c
-    tail = c[N * cb:]
     if N % world == 0:
         S = (N // world) * cb
         body = c[:N * cb]
@@ -44,8 +45,6 @@ def stitch_constraints(c, N, cb, world, rank, group=None):
         for r in range(world):
             b, e = shard_steps(N, world, r)
             dist.broadcast(c[b * cb:e * cb], src=r, group=group)
-    if tail.numel() > 0:
-        dist.broadcast(tail, src=world - 1, group=group)
     return c
 
 

@@ -170,8 +170,10 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_sync(ctd_handle* h);
 
 /* ---- multi-GPU shards (time-step partition) ------------------------------------------ */
-/* out[0..7]: step_begin, step_end, c_row_begin, c_row_end (rows this shard writes, tail rows included on the last
- * shard), vals_main_begin, vals_main_end (contiguous CSC range of the shard's step columns), owns_first, owns_last */
+/* out[0..7]: step_begin, step_end, c_row_begin, c_row_end (step rows this shard writes; in addition EVERY shard writes
+ * the p + bc tail rows [N*cb, ncon) -- final-time path and boundary constraints, x being replicated -- so stitching c
+ * is a single all-gather), vals_main_begin, vals_main_end (contiguous CSC range of the shard's step columns), owns_first,
+ * owns_last */
 int32_t ctd_shard_info(const ctd_handle* h, int64_t* out8);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */

@@ -132,6 +132,6 @@ def test_shard_info():
     b = ct.DOCP("goddard_all", N, "gauss_legendre_2", steps=(20, 40), device=-1)
     cb = full.discretization._state_stage_eqs_block + full.discretization._step_pathcons_block
     assert (a.shard.c_row_begin, a.shard.c_row_end) == (0, 20 * cb)
-    assert (b.shard.c_row_begin, b.shard.c_row_end) == (20 * cb, full.dim_NLP_constraints)
+    assert (b.shard.c_row_begin, b.shard.c_row_end) == (20 * cb, 40 * cb)
     assert a.shard.vals_main_end == b.shard.vals_main_begin
     assert a.shard.owns_first and not a.shard.owns_last and b.shard.owns_last and not b.shard.owns_first

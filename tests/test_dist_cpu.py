@@ -54,6 +54,7 @@ def _worker(rank, world, port, N, prob, sch, q):
         c = torch.full((d.dim_NLP_constraints,), 666.666, dtype=torch.float64)
         a, b = d.shard.c_row_begin, d.shard.c_row_end
         c[a:b] = torch.from_numpy(full[a:b])
+        c[N * cb:] = torch.from_numpy(full[N * cb:])     # every rank computes the tail rows (final path + boundary)
         ctdist.stitch_constraints(c, N, cb, world, rank)
         ok = bool(np.array_equal(c.numpy(), full))
         tot = ctdist.reduce_objective(float(rank + 1))

@@ -157,9 +157,13 @@ def test_shards_compose_on_gpu(torch_cuda):
             c2 = torch.full_like(cf, SENT)
             v2 = torch.full_like(vf, SENT)
             sh.cons_jac(x, c2, v2)
-            assert not bool(((c != SENT) & (c2 != SENT)).any()) and not bool(((v != SENT) & (v2 != SENT)).any())
-            rows = torch.nonzero(c2 != SENT).flatten()
+            both = (c != SENT) & (c2 != SENT)
+            cbn = N * (full.discretization._state_stage_eqs_block + full.discretization._step_pathcons_block)
+            assert not bool(both[:cbn].any()) and not bool(((v != SENT) & (v2 != SENT)).any())
+            assert torch.equal(c[both], c2[both])          # tail rows: written by every shard, identical
+            rows = torch.nonzero(c2[:cbn] != SENT).flatten()
             assert int(rows.min()) == sh.shard.c_row_begin and int(rows.max()) == sh.shard.c_row_end - 1
+            assert not bool((c2[cbn:] == SENT).any())
             c = torch.where(c2 != SENT, c2, c)
             v = torch.where(v2 != SENT, v2, v)
             sh.close()

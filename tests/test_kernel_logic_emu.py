@@ -68,7 +68,11 @@ def test_emulated_shards_compose_exactly(prob):
                 c2 = np.full_like(cf, 666.666)
                 v2 = np.full_like(vf, 666.666)
                 emu.cons_jac(pid, sid, 0, N, x, tile=3, nthr=32, step_begin=a, step_end=b, c=c2, vals=v2)
-                assert not np.any((c != 666.666) & (c2 != 666.666))      # shards write disjoint rows / CSC ranges
+                both = (c != 666.666) & (c2 != 666.666)                  # shards write disjoint step rows / CSC ranges;
+                ncb = N * (d.discretization._state_stage_eqs_block + d.discretization._step_pathcons_block)
+                assert not np.any(both[:ncb])                            # only the tail rows (final path + boundary) are
+                assert np.array_equal(c[both], c2[both])                 # computed by every shard, with identical values
+                assert np.array_equal(c2[ncb:], cf[ncb:])                # ... by EVERY shard (single all-gather stitching)
                 assert not np.any((v != 666.666) & (v2 != 666.666))
                 c = np.where(c2 != 666.666, c2, c)
                 v = np.where(v2 != 666.666, v2, v)
