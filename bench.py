@@ -158,7 +158,7 @@ def main():
                 "workload": f"{PROBLEM} / {SCHEME} (stagewise), {STEPS_PER_GPU} time steps per GPU "
                             f"(global grid {N} steps, time-step sharded); fused cons!+jac_coord! on HBM-resident x; "
                             + ("single GPU = BASELINE.json configs[1]" if world == 1 else
-                               "c stitched by in-place RCCL all-gather + tail broadcast every step; value counts one "
+                               "c stitched by in-place RCCL all-gather (one collective per step); value counts one "
                                "10000-step shard evaluation per GPU per step"),
                 "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,
                 "launch": docp.launch_info(),

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "dual.hpp"
+#include "dual2.hpp"
 #include "problems.hpp"
 
 namespace orc {
@@ -91,6 +92,8 @@ struct Docp {
     // cached pattern + colouring
     bool have_pattern = false;
     std::vector<int64_t> colptr, rowval;
+    bool have_hess_pattern = false;
+    std::vector<int64_t> hcolptr, hrowval;      // lower triangle of DOCP_Hessian_pattern, CSC, 0-based
     std::vector<int> color;
     int ncolors = 0;
     std::string err;
@@ -737,6 +740,55 @@ template <class P> static void objective_gradient(const Docp& p, const double* x
     }
 }
 
+// Lower triangle of DOCP_Hessian_pattern in CSC order: the rows/cols ADNLPModels' sparse Hessian backend reports through
+// hess_structure! (NLPModels convention row >= col) and the order hess_coord! fills.
+static void ensure_hess_pattern(Docp& p) {
+    if (p.have_hess_pattern) return;
+    IJ ij;
+    hessian_pattern_ij(p, ij);
+    std::vector<int64_t> colptr, rowval;
+    to_csc(ij, p.dim_NLP_variables, colptr, rowval);
+    p.hcolptr.assign(p.dim_NLP_variables + 1, 0);
+    p.hrowval.clear();
+    for (int64_t j = 0; j < p.dim_NLP_variables; ++j) {
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k)
+            if (rowval[k] >= j) p.hrowval.push_back(rowval[k]);
+        p.hcolptr[j + 1] = (int64_t)p.hrowval.size();
+    }
+    p.have_hess_pattern = true;
+}
+
+// hess_coord!(nlp, x, y, vals; obj_weight): values of  obj_weight * d2 f + sum_i y_i d2 c_i  on the pattern above.
+// Entries of the exact Hessian that the pattern does not hold are counted (dropped[0]: structurally present in the
+// second-order sweep, dropped[1]: of those, numerically nonzero) -- ADNLPModels would silently lose them too.
+template <class P> static void lagrangian_hessian(Docp& p, const double* xu, const double* y, double sigma, double* vals,
+                                                  int64_t* dropped) {
+    ensure_hess_pattern(p);
+    const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    std::vector<S2> z(nvar), cz(ncon);
+    for (int64_t j = 0; j < nvar; ++j) z[j] = S2::variable(xu[j], j);
+    S2::HVec acc;
+    {
+        S2 f = objective<P, S2>(p, z.data());
+        for (auto& e : f.h) acc.emplace_back(e.first, sigma * e.second);
+    }
+    constraints<P, S2>(p, z.data(), cz.data());
+    for (int64_t i = 0; i < ncon; ++i)
+        for (auto& e : cz[i].h) acc.emplace_back(e.first, y[i] * e.second);
+    s2detail::compress(acc);
+    const int64_t nnz = (int64_t)p.hrowval.size();
+    for (int64_t k = 0; k < nnz; ++k) vals[k] = 0.0;
+    dropped[0] = dropped[1] = 0;
+    for (auto& e : acc) {
+        const int64_t row = (int64_t)(e.first >> 32), col = (int64_t)(e.first & 0xffffffffu);
+        const int64_t* b = p.hrowval.data() + p.hcolptr[col];
+        const int64_t* en = p.hrowval.data() + p.hcolptr[col + 1];
+        const int64_t* it = std::lower_bound(b, en, row);
+        if (it != en && *it == row) vals[it - p.hrowval.data()] = e.second;
+        else { dropped[0]++; if (e.second != 0.0) dropped[1]++; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // problem registry
 // ---------------------------------------------------------------------------------------------
@@ -860,7 +912,7 @@ void orc_gradient(void* h, const double* xu, double* g) {
 }
 void orc_set_pattern_mode(void* h, int mode) {
     Docp& p = *(Docp*)h;
-    if (p.pattern_mode != mode) { p.pattern_mode = mode; p.have_pattern = false; }
+    if (p.pattern_mode != mode) { p.pattern_mode = mode; p.have_pattern = false; p.have_hess_pattern = false; }
 }
 int64_t orc_jac_nnz(void* h) {
     Docp& p = *(Docp*)h;
@@ -900,6 +952,23 @@ void orc_hess_nnz(void* h, int64_t* full, int64_t* lower) {
         for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k)
             if (rowval[k] >= j) ++lo;
     *lower = lo;
+}
+
+int64_t orc_hess_lower_nnz(void* h) {
+    Docp& p = *(Docp*)h;
+    orc::ensure_hess_pattern(p);
+    return (int64_t)p.hrowval.size();
+}
+// 0-based CSC of the lower triangle
+void orc_hess_pattern(void* h, int64_t* colptr, int64_t* rowval) {
+    Docp& p = *(Docp*)h;
+    orc::ensure_hess_pattern(p);
+    std::memcpy(colptr, p.hcolptr.data(), sizeof(int64_t) * p.hcolptr.size());
+    std::memcpy(rowval, p.hrowval.data(), sizeof(int64_t) * p.hrowval.size());
+}
+void orc_hess_coord(void* h, const double* xu, const double* y, double obj_weight, double* vals, int64_t* dropped2) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::lagrangian_hessian<typename decltype(tag)::type>(p, xu, y, obj_weight, vals, dropped2); });
 }
 
 }  // extern "C"

@@ -40,7 +40,7 @@ PROBLEMS = {
 
 def build(force=False):
     """Compile the oracle with g++ (a few seconds)."""
-    src = [os.path.join(_HERE, f) for f in ("ctd_oracle.cpp", "dual.hpp", "problems.hpp")]
+    src = [os.path.join(_HERE, f) for f in ("ctd_oracle.cpp", "dual.hpp", "dual2.hpp", "problems.hpp")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src if os.path.exists(s))):
         return _LIB_PATH
@@ -82,6 +82,10 @@ def lib():
         L.orc_jac_coord.argtypes = [C.c_void_p, dp, dp]
         L.orc_jac_column.argtypes = [C.c_void_p, dp, C.c_int64, dp]
         L.orc_hess_nnz.argtypes = [C.c_void_p, ip, ip]
+        L.orc_hess_lower_nnz.argtypes = [C.c_void_p]
+        L.orc_hess_lower_nnz.restype = C.c_int64
+        L.orc_hess_pattern.argtypes = [C.c_void_p, ip, ip]
+        L.orc_hess_coord.argtypes = [C.c_void_p, dp, dp, C.c_double, dp, ip]
         _lib = L
     return _lib
 
@@ -212,3 +216,21 @@ class OracleDOCP:
         full = np.zeros(1, dtype=np.int64); lower = np.zeros(1, dtype=np.int64)
         lib().orc_hess_nnz(self._h, _ip(full), _ip(lower))
         return int(full[0]), int(lower[0])
+
+    def hess_pattern(self):
+        """0-based CSC (colptr, rowval) of the lower triangle of DOCP_Hessian_pattern(docp)."""
+        nnz = int(lib().orc_hess_lower_nnz(self._h))
+        colptr = np.zeros(self.dim_NLP_variables + 1, dtype=np.int64)
+        rowval = np.zeros(nnz, dtype=np.int64)
+        lib().orc_hess_pattern(self._h, _ip(colptr), _ip(rowval))
+        return colptr, rowval
+
+    def hess_coord(self, xu, y, obj_weight=1.0, return_dropped=False):
+        """hess_coord!(nlp, x, y, vals; obj_weight): sparse second-order forward sweep over objective and constraints."""
+        xu = np.ascontiguousarray(xu, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert xu.size == self.dim_NLP_variables and y.size == self.dim_NLP_constraints
+        vals = np.zeros(int(lib().orc_hess_lower_nnz(self._h)))
+        dropped = np.zeros(2, dtype=np.int64)
+        lib().orc_hess_coord(self._h, _dp(xu), _dp(y), float(obj_weight), _dp(vals), _ip(dropped))
+        return (vals, (int(dropped[0]), int(dropped[1]))) if return_dropped else vals

@@ -25,7 +25,36 @@ def fx(h):
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.json")))
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.json")) if not os.path.basename(f).startswith("hess_"))
+
+
+def hess_golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "hess_*.json")))
+
+
+def load_hess_golden(path):
+    """Fixture of tests/golden/gen_golden_hess.py: xu, multipliers y, obj_weight and the exact lower-triangular Hessian
+    of the Lagrangian as a dict {(row, col): value} (0-based, row >= col)."""
+    with open(path) as f:
+        g = json.load(f)
+    out = dict(g)
+    out["time_grid"] = [fx(t) for t in g["time_grid"]] if g["time_grid"] else None
+    out["xu"] = np.array([fx(x) for x in g["xu"]])
+    out["y"] = np.array([fx(x) for x in g["y"]])
+    out["H"] = {(r, c): fx(v) for r, c, v in g["hess_nonzeros"]}
+    return out
+
+
+def hess_on_pattern(H, colptr, rowval):
+    """values of the fixture's Hessian dict on a lower-triangular CSC pattern + the entries the pattern leaves out"""
+    vals = np.zeros(len(rowval))
+    seen = set()
+    for j in range(len(colptr) - 1):
+        for k in range(colptr[j], colptr[j + 1]):
+            key = (int(rowval[k]), j)
+            vals[k] = H.get(key, 0.0)
+            seen.add(key)
+    return vals, [k for k in H if k not in seen]
 
 
 def load_golden(path):

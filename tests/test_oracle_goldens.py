@@ -3,7 +3,8 @@ for this path and against the 50-digit mpmath fixt
 import numpy as np
 import pytest
 
-from helpers import TOL, csc_to_set, dense_on_pattern, golden_files, load_golden, relerr
+from helpers import (TOL, csc_to_set, dense_on_pattern, golden_files, hess_golden_files, hess_on_pattern, load_golden,
+                     load_hess_golden, relerr)
 
 
 def _exact_xu(d):
@@ -161,3 +162,34 @@ def test_oracle_matches_mpmath_fixture(oracle_lib, path):
         assert all(cc >= nv0 for _, cc in missing)
     else:
         assert not missing
+
+
+@pytest.mark.parametrize("path", hess_golden_files(), ids=lambda p: p.split("/")[-1][:-5])
+def test_oracle_hessian_matches_mpmath_fixture(oracle_lib, path):
+    """hess_coord! of the oracle (sparse second-order sweep in double) against the 50-digit Hessian of the Lagrangian,
+    on the lower triangle of DOCP_Hessian_pattern; the reference's pattern holds every true nonzero of these cases."""
+    g = load_hess_golden(path)
+    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
+    first = load_golden(path.replace("hess_", ""))
+    assert np.array_equal(first["xu"], g["xu"])           # same input vector as the first-order fixture of the tag
+    colptr, rowval = d.hess_pattern()
+    assert len(rowval) == d.hess_nnz()[1]
+    for j in range(d.dim_NLP_variables):                  # lower triangle, rows sorted
+        rows = rowval[colptr[j]:colptr[j + 1]]
+        assert np.all(rows >= j) and np.all(np.diff(rows) > 0)
+    want, outside = hess_on_pattern(g["H"], colptr, rowval)
+    assert not outside
+    vals, dropped = d.hess_coord(g["xu"], g["y"], g["obj_weight"], return_dropped=True)
+    assert dropped == (0, 0)
+    assert relerr(vals, want) <= TOL
+    # linear in (obj_weight, y): obj_weight = 0 and y = 0 separate the two parts
+    a = d.hess_coord(g["xu"], 0 * g["y"], g["obj_weight"])
+    b = d.hess_coord(g["xu"], g["y"], 0.0)
+    assert relerr(a + b, want) <= TOL
+
+
+def test_G2_hessian_pattern_nnzh(oracle_lib):
+    """nnzh = 6519 for Goddard / midpoint / N = 250 (test/archives/AD_backend.md:86)."""
+    d = oracle_lib.OracleDOCP("goddard", "midpoint", 250)
+    colptr, rowval = d.hess_pattern()
+    assert len(rowval) == 6519 and colptr[-1] == 6519
