@@ -4,10 +4,10 @@ The compute path is libctdirect_hip.so (hand-written HIP for gfx950, C ABI in in
 is the thin host-side mirror of the reference's DOCP interface plus the multi-GPU stitching helper.
 """
 from . import _lib
-from .docp import (DOCP, PATTERN_MODES, PROBLEMS, SCHEMES, CTDirectError, DOCP_Jacobian_pattern, constraints,
+from .docp import (DOCP, PATTERN_MODES, PROBLEMS, SCHEMES, CTDirectError, DOCP_Hessian_pattern, DOCP_Jacobian_pattern, constraints,
                    constraints_bounds, gradient, initial_guess, objective, variables_bounds)
 
-__all__ = ["DOCP", "PROBLEMS", "SCHEMES", "PATTERN_MODES", "CTDirectError", "DOCP_Jacobian_pattern", "constraints",
+__all__ = ["DOCP", "PROBLEMS", "SCHEMES", "PATTERN_MODES", "CTDirectError", "DOCP_Hessian_pattern", "DOCP_Jacobian_pattern", "constraints",
            "constraints_bounds", "gradient", "initial_guess", "objective", "variables_bounds", "build"]
 
 

@@ -59,6 +59,13 @@ SYMBOLS = {
     "ctd_time_cons_jac_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _dp]),
     "ctd_launch_info": (C.c_int32, [_vp, _ip]),
     "ctd_debug_stamps": (C.c_int32, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_int64]),
+    "ctd_hess_structure": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_hess_csc": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_hess_coord": (C.c_int32, [_vp, _dp, _dp, C.c_double, _dp]),
+    "ctd_hess_coord_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp]),
+    "ctd_hess_coord_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp]),
+    "ctd_time_hess_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, C.c_int32, _dp]),
+    "ctd_hess_launch_info": (C.c_int32, [_vp, _ip]),
 }
 
 

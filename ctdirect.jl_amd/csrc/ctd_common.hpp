@@ -126,4 +126,79 @@ template <int K> CTD_HD Dual<K> d_sqr(const Dual<K>& a) {
 CTD_HD double d_val(double x) { return x; }
 template <int K> CTD_HD double d_val(const Dual<K>& a) { return a.v; }
 
+// ---- second-order forward number: one "outer" direction a, K "inner" directions b_k, and the mixed second
+// derivatives ab_k = d2/(da db_k).  One lane of the Hessian kernel pushes it through an OCP function to obtain K
+// entries of one row of that function's Hessian (plus the first derivative along a).  ADNLPModels gets the same
+// numbers from nested ForwardDiff duals over the whole Lagrangian (backend selection src/collocation.jl:121-125).
+template <int K>
+struct Dual2 {
+    double v, a;
+    double b[K], ab[K];
+    CTD_HD Dual2() {}
+    CTD_HD Dual2(double x) : v(x), a(0.0) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { b[i] = 0.0; ab[i] = 0.0; }
+    }
+};
+// r = f(x) given f0 = f(x.v), f1 = f'(x.v), f2 = f''(x.v)
+template <int K> CTD_HD Dual2<K> d2_chain(const Dual2<K>& x, double f0, double f1, double f2) {
+    Dual2<K> r; r.v = f0; r.a = f1 * x.a;
+    const double t = f2 * x.a;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = f1 * x.b[i]; r.ab[i] = f1 * x.ab[i] + t * x.b[i]; }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> operator+(const Dual2<K>& x, const Dual2<K>& y) {
+    Dual2<K> r; r.v = x.v + y.v; r.a = x.a + y.a;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = x.b[i] + y.b[i]; r.ab[i] = x.ab[i] + y.ab[i]; }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> operator-(const Dual2<K>& x, const Dual2<K>& y) {
+    Dual2<K> r; r.v = x.v - y.v; r.a = x.a - y.a;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = x.b[i] - y.b[i]; r.ab[i] = x.ab[i] - y.ab[i]; }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> operator-(const Dual2<K>& x) {
+    Dual2<K> r; r.v = -x.v; r.a = -x.a;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = -x.b[i]; r.ab[i] = -x.ab[i]; }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> operator*(const Dual2<K>& x, const Dual2<K>& y) {
+    Dual2<K> r; r.v = x.v * y.v; r.a = x.a * y.v + x.v * y.a;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        r.b[i] = x.b[i] * y.v + x.v * y.b[i];
+        r.ab[i] = (x.ab[i] * y.v + x.v * y.ab[i]) + (x.a * y.b[i] + x.b[i] * y.a);
+    }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> d2_recip(const Dual2<K>& y) {
+    const double q = 1.0 / y.v;
+    return d2_chain(y, q, -(q * q), 2.0 * (q * q) * q);
+}
+template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, const Dual2<K>& y) {
+    Dual2<K> r = x * d2_recip(y); r.v = x.v / y.v; return r;
+}
+template <int K> CTD_HD Dual2<K> operator+(const Dual2<K>& x, double y) { Dual2<K> r = x; r.v = x.v + y; return r; }
+template <int K> CTD_HD Dual2<K> operator+(double x, const Dual2<K>& y) { Dual2<K> r = y; r.v = x + y.v; return r; }
+template <int K> CTD_HD Dual2<K> operator-(const Dual2<K>& x, double y) { Dual2<K> r = x; r.v = x.v - y; return r; }
+template <int K> CTD_HD Dual2<K> operator-(double x, const Dual2<K>& y) { Dual2<K> r = -y; r.v = x - y.v; return r; }
+template <int K> CTD_HD Dual2<K> operator*(const Dual2<K>& x, double y) {
+    Dual2<K> r; r.v = x.v * y; r.a = x.a * y;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = x.b[i] * y; r.ab[i] = x.ab[i] * y; }
+    return r;
+}
+template <int K> CTD_HD Dual2<K> operator*(double x, const Dual2<K>& y) { return y * x; }
+template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, double y) { Dual2<K> r = x * (1.0 / y); r.v = x.v / y; return r; }
+template <int K> CTD_HD Dual2<K> operator/(double x, const Dual2<K>& y) { Dual2<K> r = d2_recip(y) * x; r.v = x / y.v; return r; }
+template <int K> CTD_HD Dual2<K> d_exp(const Dual2<K>& x) { const double e = ::exp(x.v); return d2_chain(x, e, e, e); }
+template <int K> CTD_HD Dual2<K> d_sin(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, s, c, -s); }
+template <int K> CTD_HD Dual2<K> d_cos(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, c, -s, -c); }
+template <int K> CTD_HD Dual2<K> d_sqr(const Dual2<K>& x) { return d2_chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
+template <int K> CTD_HD double d_val(const Dual2<K>& x) { return x.v; }
+
 }  // namespace ctd

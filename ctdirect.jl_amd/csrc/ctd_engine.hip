@@ -15,6 +15,7 @@
 #include "../../include/ctdirect_hip.h"
 #include "ctd_host.hpp"
 #include "ctd_kernels.hpp"
+#include "ctd_hess_kernels.hpp"
 
 using namespace ctd;
 
@@ -30,6 +31,16 @@ CTD_EXTERN_LAUNCHERS(EstimateInitialConditionOCP)
 CTD_EXTERN_LAUNCHERS(EstimateRotationRateOCP)
 CTD_EXTERN_LAUNCHERS(LeastSquaresConstraintOCP)
 CTD_EXTERN_LAUNCHERS(DoubleIntegratorFreeT0TfOCP)
+CTD_EXTERN_HESS(GoddardOCP)
+CTD_EXTERN_HESS(GoddardAllOCP)
+CTD_EXTERN_HESS(DoubleIntegratorPathOCP)
+CTD_EXTERN_HESS(QuadrotorOCP)
+CTD_EXTERN_HESS(Quadrotor12OCP)
+CTD_EXTERN_HESS(StagewiseScalarOCP)
+CTD_EXTERN_HESS(EstimateInitialConditionOCP)
+CTD_EXTERN_HESS(EstimateRotationRateOCP)
+CTD_EXTERN_HESS(LeastSquaresConstraintOCP)
+CTD_EXTERN_HESS(DoubleIntegratorFreeT0TfOCP)
 }  // namespace ctd
 
 struct ctd_handle {
@@ -61,6 +72,16 @@ struct ctd_handle {
     int gblocks = 0;
     int obj_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Hessian of the Lagrangian: tables are uploaded by the first Hessian call (hess_ready)
+    bool hess_ready = false;
+    HParams hp;
+    int hess_tile = 0;
+    size_t hess_lds_bytes = 0;
+    uint32_t *d_htptr = nullptr, *d_hterms = nullptr, *d_hvptr = nullptr, *d_hvterms = nullptr, *d_heptr = nullptr,
+             *d_hevptr = nullptr, *d_heterms = nullptr;
+    int64_t* d_hedge_idx = nullptr;
+    uint16_t *d_htasks = nullptr, *d_hbtasks = nullptr;
+    double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
     std::string err;
 };
 
@@ -96,7 +117,9 @@ static void free_device(ctd_handle* h) {
     (void)hipSetDevice(h->device);
     for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
-                    (void*)h->d_gpartial})
+                    (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
+                    (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
+                    (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -232,7 +255,7 @@ int32_t ctd_sizes(const ctd_handle* h, int64_t* nvar, int64_t* ncon, int64_t* nn
     if (nvar) *nvar = h->model.L.nvar;
     if (ncon) *ncon = h->model.L.ncon;
     if (nnzj) *nnzj = h->model.nnzj;
-    if (nnzh) *nnzh = -1;
+    if (nnzh) *nnzh = h->model.H.nnzh;
     return CTD_OK;
 }
 
@@ -538,6 +561,150 @@ int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev,
         st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev, true);
         if (st) return st;
         HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        total += (double)ms;
+    }
+    *mean_ms = total / iters;
+    return CTD_OK;
+}
+
+// ---- Hessian of the Lagrangian ----------------------------------------------------------------------------------------
+
+int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols) {
+    if (!h || !rows || !cols) return CTD_EINVAL;
+    const Model& mo = h->model;
+    std::vector<int64_t> r;
+    int64_t k = 0;
+    for (int64_t j = 0; j < mo.L.nvar; ++j) {
+        mo.hess_gen_column(j, r);
+        for (int64_t row : r) { rows[k] = row + 1; cols[k] = j + 1; ++k; }
+    }
+    return CTD_OK;
+}
+
+int32_t ctd_hess_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval) {
+    if (!h || !colptr || !rowval) return CTD_EINVAL;
+    const Model& mo = h->model;
+    std::vector<int64_t> r;
+    int64_t k = 0;
+    for (int64_t j = 0; j < mo.L.nvar; ++j) {
+        colptr[j] = k;
+        mo.hess_gen_column(j, r);
+        for (int64_t row : r) rowval[k++] = row;
+    }
+    colptr[mo.L.nvar] = k;
+    return k == mo.H.nnzh ? CTD_OK : CTD_EPATTERN;
+}
+
+static int32_t ensure_hess(ctd_handle* h) {
+    if (h->hess_ready) return CTD_OK;
+    const Model& mo = h->model;
+    const HessModel& H = mo.H;
+    if (h->step_begin != 0 || h->step_end != mo.L.N)
+        return fail(h, CTD_EINVAL, "the Hessian is evaluated on full-range handles only (its V x V block sums over every step)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->hess_tile = env_int("CTD_HESS_TILE", 0);
+    if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);
+    mo.fill_hparams(h->hp, h->hess_tile);
+    h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
+    while (h->hess_lds_bytes > 96 * 1024 && h->hess_tile > 1) {
+        h->hess_tile = (h->hess_tile + 1) / 2;
+        mo.fill_hparams(h->hp, h->hess_tile);
+        h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
+    }
+    if (h->hess_lds_bytes > 160 * 1024) return fail(h, CTD_EINVAL, "Hessian records of one step do not fit the 160 KiB LDS");
+    HIP_TRY(h, upload(&h->d_htptr, H.tptr));
+    HIP_TRY(h, upload(&h->d_hterms, H.terms));
+    HIP_TRY(h, upload(&h->d_hvptr, H.vptr));
+    HIP_TRY(h, upload(&h->d_hvterms, H.vterms));
+    HIP_TRY(h, upload(&h->d_hedge_idx, H.edge_idx));
+    HIP_TRY(h, upload(&h->d_heptr, H.eptr));
+    HIP_TRY(h, upload(&h->d_hevptr, H.evptr));
+    HIP_TRY(h, upload(&h->d_heterms, H.eterms));
+    HIP_TRY(h, upload(&h->d_htasks, H.tasks));
+    HIP_TRY(h, upload(&h->d_hbtasks, H.btasks));
+    HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(h->hp.ntiles + 1) * (H.nvv > 0 ? H.nvv : 1)));
+    HParams& hp = h->hp;
+    hp.tau = h->d_tau;
+    hp.tptr = h->d_htptr; hp.terms = h->d_hterms;
+    hp.vptr = h->d_hvptr; hp.vterms = h->d_hvterms;
+    hp.edge_idx = h->d_hedge_idx; hp.eptr = h->d_heptr; hp.evptr = h->d_hevptr; hp.eterms = h->d_heterms;
+    hp.tasks = h->d_htasks; hp.btasks = h->d_hbtasks;
+    hp.partials = h->d_hpartials;
+    h->hess_ready = true;
+    return CTD_OK;
+}
+
+static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
+                            bool timed = false) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x_dev || !y_dev || !vals_dev) return fail(h, CTD_EINVAL, "null argument");
+    int32_t st = ensure_hess(h);
+    if (st) return st;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HParams hp = h->hp;
+    hp.obj_weight = obj_weight;
+    hp.vals = vals_dev;
+    hipError_t e = hipErrorInvalidValue;
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, timed ? h->ev0 : nullptr, timed ? h->ev1 : nullptr);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return CTD_OK;
+}
+
+int32_t ctd_hess_coord_dev_async(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev) {
+    return enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);
+}
+
+int32_t ctd_hess_coord_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev) {
+    int32_t st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);
+    if (st) return st;
+    return ctd_sync(h);
+}
+
+int32_t ctd_hess_coord(ctd_handle* h, const double* x, const double* y, double obj_weight, double* vals) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x || !y || !vals) return fail(h, CTD_EINVAL, "null argument");
+    const Model& mo = h->model;
+    int32_t st = ensure_staging(h, false, false);
+    if (st) return st;
+    if (!h->d_y) HIP_TRY(h, hipMalloc((void**)&h->d_y, sizeof(double) * mo.L.ncon));
+    if (!h->d_hvals) HIP_TRY(h, hipMalloc((void**)&h->d_hvals, sizeof(double) * (mo.H.nnzh > 0 ? mo.H.nnzh : 1)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * mo.L.nvar, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_y, y, sizeof(double) * mo.L.ncon, hipMemcpyHostToDevice, h->stream));
+    st = enqueue_hess(h, h->d_x, h->d_y, obj_weight, h->d_hvals);
+    if (st) return st;
+    HIP_TRY(h, hipMemcpyAsync(vals, h->d_hvals, sizeof(double) * mo.H.nnzh, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+// out[0..5]: grid (workgroups), block, LDS bytes, steps per tile, CSC period of the lower triangle, edge entries
+int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    int32_t st = ensure_hess(h);
+    if (st) return st;
+    o[0] = h->hp.ntiles + 1; o[1] = kHessBlock; o[2] = (int64_t)h->hess_lds_bytes; o[3] = h->hess_tile; o[4] = h->hp.Lseg; o[5] = h->hp.n_edge;
+    return CTD_OK;
+}
+
+int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev, int32_t iters,
+                          double* mean_ms) {
+    if (!h || !mean_ms || iters < 1) return CTD_EINVAL;
+    int32_t st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);   // warm
+    if (st) return st;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev, true);
+        if (st) return st;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
         float ms = 0.f;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         total += (double)ms;

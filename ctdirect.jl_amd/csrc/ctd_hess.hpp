@@ -1,0 +1,118 @@
+// ctd_hess.hpp -- Hessian of the Lagrangian: record layout, term codes and kernel parameters (host + device PODs).
+//
+// Reference: ADNLPModels serves hess_structure!/hess_coord!(nlp, x, y, vals; obj_weight) from nested-dual AD over the
+// closures f and c! (backend selection src/collocation.jl:121-125) on the pattern CTDirect supplies with
+// DOCP_Hessian_pattern (src/ode/trapeze.jl:240-303, midpoint.jl:240-300, irk.jl:423-496, irk_stagewise.jl:565-638);
+// the solver sees the lower triangle of that pattern in CSC order.
+//
+// The engine uses the separability of the Lagrangian  L = obj_weight f + y' c : every nonlinear piece is an OCP
+// function (dynamics, Lagrange cost, path, boundary, Mayer) evaluated at one point  zeta = (t, x, u, v)  that depends
+// on the NLP variables of ONE time step through an (almost) linear map.  Per evaluation point the kernel forms the
+// scalar  Phi = weights' F(zeta)  and its dense Hessian HD along the md = n + m + nv directions
+//     x_0..x_{n-1} | u_0..u_{m-1} | V_0..V_{nv-1}
+// with second-order forward numbers (ctd::Dual2).  The V directions are the total derivatives through the free time
+// grid (get_time_grid, src/DOCP_data.jl:437-458): dzeta/dV_k = (dt/dv_k, dh/dv_k * sum_l a_jl K_l, 0, e_k).
+// Each output entry is then a short sum of terms  coef1 * coef2 * record[di]  (chain rule of the scheme: X_i -> 1,
+// K_i^l -> h a_jl, midpoint X_i / X_{i+1} -> 1/2, stagewise path control U_i^l -> b_l).
+#pragma once
+#include "ctd_layout.hpp"
+
+namespace ctd {
+
+// ---- per-step coefficients --------------------------------------------------------------------------------
+constexpr int kHC = 36;
+enum { HC_ONE = 0, HC_HALF = 1,
+       HC_HA = 2,     // h a_jl            at HC_HA + 3 j + l
+       HC_A = 11,     // a_jl              at HC_A + 3 j + l
+       HC_B = 20,     // b_l               at HC_B + l
+       HC_NBH = 23 }; // -b_l dh/dv_k      at HC_NBH + 3 k + l   (k < kMaxNV)
+
+constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
+
+// ---- per-slot LDS record (doubles) ---------------------------------------------------------------------
+// S stage blocks (S = max(s, 1)), each:  HD[md*md]  (row p, column q >= p)   RK[nv*n]  (Gauss-Legendre with free times:
+//     RK[k*n + a] = h HD[x_a][V_k] + dh/dv_k dPhi/dx_a, the d2/dK dV_k entry up to the factor a_jl)
+// HP[md*md]   path point of the step (Gauss-Legendre / midpoint with path constraints)
+// YX[n]       multipliers of the state-equation rows (Gauss-Legendre with free times: d2/dK^l dV_k of -h b_l y'K^l)
+// C[kHC]      coefficients
+// The boundary record holds HB[mdb*mdb], mdb = 2n + nv (directions x0 | xf | V); the final-path record uses HP.
+struct HessRecLayout {
+    int32_t md, mdb, S;
+    int32_t stage_sz, oStage, oRK;   // stage block j at oStage + j * stage_sz: HD at +0, RK at +oRK
+    int32_t oHP, oYX, oC;
+    int32_t stride;
+};
+
+constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, int s, bool free_time) {
+    HessRecLayout r{};
+    r.md = n + m + nv;
+    r.mdb = 2 * n + nv;
+    r.S = s > 0 ? s : 1;
+    const bool rk = (sc == SC_IRK) && free_time;
+    r.oRK = r.md * r.md;
+    r.stage_sz = r.oRK + (rk ? nv * n : 0);
+    r.oStage = 0;
+    r.oHP = r.oStage + r.S * r.stage_sz;
+    r.oYX = r.oHP + ((p > 0 && sc != SC_TRAPEZE) ? r.md * r.md : 0);
+    int end_step = r.oYX + (rk ? n : 0);
+    int end_b = r.mdb * r.mdb;
+    int body = end_step > end_b ? end_step : end_b;
+    r.oC = body;
+    r.stride = body + kHC;
+    if ((r.stride & 1) == 0) r.stride += 1;
+    return r;
+}
+
+// ---- 32-bit term code:  value += C[c1] * C[c2] * rec[di]  of record `slot` ----------------------------------
+// bits 0-15 di, 16-21 c1, 22-27 c2, 28-30 slot.  Inside tile templates slot is relative (0 = the entry's own step,
+// 1 = the previous step); inside the edge lists it is the absolute record id of the edge block.
+CTD_HD uint32_t pack_term(int di, int c1, int c2, int slot) {
+    return (uint32_t)di | ((uint32_t)c1 << 16) | ((uint32_t)c2 << 22) | ((uint32_t)slot << 28);
+}
+CTD_HD int term_di(uint32_t c) { return (int)(c & 0xFFFFu); }
+CTD_HD int term_c1(uint32_t c) { return (int)((c >> 16) & 0x3Fu); }
+CTD_HD int term_c2(uint32_t c) { return (int)((c >> 22) & 0x3Fu); }
+CTD_HD int term_slot(uint32_t c) { return (int)((c >> 28) & 0x7u); }
+
+// ---- kernel parameters -------------------------------------------------------------------------------------
+struct HParams {
+    Layout L;
+    HessRecLayout R;
+    const double* tau;          // normalized grid on device (N+1) or nullptr (uniform)
+    int32_t T, HL;              // steps per tile, records a tile needs below its first step (midpoint: 1)
+    int32_t ntiles;
+    // regular CSC segments of the lower triangle: step i in [reg_first, reg_last) owns
+    // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])
+    int32_t Lseg;
+    const uint32_t* tptr;       // Lseg + 1 offsets
+    const uint32_t* terms;
+    int32_t nterms;
+    int64_t seg_base, reg_first, reg_last;
+    // V x V block: entry e (nvv = nv (nv+1)/2 of them, at vals[vv_idx[e]]) is a sum over ALL evaluation points; tile
+    // contributions per step: terms [vptr[e], vptr[e+1]) of vterms (slot 0 = the step's own record)
+    int32_t nvv;
+    const uint32_t* vptr;
+    const uint32_t* vterms;
+    int64_t vv_idx[kMaxNV * (kMaxNV + 1) / 2];
+    // edge entries: explicit index + term range; the edge block also sums its share of the V x V entries
+    // (terms [evptr[e], evptr[e+1]) of eterms)
+    int32_t n_edge;
+    const int64_t* edge_idx;
+    const uint32_t* eptr;       // n_edge + 1
+    const uint32_t* evptr;      // nvv + 1
+    const uint32_t* eterms;
+    int32_t n_edge_slots;
+    int32_t edge_fp, edge_b;    // record ids of the final-path and boundary records
+    int64_t edge_steps[kMaxHessEdgeSlots];
+    // eval tasks: (p | chunk << 8) pairs of one evaluation point (ntask of them), same for the boundary point
+    const uint16_t* tasks;
+    const uint16_t* btasks;
+    int32_t ntask, nbtask;
+    FastDiv div_ntask;
+    // inputs / outputs
+    double obj_weight;
+    double* vals;
+    double* partials;           // (ntiles + 1) * nvv: V x V partial sums per workgroup (workgroup 0 = edge)
+};
+
+}  // namespace ctd

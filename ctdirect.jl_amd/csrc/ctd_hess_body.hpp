@@ -1,0 +1,545 @@
+// ctd_hess_body.hpp -- Hessian of the Lagrangian, written as phase functions (see ctd_hess.hpp for the decomposition).
+//
+// One workgroup handles a TILE of consecutive time steps:
+//   load   the tile's slice of xu, the multipliers y of its constraint rows and the normalized times go to LDS
+//   eval   one lane per (step, evaluation point, outer direction p, chunk of inner directions): the OCP functions are
+//          pushed through second-order forward numbers (ctd::Dual2) and the lane stores its K entries of the point's
+//          dense Hessian HD (row p) into the step's LDS record; one lane per step fills the chain-rule coefficients
+//   emit   lane e owns entry e of the step-periodic CSC segment and sums its terms  C[c1] C[c2] rec[di]  for every
+//          step of the tile (coalesced 8-byte stores); a few lanes add up the tile's share of the V x V block
+// Workgroup 0 is the EDGE block: first / last step columns, final-state columns, final-time path point and the
+// boundary + Mayer point (explicit entry list).  hess_finish sums the V x V partials in a fixed order.
+//
+// Reference semantics: hess_coord!(nlp, x, y, vals; obj_weight) of ADNLPModels over the closures built at
+// src/collocation.jl:137-149 -- objective src/DOCP_functions.jl:23-54 (+ integral(): trapeze.jl:78-110, midpoint.jl:79-97,
+// irk.jl:179-228, irk_stagewise.jl:344-384), constraints src/DOCP_functions.jl:80-115 (+ stepStateConstraints!:
+// trapeze.jl:118-142, midpoint.jl:124-140, irk.jl:236-308, irk_stagewise.jl:394-460).
+#pragma once
+#include "ctd_hess.hpp"
+#include "ctd_kernel_body.hpp"
+
+namespace ctd {
+
+template <class P> struct HessK { static constexpr int value = (P::NX >= 8) ? 2 : 4; };
+
+template <class P, int SC, int S> struct HRL {
+    static constexpr HessRecLayout R =
+        make_hess_layout(P::NX, P::NU, P::NV, P::NPATH, SC, SC == SC_IRK ? S : 0, (P::IT0 >= 0) || (P::ITF >= 0));
+};
+
+struct HBlockCtx {
+    int is_edge, nslots, in_stride;
+    int64_t a, b, lo;
+    double* in;     // staged xu slice
+    double* ly;     // multipliers: tile: (nslots + 1) * cb, block k + 1 = rows of step lo + k (block 0: step lo - 1);
+                    // edge: per slot [previous step | own step], then the final-path rows and the boundary rows
+    double* v;
+    double* tau;    // tile: tau[e] = tau_{lo - 1 + e}; edge: 3 per slot (previous, own, next), then tau_N
+    double* rec;
+};
+
+CTD_HD int64_t hslot_step(const HParams& hp, const HBlockCtx& cx, int k) { return cx.is_edge ? hp.edge_steps[k] : cx.lo + k; }
+CTD_HD const double* hslot_y(const HParams& hp, const HBlockCtx& cx, int k) { return cx.ly + (cx.is_edge ? 2 * k + 1 : k + 1) * hp.L.cb; }
+CTD_HD const double* hslot_yprev(const HParams& hp, const HBlockCtx& cx, int k) { return cx.ly + (cx.is_edge ? 2 * k : k) * hp.L.cb; }
+CTD_HD double hslot_tau(const HBlockCtx& cx, int k, int d) { return cx.is_edge ? cx.tau[3 * k + 1 + d] : cx.tau[k + 1 + d]; }
+
+CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
+    HBlockCtx cx;
+    const Layout& L = hp.L;
+    if (block == 0) {
+        cx.is_edge = 1;
+        cx.nslots = hp.n_edge_slots;
+        cx.in_stride = L.blk + L.n + L.m;
+        cx.a = cx.b = cx.lo = 0;
+        cx.in = lds;
+        cx.ly = cx.in + cx.nslots * cx.in_stride;
+        cx.v = cx.ly + 2 * cx.nslots * L.cb + L.p + L.bc;
+        cx.tau = cx.v + kMaxNV;
+        cx.rec = cx.tau + 3 * kMaxHessEdgeSlots + 1;
+    } else {
+        const int tile = block - 1;
+        const int cap = hp.T + hp.HL;
+        cx.is_edge = 0;
+        cx.a = (int64_t)tile * hp.T;
+        const int64_t last = (L.sc == SC_TRAPEZE) ? L.N + 1 : L.N;     // trapeze tiles walk nodes 0..N-1, node N is edge
+        (void)last;
+        cx.b = cx.a + hp.T < L.N ? cx.a + hp.T : L.N;
+        cx.lo = cx.a - hp.HL;
+        cx.nslots = (int)(cx.b - cx.a) + hp.HL;
+        cx.in_stride = L.blk;
+        cx.in = lds;
+        cx.ly = cx.in + (cap + 1) * L.blk + L.n + L.m;
+        cx.v = cx.ly + (cap + 1) * L.cb;
+        cx.tau = cx.v + kMaxNV;
+        cx.rec = cx.tau + cap + 3;
+    }
+    return cx;
+}
+
+inline int64_t hess_lds_doubles(const HParams& hp) {
+    const Layout& L = hp.L;
+    const int64_t cap = hp.T + hp.HL;
+    const int64_t tile = (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 + cap * hp.R.stride;
+    const int64_t edge = (int64_t)hp.n_edge_slots * (L.blk + L.n + L.m) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
+                         3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * hp.R.stride;
+    return tile > edge ? tile : edge;
+}
+
+CTD_HD double htau_global(const HParams& hp, int64_t i) {
+    if (i < 0) i = 0;
+    if (i > hp.L.N) i = hp.L.N;
+    return hp.tau ? hp.tau[i] : (double)i / (double)hp.L.N;
+}
+template <class P> CTD_HD double htime_of(const HParams& hp, const double* v, double tau) {
+    const double t0 = (P::IT0 >= 0) ? v[P::IT0 >= 0 ? P::IT0 : 0] : hp.L.t0;
+    const double tf = (P::ITF >= 0) ? v[P::ITF >= 0 ? P::ITF : 0] : hp.L.tf;
+    return t0 + tau * (tf - t0);
+}
+
+// multiplier of local row r of step s (rows of node N: only the final-time path rows exist)
+CTD_HD double hess_y_of(const HParams& hp, const double* __restrict__ y, int64_t s, int r) {
+    const Layout& L = hp.L;
+    if (s >= 0 && s < L.N) return y[s * L.cb + r];
+    if (s == L.N && r >= L.eqs) return y[L.N * L.cb + (r - L.eqs)];
+    return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// phase: load
+// ------------------------------------------------------------------------------------------------------
+template <class P>
+CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double* __restrict__ xu,
+                            const double* __restrict__ y, int tid, int nthr) {
+    const Layout& L = hp.L;
+    if (cx.is_edge) {
+        const int per = cx.in_stride;
+        for (int e = tid; e < cx.nslots * per; e += nthr) {
+            const int k = e / per, o = e - k * per;
+            const int64_t g = hp.edge_steps[k] * L.blk + o;
+            cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
+        }
+        for (int e = tid; e < 2 * cx.nslots * L.cb; e += nthr) {
+            const int blk2 = e / L.cb, r = e - blk2 * L.cb;
+            cx.ly[e] = hess_y_of(hp, y, hp.edge_steps[blk2 >> 1] - 1 + (blk2 & 1), r);
+        }
+        for (int e = tid; e < L.p + L.bc; e += nthr) cx.ly[2 * cx.nslots * L.cb + e] = y[L.N * L.cb + e];
+        for (int e = tid; e <= 3 * cx.nslots; e += nthr)
+            cx.tau[e] = (e == 3 * cx.nslots) ? htau_global(hp, L.N) : htau_global(hp, hp.edge_steps[e / 3] - 1 + (e % 3));
+    } else {
+        const int64_t g0 = (cx.lo < 0 ? 0 : cx.lo) * (int64_t)L.blk;
+        int64_t g1 = (cx.lo + cx.nslots) * (int64_t)L.blk + L.n + L.m;
+        if (g1 > L.v_off) g1 = L.v_off;
+        const double* __restrict__ src = xu + g0;
+        double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
+        const int cnt = (int)(g1 - g0);
+        for (int e = tid; e < cnt; e += nthr) dst[e] = src[e];
+        const int ny = (cx.nslots + 1) * L.cb;
+        for (int e = tid; e < ny; e += nthr) {
+            const int k = e / L.cb, r = e - k * L.cb;
+            cx.ly[e] = hess_y_of(hp, y, cx.lo - 1 + k, r);
+        }
+        for (int e = tid; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
+    }
+    if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// phase: eval
+// ------------------------------------------------------------------------------------------------------
+// chain-rule coefficients of one step + the state-equation multipliers the K x V terms need
+template <class P, int SC, int S>
+CTD_HD void hess_coefs(const HParams& hp, const HBlockCtx& cx, int k) {
+    constexpr int n = P::NX, nv = P::NV;
+    constexpr bool FREE = Dirs<P>::FREE;
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    const Layout& L = hp.L;
+    double* rec = cx.rec + k * R.stride;
+    double* C = rec + R.oC;
+#pragma unroll
+    for (int e = 0; e < kHC; ++e) C[e] = 0.0;
+    C[HC_ONE] = 1.0; C[HC_HALF] = 0.5;
+    const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
+    const double h = htime_of<P>(hp, cx.v, tau1) - htime_of<P>(hp, cx.v, tau0);
+    if (SC == SC_IRK) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+#pragma unroll
+            for (int l = 0; l < S; ++l) { C[HC_HA + 3 * j + l] = h * L.a[3 * j + l]; C[HC_A + 3 * j + l] = L.a[3 * j + l]; }
+            C[HC_B + j] = L.b[j];
+        }
+        if (FREE) {
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                const double dh = dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk);
+#pragma unroll
+                for (int l = 0; l < S; ++l) C[HC_NBH + 3 * kk + l] = -(L.b[l] * dh);
+            }
+            const double* y = hslot_y(hp, cx, k);
+#pragma unroll
+            for (int r = 0; r < n; ++r) rec[R.oYX + r] = y[r];
+        }
+    }
+}
+
+// seeds of one direction d (0..md-1; anything else: no direction) -- compare-and-select, no indexed registers
+template <int K> CTD_HD Dual2<K> hess_seed(double val, double sa, const double* sb) {
+    Dual2<K> r; r.v = val; r.a = sa;
+#pragma unroll
+    for (int i = 0; i < K; ++i) { r.b[i] = sb[i]; r.ab[i] = 0.0; }
+    return r;
+}
+
+// One (p, chunk) lane of a stage-type point: Gauss-Legendre stage j of step s, the midpoint of step s, or trapeze node s.
+template <class P, int SC, int S>
+CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j, int p, int c) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, K = HessK<P>::value;
+    constexpr bool FREE = Dirs<P>::FREE;
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    constexpr int md = R.md, vd = n + m;
+    using T = Dual2<K>;
+    const Layout& L = hp.L;
+    const int64_t s = hslot_step(hp, cx, k);
+    if (s < 0 || (SC == SC_TRAPEZE ? s > L.N : s >= L.N)) return;
+    const double* base = cx.in + k * cx.in_stride;
+    const double* y = hslot_y(hp, cx, k);
+    double* rec = cx.rec + k * R.stride;
+    const double taum = hslot_tau(cx, k, -1), tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
+    const double tA = htime_of<P>(hp, cx.v, tau0), tB = htime_of<P>(hp, cx.v, tau1);
+    const double h = tB - tA;
+    int q[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    // d(tau-dependent quantity)/d(direction): only the V directions move the time grid
+    auto dt_of = [&](int d, double tau) -> double {
+        const int kx = d - vd;
+        return (FREE && kx >= 0 && d < md) ? dtime_of<P>(tau, kx) : 0.0;
+    };
+    auto unit = [&](int d, int target) -> double { return d == target ? 1.0 : 0.0; };
+    double sb[K];
+
+    // step length as a second-order number (its V-derivatives are constants)
+#pragma unroll
+    for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau1) - dt_of(q[i], tau0);
+    const double hda = dt_of(p, tau1) - dt_of(p, tau0);
+    const T hh = hess_seed<K>(h, hda, sb);
+    double hdb[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) hdb[i] = sb[i];
+
+    // evaluation time
+    T t;
+    if (SC == SC_IRK) {
+        const double cj = L.c[j];
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0) + cj * hdb[i];
+        t = hess_seed<K>(tA + cj * h, dt_of(p, tau0) + cj * hda, sb);
+    } else if (SC == SC_MIDPOINT) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = 0.5 * (dt_of(q[i], tau0) + dt_of(q[i], tau1));
+        t = hess_seed<K>(0.5 * (tA + tB), 0.5 * (dt_of(p, tau0) + dt_of(p, tau1)), sb);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0);
+        t = hess_seed<K>(tA, dt_of(p, tau0), sb);
+    }
+
+    // state at the evaluation point
+    T x[n > 0 ? n : 1];
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+        if (SC == SC_IRK) {
+            const double* Kv = base + n + L.cu;
+            double kap = 0.0;
+#pragma unroll
+            for (int l = 0; l < S; ++l) kap = kap + L.a[3 * j + l] * Kv[l * n + r];
+#pragma unroll
+            for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r) + hdb[i] * kap;
+            x[r] = hess_seed<K>(base[r] + h * kap, unit(p, r) + hda * kap, sb);
+        } else {
+#pragma unroll
+            for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r);
+            const double xv = (SC == SC_MIDPOINT) ? 0.5 * (base[r] + base[L.blk + r]) : base[r];
+            x[r] = hess_seed<K>(xv, unit(p, r), sb);
+        }
+    }
+    T u[m > 0 ? m : 1];
+#pragma unroll
+    for (int b = 0; b < m; ++b) {
+        const double uv = (SC == SC_IRK && L.stagewise) ? base[n + j * m + b] : base[n + b];
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], n + b);
+        u[b] = hess_seed<K>(uv, unit(p, n + b), sb);
+    }
+    T v[nv > 0 ? nv : 1];
+#pragma unroll
+    for (int kk = 0; kk < nv; ++kk) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], vd + kk);
+        v[kk] = hess_seed<K>(cx.v[kk], unit(p, vd + kk), sb);
+    }
+
+    T f[n > 0 ? n : 1];
+    P::template dynamics<T>(f, t, x, u, v);
+    T phi(0.0);
+    if (SC == SC_IRK) {
+#pragma unroll
+        for (int r = 0; r < n; ++r) phi = phi + f[r] * (-y[n + j * n + r]);
+        if (P::HAS_LAGRANGE) phi = phi + (hh * P::template lagrange<T>(t, x, u, v)) * (hp.obj_weight * L.b[j]);
+    } else if (SC == SC_MIDPOINT) {
+        T inner(0.0);
+#pragma unroll
+        for (int r = 0; r < n; ++r) inner = inner + f[r] * (-y[r]);
+        if (P::HAS_LAGRANGE) inner = inner + P::template lagrange<T>(t, x, u, v) * hp.obj_weight;
+        phi = hh * inner;
+    } else {
+        // node s is shared by step s-1 (length hm) and step s (length hh); the clamped tau makes the missing one 0
+        const double tM = htime_of<P>(hp, cx.v, taum);
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0) - dt_of(q[i], taum);
+        const T hm = hess_seed<K>(tA - tM, dt_of(p, tau0) - dt_of(p, taum), sb);
+        const double* yp = hslot_yprev(hp, cx, k);
+#pragma unroll
+        for (int r = 0; r < n; ++r) phi = phi + f[r] * ((hm * yp[r] + hh * y[r]) * (-0.5));
+        if (P::HAS_LAGRANGE) phi = phi + P::template lagrange<T>(t, x, u, v) * ((hm + hh) * (0.5 * hp.obj_weight));
+        if (np > 0) {
+            T g[np > 0 ? np : 1];
+            P::template path<T>(g, t, x, u, v);
+#pragma unroll
+            for (int r = 0; r < np; ++r) phi = phi + g[r] * y[L.eqs + r];
+        }
+    }
+    double* HD = rec + R.oStage + j * R.stage_sz;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (q[i] < md) HD[p * md + q[i]] = phi.ab[i];
+    if (SC == SC_IRK && FREE && p < n) {
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (q[i] >= vd && q[i] < md) HD[R.oRK + (q[i] - vd) * n + p] = h * phi.ab[i] + hdb[i] * phi.a;
+    }
+}
+
+// path point: x = X_s (or X_N), u = control of the step (stagewise: sum_l b_l U^l), t = t_s; `yrow` = multipliers of the rows
+template <class P, int SC, int S>
+CTD_HD void hess_eval_path(const HParams& hp, const double* xs, const double* ub, const double* vv, double tau,
+                           const double* yrow, double* HP, int p, int c) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, K = HessK<P>::value;
+    constexpr bool FREE = Dirs<P>::FREE;
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    constexpr int md = R.md, vd = n + m;
+    using T = Dual2<K>;
+    const Layout& L = hp.L;
+    int q[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    auto dt_of = [&](int d) -> double {
+        const int kx = d - vd;
+        return (FREE && kx >= 0 && d < md) ? dtime_of<P>(tau, kx) : 0.0;
+    };
+    auto unit = [&](int d, int target) -> double { return d == target ? 1.0 : 0.0; };
+    double sb[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i]);
+    const T t = hess_seed<K>(htime_of<P>(hp, vv, tau), dt_of(p), sb);
+    T x[n > 0 ? n : 1];
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r);
+        x[r] = hess_seed<K>(xs[r], unit(p, r), sb);
+    }
+    T u[m > 0 ? m : 1];
+#pragma unroll
+    for (int b = 0; b < m; ++b) {
+        double uv;
+        if (SC == SC_IRK && L.stagewise) {
+            uv = L.b[0] * ub[b];
+#pragma unroll
+            for (int l = 1; l < S; ++l) uv = uv + L.b[l] * ub[l * m + b];
+        } else {
+            uv = ub[b];
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], n + b);
+        u[b] = hess_seed<K>(uv, unit(p, n + b), sb);
+    }
+    T v[nv > 0 ? nv : 1];
+#pragma unroll
+    for (int kk = 0; kk < nv; ++kk) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], vd + kk);
+        v[kk] = hess_seed<K>(vv[kk], unit(p, vd + kk), sb);
+    }
+    T g[np > 0 ? np : 1];
+    P::template path<T>(g, t, x, u, v);
+    T phi(0.0);
+#pragma unroll
+    for (int r = 0; r < np; ++r) phi = phi + g[r] * yrow[r];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (q[i] < md) HP[p * md + q[i]] = phi.ab[i];
+}
+
+// boundary + Mayer point: directions x0 | xf | v
+template <class P, int SC, int S>
+CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const double* xfp, const double* vv,
+                               const double* yrow, double* HB, int p, int c) {
+    constexpr int n = P::NX, nv = P::NV, nb = P::NBC, K = HessK<P>::value;
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    constexpr int mdb = R.mdb;
+    using T = Dual2<K>;
+    int q[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    auto unit = [&](int d, int target) -> double { return d == target ? 1.0 : 0.0; };
+    double sb[K];
+    T x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1];
+#pragma unroll
+    for (int r = 0; r < n; ++r) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r);
+        x0[r] = hess_seed<K>(x0p[r], unit(p, r), sb);
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], n + r);
+        xf[r] = hess_seed<K>(xfp[r], unit(p, n + r), sb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < nv; ++kk) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = unit(q[i], 2 * n + kk);
+        v[kk] = hess_seed<K>(vv[kk], unit(p, 2 * n + kk), sb);
+    }
+    T phi(0.0);
+    if (nb > 0) {
+        T r_[nb > 0 ? nb : 1];
+        P::template boundary<T>(r_, x0, xf, v);
+#pragma unroll
+        for (int r = 0; r < nb; ++r) phi = phi + r_[r] * yrow[r];
+    }
+    if (P::HAS_MAYER) phi = phi + P::template mayer<T>(x0, xf, v) * hp.obj_weight;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (q[i] < mdb) HB[p * mdb + q[i]] = phi.ab[i];
+}
+
+template <class P, int SC, int S>
+CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int nthr) {
+    constexpr int n = P::NX, np = P::NPATH;
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    constexpr bool PATH_PT = np > 0 && SC != SC_TRAPEZE;
+    constexpr int PT = R.S + (PATH_PT ? 1 : 0);
+    const Layout& L = hp.L;
+    for (int k = tid; k < cx.nslots; k += nthr) hess_coefs<P, SC, S>(hp, cx, k);
+    const int total = cx.nslots * PT * hp.ntask;
+    for (int w = tid; w < total; w += nthr) {
+        const int sp = (int)fast_div((uint32_t)w, hp.div_ntask);
+        const int tk = w - sp * hp.ntask;
+        const int k = sp / PT, pt = sp - k * PT;
+        const uint16_t code = hp.tasks[tk];
+        const int p = code & 0xFF, c = code >> 8;
+        if (pt < R.S) {
+            hess_eval_stage<P, SC, S>(hp, cx, k, pt, p, c);
+        } else if (PATH_PT) {
+            const int64_t s = hslot_step(hp, cx, k);
+            if (s >= 0 && s < L.N) {
+                const double* base = cx.in + k * cx.in_stride;
+                hess_eval_path<P, SC, S>(hp, base, base + n, cx.v, hslot_tau(cx, k, 0), hslot_y(hp, cx, k) + L.eqs,
+                                         cx.rec + k * R.stride + R.oHP, p, c);
+            }
+        }
+    }
+    if (cx.is_edge) {
+        // final-time path point (DOCP_functions.jl:100): X_N with the controls of step N-1; boundary + Mayer point
+        int kl = 0, kf = 0;
+        for (int k = 0; k < cx.nslots; ++k) {
+            if (hp.edge_steps[k] == L.N - 1) kl = k;
+            if (hp.edge_steps[k] == 0) kf = k;
+        }
+        const double* last = cx.in + kl * cx.in_stride;
+        const double* yfp = cx.ly + 2 * cx.nslots * L.cb;
+        if (PATH_PT)
+            for (int w = tid; w < hp.ntask; w += nthr) {
+                const uint16_t code = hp.tasks[w];
+                hess_eval_path<P, SC, S>(hp, last + L.blk, last + n, cx.v, cx.tau[3 * cx.nslots], yfp,
+                                         cx.rec + hp.edge_fp * R.stride + R.oHP, code & 0xFF, code >> 8);
+            }
+        if (P::NBC > 0 || P::HAS_MAYER)
+            for (int w = tid; w < hp.nbtask; w += nthr) {
+                const uint16_t code = hp.btasks[w];
+                hess_eval_boundary<P, SC, S>(hp, cx.in + kf * cx.in_stride, last + L.blk, cx.v, yfp + L.p,
+                                             cx.rec + hp.edge_b * R.stride, code & 0xFF, code >> 8);
+            }
+        // the coefficient blocks of the two extra records (terms multiply by C[HC_ONE])
+        for (int e = tid; e < 2 * kHC; e += nthr) {
+            const int which = e / kHC, ci = e - which * kHC;
+            cx.rec[(hp.edge_fp + which) * R.stride + R.oC + ci] = (ci == HC_ONE) ? 1.0 : (ci == HC_HALF ? 0.5 : 0.0);
+        }
+        if (L.stagewise)
+            for (int e = tid; e < S; e += nthr) cx.rec[hp.edge_fp * R.stride + R.oC + HC_B + e] = L.b[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// phase: emit
+// ------------------------------------------------------------------------------------------------------
+CTD_HD double hess_term(const double* rec, int stride, int oC, uint32_t code, int slot) {
+    const double* r = rec + slot * stride;
+    return (r[oC + term_c1(code)] * r[oC + term_c2(code)]) * r[term_di(code)];
+}
+
+template <class P, int SC, int S>
+CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, int tid, int nthr) {
+    constexpr HessRecLayout R = HRL<P, SC, S>::R;
+    if (cx.is_edge) {
+        for (int e = tid; e < hp.n_edge; e += nthr) {
+            double acc = 0.0;
+            for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
+                const uint32_t code = hp.eterms[t];
+                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, term_slot(code));
+            }
+            hp.vals[hp.edge_idx[e]] = acc;
+        }
+        for (int e = tid; e < hp.nvv; e += nthr) {
+            double acc = 0.0;
+            for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
+                const uint32_t code = hp.eterms[t];
+                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, term_slot(code));
+            }
+            hp.partials[e] = acc;
+        }
+        return;
+    }
+    const int64_t i0 = cx.a > hp.reg_first ? cx.a : hp.reg_first;
+    const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
+    for (int e = tid; e < hp.Lseg; e += nthr) {
+        const uint32_t t0 = hp.tptr[e], t1 = hp.tptr[e + 1];
+        double* out = hp.vals + hp.seg_base + e;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int k = (int)(i - cx.lo);
+            double acc = 0.0;
+            for (uint32_t t = t0; t < t1; ++t) {
+                const uint32_t code = hp.terms[t];
+                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, k - term_slot(code));
+            }
+            out[(i - hp.reg_first) * (int64_t)hp.Lseg] = acc;
+        }
+    }
+    // the tile's share of the V x V entries: all of its steps, in step order
+    for (int e = tid; e < hp.nvv; e += nthr) {
+        double acc = 0.0;
+        for (int64_t i = cx.a; i < cx.b; ++i) {
+            const int k = (int)(i - cx.lo);
+            for (uint32_t t = hp.vptr[e]; t < hp.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, R.oC, hp.vterms[t], k);
+        }
+        hp.partials[(int64_t)block * hp.nvv + e] = acc;
+    }
+}
+
+// V x V entries: sum of the per-workgroup partials in a fixed order (lane t takes workgroups t, t + nthr, ...; then a tree)
+CTD_HD double hess_finish_partial(const HParams& hp, int e, int tid, int nthr) {
+    double acc = 0.0;
+    for (int b = tid; b <= hp.ntiles; b += nthr) acc = acc + hp.partials[(int64_t)b * hp.nvv + e];
+    return acc;
+}
+
+}  // namespace ctd

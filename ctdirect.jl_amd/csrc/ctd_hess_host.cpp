@@ -1,0 +1,392 @@
+// ctd_hess_host.cpp -- host side of the Hessian of the Lagrangian: the lower triangle of DOCP_Hessian_pattern in CSC
+// order (without materialising it for the step-periodic middle) and the term tables the Hessian kernel consumes.
+// See ctd_hess.hpp for the decomposition.
+#include "ctd_host.hpp"
+
+#include <algorithm>
+#include <map>
+#include <set>
+
+namespace ctd {
+
+enum { ST_OK = 0, ST_EPATTERN = 4 };
+
+// ------------------------------------------------------------------------------------------------------
+// DOCP_Hessian_pattern: the add_nonzero_block! calls of each scheme (0-based, half-open; `sym` blocks pushed both ways)
+// ------------------------------------------------------------------------------------------------------
+static inline void hpush(std::vector<Block>& out, int64_t r0, int64_t r1, int64_t c0, int64_t c1, bool sym = false) {
+    if (r1 > r0 && c1 > c0) {
+        out.push_back(Block{r0, r1, c0, c1});
+        if (sym) out.push_back(Block{c0, c1, r0, r1});
+    }
+}
+
+void Model::hess_step_blocks(int64_t i, std::vector<Block>& out) const {
+    const int64_t blk = L.blk, vo = i * blk, v0 = L.v_off, v1 = L.nvar;
+    int64_t hi;
+    if (L.sc == SC_TRAPEZE) hi = vo + 2 * blk;            // trapeze.jl:262-281  [X_i U_i X_i+1 U_i+1]
+    else if (L.sc == SC_MIDPOINT) hi = vo + blk + L.n;    // midpoint.jl:262-281 [X_i U_i X_i+1]
+    else hi = vo + blk;                                   // irk.jl:445-462 / irk_stagewise.jl:587-604 [X_i U_i K_i]
+    hpush(out, vo, hi, vo, hi);
+    hpush(out, vo, hi, v0, v1, true);
+}
+
+static void build_hess_tail(Model& mo) {
+    const Layout& L = mo.L;
+    const int64_t N = L.N, n = L.n;
+    std::vector<Block>& out = mo.H.tail;
+    out.clear();
+    hpush(out, L.v_off, L.nvar, L.v_off, L.nvar);                       // variable x variable (first call of every scheme)
+    const int64_t xf0 = N * L.blk, xf1 = xf0 + n;
+    if (L.sc == SC_TRAPEZE) {                                           // trapeze.jl:284-293
+        if (mo.info.mayer || L.bc > 0) hpush(out, 0, n, xf0, xf1, true);
+        return;
+    }
+    if (L.sc == SC_MIDPOINT) {                                          // midpoint.jl:284-290
+        hpush(out, 0, n, xf0, xf1, true);
+        return;
+    }
+    // irk.jl:465-486 / irk_stagewise.jl:607-628 (u(tf) = U_N convention)
+    const int64_t uf0 = (N - 1) * L.blk + n, uf1 = uf0 + L.cu;
+    hpush(out, xf0, xf1, xf0, xf1);
+    hpush(out, uf0, uf1, uf0, uf1);
+    hpush(out, xf0, xf1, uf0, uf1, true);
+    // the reference's (xf_start:uf_end) x v block is an empty range (xf_start > uf_end): nothing pushed.  STRUCTURAL
+    // mode adds the block the surrounding comment intends
+    if (mo.pattern_mode == 1) hpush(out, xf0, xf1, L.v_off, L.nvar, true);
+    hpush(out, uf0, uf1, L.v_off, L.nvar, true);
+    hpush(out, 0, n, xf0, xf1, true);
+}
+
+void Model::hess_gen_column(int64_t j, std::vector<int64_t>& rows) const {
+    rows.clear();
+    std::vector<Block> cand;
+    if (j < L.v_off) {
+        const int64_t sj = j / L.blk;
+        for (int64_t s = sj - 1; s <= sj; ++s)
+            if (s >= 0 && s < L.N) hess_step_blocks(s, cand);
+    }
+    // (V columns: only rows >= j matter, and those lie in the V x V tail block)
+    for (const Block& b : H.tail) cand.push_back(b);
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    for (const Block& b : cand)
+        if (j >= b.c0 && j < b.c1 && b.r1 > j) iv.emplace_back(std::max(b.r0, j), b.r1);
+    std::sort(iv.begin(), iv.end());
+    int64_t next = -1;
+    for (auto& p : iv) {
+        int64_t r = std::max(p.first, next);
+        for (; r < p.second; ++r) rows.push_back(r);
+        next = std::max(next, p.second);
+    }
+}
+
+int64_t Model::hess_column_start(int64_t j) const {
+    const int64_t h = H.reg_first * L.blk, t = H.reg_last * L.blk;
+    if (j < h) return H.cp_head[j];
+    if (j < t) {
+        const int64_t i = j / L.blk;
+        return H.seg_base + (i - H.reg_first) * (int64_t)H.Lseg + H.cp_tmpl[j - i * L.blk];
+    }
+    return H.cp_tail[j - t];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// which evaluation points couple two NLP variables, and through which directions / coefficients
+// ------------------------------------------------------------------------------------------------------
+namespace {
+enum { VK_X = 0, VK_U = 1, VK_K = 2, VK_V = 3 };
+struct Var { int kind; int64_t s; int l; int c; };
+enum { PT_STAGE = 0, PT_PATH = 1, PT_LIN = 2, PT_FPATH = 3, PT_BND = 4 };
+struct Term { int pt; int64_t step; int di, c1, c2; };
+struct Dir { bool ok; int d, coef; };
+
+Var decode_var(const Layout& L, int64_t idx) {
+    if (idx >= L.v_off) return Var{VK_V, -1, 0, (int)(idx - L.v_off)};
+    const int64_t s = idx / L.blk;
+    const int q = (int)(idx - s * L.blk);
+    if (q < L.n) return Var{VK_X, s, 0, q};
+    if (q < L.n + L.cu) {
+        if (L.stagewise) return Var{VK_U, s, (q - L.n) / L.m, (q - L.n) % L.m};
+        return Var{VK_U, s, -1, q - L.n};
+    }
+    return Var{VK_K, s, (q - L.n - L.cu) / L.n, (q - L.n - L.cu) % L.n};
+}
+
+// stage point (s, j): Gauss-Legendre stage, the midpoint, or the trapeze node s
+Dir map_stage(const Layout& L, int64_t s, int j, const Var& v) {
+    const int n = L.n, m = L.m;
+    if (v.kind == VK_V) return Dir{true, n + m + v.c, HC_ONE};
+    if (L.sc == SC_IRK) {
+        if (v.s != s) return Dir{false, 0, 0};
+        if (v.kind == VK_X) return Dir{true, v.c, HC_ONE};
+        if (v.kind == VK_K) return Dir{true, v.c, HC_HA + 3 * j + v.l};
+        if (L.stagewise && v.l != j) return Dir{false, 0, 0};
+        return Dir{true, n + v.c, HC_ONE};
+    }
+    if (L.sc == SC_MIDPOINT) {
+        if (v.kind == VK_X && (v.s == s || v.s == s + 1)) return Dir{true, v.c, HC_HALF};
+        if (v.kind == VK_U && v.s == s) return Dir{true, n + v.c, HC_ONE};
+        return Dir{false, 0, 0};
+    }
+    if (v.s != s) return Dir{false, 0, 0};
+    return v.kind == VK_X ? Dir{true, v.c, HC_ONE} : Dir{true, n + v.c, HC_ONE};
+}
+// path point of step s (x = X_s, u = get_OCP_control_at_time_step; stagewise: sum_l b_l U_s^l, irk_stagewise.jl:197-205);
+// xs is the step whose state the point reads (s, or N for the final-time point which keeps the controls of step N-1)
+Dir map_path(const Layout& L, int64_t xs, int64_t us, const Var& v) {
+    const int n = L.n, m = L.m;
+    if (v.kind == VK_V) return Dir{true, n + m + v.c, HC_ONE};
+    if (v.kind == VK_X && v.s == xs) return Dir{true, v.c, HC_ONE};
+    if (v.kind == VK_U && v.s == us) return Dir{true, n + v.c, L.stagewise ? HC_B + v.l : HC_ONE};
+    return Dir{false, 0, 0};
+}
+Dir map_bnd(const Layout& L, const Var& v) {
+    if (v.kind == VK_V) return Dir{true, 2 * L.n + v.c, HC_ONE};
+    if (v.kind == VK_X && v.s == 0) return Dir{true, v.c, HC_ONE};
+    if (v.kind == VK_X && v.s == L.N) return Dir{true, L.n + v.c, HC_ONE};
+    return Dir{false, 0, 0};
+}
+inline int sym_index(int md, int a, int b) { return a <= b ? a * md + b : b * md + a; }
+}  // namespace
+
+// every term of d2 L / d(row) d(col); both variables V is handled by the V x V reduction, not here
+static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector<Term>& out) {
+    const Layout& L = mo.L;
+    const HessRecLayout& R = mo.H.R;
+    const int S = R.S;
+    const Var vr = decode_var(L, row), vc = decode_var(L, col);
+    out.clear();
+    if (vr.kind == VK_V && vc.kind == VK_V) return;
+    std::set<int64_t> steps;
+    for (const Var* v : {&vr, &vc}) {
+        if (v->kind == VK_V) continue;
+        steps.insert(v->s);
+        if (L.sc == SC_MIDPOINT && v->kind == VK_X) steps.insert(v->s - 1);
+    }
+    const int64_t last_pt = (L.sc == SC_TRAPEZE) ? L.N : L.N - 1;
+    const bool has_path_pt = L.p > 0 && L.sc != SC_TRAPEZE;
+    const bool rk = L.sc == SC_IRK && L.free_time;
+    for (int64_t s : steps) {
+        if (s < 0 || s > last_pt) continue;
+        for (int j = 0; j < S; ++j) {
+            const Dir a = map_stage(L, s, j, vr), b = map_stage(L, s, j, vc);
+            if (!a.ok || !b.ok) continue;
+            const int base = R.oStage + j * R.stage_sz;
+            const Var* kv = (vr.kind == VK_K) ? &vr : (vc.kind == VK_K ? &vc : nullptr);
+            const Var* vv = (vr.kind == VK_V) ? &vr : (vc.kind == VK_V ? &vc : nullptr);
+            if (rk && kv && vv)    // d2/dK^l_a dV_k: a_jl (h HD[x_a][V_k] + dh/dv_k dPhi/dx_a)
+                out.push_back(Term{PT_STAGE, s, base + R.oRK + vv->c * L.n + kv->c, HC_A + 3 * j + kv->l, HC_ONE});
+            else
+                out.push_back(Term{PT_STAGE, s, base + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+        }
+        if (rk) {   // state-equation row -h sum_l b_l y'K^l: d2/dK^l_a dV_k = -b_l dh/dv_k y_a for the time variables
+            const Var* kv = (vr.kind == VK_K) ? &vr : (vc.kind == VK_K ? &vc : nullptr);
+            const Var* vv = (vr.kind == VK_V) ? &vr : (vc.kind == VK_V ? &vc : nullptr);
+            if (kv && vv && kv->s == s && (vv->c == L.it0 || vv->c == L.itf))
+                out.push_back(Term{PT_LIN, s, R.oYX + kv->c, HC_NBH + 3 * vv->c + kv->l, HC_ONE});
+        }
+        if (has_path_pt && s < L.N) {
+            const Dir a = map_path(L, s, s, vr), b = map_path(L, s, s, vc);
+            if (a.ok && b.ok) out.push_back(Term{PT_PATH, s, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+        }
+    }
+    if (has_path_pt) {
+        const Dir a = map_path(L, L.N, L.N - 1, vr), b = map_path(L, L.N, L.N - 1, vc);
+        if (a.ok && b.ok) out.push_back(Term{PT_FPATH, 0, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+    }
+    if (L.bc > 0 || mo.info.mayer) {
+        const Dir a = map_bnd(L, vr), b = map_bnd(L, vc);
+        if (a.ok && b.ok) out.push_back(Term{PT_BND, 0, sym_index(R.mdb, a.d, b.d), HC_ONE, HC_ONE});
+    }
+}
+
+// template of the step-periodic segment of step i: per entry the relative row and its relative terms
+struct SegTmpl {
+    std::vector<int64_t> cp, relrow;
+    std::vector<uint32_t> tptr, terms;
+    bool operator==(const SegTmpl& o) const { return cp == o.cp && relrow == o.relrow && tptr == o.tptr && terms == o.terms; }
+};
+
+static bool segment_template(const Model& mo, int64_t i, SegTmpl& t) {
+    const Layout& L = mo.L;
+    t.cp.assign(L.blk + 1, 0);
+    t.relrow.clear(); t.tptr.assign(1, 0); t.terms.clear();
+    std::vector<int64_t> rows;
+    std::vector<Term> tt;
+    for (int lc = 0; lc < L.blk; ++lc) {
+        const int64_t col = i * L.blk + lc;
+        mo.hess_gen_column(col, rows);
+        for (int64_t row : rows) {
+            collect_terms(mo, row, col, tt);
+            for (const Term& x : tt) {
+                if (x.pt == PT_FPATH || x.pt == PT_BND) return false;
+                const int64_t rel = i - x.step;
+                if (rel < 0 || rel > mo.H.HL) return false;
+                t.terms.push_back(pack_term(x.di, x.c1, x.c2, (int)rel));
+            }
+            t.tptr.push_back((uint32_t)t.terms.size());
+            t.relrow.push_back(row >= L.v_off ? ((int64_t)1 << 40) + (row - L.v_off) : row - i * L.blk);
+        }
+        t.cp[lc + 1] = (int64_t)t.relrow.size();
+    }
+    return true;
+}
+
+int build_hess_model(Model& mo, std::string& err) {
+    const Layout& L = mo.L;
+    HessModel& H = mo.H;
+    const int64_t N = L.N;
+    H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, L.s, L.free_time != 0);
+    if (H.R.stride >= 65536) { err = "per-step Hessian record too large for 16-bit data indices"; return ST_EPATTERN; }
+    H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
+    build_hess_tail(mo);
+
+    // ---- regular range ---------------------------------------------------------------------------------------------
+    SegTmpl t1, t2;
+    H.reg_first = H.reg_last = N;
+    H.Lseg = 0;
+    H.tptr.assign(1, 0); H.terms.clear(); H.cp_tmpl.assign(L.blk + 1, 0);
+    if (N >= 5) {
+        bool ok = segment_template(mo, 1, t1);
+        if (ok)
+            for (int64_t chk : {(int64_t)2, N - 2})
+                if (!segment_template(mo, chk, t2) || !(t2 == t1)) { ok = false; break; }
+        if (!ok) { err = "Hessian pattern is not step-periodic"; return ST_EPATTERN; }
+        H.reg_first = 1;
+        H.reg_last = N - 1;
+        if (segment_template(mo, N - 1, t2) && t2 == t1) H.reg_last = N;
+        H.Lseg = (int)t1.relrow.size();
+        H.tptr = t1.tptr; H.terms = t1.terms; H.cp_tmpl = t1.cp;
+    }
+
+    // ---- column starts ----------------------------------------------------------------------------------------------
+    std::vector<int64_t> rows;
+    const int64_t head_cols = H.reg_first * L.blk;
+    H.cp_head.assign(head_cols + 1, 0);
+    int64_t nz = 0;
+    for (int64_t j = 0; j < head_cols; ++j) { H.cp_head[j] = nz; mo.hess_gen_column(j, rows); nz += (int64_t)rows.size(); }
+    H.cp_head[head_cols] = nz;
+    H.seg_base = nz;
+    nz += (H.reg_last - H.reg_first) * (int64_t)H.Lseg;
+    const int64_t tail0 = H.reg_last * L.blk, tail_cols = L.nvar - tail0;
+    H.cp_tail.assign(tail_cols + 1, 0);
+    for (int64_t jj = 0; jj < tail_cols; ++jj) { H.cp_tail[jj] = nz; mo.hess_gen_column(tail0 + jj, rows); nz += (int64_t)rows.size(); }
+    H.cp_tail[tail_cols] = nz;
+    H.nnzh = nz;
+
+    // ---- V x V entries: every step contributes the same terms ---------------------------------------------------------------
+    H.nvv = L.nv * (L.nv + 1) / 2;
+    H.vptr.assign(1, 0); H.vterms.clear();
+    {
+        int e = 0;
+        const int md = H.R.md, vd = L.n + L.m;
+        for (int kc = 0; kc < L.nv; ++kc) {
+            mo.hess_gen_column(L.v_off + kc, rows);
+            if ((int)rows.size() != L.nv - kc) { err = "internal: V x V block is not dense lower-triangular"; return ST_EPATTERN; }
+            for (int kr = kc; kr < L.nv; ++kr, ++e) {
+                H.vv_idx[e] = mo.hess_column_start(L.v_off + kc) + (kr - kc);
+                for (int j = 0; j < H.R.S; ++j)
+                    H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, 0));
+                if (L.p > 0 && L.sc != SC_TRAPEZE)
+                    H.vterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, 0));
+                H.vptr.push_back((uint32_t)H.vterms.size());
+            }
+        }
+    }
+
+    // ---- edge entries ---------------------------------------------------------------------------------------------------------
+    struct Raw { int64_t idx; std::vector<Term> tt; };
+    std::vector<Raw> raws;
+    std::set<int64_t> need;
+    need.insert(0);          // the boundary point reads X_0 from the record inputs of step 0,
+    need.insert(N - 1);      // the final-time points X_N and the controls of step N-1 from those of step N-1
+    std::vector<Term> tt;
+    auto scan_col = [&](int64_t j) {
+        if (j >= L.v_off) return;                  // V columns hold V x V rows only
+        mo.hess_gen_column(j, rows);
+        const int64_t base = mo.hess_column_start(j);
+        for (size_t t = 0; t < rows.size(); ++t) {
+            collect_terms(mo, rows[t], j, tt);
+            for (const Term& x : tt)
+                if (x.pt != PT_FPATH && x.pt != PT_BND) need.insert(x.step);
+            raws.push_back(Raw{base + (int64_t)t, tt});
+        }
+    };
+    for (int64_t j = 0; j < head_cols; ++j) scan_col(j);
+    for (int64_t j = tail0; j < L.nvar; ++j) scan_col(j);
+    if (L.sc == SC_TRAPEZE) need.insert(N);        // node N: its V x V share is summed by the edge block
+    if ((int)need.size() > kMaxHessEdgeSlots) { err = "internal: too many edge records (Hessian)"; return ST_EPATTERN; }
+    std::map<int64_t, int> slot_of;
+    H.n_edge_slots = 0;
+    for (int64_t s : need) { slot_of[s] = H.n_edge_slots; H.edge_steps[H.n_edge_slots++] = s; }
+    H.edge_fp = H.n_edge_slots;
+    H.edge_b = H.n_edge_slots + 1;
+    H.edge_idx.clear(); H.eptr.assign(1, 0); H.eterms.clear();
+    for (const Raw& r : raws) {
+        H.edge_idx.push_back(r.idx);
+        for (const Term& x : r.tt) {
+            const int slot = x.pt == PT_FPATH ? H.edge_fp : (x.pt == PT_BND ? H.edge_b : slot_of[x.step]);
+            H.eterms.push_back(pack_term(x.di, x.c1, x.c2, slot));
+        }
+        H.eptr.push_back((uint32_t)H.eterms.size());
+    }
+    // V x V share of the edge block: final-path point, boundary point, trapeze node N
+    H.evptr.assign(1, (uint32_t)H.eterms.size());
+    {
+        const int md = H.R.md, vd = L.n + L.m, mdb = H.R.mdb;
+        for (int kc = 0; kc < L.nv; ++kc)
+            for (int kr = kc; kr < L.nv; ++kr) {
+                if (L.p > 0 && L.sc != SC_TRAPEZE)
+                    H.eterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, H.edge_fp));
+                if (L.bc > 0 || mo.info.mayer)
+                    H.eterms.push_back(pack_term(sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr), HC_ONE, HC_ONE, H.edge_b));
+                if (L.sc == SC_TRAPEZE)
+                    H.eterms.push_back(pack_term(H.R.oStage + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, slot_of[N]));
+                H.evptr.push_back((uint32_t)H.eterms.size());
+            }
+    }
+
+    // ---- eval tasks: lane (p, chunk) covers HD[p][chunk*hk .. +hk); chunks entirely left of the diagonal are skipped ------
+    auto make_tasks = [&](int md, std::vector<uint16_t>& out) {
+        out.clear();
+        const int nch = (md + H.hk - 1) / H.hk;
+        for (int p = 0; p < md; ++p)
+            for (int c = p / H.hk; c < nch; ++c) out.push_back((uint16_t)(p | (c << 8)));
+    };
+    make_tasks(H.R.md, H.tasks);
+    make_tasks(H.R.mdb, H.btasks);
+    return ST_OK;
+}
+
+int default_hess_tile(const Model& mo) {
+    const Layout& L = mo.L;
+    const int64_t per_step = (int64_t)(L.blk + L.cb + mo.H.R.stride + 2) * 8;
+    const int64_t fit = (60 * 1024) / per_step - mo.H.HL - 1;
+    int64_t T = 1;
+    while (T * 2 <= fit && T * 2 <= 32) T *= 2;
+    while (T > 2 && (L.N + T - 1) / T < 256) T /= 2;
+    return (int)T;
+}
+
+void Model::fill_hparams(HParams& hp, int tile) const {
+    hp = HParams{};
+    hp.L = L;
+    hp.R = H.R;
+    hp.T = tile;
+    hp.HL = H.HL;
+    hp.ntiles = (int)((L.N + tile - 1) / tile);
+    hp.Lseg = H.Lseg;
+    hp.nterms = (int)H.terms.size();
+    hp.seg_base = H.seg_base; hp.reg_first = H.reg_first; hp.reg_last = H.reg_last;
+    hp.nvv = H.nvv;
+    for (int e = 0; e < H.nvv; ++e) hp.vv_idx[e] = H.vv_idx[e];
+    hp.n_edge = (int)H.edge_idx.size();
+    hp.n_edge_slots = H.n_edge_slots;
+    hp.edge_fp = H.edge_fp; hp.edge_b = H.edge_b;
+    for (int k = 0; k < kMaxHessEdgeSlots; ++k) hp.edge_steps[k] = H.edge_steps[k];
+    hp.ntask = (int)H.tasks.size();
+    hp.nbtask = (int)H.btasks.size();
+    hp.div_ntask = make_fastdiv((uint32_t)(hp.ntask > 0 ? hp.ntask : 1));
+}
+
+}  // namespace ctd

@@ -1,0 +1,74 @@
+// ctd_hess_kernels.hpp -- __global__ wrappers and launchers of the Hessian-of-the-Lagrangian kernels
+// (phases: ctd_hess_body.hpp).  Instantiated per OCP in ctd_hkern_*.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include "ctd_hess_body.hpp"
+#include "ctd_problems.hpp"
+
+namespace ctd {
+
+constexpr int kHessBlock = 256;
+
+template <class P, int SC, int S>
+__global__ __launch_bounds__(kHessBlock) void hess_kernel(const HParams hp, const double* __restrict__ xu,
+                                                          const double* __restrict__ y) {
+    extern __shared__ double hess_lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const HBlockCtx cx = make_hctx(hp, blockIdx.x, hess_lds);
+    hess_phase_load<P>(hp, cx, xu, y, tid, nthr);
+    __syncthreads();
+    hess_phase_eval<P, SC, S>(hp, cx, tid, nthr);
+    __syncthreads();
+    hess_phase_emit<P, SC, S>(hp, cx, blockIdx.x, tid, nthr);
+}
+
+// V x V entries: fixed-order sum of the per-workgroup partials (one workgroup)
+template <class P>
+__global__ __launch_bounds__(kHessBlock) void hess_finish_kernel(const HParams hp) {
+    __shared__ double red[kHessBlock];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int e = 0; e < hp.nvv; ++e) {
+        red[tid] = hess_finish_partial(hp, e, tid, nthr);
+        __syncthreads();
+        for (int off = nthr >> 1; off > 0; off >>= 1) {
+            if (tid < off) red[tid] = red[tid] + red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) hp.vals[hp.vv_idx[e]] = red[0];
+        __syncthreads();
+    }
+}
+
+template <class P, int SC, int S>
+hipError_t launch_hess_variant(const HParams& hp, const double* xu, const double* y, size_t lds_bytes, hipStream_t st,
+                               hipEvent_t e0, hipEvent_t e1) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)hess_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int grid = hp.ntiles + 1;
+    if (e0 || e1) hipExtLaunchKernelGGL((hess_kernel<P, SC, S>), dim3(grid), dim3(kHessBlock), lds_bytes, st, e0, e1, 0, hp, xu, y);
+    else hess_kernel<P, SC, S><<<grid, kHessBlock, lds_bytes, st>>>(hp, xu, y);
+    if (hp.nvv > 0) hess_finish_kernel<P><<<1, kHessBlock, 0, st>>>(hp);
+    return hipGetLastError();
+}
+
+template <class P>
+hipError_t launch_hess(const HParams& hp, const double* xu, const double* y, size_t lds_bytes, hipStream_t st, hipEvent_t e0,
+                       hipEvent_t e1) {
+    const int sc = hp.L.sc;
+    if (sc == SC_TRAPEZE) return launch_hess_variant<P, SC_TRAPEZE, 1>(hp, xu, y, lds_bytes, st, e0, e1);
+    if (sc == SC_MIDPOINT) return launch_hess_variant<P, SC_MIDPOINT, 1>(hp, xu, y, lds_bytes, st, e0, e1);
+    if (hp.L.s == 1) return launch_hess_variant<P, SC_IRK, 1>(hp, xu, y, lds_bytes, st, e0, e1);
+    if (hp.L.s == 2) return launch_hess_variant<P, SC_IRK, 2>(hp, xu, y, lds_bytes, st, e0, e1);
+    return launch_hess_variant<P, SC_IRK, 3>(hp, xu, y, lds_bytes, st, e0, e1);
+}
+
+#define CTD_INSTANTIATE_HESS(P) \
+    template hipError_t launch_hess<P>(const HParams&, const double*, const double*, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+#define CTD_EXTERN_HESS(P) \
+    extern template hipError_t launch_hess<P>(const HParams&, const double*, const double*, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+
+}  // namespace ctd

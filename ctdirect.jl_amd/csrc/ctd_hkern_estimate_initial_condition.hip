@@ -1,0 +1,5 @@
+// Hessian-kernel instantiations of the collocation engine for one registry entry (EstimateInitialConditionOCP); see ctd_hess_kernels.hpp.
+#include "ctd_hess_kernels.hpp"
+namespace ctd {
+CTD_INSTANTIATE_HESS(EstimateInitialConditionOCP)
+}

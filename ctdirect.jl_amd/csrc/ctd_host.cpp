@@ -2,6 +2,7 @@
 // emit tables of the kernels.  See ctd_host.hpp.
 #include "ctd_host.hpp"
 #include "ctd_kernel_body.hpp"
+#include "ctd_hess_body.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -662,6 +663,7 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.nch_dyn = Dirs<P>::NCH_DYN;
         mo.nch_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
         mo.fused = Dirs<P>::FUSED;
+        mo.H.hk = HessK<P>::value;
     });
     if (!found) { err = "problem id not in the compiled registry"; return ST_EPROBLEM; }
     if (d.scheme < 0 || d.scheme > 6) { err = "Unknown discretization method"; return ST_ESCHEME; }
@@ -676,7 +678,9 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         for (int64_t i = 0; i <= N; ++i) mo.fixed_grid[i] = mo.L.t0 + (mo.tau[i] * (mo.L.tf - mo.L.t0));
     build_bounds(mo);
     build_tail_blocks(mo);
-    return build_tables(mo, err);
+    st = build_tables(mo, err);
+    if (st) return st;
+    return build_hess_model(mo, err);
 }
 
 }  // namespace ctd

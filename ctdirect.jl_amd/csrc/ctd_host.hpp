@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "ctd_layout.hpp"
+#include "ctd_hess.hpp"
 #include "ctd_problems.hpp"
 
 namespace ctd {
@@ -19,6 +20,31 @@ struct HostDesc {
 };
 
 struct Block { int64_t r0, r1, c0, c1; };   // rows [r0,r1) x cols [c0,c1), 0-based
+
+// Hessian of the Lagrangian: lower triangle of DOCP_Hessian_pattern in CSC order + the term tables of the Hessian kernel
+// (ctd_hess_host.cpp)
+struct HessModel {
+    HessRecLayout R;
+    int hk = 4;                       // inner directions per eval lane (ctd::HessK<P>)
+    int64_t nnzh = 0;
+    std::vector<Block> tail;          // blocks that do not belong to one step (already symmetrised)
+    // regular part
+    int Lseg = 0, HL = 0;
+    int64_t seg_base = 0, reg_first = 0, reg_last = 0;
+    std::vector<uint32_t> tptr, terms;            // Lseg + 1 offsets, term codes
+    std::vector<uint32_t> vptr, vterms;           // V x V contributions of one step
+    int nvv = 0;
+    int64_t vv_idx[kMaxNV * (kMaxNV + 1) / 2] = {0};
+    // edge part
+    std::vector<int64_t> edge_idx;
+    std::vector<uint32_t> eptr, evptr, eterms;
+    int n_edge_slots = 0, edge_fp = 0, edge_b = 0;
+    int64_t edge_steps[kMaxHessEdgeSlots] = {0};
+    // eval tasks
+    std::vector<uint16_t> tasks, btasks;
+    // column starts (same scheme as the Jacobian's)
+    std::vector<int64_t> cp_head, cp_tmpl, cp_tail;
+};
 
 struct Model {
     int problem = 0, pattern_mode = 0;
@@ -62,7 +88,18 @@ struct Model {
     void gen_column(int64_t j, std::vector<int64_t>& rows) const;
     int64_t column_start(int64_t j) const;    // CSC colptr[j] without materialising the pattern
     void fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const;
+
+    // ---- Hessian (ctd_hess_host.cpp)
+    HessModel H;
+    void hess_step_blocks(int64_t i, std::vector<Block>& out) const;
+    void hess_gen_column(int64_t j, std::vector<int64_t>& rows) const;   // rows >= j of column j, sorted
+    int64_t hess_column_start(int64_t j) const;
+    void fill_hparams(HParams& hp, int tile) const;
 };
+
+// builds Model::H (pattern bookkeeping + term tables); called by build_model
+int build_hess_model(Model& m, std::string& err);
+int default_hess_tile(const Model& m);
 
 // status codes are those of include/ctdirect_hip.h; err receives a message on failure
 int build_model(const HostDesc& d, Model& m, std::string& err);

@@ -339,6 +339,49 @@ class DOCP:
                                              out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
         return out.reshape(grid, 6, 2)
 
+    # ---- Hessian of the Lagrangian ------------------------------------------------------------------------
+    def hess_structure(self):
+        """hess_structure!(nlp, rows, cols): 1-based COO (row >= col) of the lower triangle of DOCP_Hessian_pattern."""
+        rows = np.zeros(self.nnzh, dtype=np.int64)
+        cols = np.zeros(self.nnzh, dtype=np.int64)
+        self._ck(_lib.lib().ctd_hess_structure(self._h, _ip(rows), _ip(cols)))
+        return rows, cols
+
+    def hess_coord(self, x, y, obj_weight=1.0, vals=None, sync=True):
+        """hess_coord!(nlp, x, y, vals; obj_weight): obj_weight * d2 f + sum_i y_i d2 c_i on hess_structure()."""
+        L = _lib.lib()
+        self._check_x(x)
+        if _is_tensor(x):
+            import torch
+            if vals is None:
+                vals = torch.empty(self.nnzh, dtype=torch.float64, device=x.device)
+            fn = L.ctd_hess_coord_dev if sync else L.ctd_hess_coord_dev_async
+            self._ck(fn(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), self._dev_ptr(y, self.dim_NLP_constraints, "y"),
+                        float(obj_weight), self._dev_ptr(vals, self.nnzh, "vals")))
+            return vals
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if y.size != self.dim_NLP_constraints:
+            raise ValueError(f"y has {y.size} entries, expected dim_NLP_constraints = {self.dim_NLP_constraints}")
+        if vals is None:
+            vals = np.empty(self.nnzh)
+        self._ck(L.ctd_hess_coord(self._h, _dp(x), _dp(y), float(obj_weight), _dp(vals)))
+        return vals
+
+    def time_hess(self, x, y, vals, obj_weight=1.0, iters=20):
+        """Mean duration (ms) of one Hessian-kernel launch (per-dispatch HIP events on the handle's stream)."""
+        ms = C.c_double()
+        self._ck(_lib.lib().ctd_time_hess_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                              self._dev_ptr(y, self.dim_NLP_constraints, "y"), float(obj_weight),
+                                              self._dev_ptr(vals, self.nnzh, "vals"), int(iters), C.byref(ms)))
+        return ms.value
+
+    def hess_launch_info(self):
+        o = np.zeros(6, dtype=np.int64)
+        self._ck(_lib.lib().ctd_hess_launch_info(self._h, _ip(o)))
+        return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]), csc_period=int(o[4]),
+                    edge_entries=int(o[5]))
+
     def jac_structure(self):
         """jac_structure!(nlp, rows, cols): 1-based COO in CSC order."""
         rows = np.zeros(self.nnzj, dtype=np.int64)
@@ -396,6 +439,15 @@ def DOCP_Jacobian_pattern(docp):
     colptr = np.zeros(docp.dim_NLP_variables + 1, dtype=np.int64)
     rowval = np.zeros(docp.nnzj, dtype=np.int64)
     docp._ck(_lib.lib().ctd_jac_csc(docp._h, _ip(colptr), _ip(rowval)))
+    return colptr, rowval
+
+
+def DOCP_Hessian_pattern(docp):
+    """Lower triangle of `CTDirect.DOCP_Hessian_pattern(docp)` as 0-based CSC arrays (colptr, rowval) -- the part of the
+    symmetric Bool pattern ADNLPModels keeps for hess_structure!."""
+    colptr = np.zeros(docp.dim_NLP_variables + 1, dtype=np.int64)
+    rowval = np.zeros(docp.nnzh, dtype=np.int64)
+    docp._ck(_lib.lib().ctd_hess_csc(docp._h, _ip(colptr), _ip(rowval)))
     return colptr, rowval
 
 

@@ -121,7 +121,8 @@ const char* ctd_strerror(int32_t status);
 
 /* ---- sizes and static data (host) ------------------------------------------------------------------------ */
 /* docp.dim_NLP_variables, docp.dim_NLP_constraints (src/DOCP_data.jl:285-286), nlp.meta.nnzj, nlp.meta.nnzh
- * (nnzh = lower triangle of DOCP_Hessian_pattern; -1 while the Hessian row is not built) */
+ * (nnzh = entries of the lower triangle of DOCP_Hessian_pattern, e.g. 6519 for Goddard / midpoint / 250 steps,
+ * test/archives/AD_backend.md:86) */
 int32_t ctd_sizes(const ctd_handle* h, int64_t* nvar, int64_t* ncon, int64_t* nnzj, int64_t* nnzh);
 /* out[0..15]: NLP_x, NLP_u, NLP_v, path_cons, boundary_cons (DOCPdims, src/DOCP_data.jl:88-94), steps,
  * _step_variables_block, _state_stage_eqs_block, _step_pathcons_block, stage, _final_control, freet0, freetf,
@@ -190,6 +191,33 @@ int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, doub
  * CSC period L (entries per regular step), number of edge entries, pipelined driver: sub-tile steps (0 = classic
  * driver) and steps per workgroup */
 int32_t ctd_launch_info(const ctd_handle* h, int64_t* out8);
+
+
+/* ---- Hessian of the Lagrangian --------------------------------------------------------------------------------
+ * Replaces hess_structure!(nlp, rows, cols) / hess_coord!(nlp, x, y, vals; obj_weight) of the ADNLPModel built at
+ * src/collocation.jl:137-149 (sparse Hessian backend selected at :121-125).  The sparsity pattern is the lower triangle
+ * (row >= col, NLPModels convention) of DOCP_Hessian_pattern(docp) -- src/ode/trapeze.jl:240-303, midpoint.jl:240-300,
+ * irk.jl:423-496, irk_stagewise.jl:565-638 -- in CSC order; CTD_PATTERN_STRUCTURAL adds the final-state x variable
+ * block whose add_nonzero_block! call has an empty range in the reference (irk.jl:483 / irk_stagewise.jl:625).
+ * Values:  vals[k] = obj_weight * d2 f/dx_i dx_j + sum_r y[r] * d2 c_r/dx_i dx_j  at (i, j) = (rows[k], cols[k]),
+ * f = __objective (src/DOCP_functions.jl:23-54), c = __constraints! (:80-115); entries of the pattern that are
+ * structurally zero receive 0.0.  Only full-range handles (step_begin = 0, step_end = N) evaluate the Hessian. */
+/* 1-based (rows[k], cols[k]), k < nnzh, CSC order */
+int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
+/* same pattern as 0-based CSC (colptr[nvar + 1], rowval[nnzh]) */
+int32_t ctd_hess_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval);
+/* host pointers: x[nvar], y[ncon] (constraint multipliers), vals[nnzh]; includes the PCIe copies */
+int32_t ctd_hess_coord(ctd_handle* h, const double* x, const double* y, double obj_weight, double* vals);
+/* device pointers on the handle's device; the first returns after the handle's stream has drained, the second only
+ * enqueues (ctd_sync waits) */
+int32_t ctd_hess_coord_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev);
+int32_t ctd_hess_coord_dev_async(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev);
+/* measurement: mean duration (ms) of the Hessian kernel over `iters` launches, per-dispatch events on the handle's stream */
+int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
+                          int32_t iters, double* mean_ms);
+/* launch geometry of the Hessian kernel: out[0..5] = grid blocks, block threads, dynamic LDS bytes, steps per tile,
+ * CSC period of the lower triangle (entries per regular step), number of edge entries */
+int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* out6);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,12 @@
 
 #include "../../ctdirect.jl_amd/csrc/ctd_host.cpp"
 #include "../../ctdirect.jl_amd/csrc/ctd_kernel_body.hpp"
+#define ST_OK ST_OK_HESS
+#define ST_EPATTERN ST_EPATTERN_HESS
+#include "../../ctdirect.jl_amd/csrc/ctd_hess_host.cpp"
+#undef ST_OK
+#undef ST_EPATTERN
+#include "../../ctdirect.jl_amd/csrc/ctd_hess_body.hpp"
 
 using namespace ctd;
 
@@ -77,6 +83,27 @@ static void run_pipe_blocks(const KParams& kp, const double* xu, int nthr) {
             }
             if (q + 1 < Q) produce(make_sub_ctx(kp, lds.data(), A, B, q + 1));
         }
+    }
+}
+
+// serial stepping of hess_kernel + hess_finish_kernel (ctd_hess_kernels.hpp)
+template <class P, int SC, int S>
+static void run_hess_blocks(const HParams& hp, const double* xu, const double* y, int nthr) {
+    const int64_t nlds = hess_lds_doubles(hp);
+    for (int b = 0; b <= hp.ntiles; ++b) {
+        std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
+        HBlockCtx cx = make_hctx(hp, b, lds.data());
+        for (int t = 0; t < nthr; ++t) hess_phase_load<P>(hp, cx, xu, y, t, nthr);
+        for (int t = 0; t < nthr; ++t) hess_phase_eval<P, SC, S>(hp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) hess_phase_emit<P, SC, S>(hp, cx, b, t, nthr);
+    }
+    for (int e = 0; e < hp.nvv; ++e) {
+        const int fthr = 256;                             // hess_finish_kernel always runs kHessBlock lanes: same tree
+        std::vector<double> red(fthr);
+        for (int t = 0; t < fthr; ++t) red[t] = hess_finish_partial(hp, e, t, fthr);
+        for (int off = fthr >> 1; off > 0; off >>= 1)
+            for (int t = 0; t < off; ++t) red[t] = red[t] + red[t + off];
+        hp.vals[hp.vv_idx[e]] = red[0];
     }
 }
 
@@ -158,6 +185,66 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
                 if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, x, nthr);
                 else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, x, nthr);
                 else run_blocks<P, SC_IRK, 3>(kp, x, nthr);
+                break;
+        }
+    });
+    return ok ? 0 : 5;
+}
+
+int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    if (build_model(d, mo, g_err)) return -1;
+    return mo.H.nnzh;
+}
+
+// lower triangle of DOCP_Hessian_pattern, 0-based CSC
+int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* colptr, int64_t* rowval) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    std::vector<int64_t> rows;
+    int64_t nz = 0;
+    for (int64_t j = 0; j < mo.L.nvar; ++j) {
+        colptr[j] = nz;
+        if (mo.hess_column_start(j) != nz) { g_err = "hess_column_start mismatch"; return 99; }
+        mo.hess_gen_column(j, rows);
+        for (int64_t r : rows) rowval[nz++] = r;
+    }
+    colptr[mo.L.nvar] = nz;
+    if (nz != mo.H.nnzh) { g_err = "nnzh mismatch"; return 98; }
+    return 0;
+}
+
+int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
+             const double* x, const double* y, double obj_weight, double* vals) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    if (tile <= 0) tile = default_hess_tile(mo);
+    HParams hp;
+    mo.fill_hparams(hp, tile);
+    const HessModel& H = mo.H;
+    hp.tau = mo.uniform ? nullptr : mo.tau.data();
+    hp.tptr = H.tptr.data(); hp.terms = H.terms.data();
+    hp.vptr = H.vptr.data(); hp.vterms = H.vterms.data();
+    hp.edge_idx = H.edge_idx.data(); hp.eptr = H.eptr.data(); hp.evptr = H.evptr.data(); hp.eterms = H.eterms.data();
+    hp.tasks = H.tasks.data(); hp.btasks = H.btasks.data();
+    hp.obj_weight = obj_weight;
+    hp.vals = vals;
+    std::vector<double> partials((size_t)(hp.ntiles + 1) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
+    hp.partials = partials.data();
+    bool ok = for_problem(problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        switch (mo.L.sc) {
+            case SC_TRAPEZE: run_hess_blocks<P, SC_TRAPEZE, 1>(hp, x, y, nthr); break;
+            case SC_MIDPOINT: run_hess_blocks<P, SC_MIDPOINT, 1>(hp, x, y, nthr); break;
+            default:
+                if (mo.L.s == 1) run_hess_blocks<P, SC_IRK, 1>(hp, x, y, nthr);
+                else if (mo.L.s == 2) run_hess_blocks<P, SC_IRK, 2>(hp, x, y, nthr);
+                else run_hess_blocks<P, SC_IRK, 3>(hp, x, y, nthr);
                 break;
         }
     });

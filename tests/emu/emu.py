@@ -66,3 +66,39 @@ def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_
     if st:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return c, vals
+
+
+def hess_csc(problem, scheme, mode, N, time_grid=None):
+    nvar = sizes(problem, scheme, mode, N, time_grid)[0]
+    tg, n = _tg(time_grid)
+    tgp = tg.ctypes.data_as(C.c_void_p) if tg is not None else None
+    L = lib()
+    L.emu_hess_nnz.restype = C.c_int64
+    nnz = int(L.emu_hess_nnz(problem, scheme, mode, C.c_int64(N or 0), tgp, C.c_int64(n)))
+    if nnz < 0:
+        raise RuntimeError(f"emu: {L.emu_last_error().decode()}")
+    colptr = np.zeros(nvar + 1, dtype=np.int64)
+    rowval = np.zeros(nnz, dtype=np.int64)
+    st = L.emu_hess_csc(problem, scheme, mode, C.c_int64(N or 0), tgp, C.c_int64(n), colptr.ctypes.data_as(C.c_void_p),
+                        rowval.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {L.emu_last_error().decode()}")
+    return colptr, rowval
+
+
+def hess(problem, scheme, mode, N, x, y, obj_weight=1.0, time_grid=None, tile=0, nthr=64):
+    nvar, ncon, _, _ = sizes(problem, scheme, mode, N, time_grid)
+    tg, n = _tg(time_grid)
+    tgp = tg.ctypes.data_as(C.c_void_p) if tg is not None else None
+    L = lib()
+    L.emu_hess_nnz.restype = C.c_int64
+    nnz = int(L.emu_hess_nnz(problem, scheme, mode, C.c_int64(N or 0), tgp, C.c_int64(n)))
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    assert x.size == nvar and y.size == ncon
+    vals = np.full(nnz, 666.666)
+    st = L.emu_hess(problem, scheme, mode, C.c_int64(N or 0), tgp, C.c_int64(n), tile, nthr, x.ctypes.data_as(C.c_void_p),
+                    y.ctypes.data_as(C.c_void_p), C.c_double(obj_weight), vals.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {L.emu_last_error().decode()}")
+    return vals
