@@ -179,9 +179,9 @@ template <int K> CTD_HD Dual2<K> d2_recip(const Dual2<K>& y) {
     const double q = 1.0 / y.v;
     return d2_chain(y, q, -(q * q), 2.0 * (q * q) * q);
 }
-template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, const Dual2<K>& y) {
-    Dual2<K> r = x * d2_recip(y); r.v = x.v / y.v; return r;
-}
+// quotients go through one reciprocal: the VALUE of a Dual2 is never an output of the Hessian kernel (only second
+// derivatives are), so it may differ from the IEEE quotient in the last bit
+template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, const Dual2<K>& y) { return x * d2_recip(y); }
 template <int K> CTD_HD Dual2<K> operator+(const Dual2<K>& x, double y) { Dual2<K> r = x; r.v = x.v + y; return r; }
 template <int K> CTD_HD Dual2<K> operator+(double x, const Dual2<K>& y) { Dual2<K> r = y; r.v = x + y.v; return r; }
 template <int K> CTD_HD Dual2<K> operator-(const Dual2<K>& x, double y) { Dual2<K> r = x; r.v = x.v - y; return r; }
@@ -193,8 +193,8 @@ template <int K> CTD_HD Dual2<K> operator*(const Dual2<K>& x, double y) {
     return r;
 }
 template <int K> CTD_HD Dual2<K> operator*(double x, const Dual2<K>& y) { return y * x; }
-template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, double y) { Dual2<K> r = x * (1.0 / y); r.v = x.v / y; return r; }
-template <int K> CTD_HD Dual2<K> operator/(double x, const Dual2<K>& y) { Dual2<K> r = d2_recip(y) * x; r.v = x / y.v; return r; }
+template <int K> CTD_HD Dual2<K> operator/(const Dual2<K>& x, double y) { return x * (1.0 / y); }
+template <int K> CTD_HD Dual2<K> operator/(double x, const Dual2<K>& y) { return d2_recip(y) * x; }
 template <int K> CTD_HD Dual2<K> d_exp(const Dual2<K>& x) { const double e = ::exp(x.v); return d2_chain(x, e, e, e); }
 template <int K> CTD_HD Dual2<K> d_sin(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, s, c, -s); }
 template <int K> CTD_HD Dual2<K> d_cos(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, c, -s, -c); }

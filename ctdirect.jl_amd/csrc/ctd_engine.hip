@@ -80,7 +80,7 @@ struct ctd_handle {
     uint32_t *d_htptr = nullptr, *d_hterms = nullptr, *d_hvptr = nullptr, *d_hvterms = nullptr, *d_heptr = nullptr,
              *d_hevptr = nullptr, *d_heterms = nullptr;
     int64_t* d_hedge_idx = nullptr;
-    uint16_t *d_htasks = nullptr, *d_hbtasks = nullptr;
+    uint16_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
     std::string err;
 };
@@ -119,7 +119,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -623,6 +623,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     HIP_TRY(h, upload(&h->d_hevptr, H.evptr));
     HIP_TRY(h, upload(&h->d_heterms, H.eterms));
     HIP_TRY(h, upload(&h->d_htasks, H.tasks));
+    HIP_TRY(h, upload(&h->d_hptasks, H.ptasks));
     HIP_TRY(h, upload(&h->d_hbtasks, H.btasks));
     HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(h->hp.ntiles + 1) * (H.nvv > 0 ? H.nvv : 1)));
     HParams& hp = h->hp;
@@ -630,8 +631,9 @@ static int32_t ensure_hess(ctd_handle* h) {
     hp.tptr = h->d_htptr; hp.terms = h->d_hterms;
     hp.vptr = h->d_hvptr; hp.vterms = h->d_hvterms;
     hp.edge_idx = h->d_hedge_idx; hp.eptr = h->d_heptr; hp.evptr = h->d_hevptr; hp.eterms = h->d_heterms;
-    hp.tasks = h->d_htasks; hp.btasks = h->d_hbtasks;
+    hp.tasks = h->d_htasks; hp.ptasks = h->d_hptasks; hp.btasks = h->d_hbtasks;
     hp.partials = h->d_hpartials;
+    hp.debug_stop = env_int("CTD_HESS_STOP", 0);
     h->hess_ready = true;
     return CTD_OK;
 }
@@ -684,14 +686,38 @@ int32_t ctd_hess_coord(ctd_handle* h, const double* x, const double* y, double o
     return CTD_OK;
 }
 
-// out[0..5]: grid (workgroups), block, LDS bytes, steps per tile, CSC period of the lower triangle, edge entries
+// out[0..9]: grid (workgroups), block, LDS bytes, steps per tile, CSC period of the lower triangle, edge entries, eval lanes
+// per stage point / path point / boundary point, terms of the periodic segment
 int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* o) {
     if (!h || !o) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
     int32_t st = ensure_hess(h);
     if (st) return st;
     o[0] = h->hp.ntiles + 1; o[1] = kHessBlock; o[2] = (int64_t)h->hess_lds_bytes; o[3] = h->hess_tile; o[4] = h->hp.Lseg; o[5] = h->hp.n_edge;
+    o[6] = h->hp.ntask; o[7] = h->hp.nptask; o[8] = h->hp.nbtask; o[9] = h->hp.nterms;
     return CTD_OK;
+}
+
+int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
+                              uint64_t* out, int64_t cap) {
+    if (!h || !out) return CTD_EINVAL;
+    int32_t st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);     // warm, no stamps
+    if (st) return st;
+    const int64_t words = (int64_t)(h->hp.ntiles + 1) * 10;
+    if (cap < words) return fail(h, CTD_EINVAL, "stamp buffer too small");
+    unsigned long long* d_st = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&d_st, sizeof(unsigned long long) * words));
+    HIP_TRY(h, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * words, h->stream));
+    h->hp.stamps = d_st;
+    st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);
+    h->hp.stamps = nullptr;
+    if (st == CTD_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_st, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) st = fail(h, CTD_EHIP, hipGetErrorString(e));
+    }
+    (void)hipFree(d_st);
+    return st;
 }
 
 int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev, int32_t iters,

@@ -27,6 +27,8 @@ enum { HC_ONE = 0, HC_HALF = 1,
        HC_B = 20,     // b_l               at HC_B + l
        HC_NBH = 23 }; // -b_l dh/dv_k      at HC_NBH + 3 k + l   (k < kMaxNV)
 
+constexpr int kMaxPairs = 64;          // distinct coefficient products C[c1] * C[c2] the term tables may use
+constexpr int kMaxTerms = 6;           // terms per output entry (S stage points + path point + state-equation row)
 constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
 
 // ---- per-slot LDS record (doubles) ---------------------------------------------------------------------
@@ -34,12 +36,12 @@ constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3
 //     RK[k*n + a] = h HD[x_a][V_k] + dh/dv_k dPhi/dx_a, the d2/dK dV_k entry up to the factor a_jl)
 // HP[md*md]   path point of the step (Gauss-Legendre / midpoint with path constraints)
 // YX[n]       multipliers of the state-equation rows (Gauss-Legendre with free times: d2/dK^l dV_k of -h b_l y'K^l)
-// C[kHC]      coefficients
+// CP[kMaxPairs] products C[c1] C[c2] of the chain-rule coefficients, one per pair the term tables use (HParams::pairs)
 // The boundary record holds HB[mdb*mdb], mdb = 2n + nv (directions x0 | xf | V); the final-path record uses HP.
 struct HessRecLayout {
     int32_t md, mdb, S;
     int32_t stage_sz, oStage, oRK;   // stage block j at oStage + j * stage_sz: HD at +0, RK at +oRK
-    int32_t oHP, oYX, oC;
+    int32_t oHP, oYX, oZero, oCP;   // rec[oZero] = 0.0: target of padded (absent) terms
     int32_t stride;
 };
 
@@ -57,22 +59,22 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
     int end_step = r.oYX + (rk ? n : 0);
     int end_b = r.mdb * r.mdb;
     int body = end_step > end_b ? end_step : end_b;
-    r.oC = body;
-    r.stride = body + kHC;
+    r.oZero = body;
+    r.oCP = body + 1;
+    r.stride = body + 1 + kMaxPairs;
     if ((r.stride & 1) == 0) r.stride += 1;
     return r;
 }
 
-// ---- 32-bit term code:  value += C[c1] * C[c2] * rec[di]  of record `slot` ----------------------------------
-// bits 0-15 di, 16-21 c1, 22-27 c2, 28-30 slot.  Inside tile templates slot is relative (0 = the entry's own step,
+// ---- 32-bit term code:  value += CP[pair] * rec[di]  of record `slot` ------------------------------------------
+// bits 0-15 di, 16-23 pair id, 24-26 slot.  Inside tile templates slot is relative (0 = the entry's own step,
 // 1 = the previous step); inside the edge lists it is the absolute record id of the edge block.
-CTD_HD uint32_t pack_term(int di, int c1, int c2, int slot) {
-    return (uint32_t)di | ((uint32_t)c1 << 16) | ((uint32_t)c2 << 22) | ((uint32_t)slot << 28);
+CTD_HD uint32_t pack_term(int di, int pair, int slot) {
+    return (uint32_t)di | ((uint32_t)pair << 16) | ((uint32_t)slot << 24);
 }
 CTD_HD int term_di(uint32_t c) { return (int)(c & 0xFFFFu); }
-CTD_HD int term_c1(uint32_t c) { return (int)((c >> 16) & 0x3Fu); }
-CTD_HD int term_c2(uint32_t c) { return (int)((c >> 22) & 0x3Fu); }
-CTD_HD int term_slot(uint32_t c) { return (int)((c >> 28) & 0x7u); }
+CTD_HD int term_pair(uint32_t c) { return (int)((c >> 16) & 0xFFu); }
+CTD_HD int term_slot(uint32_t c) { return (int)((c >> 24) & 0x7u); }
 
 // ---- kernel parameters -------------------------------------------------------------------------------------
 struct HParams {
@@ -93,6 +95,7 @@ struct HParams {
     int32_t nvv;
     const uint32_t* vptr;
     const uint32_t* vterms;
+    int32_t nvterms;
     int64_t vv_idx[kMaxNV * (kMaxNV + 1) / 2];
     // edge entries: explicit index + term range; the edge block also sums its share of the V x V entries
     // (terms [evptr[e], evptr[e+1]) of eterms)
@@ -104,15 +107,24 @@ struct HParams {
     int32_t n_edge_slots;
     int32_t edge_fp, edge_b;    // record ids of the final-path and boundary records
     int64_t edge_steps[kMaxHessEdgeSlots];
+    // coefficient pairs: CP[i] = C[pairs[i] & 0xFF] * C[pairs[i] >> 8], i < npairs (pair 0 is ONE * ONE)
+    int32_t npairs;
+    uint16_t pairs[kMaxPairs];
     // eval tasks: (p | chunk << 8) pairs of one evaluation point (ntask of them), same for the boundary point
-    const uint16_t* tasks;
-    const uint16_t* btasks;
-    int32_t ntask, nbtask;
-    FastDiv div_ntask;
+    const uint16_t* tasks;      // stage-type points
+    const uint16_t* ptasks;     // path points
+    const uint16_t* btasks;     // boundary + Mayer point
+    int32_t ntask, nptask, nbtask;
+    int32_t slot_tasks;         // S * ntask + nptask
+    FastDiv div_ntask, div_slot_tasks, div_Lseg;
     // inputs / outputs
     double obj_weight;
     double* vals;
     double* partials;           // (ntiles + 1) * nvv: V x V partial sums per workgroup (workgroup 0 = edge)
+    // diagnostics only (env CTD_HESS_STOP): 0 normal; 1 return after load, 2 after eval (ablation timing, outputs incomplete)
+    int32_t debug_stop;
+    // diagnostics only (ctd_hess_debug_stamps): lane 0 of every workgroup stores 5 x {100 MHz realtime, shader cycles}
+    unsigned long long* stamps;
 };
 
 }  // namespace ctd

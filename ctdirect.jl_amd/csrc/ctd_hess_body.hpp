@@ -36,7 +36,19 @@ struct HBlockCtx {
     double* v;
     double* tau;    // tile: tau[e] = tau_{lo - 1 + e}; edge: 3 per slot (previous, own, next), then tau_N
     double* rec;
+    double* red;    // tile: nvv * T per-step V x V contributions (summed in step order by hess_phase_vvsum)
+    // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
+    const uint32_t *tptr, *terms, *vptr, *vterms;
+    const uint16_t *tasks, *ptasks;
 };
+
+// words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks+ptasks (2 per word)
+constexpr int kMaxStagedHessWords = 3072;
+CTD_HD int hess_table_words(const HParams& hp) {
+    return (hp.Lseg + 1) + hp.nterms + (hp.nvv + 1) + hp.nvterms + (hp.ntask + hp.nptask + 1) / 2;
+}
+CTD_HD bool hess_tables_staged(const HParams& hp) { return hess_table_words(hp) <= kMaxStagedHessWords; }
+CTD_HD int hess_table_doubles(const HParams& hp) { return hess_tables_staged(hp) ? (hess_table_words(hp) + 1) / 2 : 0; }
 
 CTD_HD int64_t hslot_step(const HParams& hp, const HBlockCtx& cx, int k) { return cx.is_edge ? hp.edge_steps[k] : cx.lo + k; }
 CTD_HD const double* hslot_y(const HParams& hp, const HBlockCtx& cx, int k) { return cx.ly + (cx.is_edge ? 2 * k + 1 : k + 1) * hp.L.cb; }
@@ -46,6 +58,8 @@ CTD_HD double hslot_tau(const HBlockCtx& cx, int k, int d) { return cx.is_edge ?
 CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     HBlockCtx cx;
     const Layout& L = hp.L;
+    cx.tptr = hp.tptr; cx.terms = hp.terms; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
+    cx.tasks = hp.tasks; cx.ptasks = hp.ptasks;
     if (block == 0) {
         cx.is_edge = 1;
         cx.nslots = hp.n_edge_slots;
@@ -56,9 +70,20 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.v = cx.ly + 2 * cx.nslots * L.cb + L.p + L.bc;
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + 3 * kMaxHessEdgeSlots + 1;
+        cx.red = cx.rec;
     } else {
         const int tile = block - 1;
         const int cap = hp.T + hp.HL;
+        if (hess_tables_staged(hp)) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
+            cx.tptr = w; w += hp.Lseg + 1;
+            cx.terms = w; w += hp.nterms;
+            cx.vptr = w; w += hp.nvv + 1;
+            cx.vterms = w; w += hp.nvterms;
+            cx.tasks = reinterpret_cast<const uint16_t*>(w);
+            cx.ptasks = cx.tasks + hp.ntask;
+            lds += hess_table_doubles(hp);
+        }
         cx.is_edge = 0;
         cx.a = (int64_t)tile * hp.T;
         const int64_t last = (L.sc == SC_TRAPEZE) ? L.N + 1 : L.N;     // trapeze tiles walk nodes 0..N-1, node N is edge
@@ -72,6 +97,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.v = cx.ly + (cap + 1) * L.cb;
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + cap + 3;
+        cx.red = cx.rec + cap * hp.R.stride;
     }
     return cx;
 }
@@ -79,7 +105,8 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
 inline int64_t hess_lds_doubles(const HParams& hp) {
     const Layout& L = hp.L;
     const int64_t cap = hp.T + hp.HL;
-    const int64_t tile = (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 + cap * hp.R.stride;
+    const int64_t tile = hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
+                         cap * hp.R.stride + (int64_t)hp.nvv * hp.T;
     const int64_t edge = (int64_t)hp.n_edge_slots * (L.blk + L.n + L.m) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
                          3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * hp.R.stride;
     return tile > edge ? tile : edge;
@@ -133,12 +160,24 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
         const int cnt = (int)(g1 - g0);
         for (int e = tid; e < cnt; e += nthr) dst[e] = src[e];
+        // rows of steps lo-1 .. lo+nslots-1 are contiguous in y; tiles never hold node N (its rows sit after N * cb)
         const int ny = (cx.nslots + 1) * L.cb;
+        const int64_t yb = (cx.lo - 1) * (int64_t)L.cb, ylim = L.N * (int64_t)L.cb;
         for (int e = tid; e < ny; e += nthr) {
-            const int k = e / L.cb, r = e - k * L.cb;
-            cx.ly[e] = hess_y_of(hp, y, cx.lo - 1 + k, r);
+            const int64_t g = yb + e;
+            cx.ly[e] = (g >= 0 && g < ylim) ? y[g] : 0.0;
         }
         for (int e = tid; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
+        if (hess_tables_staged(hp)) {
+            uint32_t* d;
+            d = const_cast<uint32_t*>(cx.tptr);   for (int e = tid; e <= hp.Lseg; e += nthr) d[e] = hp.tptr[e];
+            d = const_cast<uint32_t*>(cx.terms);  for (int e = tid; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
+            d = const_cast<uint32_t*>(cx.vptr);   for (int e = tid; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
+            d = const_cast<uint32_t*>(cx.vterms); for (int e = tid; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
+            uint16_t* q = const_cast<uint16_t*>(cx.tasks);
+            for (int e = tid; e < hp.ntask; e += nthr) q[e] = hp.tasks[e];
+            for (int e = tid; e < hp.nptask; e += nthr) q[hp.ntask + e] = hp.ptasks[e];
+        }
     }
     if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
 }
@@ -146,38 +185,35 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
 // ------------------------------------------------------------------------------------------------------
 // phase: eval
 // ------------------------------------------------------------------------------------------------------
-// chain-rule coefficients of one step + the state-equation multipliers the K x V terms need
+// value of chain-rule coefficient ci for a step of length h (dh[k] = dh/dv_k); see the HC_* enum
+template <class P>
+CTD_HD double hess_coef_value(const Layout& L, int ci, double h, double tau0, double tau1) {
+    if (ci == HC_ONE) return 1.0;
+    if (ci == HC_HALF) return 0.5;
+    if (ci < HC_A) return h * L.a[ci - HC_HA];
+    if (ci < HC_B) return L.a[ci - HC_A];
+    if (ci < HC_NBH) return L.b[ci - HC_B];
+    const int k = (ci - HC_NBH) / 3, l = (ci - HC_NBH) - 3 * k;
+    const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, k) - dtime_of<P>(tau0, k) : 0.0;
+    return -(L.b[l] * dh);
+}
+
+// coefficient products of one record (slot k, pair id) + the state-equation multipliers the K x V terms need
 template <class P, int SC, int S>
-CTD_HD void hess_coefs(const HParams& hp, const HBlockCtx& cx, int k) {
-    constexpr int n = P::NX, nv = P::NV;
-    constexpr bool FREE = Dirs<P>::FREE;
+CTD_HD void hess_pair(const HParams& hp, const HBlockCtx& cx, int k, int pid) {
+    constexpr int n = P::NX;
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     const Layout& L = hp.L;
     double* rec = cx.rec + k * R.stride;
-    double* C = rec + R.oC;
-#pragma unroll
-    for (int e = 0; e < kHC; ++e) C[e] = 0.0;
-    C[HC_ONE] = 1.0; C[HC_HALF] = 0.5;
     const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
     const double h = htime_of<P>(hp, cx.v, tau1) - htime_of<P>(hp, cx.v, tau0);
-    if (SC == SC_IRK) {
+    const int code = hp.pairs[pid];
+    rec[R.oCP + pid] = hess_coef_value<P>(L, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(L, code >> 8, h, tau0, tau1);
+    if (pid == 0) rec[R.oZero] = 0.0;
+    if (SC == SC_IRK && Dirs<P>::FREE && pid == 0) {
+        const double* y = hslot_y(hp, cx, k);
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-#pragma unroll
-            for (int l = 0; l < S; ++l) { C[HC_HA + 3 * j + l] = h * L.a[3 * j + l]; C[HC_A + 3 * j + l] = L.a[3 * j + l]; }
-            C[HC_B + j] = L.b[j];
-        }
-        if (FREE) {
-#pragma unroll
-            for (int kk = 0; kk < nv; ++kk) {
-                const double dh = dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk);
-#pragma unroll
-                for (int l = 0; l < S; ++l) C[HC_NBH + 3 * kk + l] = -(L.b[l] * dh);
-            }
-            const double* y = hslot_y(hp, cx, k);
-#pragma unroll
-            for (int r = 0; r < n; ++r) rec[R.oYX + r] = y[r];
-        }
+        for (int r = 0; r < n; ++r) rec[R.oYX + r] = y[r];
     }
 }
 
@@ -429,22 +465,25 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
     constexpr bool PATH_PT = np > 0 && SC != SC_TRAPEZE;
     constexpr int PT = R.S + (PATH_PT ? 1 : 0);
     const Layout& L = hp.L;
-    for (int k = tid; k < cx.nslots; k += nthr) hess_coefs<P, SC, S>(hp, cx, k);
-    const int total = cx.nslots * PT * hp.ntask;
+    for (int w = tid; w < cx.nslots * hp.npairs; w += nthr) {
+        const int k = w / hp.npairs;
+        hess_pair<P, SC, S>(hp, cx, k, w - k * hp.npairs);
+    }
+    const int total = cx.nslots * hp.slot_tasks;
     for (int w = tid; w < total; w += nthr) {
-        const int sp = (int)fast_div((uint32_t)w, hp.div_ntask);
-        const int tk = w - sp * hp.ntask;
-        const int k = sp / PT, pt = sp - k * PT;
-        const uint16_t code = hp.tasks[tk];
-        const int p = code & 0xFF, c = code >> 8;
-        if (pt < R.S) {
-            hess_eval_stage<P, SC, S>(hp, cx, k, pt, p, c);
+        const int k = (int)fast_div((uint32_t)w, hp.div_slot_tasks);
+        const int r = w - k * hp.slot_tasks;
+        if (r < R.S * hp.ntask) {
+            const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
+            const uint16_t code = cx.tasks[r - j * hp.ntask];
+            hess_eval_stage<P, SC, S>(hp, cx, k, j, code & 0xFF, code >> 8);
         } else if (PATH_PT) {
+            const uint16_t code = cx.ptasks[r - R.S * hp.ntask];
             const int64_t s = hslot_step(hp, cx, k);
             if (s >= 0 && s < L.N) {
                 const double* base = cx.in + k * cx.in_stride;
                 hess_eval_path<P, SC, S>(hp, base, base + n, cx.v, hslot_tau(cx, k, 0), hslot_y(hp, cx, k) + L.eqs,
-                                         cx.rec + k * R.stride + R.oHP, p, c);
+                                         cx.rec + k * R.stride + R.oHP, code & 0xFF, code >> 8);
             }
         }
     }
@@ -458,8 +497,8 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const double* last = cx.in + kl * cx.in_stride;
         const double* yfp = cx.ly + 2 * cx.nslots * L.cb;
         if (PATH_PT)
-            for (int w = tid; w < hp.ntask; w += nthr) {
-                const uint16_t code = hp.tasks[w];
+            for (int w = tid; w < hp.nptask; w += nthr) {
+                const uint16_t code = hp.ptasks[w];
                 hess_eval_path<P, SC, S>(hp, last + L.blk, last + n, cx.v, cx.tau[3 * cx.nslots], yfp,
                                          cx.rec + hp.edge_fp * R.stride + R.oHP, code & 0xFF, code >> 8);
             }
@@ -469,22 +508,57 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
                 hess_eval_boundary<P, SC, S>(hp, cx.in + kf * cx.in_stride, last + L.blk, cx.v, yfp + L.p,
                                              cx.rec + hp.edge_b * R.stride, code & 0xFF, code >> 8);
             }
-        // the coefficient blocks of the two extra records (terms multiply by C[HC_ONE])
-        for (int e = tid; e < 2 * kHC; e += nthr) {
-            const int which = e / kHC, ci = e - which * kHC;
-            cx.rec[(hp.edge_fp + which) * R.stride + R.oC + ci] = (ci == HC_ONE) ? 1.0 : (ci == HC_HALF ? 0.5 : 0.0);
+        // coefficient products of the two extra records: no step length (only ONE, HALF and the b_l can occur)
+        for (int e = tid; e < 2 * hp.npairs; e += nthr) {
+            const int which = e / hp.npairs, pid = e - which * hp.npairs;
+            const int code = hp.pairs[pid];
+            cx.rec[(hp.edge_fp + which) * R.stride + R.oCP + pid] =
+                hess_coef_value<P>(L, code & 0xFF, 0.0, 0.0, 0.0) * hess_coef_value<P>(L, code >> 8, 0.0, 0.0, 0.0);
         }
-        if (L.stagewise)
-            for (int e = tid; e < S; e += nthr) cx.rec[hp.edge_fp * R.stride + R.oC + HC_B + e] = L.b[e];
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // phase: emit
 // ------------------------------------------------------------------------------------------------------
-CTD_HD double hess_term(const double* rec, int stride, int oC, uint32_t code, int slot) {
+CTD_HD double hess_term(const double* rec, int stride, int oCP, uint32_t code, int slot) {
     const double* r = rec + slot * stride;
-    return (r[oC + term_c1(code)] * r[oC + term_c2(code)]) * r[term_di(code)];
+    return r[oCP + term_pair(code)] * r[term_di(code)];
+}
+
+// largest term count among the (up to 64) segment positions w0 .. w0 + nwl - 1 handled by one wave: wave-uniform by
+// construction (every lane walks the same range), so the switch on it below does not diverge
+CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDiv div_Lseg, int Lseg, int nwl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int m = own;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    return m;
+#else
+    int m = 0;
+    for (int w = w0; w < w0 + nwl && w < wend; ++w) {
+        const int g = (int)fast_div((uint32_t)w, div_Lseg), e = w - g * Lseg;
+        const int nt = (int)(tptr[e + 1] - tptr[e]);
+        m = nt > m ? nt : m;
+    }
+    return m;
+#endif
+}
+
+// the steps ibeg, ibeg + G, ... < iend of one segment entry with NT (possibly padded) terms
+template <int NT>
+CTD_HD void hess_emit_steps(const double* rec, int stride, const int* cpo, const int* dio, double* out, int64_t ibeg, int64_t iend,
+                            int G, int64_t lo, int64_t reg_first, int Lseg) {
+    for (int64_t i = ibeg; i < iend; i += G) {
+        const double* rk = rec + (int)(i - lo) * stride;
+        double a[NT > 0 ? NT : 1], b[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { a[t] = rk[cpo[t]]; b[t] = rk[dio[t]]; }
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc = acc + a[t] * b[t];
+        out[(i - reg_first) * (int64_t)Lseg] = acc;
+    }
 }
 
 template <class P, int SC, int S>
@@ -495,7 +569,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
             double acc = 0.0;
             for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];
-                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, term_slot(code));
+                acc = acc + hess_term(cx.rec, R.stride, R.oCP, code, term_slot(code));
             }
             hp.vals[hp.edge_idx[e]] = acc;
         }
@@ -503,7 +577,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
             double acc = 0.0;
             for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];
-                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, term_slot(code));
+                acc = acc + hess_term(cx.rec, R.stride, R.oCP, code, term_slot(code));
             }
             hp.partials[e] = acc;
         }
@@ -511,26 +585,58 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
     }
     const int64_t i0 = cx.a > hp.reg_first ? cx.a : hp.reg_first;
     const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
-    for (int e = tid; e < hp.Lseg; e += nthr) {
-        const uint32_t t0 = hp.tptr[e], t1 = hp.tptr[e + 1];
+    // lane (e, g) owns entry e of the segment for the steps i0 + g, i0 + g + G, ...: its (few) term codes are read once,
+    // then it walks its steps; short segments are replicated G times across the workgroup.  Inside a wave every lane
+    // runs the same number of terms (the wave's maximum, absent terms read 1.0 * rec[oZero]) so that all LDS reads of a
+    // step are in flight together instead of one exec-masked read-wait-fma chain per term.
+    const int G = (hp.Lseg > 0 && hp.Lseg < nthr) ? nthr / hp.Lseg : 1;
+    const int wave_lo = tid & ~63, nwl = nthr - wave_lo < 64 ? nthr - wave_lo : 64;
+    for (int w0 = wave_lo; w0 < hp.Lseg * G; w0 += nthr) {
+        const int w = w0 + (tid - wave_lo);
+        const bool live = w < hp.Lseg * G;
+        const int g = live ? (int)fast_div((uint32_t)w, hp.div_Lseg) : 0;
+        const int e = live ? w - g * hp.Lseg : 0;
+        const uint32_t t0 = cx.tptr[e];
+        const int nt = live ? (int)(cx.tptr[e + 1] - t0) : 0;
+        int cpo[kMaxTerms], dio[kMaxTerms];
+#pragma unroll
+        for (int t = 0; t < kMaxTerms; ++t) {
+            const uint32_t code = (t < nt) ? cx.terms[t0 + t] : 0u;
+            const int so = (t < nt) ? term_slot(code) * R.stride : 0;
+            cpo[t] = R.oCP + ((t < nt) ? term_pair(code) : 0) - so;
+            dio[t] = ((t < nt) ? term_di(code) : R.oZero) - so;
+        }
+        const int wmax = hess_wave_max(nt, w0, hp.Lseg * G, cx.tptr, hp.div_Lseg, hp.Lseg, nwl);
         double* out = hp.vals + hp.seg_base + e;
-        for (int64_t i = i0; i < i1; ++i) {
-            const int k = (int)(i - cx.lo);
-            double acc = 0.0;
-            for (uint32_t t = t0; t < t1; ++t) {
-                const uint32_t code = hp.terms[t];
-                acc = acc + hess_term(cx.rec, R.stride, R.oC, code, k - term_slot(code));
-            }
-            out[(i - hp.reg_first) * (int64_t)hp.Lseg] = acc;
+        const int64_t ibeg = live ? i0 + g : i1;
+        switch (wmax) {
+            case 0: hess_emit_steps<0>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 1: hess_emit_steps<1>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 2: hess_emit_steps<2>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 3: hess_emit_steps<3>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 4: hess_emit_steps<4>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 5: hess_emit_steps<5>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            default: hess_emit_steps<kMaxTerms>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
         }
     }
-    // the tile's share of the V x V entries: all of its steps, in step order
+    // V x V entries: one lane per (step of the tile, entry) adds up that step's terms; hess_phase_vvsum then sums the steps
+    const int ns = (int)(cx.b - cx.a);
+    for (int w = tid; w < ns * hp.nvv; w += nthr) {
+        const int si = w / hp.nvv, e = w - si * hp.nvv;
+        const int k = si + (int)(cx.a - cx.lo);
+        double acc = 0.0;
+        for (uint32_t t = cx.vptr[e]; t < cx.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, R.oCP, cx.vterms[t], k);
+        cx.red[e * hp.T + si] = acc;
+    }
+}
+
+// the tile's share of the V x V entries: its steps in step order (fixed summation order)
+CTD_HD void hess_phase_vvsum(const HParams& hp, const HBlockCtx& cx, int block, int tid, int nthr) {
+    if (cx.is_edge) return;
+    const int ns = (int)(cx.b - cx.a);
     for (int e = tid; e < hp.nvv; e += nthr) {
         double acc = 0.0;
-        for (int64_t i = cx.a; i < cx.b; ++i) {
-            const int k = (int)(i - cx.lo);
-            for (uint32_t t = hp.vptr[e]; t < hp.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, R.oC, hp.vterms[t], k);
-        }
+        for (int si = 0; si < ns; ++si) acc = acc + cx.red[e * hp.T + si];
         hp.partials[(int64_t)block * hp.nvv + e] = acc;
     }
 }

@@ -91,6 +91,117 @@ int64_t Model::hess_column_start(int64_t j) const {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// structural sparsity of the evaluation points' Hessians: dependency masks pushed through the OCP functors
+// ------------------------------------------------------------------------------------------------------
+// value -> (set of directions it depends on, set of direction pairs with a structurally nonzero second derivative)
+struct SP {
+    uint32_t m1;
+    uint32_t m2[32];
+    SP() : m1(0) { for (uint32_t& r : m2) r = 0; }
+    SP(double) : m1(0) { for (uint32_t& r : m2) r = 0; }
+    static SP dir(uint32_t mask) { SP r; r.m1 = mask; return r; }
+};
+static inline SP sp_lin(const SP& a, const SP& b) {
+    SP r; r.m1 = a.m1 | b.m1;
+    for (int i = 0; i < 32; ++i) r.m2[i] = a.m2[i] | b.m2[i];
+    return r;
+}
+static inline void sp_outer(SP& r, uint32_t a, uint32_t b) {
+    for (int i = 0; i < 32; ++i) {
+        if (a >> i & 1u) r.m2[i] |= b;
+        if (b >> i & 1u) r.m2[i] |= a;
+    }
+}
+static inline SP sp_nonlin(const SP& a) { SP r = a; sp_outer(r, a.m1, a.m1); return r; }
+inline SP operator+(const SP& a, const SP& b) { return sp_lin(a, b); }
+inline SP operator-(const SP& a, const SP& b) { return sp_lin(a, b); }
+inline SP operator-(const SP& a) { return a; }
+inline SP operator*(const SP& a, const SP& b) { SP r = sp_lin(a, b); sp_outer(r, a.m1, b.m1); return r; }
+inline SP operator/(const SP& a, const SP& b) { return a * sp_nonlin(b); }
+inline SP operator+(const SP& a, double) { return a; }
+inline SP operator+(double, const SP& a) { return a; }
+inline SP operator-(const SP& a, double) { return a; }
+inline SP operator-(double, const SP& a) { return a; }
+inline SP operator*(const SP& a, double) { return a; }
+inline SP operator*(double, const SP& a) { return a; }
+inline SP operator/(const SP& a, double) { return a; }
+inline SP operator/(double, const SP& a) { return sp_nonlin(a); }
+inline SP d_exp(const SP& a) { return sp_nonlin(a); }
+inline SP d_sin(const SP& a) { return sp_nonlin(a); }
+inline SP d_cos(const SP& a) { return sp_nonlin(a); }
+inline SP d_sqr(const SP& a) { return sp_nonlin(a); }
+
+template <class P>
+static void probe_structure(Model& mo) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, nb = P::NBC;
+    const Layout& L = mo.L;
+    HessModel& H = mo.H;
+    const int md = H.R.md, mdb = H.R.mdb, vd = n + m;
+    const bool free_time = L.free_time != 0;
+    uint32_t TV = 0;                                   // directions that move the time grid
+    if (L.it0 >= 0) TV |= 1u << (vd + L.it0);
+    if (L.itf >= 0) TV |= 1u << (vd + L.itf);
+    auto fill = [&](const SP& phi, int dim, std::vector<uint8_t>& out) {
+        out.assign((size_t)dim * dim, 0);
+        for (int p = 0; p < dim; ++p)
+            for (int q = 0; q < dim; ++q)
+                if ((phi.m2[p] >> q & 1u) || (phi.m2[q] >> p & 1u)) out[p * dim + q] = 1;
+    };
+    const SP hh = SP::dir(TV), t = SP::dir(TV);
+    SP x[n > 0 ? n : 1], u[m > 0 ? m : 1], v[nv > 0 ? nv : 1];
+    for (int r = 0; r < n; ++r) x[r] = SP::dir((1u << r) | ((L.sc == SC_IRK && free_time) ? TV : 0u));
+    for (int b = 0; b < m; ++b) u[b] = SP::dir(1u << (n + b));
+    for (int k = 0; k < nv; ++k) v[k] = SP::dir(1u << (vd + k));
+    // stage-type point
+    {
+        SP f[n > 0 ? n : 1];
+        P::template dynamics<SP>(f, t, x, u, v);
+        SP phi;
+        for (int r = 0; r < n; ++r) phi = phi + f[r] * (L.sc == SC_IRK ? SP() : hh);
+        if (P::HAS_LAGRANGE) phi = phi + hh * P::template lagrange<SP>(t, x, u, v);
+        if (L.sc == SC_TRAPEZE && np > 0) {
+            SP g[np > 0 ? np : 1];
+            P::template path<SP>(g, t, x, u, v);
+            for (int r = 0; r < np; ++r) phi = phi + g[r];
+        }
+        fill(phi, md, H.need_stage);
+        H.need_rk.assign((size_t)(nv > 0 ? nv : 1) * (n > 0 ? n : 1), 0);
+        if (L.sc == SC_IRK && free_time)
+            for (int k = 0; k < nv; ++k)
+                for (int a = 0; a < n; ++a) {
+                    const bool time_var = (k == L.it0 || k == L.itf);
+                    if (H.need_stage[a * md + vd + k] || (time_var && (phi.m1 >> a & 1u))) H.need_rk[k * n + a] = 1;
+                }
+    }
+    // path point (x = X_i exactly: no dependence on the time grid through the state)
+    H.need_path.assign((size_t)md * md, 0);
+    if (np > 0 && L.sc != SC_TRAPEZE) {
+        SP xp[n > 0 ? n : 1];
+        for (int r = 0; r < n; ++r) xp[r] = SP::dir(1u << r);
+        SP g[np > 0 ? np : 1];
+        P::template path<SP>(g, t, xp, u, v);
+        SP phi;
+        for (int r = 0; r < np; ++r) phi = phi + g[r];
+        fill(phi, md, H.need_path);
+    }
+    // boundary + Mayer point
+    H.need_bnd.assign((size_t)mdb * mdb, 0);
+    {
+        SP x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], vb[nv > 0 ? nv : 1];
+        for (int r = 0; r < n; ++r) { x0[r] = SP::dir(1u << r); xf[r] = SP::dir(1u << (n + r)); }
+        for (int k = 0; k < nv; ++k) vb[k] = SP::dir(1u << (2 * n + k));
+        SP phi;
+        if (nb > 0) {
+            SP r_[nb > 0 ? nb : 1];
+            P::template boundary<SP>(r_, x0, xf, vb);
+            for (int r = 0; r < nb; ++r) phi = phi + r_[r];
+        }
+        if (P::HAS_MAYER) phi = phi + P::template mayer<SP>(x0, xf, vb);
+        fill(phi, mdb, H.need_bnd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // which evaluation points couple two NLP variables, and through which directions / coefficients
 // ------------------------------------------------------------------------------------------------------
 namespace {
@@ -174,10 +285,12 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
             const int base = R.oStage + j * R.stage_sz;
             const Var* kv = (vr.kind == VK_K) ? &vr : (vc.kind == VK_K ? &vc : nullptr);
             const Var* vv = (vr.kind == VK_V) ? &vr : (vc.kind == VK_V ? &vc : nullptr);
-            if (rk && kv && vv)    // d2/dK^l_a dV_k: a_jl (h HD[x_a][V_k] + dh/dv_k dPhi/dx_a)
-                out.push_back(Term{PT_STAGE, s, base + R.oRK + vv->c * L.n + kv->c, HC_A + 3 * j + kv->l, HC_ONE});
-            else
+            if (rk && kv && vv) {  // d2/dK^l_a dV_k: a_jl (h HD[x_a][V_k] + dh/dv_k dPhi/dx_a)
+                if (mo.H.need_rk[vv->c * L.n + kv->c])
+                    out.push_back(Term{PT_STAGE, s, base + R.oRK + vv->c * L.n + kv->c, HC_A + 3 * j + kv->l, HC_ONE});
+            } else if (mo.H.need_stage[sym_index(R.md, a.d, b.d)]) {
                 out.push_back(Term{PT_STAGE, s, base + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+            }
         }
         if (rk) {   // state-equation row -h sum_l b_l y'K^l: d2/dK^l_a dV_k = -b_l dh/dv_k y_a for the time variables
             const Var* kv = (vr.kind == VK_K) ? &vr : (vc.kind == VK_K ? &vc : nullptr);
@@ -187,17 +300,31 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
         }
         if (has_path_pt && s < L.N) {
             const Dir a = map_path(L, s, s, vr), b = map_path(L, s, s, vc);
-            if (a.ok && b.ok) out.push_back(Term{PT_PATH, s, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+            if (a.ok && b.ok && mo.H.need_path[sym_index(R.md, a.d, b.d)])
+                out.push_back(Term{PT_PATH, s, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
         }
     }
     if (has_path_pt) {
         const Dir a = map_path(L, L.N, L.N - 1, vr), b = map_path(L, L.N, L.N - 1, vc);
-        if (a.ok && b.ok) out.push_back(Term{PT_FPATH, 0, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+        if (a.ok && b.ok && mo.H.need_path[sym_index(R.md, a.d, b.d)])
+            out.push_back(Term{PT_FPATH, 0, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
     }
     if (L.bc > 0 || mo.info.mayer) {
         const Dir a = map_bnd(L, vr), b = map_bnd(L, vc);
-        if (a.ok && b.ok) out.push_back(Term{PT_BND, 0, sym_index(R.mdb, a.d, b.d), HC_ONE, HC_ONE});
+        if (a.ok && b.ok && mo.H.need_bnd[sym_index(R.mdb, a.d, b.d)])
+            out.push_back(Term{PT_BND, 0, sym_index(R.mdb, a.d, b.d), HC_ONE, HC_ONE});
     }
+}
+
+// id of the coefficient product C[c1] * C[c2] (registered on first use; -1 when the table is full)
+static int pair_id(HessModel& H, int c1, int c2) {
+    if (c1 > c2) std::swap(c1, c2);
+    const uint16_t code = (uint16_t)(c1 | (c2 << 8));
+    for (size_t i = 0; i < H.pairs.size(); ++i)
+        if (H.pairs[i] == code) return (int)i;
+    if ((int)H.pairs.size() >= kMaxPairs) return -1;
+    H.pairs.push_back(code);
+    return (int)H.pairs.size() - 1;
 }
 
 // template of the step-periodic segment of step i: per entry the relative row and its relative terms
@@ -207,7 +334,7 @@ struct SegTmpl {
     bool operator==(const SegTmpl& o) const { return cp == o.cp && relrow == o.relrow && tptr == o.tptr && terms == o.terms; }
 };
 
-static bool segment_template(const Model& mo, int64_t i, SegTmpl& t) {
+static bool segment_template(Model& mo, int64_t i, SegTmpl& t) {
     const Layout& L = mo.L;
     t.cp.assign(L.blk + 1, 0);
     t.relrow.clear(); t.tptr.assign(1, 0); t.terms.clear();
@@ -222,8 +349,11 @@ static bool segment_template(const Model& mo, int64_t i, SegTmpl& t) {
                 if (x.pt == PT_FPATH || x.pt == PT_BND) return false;
                 const int64_t rel = i - x.step;
                 if (rel < 0 || rel > mo.H.HL) return false;
-                t.terms.push_back(pack_term(x.di, x.c1, x.c2, (int)rel));
+                const int pid = pair_id(mo.H, x.c1, x.c2);
+                if (pid < 0) return false;
+                t.terms.push_back(pack_term(x.di, pid, (int)rel));
             }
+            if (tt.size() > (size_t)kMaxTerms) return false;
             t.tptr.push_back((uint32_t)t.terms.size());
             t.relrow.push_back(row >= L.v_off ? ((int64_t)1 << 40) + (row - L.v_off) : row - i * L.blk);
         }
@@ -239,6 +369,10 @@ int build_hess_model(Model& mo, std::string& err) {
     H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, L.s, L.free_time != 0);
     if (H.R.stride >= 65536) { err = "per-step Hessian record too large for 16-bit data indices"; return ST_EPATTERN; }
     H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
+    H.pairs.clear();
+    pair_id(H, HC_ONE, HC_ONE);           // pair 0
+    if (H.R.md > 32 || H.R.mdb > 32) { err = "more than 32 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
+    for_problem(mo.problem, [&](auto tag) { probe_structure<typename decltype(tag)::type>(mo); });
     build_hess_tail(mo);
 
     // ---- regular range ---------------------------------------------------------------------------------------------
@@ -286,9 +420,10 @@ int build_hess_model(Model& mo, std::string& err) {
             for (int kr = kc; kr < L.nv; ++kr, ++e) {
                 H.vv_idx[e] = mo.hess_column_start(L.v_off + kc) + (kr - kc);
                 for (int j = 0; j < H.R.S; ++j)
-                    H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, 0));
-                if (L.p > 0 && L.sc != SC_TRAPEZE)
-                    H.vterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, 0));
+                    if (H.need_stage[sym_index(md, vd + kc, vd + kr)])
+                        H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + sym_index(md, vd + kc, vd + kr), 0, 0));
+                if (L.p > 0 && L.sc != SC_TRAPEZE && H.need_path[sym_index(md, vd + kc, vd + kr)])
+                    H.vterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), 0, 0));
                 H.vptr.push_back((uint32_t)H.vterms.size());
             }
         }
@@ -326,7 +461,9 @@ int build_hess_model(Model& mo, std::string& err) {
         H.edge_idx.push_back(r.idx);
         for (const Term& x : r.tt) {
             const int slot = x.pt == PT_FPATH ? H.edge_fp : (x.pt == PT_BND ? H.edge_b : slot_of[x.step]);
-            H.eterms.push_back(pack_term(x.di, x.c1, x.c2, slot));
+            const int pid = pair_id(H, x.c1, x.c2);
+            if (pid < 0) { err = "internal: coefficient pair table full (Hessian)"; return ST_EPATTERN; }
+            H.eterms.push_back(pack_term(x.di, pid, slot));
         }
         H.eptr.push_back((uint32_t)H.eterms.size());
     }
@@ -336,25 +473,34 @@ int build_hess_model(Model& mo, std::string& err) {
         const int md = H.R.md, vd = L.n + L.m, mdb = H.R.mdb;
         for (int kc = 0; kc < L.nv; ++kc)
             for (int kr = kc; kr < L.nv; ++kr) {
-                if (L.p > 0 && L.sc != SC_TRAPEZE)
-                    H.eterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, H.edge_fp));
-                if (L.bc > 0 || mo.info.mayer)
-                    H.eterms.push_back(pack_term(sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr), HC_ONE, HC_ONE, H.edge_b));
-                if (L.sc == SC_TRAPEZE)
-                    H.eterms.push_back(pack_term(H.R.oStage + sym_index(md, vd + kc, vd + kr), HC_ONE, HC_ONE, slot_of[N]));
+                if (L.p > 0 && L.sc != SC_TRAPEZE && H.need_path[sym_index(md, vd + kc, vd + kr)])
+                    H.eterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), 0, H.edge_fp));
+                if ((L.bc > 0 || mo.info.mayer) && H.need_bnd[sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr)])
+                    H.eterms.push_back(pack_term(sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr), 0, H.edge_b));
+                if (L.sc == SC_TRAPEZE && H.need_stage[sym_index(md, vd + kc, vd + kr)])
+                    H.eterms.push_back(pack_term(H.R.oStage + sym_index(md, vd + kc, vd + kr), 0, slot_of[N]));
                 H.evptr.push_back((uint32_t)H.eterms.size());
             }
     }
 
-    // ---- eval tasks: lane (p, chunk) covers HD[p][chunk*hk .. +hk); chunks entirely left of the diagonal are skipped ------
-    auto make_tasks = [&](int md, std::vector<uint16_t>& out) {
+    // ---- eval tasks: lane (p, chunk) covers HD[p][chunk*hk .. +hk); only chunks holding a structural nonzero at or right
+    // of the diagonal (or an RK entry) are evaluated ------------------------------------------------------------------------
+    auto make_tasks = [&](int md, const std::vector<uint8_t>& need, bool with_rk, std::vector<uint16_t>& out) {
         out.clear();
-        const int nch = (md + H.hk - 1) / H.hk;
+        const int nch = (md + H.hk - 1) / H.hk, vd = L.n + L.m;
         for (int p = 0; p < md; ++p)
-            for (int c = p / H.hk; c < nch; ++c) out.push_back((uint16_t)(p | (c << 8)));
+            for (int c = p / H.hk; c < nch; ++c) {
+                bool any = false;
+                for (int q = std::max(p, c * H.hk); q < std::min(md, (c + 1) * H.hk); ++q) {
+                    if (need[p * md + q]) any = true;
+                    if (with_rk && p < L.n && q >= vd && H.need_rk[(q - vd) * L.n + p]) any = true;
+                }
+                if (any) out.push_back((uint16_t)(p | (c << 8)));
+            }
     };
-    make_tasks(H.R.md, H.tasks);
-    make_tasks(H.R.mdb, H.btasks);
+    make_tasks(H.R.md, H.need_stage, L.sc == SC_IRK && L.free_time, H.tasks);
+    make_tasks(H.R.md, H.need_path, false, H.ptasks);
+    make_tasks(H.R.mdb, H.need_bnd, false, H.btasks);
     return ST_OK;
 }
 
@@ -377,6 +523,7 @@ void Model::fill_hparams(HParams& hp, int tile) const {
     hp.ntiles = (int)((L.N + tile - 1) / tile);
     hp.Lseg = H.Lseg;
     hp.nterms = (int)H.terms.size();
+    hp.nvterms = (int)H.vterms.size();
     hp.seg_base = H.seg_base; hp.reg_first = H.reg_first; hp.reg_last = H.reg_last;
     hp.nvv = H.nvv;
     for (int e = 0; e < H.nvv; ++e) hp.vv_idx[e] = H.vv_idx[e];
@@ -384,9 +531,15 @@ void Model::fill_hparams(HParams& hp, int tile) const {
     hp.n_edge_slots = H.n_edge_slots;
     hp.edge_fp = H.edge_fp; hp.edge_b = H.edge_b;
     for (int k = 0; k < kMaxHessEdgeSlots; ++k) hp.edge_steps[k] = H.edge_steps[k];
+    hp.npairs = (int)H.pairs.size();
+    for (int i = 0; i < hp.npairs; ++i) hp.pairs[i] = H.pairs[i];
     hp.ntask = (int)H.tasks.size();
+    hp.nptask = (int)H.ptasks.size();
     hp.nbtask = (int)H.btasks.size();
+    hp.slot_tasks = H.R.S * hp.ntask + hp.nptask;
     hp.div_ntask = make_fastdiv((uint32_t)(hp.ntask > 0 ? hp.ntask : 1));
+    hp.div_slot_tasks = make_fastdiv((uint32_t)(hp.slot_tasks > 0 ? hp.slot_tasks : 1));
+    hp.div_Lseg = make_fastdiv((uint32_t)(H.Lseg > 0 ? H.Lseg : 1));
 }
 
 }  // namespace ctd

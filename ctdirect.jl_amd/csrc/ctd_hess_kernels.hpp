@@ -10,17 +10,40 @@ namespace ctd {
 
 constexpr int kHessBlock = 256;
 
+__device__ __forceinline__ void hess_stamp(const HParams& hp, int slot) {
+    if (hp.stamps && threadIdx.x == 0) {
+        unsigned long long* p = hp.stamps + ((size_t)blockIdx.x * 5 + slot) * 2;
+        p[0] = wall_clock64();
+        p[1] = clock64();
+    }
+}
+
 template <class P, int SC, int S>
 __global__ __launch_bounds__(kHessBlock) void hess_kernel(const HParams hp, const double* __restrict__ xu,
                                                           const double* __restrict__ y) {
     extern __shared__ double hess_lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
+    hess_stamp(hp, 0);
     const HBlockCtx cx = make_hctx(hp, blockIdx.x, hess_lds);
     hess_phase_load<P>(hp, cx, xu, y, tid, nthr);
     __syncthreads();
+    hess_stamp(hp, 1);
+    if (hp.debug_stop == 1) return;
     hess_phase_eval<P, SC, S>(hp, cx, tid, nthr);
     __syncthreads();
+    hess_stamp(hp, 2);
+    if (hp.debug_stop == 2) return;
     hess_phase_emit<P, SC, S>(hp, cx, blockIdx.x, tid, nthr);
+    if (hp.nvv > 0) {
+        __syncthreads();
+        hess_phase_vvsum(hp, cx, blockIdx.x, tid, nthr);
+    }
+    hess_stamp(hp, 3);
+    if (hp.stamps) {             // diagnostics: time until this workgroup's stores have left the CU
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        hess_stamp(hp, 4);
+    }
 }
 
 // V x V entries: fixed-order sum of the per-workgroup partials (one workgroup)

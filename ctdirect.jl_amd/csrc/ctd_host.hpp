@@ -40,8 +40,13 @@ struct HessModel {
     std::vector<uint32_t> eptr, evptr, eterms;
     int n_edge_slots = 0, edge_fp = 0, edge_b = 0;
     int64_t edge_steps[kMaxHessEdgeSlots] = {0};
-    // eval tasks
-    std::vector<uint16_t> tasks, btasks;
+    // structural nonzeros of the evaluation points' dense Hessians (row-major md x md / mdb x mdb, upper triangle used)
+    // and of the K x V helper RK (nv x n): found by pushing dependency masks through the OCP functions
+    std::vector<uint8_t> need_stage, need_path, need_bnd, need_rk;
+    // eval tasks (stage-type points, path points, boundary point)
+    std::vector<uint16_t> tasks, ptasks, btasks;
+    // coefficient pairs referenced by the term codes (pair 0 = ONE * ONE)
+    std::vector<uint16_t> pairs;
     // column starts (same scheme as the Jacobian's)
     std::vector<int64_t> cp_head, cp_tmpl, cp_tail;
 };

@@ -376,11 +376,22 @@ class DOCP:
                                               self._dev_ptr(vals, self.nnzh, "vals"), int(iters), C.byref(ms)))
         return ms.value
 
+    def hess_debug_stamps(self, x, y, vals, obj_weight=1.0):
+        """Diagnostics: per-workgroup phase stamps of one Hessian launch, array [grid, 5, 2] (realtime 100 MHz, cycles)."""
+        grid = self.hess_launch_info()["grid"]
+        out = np.zeros(grid * 10, dtype=np.uint64)
+        self._ck(_lib.lib().ctd_hess_debug_stamps(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                                  self._dev_ptr(y, self.dim_NLP_constraints, "y"), float(obj_weight),
+                                                  self._dev_ptr(vals, self.nnzh, "vals"),
+                                                  out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        return out.reshape(grid, 5, 2)
+
     def hess_launch_info(self):
-        o = np.zeros(6, dtype=np.int64)
+        o = np.zeros(10, dtype=np.int64)
         self._ck(_lib.lib().ctd_hess_launch_info(self._h, _ip(o)))
         return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]), csc_period=int(o[4]),
-                    edge_entries=int(o[5]))
+                    edge_entries=int(o[5]), stage_lanes=int(o[6]), path_lanes=int(o[7]), boundary_lanes=int(o[8]),
+                    segment_terms=int(o[9]))
 
     def jac_structure(self):
         """jac_structure!(nlp, rows, cols): 1-based COO in CSC order."""

@@ -215,9 +215,15 @@ int32_t ctd_hess_coord_dev_async(ctd_handle* h, const double* x_dev, const doubl
 /* measurement: mean duration (ms) of the Hessian kernel over `iters` launches, per-dispatch events on the handle's stream */
 int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
                           int32_t iters, double* mean_ms);
-/* launch geometry of the Hessian kernel: out[0..5] = grid blocks, block threads, dynamic LDS bytes, steps per tile,
- * CSC period of the lower triangle (entries per regular step), number of edge entries */
-int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* out6);
+/* launch geometry of the Hessian kernel: out[0..9] = grid blocks, block threads, dynamic LDS bytes, steps per tile,
+ * CSC period of the lower triangle (entries per regular step), number of edge entries, second-order eval lanes per
+ * stage point / path point / boundary point (after the structural-sparsity probe), terms of the periodic segment */
+int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* out10);
+/* Diagnostics: one launch of the Hessian kernel with in-kernel phase stamps: per workgroup 5 pairs {100 MHz realtime
+ * counter, shader cycle counter} at start, after load, after eval, after emit issue, after the stores drained.
+ * cap = capacity of out in uint64 words (needs grid * 10). */
+int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
+                              uint64_t* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,7 @@ static void run_hess_blocks(const HParams& hp, const double* xu, const double* y
         for (int t = 0; t < nthr; ++t) hess_phase_load<P>(hp, cx, xu, y, t, nthr);
         for (int t = 0; t < nthr; ++t) hess_phase_eval<P, SC, S>(hp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) hess_phase_emit<P, SC, S>(hp, cx, b, t, nthr);
+        for (int t = 0; t < nthr; ++t) hess_phase_vvsum(hp, cx, b, t, nthr);
     }
     for (int e = 0; e < hp.nvv; ++e) {
         const int fthr = 256;                             // hess_finish_kernel always runs kHessBlock lanes: same tree
@@ -231,7 +232,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     hp.tptr = H.tptr.data(); hp.terms = H.terms.data();
     hp.vptr = H.vptr.data(); hp.vterms = H.vterms.data();
     hp.edge_idx = H.edge_idx.data(); hp.eptr = H.eptr.data(); hp.evptr = H.evptr.data(); hp.eterms = H.eterms.data();
-    hp.tasks = H.tasks.data(); hp.btasks = H.btasks.data();
+    hp.tasks = H.tasks.data(); hp.ptasks = H.ptasks.data(); hp.btasks = H.btasks.data();
     hp.obj_weight = obj_weight;
     hp.vals = vals;
     std::vector<double> partials((size_t)(hp.ntiles + 1) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
