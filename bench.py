@@ -140,6 +140,24 @@ def main():
             d2.close()
             del x2, c2, v2
 
+    # the Hessian-of-the-Lagrangian row (hess_coord!): kernel-only figures, not part of `value`.
+    # Algorithmic bytes: read x and y, write the lower-triangular values: 8 (nvar + ncon + nnzh).
+    hessian = []
+    if world == 1:
+        import numpy as np
+        for prob, sch, n in ((PROBLEM, SCHEME, STEPS_PER_GPU), ("goddard", "gauss_legendre_3", 80000),
+                             ("quadrotor", "gauss_legendre_3", 20000)):
+            d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch")
+            x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
+            y2 = torch.from_numpy(0.6 + 0.4 * np.sin(0.7 * np.arange(d2.dim_NLP_constraints) + 0.3)).to(dev)
+            h2 = torch.zeros(d2.nnzh, dtype=torch.float64, device=dev)
+            ms2 = d2.time_hess(x2, y2, h2, 1.0, iters=50)
+            b2 = 8 * (d2.dim_NLP_variables + d2.dim_NLP_constraints + d2.nnzh)
+            hessian.append({"workload": f"{prob}/{sch} N={n}", "nnzh": d2.nnzh, "kernel_ms": ms2, "algorithmic_bytes": b2,
+                            "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            d2.close()
+            del x2, y2, h2
+
     if rank == 0:
         out = {
             "metric": "NLP callback evals/s (constraints+sparse Jac), N-step Goddard, 1/2/4/8 GPU",
@@ -168,6 +186,7 @@ def main():
                          "kernel": "ctd::cons_jac_kernel<GoddardOCP, SC_IRK>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "other_configs_kernel_only": others,
+            "hessian_kernel_only": hessian,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_host)

@@ -80,7 +80,7 @@ struct ctd_handle {
     uint32_t *d_htptr = nullptr, *d_hterms = nullptr, *d_hvptr = nullptr, *d_hvterms = nullptr, *d_heptr = nullptr,
              *d_hevptr = nullptr, *d_heterms = nullptr;
     int64_t* d_hedge_idx = nullptr;
-    uint16_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
+    uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
     std::string err;
 };

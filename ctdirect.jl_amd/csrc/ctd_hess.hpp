@@ -110,10 +110,10 @@ struct HParams {
     // coefficient pairs: CP[i] = C[pairs[i] & 0xFF] * C[pairs[i] >> 8], i < npairs (pair 0 is ONE * ONE)
     int32_t npairs;
     uint16_t pairs[kMaxPairs];
-    // eval tasks: (p | chunk << 8) pairs of one evaluation point (ntask of them), same for the boundary point
-    const uint16_t* tasks;      // stage-type points
-    const uint16_t* ptasks;     // path points
-    const uint16_t* btasks;     // boundary + Mayer point
+    // eval tasks: outer direction p (bits 0-4) and up to 4 inner directions q_i (bits 5+5i, 31 = none) per lane
+    const uint32_t* tasks;      // stage-type points
+    const uint32_t* ptasks;     // path points
+    const uint32_t* btasks;     // boundary + Mayer point
     int32_t ntask, nptask, nbtask;
     int32_t slot_tasks;         // S * ntask + nptask
     FastDiv div_ntask, div_slot_tasks, div_Lseg;

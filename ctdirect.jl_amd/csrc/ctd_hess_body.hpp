@@ -39,13 +39,13 @@ struct HBlockCtx {
     double* red;    // tile: nvv * T per-step V x V contributions (summed in step order by hess_phase_vvsum)
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
     const uint32_t *tptr, *terms, *vptr, *vterms;
-    const uint16_t *tasks, *ptasks;
+    const uint32_t *tasks, *ptasks;
 };
 
-// words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks+ptasks (2 per word)
+// words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks | ptasks
 constexpr int kMaxStagedHessWords = 3072;
 CTD_HD int hess_table_words(const HParams& hp) {
-    return (hp.Lseg + 1) + hp.nterms + (hp.nvv + 1) + hp.nvterms + (hp.ntask + hp.nptask + 1) / 2;
+    return (hp.Lseg + 1) + hp.nterms + (hp.nvv + 1) + hp.nvterms + hp.ntask + hp.nptask;
 }
 CTD_HD bool hess_tables_staged(const HParams& hp) { return hess_table_words(hp) <= kMaxStagedHessWords; }
 CTD_HD int hess_table_doubles(const HParams& hp) { return hess_tables_staged(hp) ? (hess_table_words(hp) + 1) / 2 : 0; }
@@ -80,7 +80,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
             cx.terms = w; w += hp.nterms;
             cx.vptr = w; w += hp.nvv + 1;
             cx.vterms = w; w += hp.nvterms;
-            cx.tasks = reinterpret_cast<const uint16_t*>(w);
+            cx.tasks = w;
             cx.ptasks = cx.tasks + hp.ntask;
             lds += hess_table_doubles(hp);
         }
@@ -174,7 +174,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
             d = const_cast<uint32_t*>(cx.terms);  for (int e = tid; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
             d = const_cast<uint32_t*>(cx.vptr);   for (int e = tid; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
             d = const_cast<uint32_t*>(cx.vterms); for (int e = tid; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
-            uint16_t* q = const_cast<uint16_t*>(cx.tasks);
+            uint32_t* q = const_cast<uint32_t*>(cx.tasks);
             for (int e = tid; e < hp.ntask; e += nthr) q[e] = hp.tasks[e];
             for (int e = tid; e < hp.nptask; e += nthr) q[hp.ntask + e] = hp.ptasks[e];
         }
@@ -227,7 +227,7 @@ template <int K> CTD_HD Dual2<K> hess_seed(double val, double sa, const double* 
 
 // One (p, chunk) lane of a stage-type point: Gauss-Legendre stage j of step s, the midpoint of step s, or trapeze node s.
 template <class P, int SC, int S>
-CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j, int p, int c) {
+CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j, uint32_t task) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, K = HessK<P>::value;
     constexpr bool FREE = Dirs<P>::FREE;
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
@@ -242,9 +242,10 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     const double taum = hslot_tau(cx, k, -1), tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
     const double tA = htime_of<P>(hp, cx.v, tau0), tB = htime_of<P>(hp, cx.v, tau1);
     const double h = tB - tA;
+    const int p = (int)(task & 31u);
     int q[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    for (int i = 0; i < K; ++i) q[i] = (int)((task >> (5 + 5 * i)) & 31u);      // 31: no direction (>= md)
     // d(tau-dependent quantity)/d(direction): only the V directions move the time grid
     auto dt_of = [&](int d, double tau) -> double {
         const int kx = d - vd;
@@ -347,27 +348,31 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     double* HD = rec + R.oStage + j * R.stage_sz;
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < md) HD[p * md + q[i]] = phi.ab[i];
-    if (SC == SC_IRK && FREE && p < n) {
+        if (q[i] < md) HD[p <= q[i] ? p * md + q[i] : q[i] * md + p] = phi.ab[i];
+    if (SC == SC_IRK && FREE) {
+        // RK[k][a] = h d2Phi/dx_a dV_k + dh/dv_k dPhi/dx_a, from whichever of the two directions is the outer one
 #pragma unroll
-        for (int i = 0; i < K; ++i)
-            if (q[i] >= vd && q[i] < md) HD[R.oRK + (q[i] - vd) * n + p] = h * phi.ab[i] + hdb[i] * phi.a;
+        for (int i = 0; i < K; ++i) {
+            if (p < n && q[i] >= vd && q[i] < md) HD[R.oRK + (q[i] - vd) * n + p] = h * phi.ab[i] + hdb[i] * phi.a;
+            if (p >= vd && q[i] < n) HD[R.oRK + (p - vd) * n + q[i]] = h * phi.ab[i] + hda * phi.b[i];
+        }
     }
 }
 
 // path point: x = X_s (or X_N), u = control of the step (stagewise: sum_l b_l U^l), t = t_s; `yrow` = multipliers of the rows
 template <class P, int SC, int S>
 CTD_HD void hess_eval_path(const HParams& hp, const double* xs, const double* ub, const double* vv, double tau,
-                           const double* yrow, double* HP, int p, int c) {
+                           const double* yrow, double* HP, uint32_t task) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, K = HessK<P>::value;
     constexpr bool FREE = Dirs<P>::FREE;
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     constexpr int md = R.md, vd = n + m;
     using T = Dual2<K>;
     const Layout& L = hp.L;
+    const int p = (int)(task & 31u);
     int q[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    for (int i = 0; i < K; ++i) q[i] = (int)((task >> (5 + 5 * i)) & 31u);
     auto dt_of = [&](int d) -> double {
         const int kx = d - vd;
         return (FREE && kx >= 0 && d < md) ? dtime_of<P>(tau, kx) : 0.0;
@@ -413,20 +418,21 @@ CTD_HD void hess_eval_path(const HParams& hp, const double* xs, const double* ub
     for (int r = 0; r < np; ++r) phi = phi + g[r] * yrow[r];
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < md) HP[p * md + q[i]] = phi.ab[i];
+        if (q[i] < md) HP[p <= q[i] ? p * md + q[i] : q[i] * md + p] = phi.ab[i];
 }
 
 // boundary + Mayer point: directions x0 | xf | v
 template <class P, int SC, int S>
 CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const double* xfp, const double* vv,
-                               const double* yrow, double* HB, int p, int c) {
+                               const double* yrow, double* HB, uint32_t task) {
     constexpr int n = P::NX, nv = P::NV, nb = P::NBC, K = HessK<P>::value;
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     constexpr int mdb = R.mdb;
     using T = Dual2<K>;
+    const int p = (int)(task & 31u);
     int q[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) q[i] = c * K + i;
+    for (int i = 0; i < K; ++i) q[i] = (int)((task >> (5 + 5 * i)) & 31u);
     auto unit = [&](int d, int target) -> double { return d == target ? 1.0 : 0.0; };
     double sb[K];
     T x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1];
@@ -455,7 +461,7 @@ CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const doubl
     if (P::HAS_MAYER) phi = phi + P::template mayer<T>(x0, xf, v) * hp.obj_weight;
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < mdb) HB[p * mdb + q[i]] = phi.ab[i];
+        if (q[i] < mdb) HB[p <= q[i] ? p * mdb + q[i] : q[i] * mdb + p] = phi.ab[i];
 }
 
 template <class P, int SC, int S>
@@ -475,15 +481,14 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int r = w - k * hp.slot_tasks;
         if (r < R.S * hp.ntask) {
             const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-            const uint16_t code = cx.tasks[r - j * hp.ntask];
-            hess_eval_stage<P, SC, S>(hp, cx, k, j, code & 0xFF, code >> 8);
+            hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
         } else if (PATH_PT) {
-            const uint16_t code = cx.ptasks[r - R.S * hp.ntask];
+            const uint32_t code = cx.ptasks[r - R.S * hp.ntask];
             const int64_t s = hslot_step(hp, cx, k);
             if (s >= 0 && s < L.N) {
                 const double* base = cx.in + k * cx.in_stride;
                 hess_eval_path<P, SC, S>(hp, base, base + n, cx.v, hslot_tau(cx, k, 0), hslot_y(hp, cx, k) + L.eqs,
-                                         cx.rec + k * R.stride + R.oHP, code & 0xFF, code >> 8);
+                                         cx.rec + k * R.stride + R.oHP, code);
             }
         }
     }
@@ -498,15 +503,13 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const double* yfp = cx.ly + 2 * cx.nslots * L.cb;
         if (PATH_PT)
             for (int w = tid; w < hp.nptask; w += nthr) {
-                const uint16_t code = hp.ptasks[w];
                 hess_eval_path<P, SC, S>(hp, last + L.blk, last + n, cx.v, cx.tau[3 * cx.nslots], yfp,
-                                         cx.rec + hp.edge_fp * R.stride + R.oHP, code & 0xFF, code >> 8);
+                                         cx.rec + hp.edge_fp * R.stride + R.oHP, hp.ptasks[w]);
             }
         if (P::NBC > 0 || P::HAS_MAYER)
             for (int w = tid; w < hp.nbtask; w += nthr) {
-                const uint16_t code = hp.btasks[w];
                 hess_eval_boundary<P, SC, S>(hp, cx.in + kf * cx.in_stride, last + L.blk, cx.v, yfp + L.p,
-                                             cx.rec + hp.edge_b * R.stride, code & 0xFF, code >> 8);
+                                             cx.rec + hp.edge_b * R.stride, hp.btasks[w]);
             }
         // coefficient products of the two extra records: no step length (only ONE, HALF and the b_l can occur)
         for (int e = tid; e < 2 * hp.npairs; e += nthr) {

@@ -371,7 +371,7 @@ int build_hess_model(Model& mo, std::string& err) {
     H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
     H.pairs.clear();
     pair_id(H, HC_ONE, HC_ONE);           // pair 0
-    if (H.R.md > 32 || H.R.mdb > 32) { err = "more than 32 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
+    if (H.R.md > 31 || H.R.mdb > 31 || H.hk > 4) { err = "more than 31 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
     for_problem(mo.problem, [&](auto tag) { probe_structure<typename decltype(tag)::type>(mo); });
     build_hess_tail(mo);
 
@@ -483,20 +483,47 @@ int build_hess_model(Model& mo, std::string& err) {
             }
     }
 
-    // ---- eval tasks: lane (p, chunk) covers HD[p][chunk*hk .. +hk); only chunks holding a structural nonzero at or right
-    // of the diagonal (or an RK entry) are evaluated ------------------------------------------------------------------------
-    auto make_tasks = [&](int md, const std::vector<uint8_t>& need, bool with_rk, std::vector<uint16_t>& out) {
+    // ---- eval tasks: a lane differentiates along one outer direction p and up to hk inner directions q_i and produces
+    // the pairs (p, q_i).  Every structurally nonzero pair {a, b} (and every pair an RK entry needs) is assigned to one
+    // lane, with p = a or p = b (the Hessian is symmetric): greedy packing, busiest direction first -----------------------
+    auto make_tasks = [&](int md, const std::vector<uint8_t>& need, bool with_rk, std::vector<uint32_t>& out) {
         out.clear();
-        const int nch = (md + H.hk - 1) / H.hk, vd = L.n + L.m;
-        for (int p = 0; p < md; ++p)
-            for (int c = p / H.hk; c < nch; ++c) {
-                bool any = false;
-                for (int q = std::max(p, c * H.hk); q < std::min(md, (c + 1) * H.hk); ++q) {
-                    if (need[p * md + q]) any = true;
-                    if (with_rk && p < L.n && q >= vd && H.need_rk[(q - vd) * L.n + p]) any = true;
-                }
-                if (any) out.push_back((uint16_t)(p | (c << 8)));
+        const int vd = L.n + L.m;
+        std::vector<std::vector<int>> adj(md);                 // remaining pairs per direction (self pair: d in adj[d])
+        auto has = [&](int a, int b) {
+            if (need[a * md + b] || need[b * md + a]) return true;
+            if (with_rk) {
+                const int x = std::min(a, b), v = std::max(a, b);
+                if (x < L.n && v >= vd && H.need_rk[(v - vd) * L.n + x]) return true;
             }
+            return false;
+        };
+        for (int a = 0; a < md; ++a)
+            for (int b = a; b < md; ++b)
+                if (has(a, b)) { adj[a].push_back(b); if (b != a) adj[b].push_back(a); }
+        auto drop = [&](int a, int b) {
+            adj[a].erase(std::find(adj[a].begin(), adj[a].end(), b));
+            if (a != b) adj[b].erase(std::find(adj[b].begin(), adj[b].end(), a));
+        };
+        for (;;) {
+            int best = -1;
+            for (int d = 0; d < md; ++d)
+                if (!adj[d].empty() && (best < 0 || adj[d].size() > adj[best].size())) best = d;
+            if (best < 0) break;
+            // partners with the fewest other pairs first: they are the hardest to place elsewhere
+            std::vector<int> part = adj[best];
+            std::stable_sort(part.begin(), part.end(), [&](int x, int y) { return adj[x].size() < adj[y].size(); });
+            uint32_t code = (uint32_t)best;
+            int cnt = 0;
+            for (int q : part) {
+                if (cnt == H.hk) break;
+                code |= (uint32_t)q << (5 + 5 * cnt);
+                drop(best, q);
+                ++cnt;
+            }
+            for (; cnt < 4; ++cnt) code |= 31u << (5 + 5 * cnt);
+            out.push_back(code);
+        }
     };
     make_tasks(H.R.md, H.need_stage, L.sc == SC_IRK && L.free_time, H.tasks);
     make_tasks(H.R.md, H.need_path, false, H.ptasks);

@@ -44,7 +44,7 @@ struct HessModel {
     // and of the K x V helper RK (nv x n): found by pushing dependency masks through the OCP functions
     std::vector<uint8_t> need_stage, need_path, need_bnd, need_rk;
     // eval tasks (stage-type points, path points, boundary point)
-    std::vector<uint16_t> tasks, ptasks, btasks;
+    std::vector<uint32_t> tasks, ptasks, btasks;   // p | q_0 << 5 | q_1 << 10 | .. (31 = no direction)
     // coefficient pairs referenced by the term codes (pair 0 = ONE * ONE)
     std::vector<uint16_t> pairs;
     // column starts (same scheme as the Jacobian's)
