@@ -1,0 +1,84 @@
+"""End-to-end second-order checks (SURVEY.md section 8 f1 + f3): solvers that consume the exact Hessian of the Lagrangian
+served by ctd_hess_structure / ctd_hess_coord, next to the first-order callbacks, all through the C ABI on the GPU.
+
+  * a Newton-KKT step on the min-energy double integrator (quadratic cost, linear dynamics): with the exact Hessian ONE
+    step from the default initial guess lands on the solution -- checks values, symmetry handling and the sign convention
+    L = obj_weight f + y'c  (NLPModels hess_coord!) in one go;
+  * scipy's trust-constr interior-point method with exact Hessians on the catalogued problems, accepted with the
+    reference's rule objective ~ prob.obj, rtol = 1e-2 (test/runtests.jl:5-11)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+from scipy.optimize import Bounds, NonlinearConstraint, minimize
+
+import ctdirect_jl_amd as ct
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym(d, vals):
+    hr, hc = d.hess_structure()
+    L = sp.coo_matrix((vals, (hr - 1, hc - 1)), shape=(d.dim_NLP_variables,) * 2).tocsr()
+    return L + L.T - sp.diags(L.diagonal())
+
+
+def _jac(d, x):
+    jr, jc = d.jac_structure()
+    return sp.csr_matrix((d.jac_coord(x), (jr - 1, jc - 1)), shape=(d.dim_NLP_constraints, d.dim_NLP_variables))
+
+
+def test_newton_kkt_step_solves_the_quadratic_program():
+    N = 40
+    d = ct.DOCP("double_integrator_path", N, "gauss_legendre_2", device=0)
+    nvar = d.dim_NLP_variables
+    lc, uc = ct.constraints_bounds(d)
+    eq = np.where(lc == uc)[0]                         # dynamics + boundary rows; the path rows stay inactive
+    x = ct.initial_guess(d)
+    y = np.zeros(d.dim_NLP_constraints)
+    # KKT system of  min f(x)  s.t.  c_eq(x) = lc_eq  at (x, y):  [H J'; J 0] [dx; y+] = -[grad f; c - lc]
+    H = _sym(d, d.hess_coord(x, y, 1.0))
+    J = _jac(d, x)[eq]
+    K = sp.bmat([[H, J.T], [J, None]], format="csc")
+    rhs = -np.concatenate([d.grad(x), (d.cons(x) - lc)[eq]])
+    sol = spla.spsolve(K, rhs)
+    x1 = x + sol[:nvar]
+    y1 = np.zeros_like(y)
+    y1[eq] = sol[nvar:]
+    # one step is exact for a QP: feasible, stationary, and it is the analytic solution (cost 1.5, u = 1.5 - 1.5 t)
+    assert np.max(np.abs((d.cons(x1) - lc)[eq])) <= 1e-10
+    assert np.max(np.abs(d.grad(x1) + _jac(d, x1).T @ y1)) <= 1e-9
+    assert abs(d.obj(x1) - 1.5) <= 1e-6
+    c1 = d.cons(x1)
+    assert np.all(c1 <= uc + 1e-9)                     # q + 0.1 w^2 <= 1.05 indeed inactive
+    # the Hessian of this problem does not depend on x (checked at the solution, with the new multipliers)
+    assert np.max(np.abs(d.hess_coord(x1, y1, 1.0) - d.hess_coord(x, y1, 1.0))) <= 1e-12
+
+
+def _trust_constr(prob, scheme, N, init=None, maxiter=500):
+    d = ct.DOCP(prob, N, scheme, pattern="structural", device=0)
+    ncon = d.dim_NLP_constraints
+    lc, uc = ct.constraints_bounds(d)
+    lv, uv = ct.variables_bounds(d)
+    x0 = np.clip(ct.initial_guess(d, init), lv, uv)
+    sign = -1.0 if d.flags.max else 1.0                # minimize = !docp.flags.max (src/collocation.jl:145)
+    con = NonlinearConstraint(lambda x: d.cons(x), lc, uc, jac=lambda x: _jac(d, x),
+                              hess=lambda x, v: _sym(d, d.hess_coord(x, v, 0.0)))
+    res = minimize(lambda x: sign * d.obj(x), x0, jac=lambda x: sign * d.grad(x),
+                   hess=lambda x: _sym(d, d.hess_coord(x, np.zeros(ncon), sign)), constraints=[con], bounds=Bounds(lv, uv),
+                   method="trust-constr", options={"maxiter": maxiter, "gtol": 1e-8, "xtol": 1e-10})
+    c = d.cons(res.x)
+    viol = max(float(np.max(np.maximum(lc - c, 0.0))), float(np.max(np.maximum(c - uc, 0.0))))
+    return d, res, sign * res.fun, viol
+
+
+def test_second_order_solves_reach_the_catalogued_objectives():
+    d, res, obj, viol = _trust_constr("double_integrator_path", "midpoint", 50)
+    assert res.status in (1, 2) and viol <= 1e-8 and abs(obj - 1.5) <= 1e-2 * 1.5
+    d, res, obj, viol = _trust_constr("stagewise_scalar", "gauss_legendre_2", 20)     # test_discretization_stagewise.jl:103-116
+    assert res.status in (1, 2) and viol <= 1e-8 and abs(obj - 1.0) <= 1e-2
+    # Goddard (test/problems/goddard.jl:48, obj 1.01257): the interior-point iteration creeps along the singular arc, so
+    # it is stopped by the iteration cap; the iterate is feasible and the objective meets the reference's rtol = 1e-2
+    d, res, obj, viol = _trust_constr("goddard", "midpoint", 60, init="problem", maxiter=1000)
+    print(f"goddard trust-constr: status={res.status} nit={res.nit} objective={obj:.6f} violation={viol:.2e}")
+    assert viol <= 1e-5 and abs(obj - 1.01257) <= 1e-2 * 1.01257
