@@ -27,6 +27,16 @@ class ctd_init(C.Structure):
                 ("control", C.POINTER(C.c_double)), ("variable", C.POINTER(C.c_double))]
 
 
+class ctd_ocp_def(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("n", C.c_int32), ("m", C.c_int32), ("nv", C.c_int32), ("npath", C.c_int32),
+                ("nbc", C.c_int32), ("it0", C.c_int32), ("itf", C.c_int32), ("t0", C.c_double), ("tf", C.c_double),
+                ("maximize", C.c_int32), ("reserved", C.c_int32), ("dynamics", C.POINTER(C.c_char_p)),
+                ("lagrange", C.c_char_p), ("mayer", C.c_char_p), ("path", C.POINTER(C.c_char_p)),
+                ("boundary", C.POINTER(C.c_char_p)), ("constants", C.c_char_p)] + \
+               [(k, C.POINTER(C.c_double)) for k in ("state_lb", "state_ub", "control_lb", "control_ub", "variable_lb",
+                                                     "variable_ub", "path_lb", "path_ub", "boundary_lb", "boundary_ub")]
+
+
 # every symbol include/ctdirect_hip.h declares: name -> (restype, argtypes)
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -59,6 +69,9 @@ SYMBOLS = {
     "ctd_time_cons_jac_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int32, _dp]),
     "ctd_launch_info": (C.c_int32, [_vp, _ip]),
     "ctd_debug_stamps": (C.c_int32, [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_int64]),
+    "ctd_register_ocp": (C.c_int32, [C.POINTER(ctd_ocp_def), C.POINTER(C.c_int32)]),
+    "ctd_ocp_source": (C.c_int32, [C.c_int32, C.c_char_p, C.c_int64]),
+    "ctd_jit_check": (C.c_int32, [C.c_int32, C.c_int32]),
     "ctd_hess_structure": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_hess_csc": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_hess_coord": (C.c_int32, [_vp, _dp, _dp, C.c_double, _dp]),

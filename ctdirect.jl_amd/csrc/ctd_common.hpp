@@ -1,10 +1,24 @@
 // ctd_common.hpp -- shared host/device definitions of the collocation engine.
 #pragma once
+// __HIPCC_RTC__: the same headers are compiled at run time by hiprtc for OCPs registered through ctd_register_ocp
+// (ctd_jit.cpp); hiprtc pre-includes the HIP runtime and has no C++ standard library headers
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
 #include <cstdint>
 #include <cstddef>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+using __hip_internal::int32_t;
+using __hip_internal::uint32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint64_t;
+using __hip_internal::uint16_t;
+using __hip_internal::uint8_t;
+typedef unsigned long uintptr_t;
+#define CTD_HD __host__ __device__ __forceinline__
+#define CTD_STORE2(p, a, b) (*reinterpret_cast<double2*>(p) = make_double2((a), (b)))
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CTD_HD __host__ __device__ __forceinline__
 // one 16-byte store of two consecutive doubles (p is 16-byte aligned)
@@ -123,6 +137,19 @@ template <int K> CTD_HD Dual<K> d_sqr(const Dual<K>& a) {
     for (int i = 0; i < K; ++i) r.d[i] = t * a.d[i];
     return r;
 }
+CTD_HD double d_sqrt(double x) { return ::sqrt(x); }
+template <int K> CTD_HD Dual<K> d_sqrt(const Dual<K>& a) {
+    Dual<K> r; const double s = ::sqrt(a.v); r.v = s; const double w = 0.5 / s;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r.d[i] = w * a.d[i];
+    return r;
+}
+// x^k for a small non-negative integer k by repeated multiplication (run-time defined OCPs, ctd_jit.cpp)
+template <class T> CTD_HD T d_powi(const T& x, int k) {
+    T r = x;
+    for (int i = 1; i < k; ++i) r = r * x;
+    return r;
+}
 CTD_HD double d_val(double x) { return x; }
 template <int K> CTD_HD double d_val(const Dual<K>& a) { return a.v; }
 
@@ -199,6 +226,7 @@ template <int K> CTD_HD Dual2<K> d_exp(const Dual2<K>& x) { const double e = ::e
 template <int K> CTD_HD Dual2<K> d_sin(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, s, c, -s); }
 template <int K> CTD_HD Dual2<K> d_cos(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, c, -s, -c); }
 template <int K> CTD_HD Dual2<K> d_sqr(const Dual2<K>& x) { return d2_chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
+template <int K> CTD_HD Dual2<K> d_sqrt(const Dual2<K>& x) { const double s = ::sqrt(x.v); return d2_chain(x, s, 0.5 / s, -0.25 / (s * x.v)); }
 template <int K> CTD_HD double d_val(const Dual2<K>& x) { return x.v; }
 
 }  // namespace ctd

@@ -3,8 +3,12 @@
 // There is no CPU compute path in this library: every hot-path entry point launches the HIP kernels of
 // ctd_kernels.hpp on the handle's device and fails with CTD_ENODEVICE when the handle has none.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
 
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -16,6 +20,7 @@
 #include "ctd_host.hpp"
 #include "ctd_kernels.hpp"
 #include "ctd_hess_kernels.hpp"
+#include "ctd_jit.hpp"
 
 using namespace ctd;
 
@@ -72,6 +77,11 @@ struct ctd_handle {
     int gblocks = 0;
     int obj_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // run-time defined OCP (ctd_register_ocp): kernels compiled with hiprtc and launched through the module API
+    const RtOcp* rt = nullptr;
+    hipModule_t jit_mod = nullptr, jit_hmod = nullptr;
+    hipFunction_t f_cons_jac = nullptr, f_obj_partial = nullptr, f_obj_finish = nullptr, f_grad_units = nullptr,
+                  f_grad_finish = nullptr, f_hess = nullptr, f_hess_finish = nullptr;
     // Hessian of the Lagrangian: tables are uploaded by the first Hessian call (hess_ready)
     bool hess_ready = false;
     HParams hp;
@@ -124,6 +134,111 @@ static void free_device(ctd_handle* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->jit_mod) (void)hipModuleUnload(h->jit_mod);
+    if (h->jit_hmod) (void)hipModuleUnload(h->jit_hmod);
+}
+
+// ---- run-time compilation of the kernel templates for a registered OCP -------------------------------------------------
+namespace {
+std::string jit_include_dir() {
+    const char* env = std::getenv("CTD_JIT_INCLUDE");
+    if (env && *env) return env;
+    Dl_info info;
+    if (dladdr((const void*)&free_device, &info) && info.dli_fname) {
+        std::string path(info.dli_fname);
+        const size_t slash = path.find_last_of('/');
+        return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/csrc";
+    }
+    return "csrc";
+}
+
+std::mutex g_jit_mu;
+std::map<std::string, std::pair<std::string, std::vector<std::string>>> g_jit_cache;   // key -> (code object, lowered names)
+
+// compiles `header` + the OCP's functor for gfx950 and returns the code object and the lowered names of `exprs`
+int32_t jit_compile(const RtOcp& ro, const char* header, const std::vector<std::string>& exprs, const char* fp_contract,
+                    std::string& code, std::vector<std::string>& lowered, std::string& err) {
+    std::string key = ro.name + "|" + std::to_string((size_t)&ro) + "|" + header;
+    for (const std::string& e : exprs) key += "|" + e;
+    {
+        std::lock_guard<std::mutex> lk(g_jit_mu);
+        auto it = g_jit_cache.find(key);
+        if (it != g_jit_cache.end()) { code = it->second.first; lowered = it->second.second; return CTD_OK; }
+    }
+    const std::string src = std::string("#include \"") + header + "\"\n" + ro.functor_src;
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "ctd_user_ocp.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        err = "hiprtcCreateProgram failed";
+        return CTD_EHIP;
+    }
+    for (const std::string& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
+    const std::string inc = "-I" + jit_include_dir();
+    const std::string fpc = std::string("-ffp-contract=") + fp_contract;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", fpc.c_str(), inc.c_str()};
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        (void)hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) (void)hiprtcGetProgramLog(prog, &log[0]);
+        err = "run-time compilation of OCP '" + ro.name + "' failed: " + log.substr(0, 4000);
+        (void)hiprtcDestroyProgram(&prog);
+        return CTD_EHIP;
+    }
+    lowered.clear();
+    for (const std::string& e : exprs) {
+        const char* ln = nullptr;
+        if (hiprtcGetLoweredName(prog, e.c_str(), &ln) != HIPRTC_SUCCESS || !ln) { err = "no lowered name for " + e; (void)hiprtcDestroyProgram(&prog); return CTD_EHIP; }
+        lowered.emplace_back(ln);
+    }
+    size_t cs = 0;
+    (void)hiprtcGetCodeSize(prog, &cs);
+    code.assign(cs, '\0');
+    (void)hiprtcGetCode(prog, &code[0]);
+    (void)hiprtcDestroyProgram(&prog);
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    g_jit_cache[key] = {code, lowered};
+    return CTD_OK;
+}
+
+std::vector<std::string> jit_first_exprs(int sc, int s) {
+    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
+    return {"ctd::cons_jac_kernel<" + P + ", " + a + ", " + b + ">", "ctd::obj_partial_kernel<" + P + ", " + a + ">",
+            "ctd::obj_finish_kernel<" + P + ">", "ctd::grad_units_kernel<" + P + ", " + a + ", " + b + ">",
+            "ctd::grad_finish_kernel<" + P + ">"};
+}
+std::vector<std::string> jit_hess_exprs(int sc, int s) {
+    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
+    return {"ctd::hess_kernel<" + P + ", " + a + ", " + b + ">", "ctd::hess_finish_kernel<" + P + ">"};
+}
+
+hipError_t jit_launch(hipFunction_t f, int grid, int block, size_t lds, hipStream_t st, void** args, hipEvent_t e0 = nullptr,
+                      hipEvent_t e1 = nullptr) {
+    if (e0 || e1)
+        return hipExtModuleLaunchKernel(f, (uint32_t)grid * (uint32_t)block, 1, 1, (uint32_t)block, 1, 1, lds, st, args, nullptr, e0, e1, 0);
+    return hipModuleLaunchKernel(f, (uint32_t)grid, 1, 1, (uint32_t)block, 1, 1, (uint32_t)lds, st, args, nullptr);
+}
+}  // namespace
+
+static int32_t jit_load_first(ctd_handle* h) {
+    std::string code, err;
+    std::vector<std::string> names;
+    int32_t st = jit_compile(*h->rt, "ctd_kernels.hpp", jit_first_exprs(h->model.L.sc, h->model.L.s), "off", code, names, err);
+    if (st) return fail(nullptr, st, err);
+    HIP_TRY(nullptr, hipModuleLoadData(&h->jit_mod, code.data()));
+    hipFunction_t* f[] = {&h->f_cons_jac, &h->f_obj_partial, &h->f_obj_finish, &h->f_grad_units, &h->f_grad_finish};
+    for (int i = 0; i < 5; ++i) HIP_TRY(nullptr, hipModuleGetFunction(f[i], h->jit_mod, names[i].c_str()));
+    return CTD_OK;
+}
+static int32_t jit_load_hess(ctd_handle* h) {
+    std::string code, err;
+    std::vector<std::string> names;
+    int32_t st = jit_compile(*h->rt, "ctd_hess_kernels.hpp", jit_hess_exprs(h->model.L.sc, h->model.L.s), "fast", code, names, err);
+    if (st) return fail(h, st, err);
+    HIP_TRY(h, hipModuleLoadData(&h->jit_hmod, code.data()));
+    HIP_TRY(h, hipModuleGetFunction(&h->f_hess, h->jit_hmod, names[0].c_str()));
+    HIP_TRY(h, hipModuleGetFunction(&h->f_hess_finish, h->jit_hmod, names[1].c_str()));
+    return CTD_OK;
 }
 
 extern "C" {
@@ -170,13 +285,16 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     if (h->tile <= 0) h->tile = default_tile(mo);
     int maxb = 256;
     for_problem(mo.problem, [&](auto tag) { maxb = decltype(tag)::type::MAXB; });
+    h->rt = runtime_ocp(mo.problem);
+    if (h->rt) maxb = h->rt->maxb;
     h->block = env_int("CTD_BLOCK", 256);
     if (h->block < 64 || (h->block % 64)) h->block = 256;
     if (h->block > maxb) h->block = maxb;
     mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
     h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
     const int debug_stop = env_int("CTD_DEBUG_STOP", 0);
-    while (h->lds_bytes > 80 * 1024 && h->tile > 1) {      // a requested tile that does not fit (2 workgroups / CU) is shrunk, not rejected
+    const size_t lds_cap = h->rt ? 64 * 1024 : 80 * 1024;   // module-API kernels stay inside the default 64 KiB of dynamic LDS
+    while (h->lds_bytes > lds_cap && h->tile > 1) {        // a requested tile that does not fit (2 workgroups / CU) is shrunk, not rejected
         h->tile = (h->tile + 1) / 2;
         mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
         h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
@@ -187,6 +305,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     // 0 classic driver (default: on MI355X the pipelined driver measured within 1 us of it, profiles/r01_pipeline.md),
     // 1 pipelined driver, -1 automatic choice (pipelined for Gauss-Legendre grids with >= 3 sub-tiles per workgroup)
     h->pipe_mode = env_int("CTD_PIPE", 0);
+    if (h->rt) h->pipe_mode = 0;
     if (h->device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || h->device >= ndev)
@@ -211,6 +330,11 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         HIP_TRY(nullptr, hipMalloc((void**)&hp->d_obj, sizeof(double)));
         HIP_TRY(nullptr, hipEventCreate(&hp->ev0));
         HIP_TRY(nullptr, hipEventCreate(&hp->ev1));
+        if (hp->rt) {
+            if (hp->lds_bytes > 64 * 1024) return fail(nullptr, CTD_EINVAL, "ctd_create: one step of this run-time OCP does not fit 64 KiB of LDS");
+            int32_t jst = jit_load_first(hp);
+            if (jst) return jst;
+        }
         // pipelined driver: sub-tiles of Ts steps, as many chunks as workgroups are resident at once
         if (hp->pipe_mode != 0 && hp->block >= 128) {
             KParams pk = hp->kp;
@@ -240,6 +364,37 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         }
     }
     *out = h.release();
+    return CTD_OK;
+}
+
+int32_t ctd_register_ocp(const ctd_ocp_def* def, int32_t* problem_id) {
+    std::string err;
+    int id = -1;
+    const int st = register_runtime_ocp(def, &id, err);
+    if (st) return fail(nullptr, st, "ctd_register_ocp: " + err);
+    *problem_id = id;
+    return CTD_OK;
+}
+
+int32_t ctd_ocp_source(int32_t problem_id, char* buf, int64_t cap) {
+    const RtOcp* ro = runtime_ocp(problem_id);
+    if (!ro || !buf || cap < 1) return CTD_EINVAL;
+    std::snprintf(buf, (size_t)cap, "%s", ro->functor_src.c_str());
+    return CTD_OK;
+}
+
+// compile-only check (no device needed): the kernels of `scheme` for a registered OCP build for gfx950
+int32_t ctd_jit_check(int32_t problem_id, int32_t scheme) {
+    const RtOcp* ro = runtime_ocp(problem_id);
+    if (!ro) return fail(nullptr, CTD_EPROBLEM, "ctd_jit_check: not a run-time problem id");
+    if (scheme < 0 || scheme > 6) return fail(nullptr, CTD_ESCHEME, "Unknown discretization method");
+    const int sc = scheme == 0 ? SC_TRAPEZE : (scheme == 1 ? SC_MIDPOINT : SC_IRK);
+    const int s = scheme < 2 ? 0 : (scheme <= 4 ? scheme - 1 : scheme - 3);
+    std::string code, err;
+    std::vector<std::string> names;
+    int32_t st = jit_compile(*ro, "ctd_kernels.hpp", jit_first_exprs(sc, s), "off", code, names, err);
+    if (st == CTD_OK) st = jit_compile(*ro, "ctd_hess_kernels.hpp", jit_hess_exprs(sc, s), "fast", code, names, err);
+    if (st) return fail(nullptr, st, err);
     return CTD_OK;
 }
 
@@ -371,6 +526,10 @@ static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_de
     kp.vals = vals_dev;
     hipError_t e = hipErrorInvalidValue;
     const int sc = h->model.L.sc;
+    if (h->rt) {
+        void* args[] = {&kp, &x_dev};
+        e = jit_launch(h->f_cons_jac, h->grid, h->block, h->lds_bytes, h->stream, args, timed ? h->ev0 : nullptr, timed ? h->ev1 : nullptr);
+    }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         e = launch_cons_jac<P>(sc, kp, x_dev, h->grid, h->block, h->lds_bytes, h->stream, timed ? h->ev0 : nullptr,
@@ -458,6 +617,11 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
     if (blocks < 1) blocks = 1;
     op.nblocks = blocks;
     hipError_t e = hipErrorInvalidValue;
+    if (h->rt) {
+        void* args[] = {&op, &x_dev};
+        e = jit_launch(h->f_obj_partial, blocks, 256, 0, h->stream, args);
+        if (e == hipSuccess) e = jit_launch(h->f_obj_finish, 1, 64, 0, h->stream, args);
+    }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         e = launch_obj<P>(L.sc, op, x_dev, blocks, 256, h->stream);
@@ -491,6 +655,11 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
     gp.nblocks = blocks;
     HIP_TRY(h, hipMemsetAsync(g_dev, 0, sizeof(double) * L.nvar, h->stream));
     hipError_t e = hipErrorInvalidValue;
+    if (h->rt) {
+        void* args[] = {&gp, &x_dev};
+        e = jit_launch(h->f_grad_units, blocks, 256, 0, h->stream, args);
+        if (e == hipSuccess) e = jit_launch(h->f_grad_finish, 1, 64, 0, h->stream, args);
+    }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         e = launch_grad<P>(L.sc, L.s, gp, x_dev, blocks, h->stream);
@@ -608,12 +777,17 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);
     mo.fill_hparams(h->hp, h->hess_tile);
     h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
-    while (h->hess_lds_bytes > 96 * 1024 && h->hess_tile > 1) {
+    const size_t hess_cap = h->rt ? 64 * 1024 : 96 * 1024;
+    while (h->hess_lds_bytes > hess_cap && h->hess_tile > 1) {
         h->hess_tile = (h->hess_tile + 1) / 2;
         mo.fill_hparams(h->hp, h->hess_tile);
         h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
     }
-    if (h->hess_lds_bytes > 160 * 1024) return fail(h, CTD_EINVAL, "Hessian records of one step do not fit the 160 KiB LDS");
+    if (h->hess_lds_bytes > (h->rt ? 64u : 160u) * 1024) return fail(h, CTD_EINVAL, "Hessian records of one step do not fit the LDS");
+    if (h->rt && !h->jit_hmod) {
+        int32_t jst = jit_load_hess(h);
+        if (jst) return jst;
+    }
     HIP_TRY(h, upload(&h->d_htptr, H.tptr));
     HIP_TRY(h, upload(&h->d_hterms, H.terms));
     HIP_TRY(h, upload(&h->d_hvptr, H.vptr));
@@ -650,6 +824,12 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     hp.obj_weight = obj_weight;
     hp.vals = vals_dev;
     hipError_t e = hipErrorInvalidValue;
+    if (h->rt) {
+        void* args[] = {&hp, &x_dev, &y_dev};
+        e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, timed ? h->ev0 : nullptr,
+                       timed ? h->ev1 : nullptr);
+        if (e == hipSuccess && hp.nvv > 0) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
+    }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, timed ? h->ev0 : nullptr, timed ? h->ev1 : nullptr);

@@ -372,7 +372,13 @@ int build_hess_model(Model& mo, std::string& err) {
     H.pairs.clear();
     pair_id(H, HC_ONE, HC_ONE);           // pair 0
     if (H.R.md > 31 || H.R.mdb > 31 || H.hk > 4) { err = "more than 31 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
-    for_problem(mo.problem, [&](auto tag) { probe_structure<typename decltype(tag)::type>(mo); });
+    if (!for_problem(mo.problem, [&](auto tag) { probe_structure<typename decltype(tag)::type>(mo); })) {
+        // run-time defined OCP: its functor only exists as device code, assume every pair of directions is coupled
+        H.need_stage.assign((size_t)H.R.md * H.R.md, 1);
+        H.need_path.assign((size_t)H.R.md * H.R.md, (L.p > 0 && L.sc != SC_TRAPEZE) ? 1 : 0);
+        H.need_bnd.assign((size_t)H.R.mdb * H.R.mdb, 1);
+        H.need_rk.assign((size_t)(L.nv > 0 ? L.nv : 1) * L.n, (L.sc == SC_IRK && L.free_time) ? 1 : 0);
+    }
     build_hess_tail(mo);
 
     // ---- regular range ---------------------------------------------------------------------------------------------

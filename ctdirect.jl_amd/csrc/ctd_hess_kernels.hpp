@@ -1,10 +1,14 @@
 // ctd_hess_kernels.hpp -- __global__ wrappers and launchers of the Hessian-of-the-Lagrangian kernels
 // (phases: ctd_hess_body.hpp).  Instantiated per OCP in ctd_hkern_*.hip.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#endif
 #include "ctd_hess_body.hpp"
+#if !defined(__HIPCC_RTC__)
 #include "ctd_problems.hpp"
+#endif
 
 namespace ctd {
 
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(kHessBlock) void hess_finish_kernel(const HParams h
     }
 }
 
+#if !defined(__HIPCC_RTC__)
 template <class P, int SC, int S>
 hipError_t launch_hess_variant(const HParams& hp, const double* xu, const double* y, size_t lds_bytes, hipStream_t st,
                                hipEvent_t e0, hipEvent_t e1) {
@@ -93,5 +98,7 @@ hipError_t launch_hess(const HParams& hp, const double* xu, const double* y, siz
     template hipError_t launch_hess<P>(const HParams&, const double*, const double*, size_t, hipStream_t, hipEvent_t, hipEvent_t);
 #define CTD_EXTERN_HESS(P) \
     extern template hipError_t launch_hess<P>(const HParams&, const double*, const double*, size_t, hipStream_t, hipEvent_t, hipEvent_t);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace ctd

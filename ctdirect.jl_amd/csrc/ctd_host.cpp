@@ -3,6 +3,7 @@
 #include "ctd_host.hpp"
 #include "ctd_kernel_body.hpp"
 #include "ctd_hess_body.hpp"
+#include "ctd_jit.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -665,7 +666,19 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.fused = Dirs<P>::FUSED;
         mo.H.hk = HessK<P>::value;
     });
-    if (!found) { err = "problem id not in the compiled registry"; return ST_EPROBLEM; }
+    if (!found) {
+        const RtOcp* ro = runtime_ocp(d.problem);          // registered at run time (ctd_register_ocp)
+        if (!ro) { err = "problem id not in the compiled registry"; return ST_EPROBLEM; }
+        mo.info = ro->info;
+        mo.dyn_t = ro->dyn_t;
+        mo.dyn_v = ro->dyn_v;
+        const int dyn = ro->info.n + ro->info.m + (ro->dyn_t ? 1 : 0) + (ro->dyn_v ? ro->info.nv : 0);
+        const int pth = ro->info.n + ro->info.m + (ro->path_t ? 1 : 0) + (ro->path_v ? ro->info.nv : 0);
+        mo.nch_dyn = (dyn + ro->dc - 1) / ro->dc;
+        mo.nch_path = ro->info.npath > 0 ? (pth + ro->dc - 1) / ro->dc : 0;
+        mo.fused = mo.nch_dyn == 1 && (ro->info.npath == 0 || mo.nch_path == 1);      // Dirs<P>::FUSED
+        mo.H.hk = ro->hk;
+    }
     if (d.scheme < 0 || d.scheme > 6) { err = "Unknown discretization method"; return ST_ESCHEME; }
     int64_t N = 0;
     int st = build_time(mo, d, N, err);

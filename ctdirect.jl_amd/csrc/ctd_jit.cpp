@@ -1,0 +1,292 @@
+// ctd_jit.cpp -- run-time OCP registry: expression parser, functor generator (host only; the hiprtc side is in
+// ctd_engine.hip).  See ctd_jit.hpp.
+#include "ctd_jit.hpp"
+
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+
+#include "../../include/ctdirect_hip.h"
+
+namespace ctd {
+
+// ------------------------------------------------------------------------------------------------------
+// expressions:  expr := term (('+'|'-') term)* ; term := unary (('*'|'/') unary)* ; unary := '-' unary | power ;
+//               power := atom ('^' integer)? ; atom := number | name | func '(' expr ')' | '(' expr ')'
+// names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants; functions exp sin cos sqrt
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct Parser {
+    const std::string& s;
+    const ExprCtx& cx;
+    size_t pos = 0;
+    bool uses_t = false, uses_v = false;
+    std::string err;
+    struct Val { std::string code; bool is_const; };
+
+    Parser(const std::string& s_, const ExprCtx& cx_) : s(s_), cx(cx_) {}
+    void skip() { while (pos < s.size() && std::isspace((unsigned char)s[pos])) ++pos; }
+    bool fail(const std::string& m) { if (err.empty()) err = m + " at column " + std::to_string(pos + 1) + " of \"" + s + "\""; return false; }
+    static std::string num(double v) {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "%.17g", v);
+        std::string r(buf);
+        if (r.find_first_of(".eEn") == std::string::npos) r += ".0";      // always a double literal
+        return r;
+    }
+    bool index_of(const std::string& name, size_t prefix, int limit, int& k) {
+        if (name.size() <= prefix) return false;
+        for (size_t i = prefix; i < name.size(); ++i) if (!std::isdigit((unsigned char)name[i])) return false;
+        k = std::atoi(name.c_str() + prefix);
+        return k >= 1 && k <= limit;
+    }
+    bool expr(Val& out) {
+        if (!term(out)) return false;
+        for (;;) {
+            skip();
+            if (pos < s.size() && (s[pos] == '+' || s[pos] == '-')) {
+                const char op = s[pos++];
+                Val r;
+                if (!term(r)) return false;
+                out.code = "(" + out.code + " " + op + " " + r.code + ")";
+                out.is_const = out.is_const && r.is_const;
+            } else return true;
+        }
+    }
+    bool term(Val& out) {
+        if (!unary(out)) return false;
+        for (;;) {
+            skip();
+            if (pos < s.size() && (s[pos] == '*' || s[pos] == '/')) {
+                const char op = s[pos++];
+                Val r;
+                if (!unary(r)) return false;
+                out.code = "(" + out.code + " " + op + " " + r.code + ")";
+                out.is_const = out.is_const && r.is_const;
+            } else return true;
+        }
+    }
+    bool unary(Val& out) {
+        skip();
+        if (pos < s.size() && s[pos] == '-') {
+            ++pos;
+            Val r;
+            if (!unary(r)) return false;
+            out.code = "(-" + r.code + ")";
+            out.is_const = r.is_const;
+            return true;
+        }
+        if (pos < s.size() && s[pos] == '+') { ++pos; return unary(out); }
+        return power(out);
+    }
+    bool power(Val& out) {
+        if (!atom(out)) return false;
+        skip();
+        if (pos < s.size() && s[pos] == '^') {
+            ++pos; skip();
+            size_t b = pos;
+            while (pos < s.size() && std::isdigit((unsigned char)s[pos])) ++pos;
+            if (b == pos) return fail("'^' needs a non-negative integer exponent (write 1/x^k for negative powers)");
+            const int k = std::atoi(s.substr(b, pos - b).c_str());
+            if (k > 64) return fail("exponent too large");
+            if (k == 0) { out.code = "1.0"; out.is_const = true; }
+            else if (k == 2) out.code = "d_sqr(" + out.code + ")";
+            else if (k > 2) out.code = "d_powi(" + out.code + ", " + std::to_string(k) + ")";
+        }
+        return true;
+    }
+    bool atom(Val& out) {
+        skip();
+        if (pos >= s.size()) return fail("unexpected end of expression");
+        const char c = s[pos];
+        if (c == '(') {
+            ++pos;
+            if (!expr(out)) return false;
+            skip();
+            if (pos >= s.size() || s[pos] != ')') return fail("')' expected");
+            ++pos;
+            return true;
+        }
+        if (std::isdigit((unsigned char)c) || c == '.') {
+            char* end = nullptr;
+            const double v = std::strtod(s.c_str() + pos, &end);
+            if (end == s.c_str() + pos) return fail("malformed number");
+            pos = (size_t)(end - s.c_str());
+            out.code = num(v); out.is_const = true;
+            return true;
+        }
+        if (std::isalpha((unsigned char)c) || c == '_') {
+            size_t b = pos;
+            while (pos < s.size() && (std::isalnum((unsigned char)s[pos]) || s[pos] == '_')) ++pos;
+            const std::string name = s.substr(b, pos - b);
+            skip();
+            if (pos < s.size() && s[pos] == '(') {          // function call
+                static const char* fn[][2] = {{"exp", "d_exp"}, {"sin", "d_sin"}, {"cos", "d_cos"}, {"sqrt", "d_sqrt"}};
+                const char* target = nullptr;
+                for (auto& f : fn) if (name == f[0]) target = f[1];
+                if (!target) return fail("unknown function '" + name + "' (available: exp, sin, cos, sqrt)");
+                ++pos;
+                Val a;
+                if (!expr(a)) return false;
+                skip();
+                if (pos >= s.size() || s[pos] != ')') return fail("')' expected");
+                ++pos;
+                out.code = std::string(target) + "(" + a.code + ")";
+                out.is_const = a.is_const;
+                return true;
+            }
+            int k = 0;
+            out.is_const = false;
+            if (cx.kind == 0) {
+                if (name == "t") { uses_t = true; out.code = "t"; return true; }
+                if (name[0] == 'x' && index_of(name, 1, cx.n, k)) { out.code = "x[" + std::to_string(k - 1) + "]"; return true; }
+                if (name[0] == 'u' && index_of(name, 1, cx.m, k)) { out.code = "u[" + std::to_string(k - 1) + "]"; return true; }
+            } else {
+                if (name.rfind("x0_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "x0[" + std::to_string(k - 1) + "]"; return true; }
+                if (name.rfind("xf_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "xf[" + std::to_string(k - 1) + "]"; return true; }
+            }
+            if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; return true; }
+            auto it = cx.constants.find(name);
+            if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; return true; }
+            return fail("unknown name '" + name + "'");
+        }
+        return fail(std::string("unexpected character '") + c + "'");
+    }
+};
+
+bool parse_constants(const char* text, std::map<std::string, double>& out, std::string& err) {
+    out.clear();
+    if (!text) return true;
+    std::string s(text);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find(';', pos);
+        if (end == std::string::npos) end = s.size();
+        std::string item = s.substr(pos, end - pos);
+        pos = end + 1;
+        size_t eq = item.find('=');
+        auto trim = [](std::string v) {
+            size_t a = v.find_first_not_of(" \t\n"), b = v.find_last_not_of(" \t\n");
+            return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+        };
+        if (trim(item).empty()) continue;
+        if (eq == std::string::npos) { err = "constant '" + item + "' needs the form name=value"; return false; }
+        const std::string name = trim(item.substr(0, eq)), val = trim(item.substr(eq + 1));
+        if (name.empty() || !(std::isalpha((unsigned char)name[0]) || name[0] == '_')) { err = "bad constant name '" + name + "'"; return false; }
+        for (char ch : name) if (!(std::isalnum((unsigned char)ch) || ch == '_')) { err = "bad constant name '" + name + "'"; return false; }
+        char* e = nullptr;
+        const double v = std::strtod(val.c_str(), &e);
+        if (val.empty() || *e != 0) { err = "constant '" + name + "' has no numeric value"; return false; }
+        out[name] = v;
+    }
+    return true;
+}
+
+std::mutex g_mu;
+std::vector<std::unique_ptr<RtOcp>> g_ocps;
+}  // namespace
+
+bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
+                 std::string& err) {
+    Parser p(expr, cx);
+    Parser::Val v;
+    if (!p.expr(v)) { err = p.err; return false; }
+    p.skip();
+    if (p.pos != expr.size()) { p.fail("unexpected trailing input"); err = p.err; return false; }
+    out = v.code; is_const = v.is_const; uses_t = p.uses_t; uses_v = p.uses_v;
+    return true;
+}
+
+const RtOcp* runtime_ocp(int id) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int k = id - kRuntimeIdBase;
+    return (k >= 0 && k < (int)g_ocps.size()) ? g_ocps[k].get() : nullptr;
+}
+
+int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
+    if (!d || !id) { err = "null argument"; return CTD_EINVAL; }
+    if (d->n < 1 || d->n > 24 || d->m < 0 || d->m > 12 || d->nv < 0 || d->nv > kMaxNV || d->npath < 0 || d->npath > 16 ||
+        d->nbc < 0 || d->nbc > 64) { err = "dimensions out of range (1 <= n <= 24, m <= 12, nv <= 4, npath <= 16, nbc <= 64)"; return CTD_EINVAL; }
+    if (2 * d->n + d->nv > 31 || d->n + d->m + d->nv > 31) { err = "too many differentiation directions (n + m + nv and 2 n + nv must be <= 31)"; return CTD_EINVAL; }
+    if (d->it0 >= d->nv || d->itf >= d->nv || d->it0 < -1 || d->itf < -1 || (d->it0 >= 0 && d->it0 == d->itf)) { err = "it0 / itf must be -1 or distinct indices into v"; return CTD_EINVAL; }
+    if (!d->dynamics) { err = "dynamics expressions missing"; return CTD_EINVAL; }
+    if ((d->npath > 0 && !d->path) || (d->nbc > 0 && !d->boundary)) { err = "path / boundary expressions missing"; return CTD_EINVAL; }
+    auto o = std::make_unique<RtOcp>();
+    o->name = d->name ? d->name : "user_ocp";
+    ExprCtx c0{d->n, d->m, d->nv, 0, {}}, c1{d->n, d->m, d->nv, 1, {}};
+    if (!parse_constants(d->constants, c0.constants, err)) return CTD_EINVAL;
+    c1.constants = c0.constants;
+    o->dyn_t = o->dyn_v = o->path_t = o->path_v = o->lag_t = o->lag_v = false;
+    std::string body_dyn, body_lag, body_may, body_path, body_bnd;
+    auto emit = [&](const char* text, const ExprCtx& cx, const std::string& lhs, std::string& body, bool& ut, bool& uv, const char* what, int idx) {
+        if (!text) { err = std::string(what) + " expression " + std::to_string(idx + 1) + " is null"; return false; }
+        std::string code, e;
+        bool isc = false, t_ = false, v_ = false;
+        if (!expr_to_cpp(text, cx, code, isc, t_, v_, e)) { err = std::string(what) + " " + std::to_string(idx + 1) + ": " + e; return false; }
+        ut = ut || t_; uv = uv || v_;
+        body += "        " + lhs + (isc ? " T(" + code + ");\n" : " " + code + ";\n");
+        return true;
+    };
+    bool dummy_t = false, dummy_v = false;
+    for (int r = 0; r < d->n; ++r)
+        if (!emit(d->dynamics[r], c0, "dx[" + std::to_string(r) + "] =", body_dyn, o->dyn_t, o->dyn_v, "dynamics", r)) return CTD_EINVAL;
+    const bool has_lag = d->lagrange && *d->lagrange, has_may = d->mayer && *d->mayer;
+    if (has_lag && !emit(d->lagrange, c0, "return", body_lag, o->lag_t, o->lag_v, "lagrange", 0)) return CTD_EINVAL;
+    if (has_may && !emit(d->mayer, c1, "return", body_may, dummy_t, dummy_v, "mayer", 0)) return CTD_EINVAL;
+    for (int r = 0; r < d->npath; ++r)
+        if (!emit(d->path[r], c0, "r[" + std::to_string(r) + "] =", body_path, o->path_t, o->path_v, "path", r)) return CTD_EINVAL;
+    for (int r = 0; r < d->nbc; ++r)
+        if (!emit(d->boundary[r], c1, "r[" + std::to_string(r) + "] =", body_bnd, dummy_t, dummy_v, "boundary", r)) return CTD_EINVAL;
+    if (!has_lag) body_lag = "        return T(0.0);\n";
+    if (!has_may) body_may = "        return T(0.0);\n";
+    o->dc = 4;
+    o->hk = d->n >= 8 ? 2 : 4;
+    o->maxb = 256;
+    auto B = [](bool b) { return b ? "true" : "false"; };
+    std::string& s = o->functor_src;
+    s = "namespace ctd {\n// generated by ctd_register_ocp from the expressions of '" + o->name + "'\nstruct UserOCP {\n";
+    s += "    static constexpr int NX = " + std::to_string(d->n) + ", NU = " + std::to_string(d->m) + ", NV = " + std::to_string(d->nv) +
+         ", NPATH = " + std::to_string(d->npath) + ", NBC = " + std::to_string(d->nbc) + ";\n";
+    s += "    static constexpr int IT0 = " + std::to_string(d->it0) + ", ITF = " + std::to_string(d->itf) + ";\n";
+    s += std::string("    static constexpr bool HAS_LAGRANGE = ") + B(has_lag) + ", HAS_MAYER = " + B(has_may) + ";\n";
+    s += std::string("    static constexpr bool DYN_T = ") + B(o->dyn_t) + ", DYN_V = " + B(o->dyn_v) + ", PATH_T = " + B(o->path_t) +
+         ", PATH_V = " + B(o->path_v) + ", LAG_T = " + B(o->lag_t) + ", LAG_V = " + B(o->lag_v) + ";\n";
+    s += "    static constexpr int DC = " + std::to_string(o->dc) + ", MAXB = " + std::to_string(o->maxb) + ";\n";
+    s += "    template <class T> CTD_HD static void dynamics(T* dx, const T& t, const T* x, const T* u, const T* v) {\n" + body_dyn + "    }\n";
+    s += "    template <class T> CTD_HD static T lagrange(const T& t, const T* x, const T* u, const T* v) {\n" + body_lag + "    }\n";
+    s += "    template <class T> CTD_HD static T mayer(const T* x0, const T* xf, const T* v) {\n" + body_may + "    }\n";
+    s += "    template <class T> CTD_HD static void path(T* r, const T& t, const T* x, const T* u, const T* v) {\n" + body_path + "    }\n";
+    s += "    template <class T> CTD_HD static void boundary(T* r, const T* x0, const T* xf, const T* v) {\n" + body_bnd + "    }\n";
+    s += "};\n}  // namespace ctd\n";
+
+    ProblemInfo& pi = o->info;
+    pi.name = o->name.c_str();
+    pi.n = d->n; pi.m = d->m; pi.nv = d->nv; pi.npath = d->npath; pi.nbc = d->nbc;
+    pi.it0 = d->it0; pi.itf = d->itf; pi.t0 = d->t0; pi.tf = d->tf;
+    pi.lagrange = has_lag; pi.mayer = has_may; pi.maximize = d->maximize != 0;
+    auto box = [](int dim, const double* lb, const double* ub, std::vector<BoxItem>& out) {
+        out.clear();
+        for (int k = 0; k < dim; ++k) {
+            const double l = lb ? lb[k] : -kInf, u = ub ? ub[k] : kInf;
+            if (l > -kInf || u < kInf) out.push_back(BoxItem{k, l, u});
+        }
+    };
+    box(d->n, d->state_lb, d->state_ub, pi.state_box);
+    box(d->m, d->control_lb, d->control_ub, pi.control_box);
+    box(d->nv, d->variable_lb, d->variable_ub, pi.variable_box);
+    pi.path_lb.assign(d->npath, 0.0); pi.path_ub.assign(d->npath, 0.0);
+    pi.bc_lb.assign(d->nbc, 0.0); pi.bc_ub.assign(d->nbc, 0.0);
+    for (int k = 0; k < d->npath; ++k) { if (d->path_lb) pi.path_lb[k] = d->path_lb[k]; if (d->path_ub) pi.path_ub[k] = d->path_ub[k]; }
+    for (int k = 0; k < d->nbc; ++k) { if (d->boundary_lb) pi.bc_lb[k] = d->boundary_lb[k]; if (d->boundary_ub) pi.bc_ub[k] = d->boundary_ub[k]; }
+    pi.init_state = no_init_t; pi.init_control = no_init_t; pi.init_variable = no_init_v;
+
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_ocps.push_back(std::move(o));
+    *id = kRuntimeIdBase + (int)g_ocps.size() - 1;
+    return CTD_OK;
+}
+
+}  // namespace ctd

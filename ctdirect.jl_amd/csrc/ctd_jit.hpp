@@ -1,0 +1,47 @@
+// ctd_jit.hpp -- OCPs defined at run time.
+//
+// In the reference the OCP functions are Julia closures produced by CTModels / CTParser (called at src/ode/trapeze.jl:66,
+// midpoint.jl:64, irk.jl:291, irk_stagewise.jl:441, src/DOCP_functions.jl:35-48,108-110,136-138).  Closures cannot cross a
+// C ABI, so besides the compiled registry (ctd_problems.hpp) the engine accepts an OCP as TEXT: one arithmetic expression
+// per output of dynamics / Lagrange cost / Mayer cost / path constraints / boundary constraints (ctd_ocp_def in
+// include/ctdirect_hip.h).  The expressions are parsed here (no C++ is accepted from the caller), turned into a functor with
+// the same shape as the registry's, and the SAME kernel templates are compiled for it with hiprtc for gfx950 when a handle is
+// created -- a run-time defined problem runs the same code path at the same speed as a built-in one.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ctd_layout.hpp"
+#include "ctd_problems.hpp"
+
+struct ctd_ocp_def;
+
+namespace ctd {
+
+constexpr int kRuntimeIdBase = 1000;
+
+struct RtOcp {
+    std::string name;
+    ProblemInfo info;                  // info.name points into `name`
+    bool dyn_t, dyn_v, path_t, path_v, lag_t, lag_v;
+    int dc, hk, maxb;
+    std::string functor_src;           // namespace ctd { struct UserOCP { ... }; }
+};
+
+inline bool is_runtime_problem(int id) { return id >= kRuntimeIdBase; }
+const RtOcp* runtime_ocp(int id);
+// parses and registers; returns a status code of include/ctdirect_hip.h (0 = ok) and the new problem id
+int register_runtime_ocp(const ctd_ocp_def* def, int* id, std::string& err);
+
+// Expression -> C++ (exposed for tests).  `kind`: 0 dynamics / Lagrange / path (t, x, u, v), 1 Mayer / boundary (x0, xf, v).
+// uses_t / uses_v report explicit dependence.  Returns false and sets err on a syntax / name error.
+struct ExprCtx {
+    int n, m, nv;
+    int kind;
+    std::map<std::string, double> constants;
+};
+bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
+                 std::string& err);
+
+}  // namespace ctd

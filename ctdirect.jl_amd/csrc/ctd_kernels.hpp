@@ -2,11 +2,15 @@
 // Included by the per-problem translation units (ctd_kern_*.hip), which explicitly instantiate launch_* for one OCP
 // so the registry compiles in parallel.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#endif
 
 #include "ctd_kernel_body.hpp"
+#if !defined(__HIPCC_RTC__)
 #include "ctd_problems.hpp"
+#endif
 
 namespace ctd {
 
@@ -484,6 +488,7 @@ __global__ void grad_finish_kernel(const GradParams gp, const double* __restrict
     for (int k = 0; k < nv; ++k) gp.g[L.v_off + k] = gvs[k];
 }
 
+#if !defined(__HIPCC_RTC__)
 template <class P>
 hipError_t launch_grad(int sc, int s, const GradParams& gp, const double* xu, int grid, hipStream_t st) {
     if (sc == SC_TRAPEZE) grad_units_kernel<P, SC_TRAPEZE, 1><<<grid, 256, 0, st>>>(gp, xu);
@@ -495,6 +500,9 @@ hipError_t launch_grad(int sc, int s, const GradParams& gp, const double* xu, in
     return hipGetLastError();
 }
 
+#endif
+
+#if !defined(__HIPCC_RTC__)
 // ---- launchers ---------------------------------------------------------------------------------------------------
 // Defined here as templates; each per-problem translation unit (ctd_kern_*.hip) explicitly instantiates them for one
 // OCP so the registry compiles in parallel, and ctd_engine.hip only sees `extern template` declarations.
@@ -574,5 +582,7 @@ hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, i
     extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);               \
     extern template int pipe_occupancy<P>(int, int, int, size_t);                                                         \
     extern template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace ctd

@@ -73,6 +73,73 @@ def _is_tensor(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
+def register_ocp(name, *, dynamics, n=None, m=0, nv=0, lagrange=None, mayer=None, path=(), boundary=(), constants=None,
+                 t0=0.0, tf=1.0, it0=-1, itf=-1, maximize=False, state_box=None, control_box=None, variable_box=None,
+                 path_bounds=None, boundary_bounds=None):
+    """Defines an OCP at run time from arithmetic expressions (the stand-in for the Julia closures of a CTModels.Model,
+    include/ctdirect_hip.h `ctd_ocp_def`) and returns `name`, usable as the `ocp` argument of DOCP.
+
+    dynamics / path: expressions in t, x1..xn, u1..um, v1..vnv; mayer / boundary: in x0_k, xf_k, vk; `constants` a dict.
+    Boxes and bounds are (lb, ub) pairs of sequences (None = free boxes / equality-with-zero rows); it0 / itf are the
+    0-based positions of a free initial / final time inside v.  The kernels are compiled with hiprtc when a DOCP is built."""
+    L = _lib.lib()
+    dynamics = list(dynamics)
+    n = len(dynamics) if n is None else int(n)
+    path, boundary = list(path), list(boundary)
+    d = _lib.ctd_ocp_def()
+    keep = []
+
+    def strs(items):
+        arr = (C.c_char_p * max(len(items), 1))(*[s.encode() for s in items])
+        keep.append(arr)
+        return C.cast(arr, C.POINTER(C.c_char_p))
+
+    def dbl(seq, dim, fill):
+        a = np.full(dim, fill, dtype=np.float64) if seq is None else np.ascontiguousarray(seq, dtype=np.float64)
+        if a.size != dim:
+            raise ValueError(f"bound array has {a.size} entries, expected {dim}")
+        keep.append(a)
+        return _dp(a) if dim else None
+
+    d.name = name.encode()
+    d.n, d.m, d.nv, d.npath, d.nbc = n, int(m), int(nv), len(path), len(boundary)
+    d.it0, d.itf, d.t0, d.tf, d.maximize = int(it0), int(itf), float(t0), float(tf), int(bool(maximize))
+    d.dynamics, d.path, d.boundary = strs(dynamics), strs(path), strs(boundary)
+    d.lagrange = lagrange.encode() if lagrange else None
+    d.mayer = mayer.encode() if mayer else None
+    d.constants = "; ".join(f"{k}={float(v)!r}" for k, v in constants.items()).encode() if constants else None
+    inf = float("inf")
+    for key, box, dim in (("state", state_box, n), ("control", control_box, int(m)), ("variable", variable_box, int(nv))):
+        setattr(d, key + "_lb", dbl(None if box is None else box[0], dim, -inf))
+        setattr(d, key + "_ub", dbl(None if box is None else box[1], dim, inf))
+    for key, bnd, dim in (("path", path_bounds, len(path)), ("boundary", boundary_bounds, len(boundary))):
+        setattr(d, key + "_lb", dbl(None if bnd is None else bnd[0], dim, 0.0))
+        setattr(d, key + "_ub", dbl(None if bnd is None else bnd[1], dim, 0.0))
+    pid = C.c_int32()
+    st = L.ctd_register_ocp(C.byref(d), C.byref(pid))
+    if st != _lib.CTD_OK:
+        _raise(st, L.ctd_last_error(None).decode())
+    PROBLEMS[name] = pid.value
+    return name
+
+
+def ocp_source(name):
+    """The functor text generated for a run-time OCP (diagnostics)."""
+    buf = C.create_string_buffer(1 << 16)
+    st = _lib.lib().ctd_ocp_source(PROBLEMS[name], buf, len(buf))
+    if st != _lib.CTD_OK:
+        _raise(st, "not a run-time problem")
+    return buf.value.decode()
+
+
+def jit_check(name, scheme):
+    """Compile-only check (no GPU needed): the kernels of `scheme` build for gfx950 for a run-time OCP."""
+    L = _lib.lib()
+    st = L.ctd_jit_check(PROBLEMS[name], SCHEMES[scheme] if isinstance(scheme, str) else int(scheme))
+    if st != _lib.CTD_OK:
+        _raise(st, L.ctd_last_error(None).decode())
+
+
 class DOCP:
     """Discretised OCP handle; mirrors `CTDirect.DOCP(ocp, grid_size, 1, scheme, time_grid)`.
 

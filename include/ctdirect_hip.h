@@ -112,6 +112,39 @@ typedef struct ctd_init {
     const double* variable;      /* variable guess [nv] or NULL                                             */
 } ctd_init;
 
+/* ---- OCPs defined at run time ----------------------------------------------------------------------------------
+ * The reference obtains the OCP functions as Julia closures from CTModels (CTModels.dynamics(ocp)(dx, t, x, u, v) called
+ * at src/ode/trapeze.jl:66, midpoint.jl:64, irk.jl:291, irk_stagewise.jl:441; lagrange / mayer src/DOCP_functions.jl:35-48;
+ * path / boundary constraints :108-110,136-138).  A closure cannot cross a C ABI, so an OCP that is not in the compiled
+ * registry is handed over as TEXT: one arithmetic expression per output.  Grammar: + - * / ^(integer) parentheses, numbers,
+ * exp sin cos sqrt, the names t, x1..xn, u1..um, v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer,
+ * boundary), and the constants declared in `constants` ("Cd=310; beta=500").  No C++ is accepted.  ctd_register_ocp parses
+ * the expressions, generates a functor of the registry's shape and returns a problem id (>= 1000) for ctd_desc.problem;
+ * ctd_create then compiles the SAME kernel templates for it with hiprtc (gfx950) -- same code path as a built-in problem.
+ * dims, flags and bounds restate DOCPdims / DOCPFlags (src/DOCP_data.jl:24-30,88-94) and the boxes of CTModels
+ * (src/DOCP_variables.jl:88-98).  Bound arrays may be NULL (boxes: free; path / boundary: equality with 0). */
+typedef struct ctd_ocp_def {
+    const char* name;
+    int32_t n, m, nv, npath, nbc;        /* state, control, variable, path-constraint, boundary-constraint dimensions */
+    int32_t it0, itf;                    /* 0-based index of t0 / tf inside v, -1 = fixed                             */
+    double t0, tf;                       /* fixed values when the index is -1                                          */
+    int32_t maximize;                    /* DOCPFlags.max                                                              */
+    int32_t reserved;
+    const char* const* dynamics;         /* n expressions                                                              */
+    const char* lagrange;                /* running cost or NULL                                                       */
+    const char* mayer;                   /* terminal cost or NULL                                                      */
+    const char* const* path;             /* npath expressions                                                          */
+    const char* const* boundary;         /* nbc expressions                                                            */
+    const char* constants;               /* "name=value; ..." or NULL                                                  */
+    const double *state_lb, *state_ub, *control_lb, *control_ub, *variable_lb, *variable_ub;
+    const double *path_lb, *path_ub, *boundary_lb, *boundary_ub;
+} ctd_ocp_def;
+int32_t ctd_register_ocp(const ctd_ocp_def* def, int32_t* problem_id);
+/* the functor text generated for a registered OCP (diagnostics / tests) */
+int32_t ctd_ocp_source(int32_t problem_id, char* buf, int64_t cap);
+/* compile-only check, no device needed: the kernels of `scheme` build for gfx950 (ctd_last_error(NULL) holds the log) */
+int32_t ctd_jit_check(int32_t problem_id, int32_t scheme);
+
 /* ---- lifecycle ------------------------------------------------------------------------------------------ */
 /* get_docp: DOCP(...) + __variables_bounds! + __constraints_bounds!   (src/collocation.jl:57-73) */
 int32_t ctd_create(const ctd_desc* desc, ctd_handle** out);

@@ -673,6 +673,7 @@ static void hessian_pattern_ij(const Docp& p, IJ& ij) {
     ij.block(uf_start, uf_end, uf_start, uf_end);
     ij.block(xf_start, xf_end, uf_start, uf_end, true);
     ij.block(xf_start, uf_end, v_start, v_end, true);                  // empty range (hazard H3)
+    if (p.pattern_mode == 1) ij.block(xf_start, xf_end, v_start, v_end, true);    // STRUCTURAL: the block the comment there intends
     ij.block(uf_start, uf_end, v_start, v_end, true);
     ij.block(1, dm.NLP_x, xf_start, xf_end, true);
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../ctdirect.jl_amd/csrc/ctd_host.cpp"
+#include "../../ctdirect.jl_amd/csrc/ctd_jit.cpp"
 #include "../../ctdirect.jl_amd/csrc/ctd_kernel_body.hpp"
 #define ST_OK ST_OK_HESS
 #define ST_EPATTERN ST_EPATTERN_HESS

@@ -1,0 +1,101 @@
+"""Run-time OCP definitions used by the JIT tests: the registry problems restated as expressions (to compare the
+hiprtc-compiled kernels with the built-in ones) and one problem that exists nowhere else (checked against an on-the-fly
+50-digit mpmath evaluation through tests/golden/gen_golden.py)."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import gen_golden as gg  # noqa: E402
+from mpmath import mpf  # noqa: E402
+
+import ctdirect_jl_amd as ct  # noqa: E402
+
+INF = float("inf")
+
+# name of the registry twin -> keyword arguments of ct.register_ocp (expressions follow the problem files cited in
+# ctdirect.jl_amd/csrc/ctd_problems.hpp)
+TWINS = {
+    "goddard": dict(
+        dynamics=["x2", "-Cd*x2^2*exp(-beta*(x1-1))/x3 - 1/x1^2 + u1*(Tmax/x3)", "u1*(-b*Tmax)"], m=1, nv=1, mayer="xf_1",
+        boundary=["x0_1", "x0_2", "x0_3", "xf_3"], constants=dict(Cd=310, beta=500, b=2, Tmax=3.5), itf=0, maximize=True,
+        state_box=([1, 0, 0.6], [1.1, 0.1, 1]), control_box=([0], [1]), variable_box=([0.01], [INF]),
+        boundary_bounds=([1, 0, 1, 0.6], [1, 0, 1, 0.6])),
+    "goddard_all": dict(
+        dynamics=["x2", "-Cd*x2^2*exp(-beta*(x1-1))/x3 - 1/x1^2 + u1*Tmax/x3", "-b*Tmax*u1"], m=1, nv=1, mayer="xf_1",
+        path=["x2", "u1", "x1 + x2 + x3 + u1 + v1"], boundary=["x0_1", "x0_2", "x0_3", "xf_3"],
+        constants=dict(Cd=310, beta=500, b=2, Tmax=3.5), itf=0, maximize=True,
+        state_box=([1, 0, 0], [INF, INF, 1]), control_box=([0], [INF]), variable_box=([0.01], [INF]),
+        path_bounds=([-INF, -INF, 0], [0.1, 1, INF]), boundary_bounds=([1, 0, 1, 0.6], [1, 0, 1, 0.6])),
+    "double_integrator_path": dict(
+        dynamics=["x2", "u1"], m=1, lagrange="u1^2", path=["x1 + 0.1*x2^2"], boundary=["x0_1", "x0_2", "xf_1", "xf_2"],
+        t0=0.0, tf=2.0, control_box=([-5], [5]), path_bounds=([-INF], [1.05]), boundary_bounds=([0, 0, 1, 0], [0, 0, 1, 0])),
+    "quadrotor": dict(
+        dynamics=["x4", "x5", "x6", "(cos(u4)*sin(x8)*cos(x7) + sin(u4)*sin(x7))*u1",
+                  "(sin(u4)*sin(x8)*cos(x7) - cos(u4)*sin(x7))*u1", "(cos(x8)*cos(x7))*u1 - g", "u2", "u3"],
+        m=4, nv=1, lagrange="1e-8*(x7^2 + x8^2 + u4^2 + u1^2) + 1e2*u4^2", mayer="v1", path=["cos(x8)*cos(x7)"],
+        boundary=[f"x0_{i}" for i in range(1, 9)] + [f"xf_{i}" for i in range(1, 7)], constants=dict(g=9.81), itf=0,
+        state_box=([-INF] * 6 + [-math.pi / 2] * 2, [INF] * 6 + [math.pi / 2] * 2),
+        control_box=([0, -3, -3, -INF], [9.18 * 5, 3, 3, INF]), variable_box=([0.1], [INF]),
+        path_bounds=([math.cos(1.1 / 2)], [INF]),
+        boundary_bounds=([0, 0, 2.5, 0, 0, 0, 0, 0, 0.01, 5, 2.5, 0, 0, 0], [0, 0, 2.5, 0, 0, 0, 0, 0, 0.01, 5, 2.5, 0, 0, 0])),
+    "double_integrator_freet0tf": dict(
+        dynamics=["x2", "u1"], m=1, nv=2, mayer="v1", boundary=["x0_1", "x0_2", "xf_1", "xf_2", "v2 - v1"], it0=0, itf=1,
+        maximize=True, control_box=([-1], [1]), variable_box=([0.05, 0.05], [10, 10]),
+        boundary_bounds=([0, 0, 1, 0, 0.01], [0, 0, 1, 0, INF])),
+    "least_squares_with_constraint": dict(
+        dynamics=["-x2", "x1"], nv=2, lagrange="(t - 0.5)^2*((x1 - 0.7)^2 + (x2 - 0.7)^2)", mayer="0.01*(v1^2 + v2^2)",
+        path=["x1^2 + x2^2"], boundary=["x0_1 - v1", "x0_2 - v2"], t0=0.0, tf=1.0, path_bounds=([-INF], [2.0])),
+}
+
+_registered = {}
+
+
+def twin(name):
+    """registers the expression twin of a registry problem once; returns its run-time name"""
+    if name not in _registered:
+        _registered[name] = ct.register_ocp(name + "_rt", **TWINS[name])
+    return _registered[name]
+
+
+# ---- a problem that only exists as expressions: forced Van der Pol with a parameter, time-dependent dynamics and cost,
+# a state-control path constraint that depends on the parameter, a nonlinear boundary constraint and a Bolza cost
+VDP = dict(
+    dynamics=["x2", "v1*(1 - x1^2)*x2 - x1 + u1 + 0.1*sin(3*t)"], m=1, nv=2,
+    lagrange="x1^2 + x2^2 + (1 + 0.5*t)*u1^2 + 0.01*v1*u1", mayer="v1^2 + xf_1*xf_2 + 0.3*v2",
+    path=["x2 + 0.2*x1^2 + 0.05*v1*u1", "sqrt(1 + x1^2) - t*u1"], boundary=["x0_1", "x0_2", "xf_1^2 + xf_2^2", "v2 - 0.1*x0_1"],
+    itf=1, t0=0.25, variable_box=([0.1, 0.5], [3.0, 6.0]), control_box=([-2], [2]),
+    path_bounds=([-INF, 0.0], [1.5, INF]), boundary_bounds=([1, 0, 0, 1.0], [1, 0, 0.5, INF]))
+
+
+class VdpMp(gg.Problem):
+    """the same problem for the mpmath restatement (tests/golden/gen_golden.py): Du / dsin are looked up at call time so
+    that the second-order number of gen_golden_hess.py can be swapped in"""
+    name = "vdp_rt"
+    n, m, nv, p, bc = 2, 1, 2, 2, 4
+    freetf, lagrange, mayer = True, True, True
+
+    def t0(self, v): return gg.Du(mpf("0.25"))
+    def tf(self, v): return v[1]
+
+    def dynamics(self, t, x, u, v):
+        return [x[1] + 0, v[0] * (1 - x[0] ** 2) * x[1] - x[0] + u[0] + mpf("0.1") * gg.dsin(3 * gg.Du.lift(t))]
+
+    def lagr(self, t, x, u, v):
+        return x[0] ** 2 + x[1] ** 2 + (1 + mpf("0.5") * t) * u[0] ** 2 + mpf("0.01") * v[0] * u[0]
+
+    def may(self, x0, xf, v): return v[0] ** 2 + xf[0] * xf[1] + mpf("0.3") * v[1]
+
+    def path(self, t, x, u, v):
+        return [x[1] + mpf("0.2") * x[0] ** 2 + mpf("0.05") * v[0] * u[0], dsqrt(1 + x[0] ** 2) - t * u[0]]
+
+    def boundary(self, x0, xf, v): return [x0[0] + 0, x0[1] + 0, xf[0] ** 2 + xf[1] ** 2, v[1] - mpf("0.1") * x0[0]]
+
+
+def dsqrt(x):
+    """sqrt for whichever dual type gen_golden currently uses (first order Du or the second-order Du2)"""
+    from mpmath import mp
+    s = mp.sqrt(x.v)
+    if hasattr(x, "chain"):
+        return x.chain(s, 1 / (2 * s), -1 / (4 * s * x.v))
+    return gg.Du(s, [a / (2 * s) for a in x.d])

@@ -1,0 +1,120 @@
+"""GPU tests of the run-time OCP path (run with -m gpu on an MI355X): OCPs handed over as expressions (ctd_register_ocp),
+kernels compiled with hiprtc at ctd_create and launched through the same C-ABI entry points.
+
+  * registry twins: a problem of the compiled registry restated as expressions gives the same constraints, Jacobian,
+    objective, gradient and Hessian as the built-in handle (<= 1e-10; operation order inside an expression may differ
+    from the hand-written functor by a rounding) and as the oracle;
+  * a problem that exists only as expressions (forced Van der Pol, free final time, time- and parameter-dependent
+    dynamics / cost / path constraints, nonlinear boundary constraint, sqrt) against an on-the-fly 50-digit mpmath evaluation
+    of the reference's formulas (tests/golden/gen_golden.py machinery) on every scheme."""
+import numpy as np
+import pytest
+from mpmath import mpf
+
+import ctdirect_jl_amd as ct
+import jit_defs
+from jit_defs import gg
+from helpers import TOL, bench_inputs, describe, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+PAIRS = [(p, s) for p in sorted(jit_defs.TWINS) for s in ct.SCHEMES]
+
+
+@pytest.mark.parametrize("prob,sch", PAIRS, ids=[f"{p}-{s}" for p, s in PAIRS])
+def test_runtime_twin_matches_registry_and_oracle(oracle_lib, torch_cuda, prob, sch):
+    torch = torch_cuda
+    if prob == "quadrotor" and sch not in ("midpoint", "gauss_legendre_2", "gauss_legendre_3", "trapeze"):
+        pytest.skip("quadrotor twin: four schemes are enough (compile time)")
+    rt = jit_defs.twin(prob)
+    rng = np.random.default_rng(21)
+    for N in (4, 41):
+        # structural pattern: on the reference's manual trapeze pattern a coloured Jacobian is wrong (hazard H1)
+        a, b = ct.DOCP(prob, N, sch, pattern="structural", device=0), ct.DOCP(rt, N, sch, pattern="structural", device=0)
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        o.set_pattern_mode(1)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+        y = rng.standard_normal(o.dim_NLP_constraints)
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        ca, va = a.cons_jac(xd)
+        cb, vb = b.cons_jac(xd)
+        assert relerr(cb.cpu().numpy(), ca.cpu().numpy()) <= TOL and relerr(vb.cpu().numpy(), va.cpu().numpy()) <= TOL
+        assert relerr(cb.cpu().numpy(), o.constraints(x)) <= TOL and relerr(vb.cpu().numpy(), o.jac_coord(x)) <= TOL
+        assert abs(b.obj(xd) - o.objective(x)) <= TOL * max(1.0, abs(o.objective(x)))
+        assert relerr(b.grad(xd).cpu().numpy(), o.gradient(x)) <= TOL
+        hb = b.hess_coord(xd, yd, 0.7).cpu().numpy()
+        assert relerr(hb, a.hess_coord(xd, yd, 0.7).cpu().numpy()) <= TOL
+        assert relerr(hb, o.hess_coord(x, y, 0.7)) <= TOL
+        # host-pointer entry points take the same path
+        c2, v2 = b.cons_jac(x)
+        assert np.array_equal(c2, cb.cpu().numpy()) and np.array_equal(v2, vb.cpu().numpy())
+        a.close(); b.close()
+
+
+def _mp_reference(P, scheme, N, xu, y, sigma):
+    """c, dense Jacobian, objective, gradient (first-order dense dual) and the Hessian of the Lagrangian (sparse
+    second-order number) of the mpmath restatement"""
+    import gen_golden_hess as gh
+    d = gg.Docp(P, scheme, N=N)
+    nvar = d.nvar
+    gg.Du.NV = nvar
+    z = []
+    for j, v in enumerate(xu):
+        der = [mpf(0)] * nvar
+        der[j] = mpf(1)
+        z.append(gg.Du(mpf(float(v)), der))
+    c = [gg.Du.lift(e) for e in d.constraints(z)]
+    obj = gg.Du.lift(d.objective(z))
+    cval = np.array([float(e.v) for e in c])
+    J = np.array([[float(g) for g in e.d] for e in c])
+    grad = np.array([float(g) for g in obj.d])
+    first = (gg.Du, gg.dexp, gg.dsin, gg.dcos)
+    try:
+        gg.Du, gg.dexp, gg.dsin, gg.dcos = gh.Du2, gh.dexp2, gh.dsin2, gh.dcos2
+        z2 = [gh.Du2(mpf(float(v)), {j: mpf(1)}) for j, v in enumerate(xu)]
+        lag = mpf(sigma) * gh.Du2.lift(d.objective(z2))
+        for r, e in enumerate(d.constraints(z2)):
+            lag = lag + mpf(float(y[r])) * gh.Du2.lift(e)
+        H = {k: float(v) for k, v in lag.h.items()}
+    finally:
+        gg.Du, gg.dexp, gg.dsin, gg.dcos = first
+    return d, cval, J, float(obj.v), grad, H
+
+
+@pytest.mark.parametrize("sch", list(ct.SCHEMES))
+def test_expression_only_problem_against_mpmath(torch_cuda, sch):
+    torch = torch_cuda
+    name = "vdp_rt" if "vdp_rt" in ct.PROBLEMS else ct.register_ocp("vdp_rt", **jit_defs.VDP)
+    N = 5
+    d = ct.DOCP(name, N, sch, pattern="structural", device=0)
+    rng = np.random.default_rng(33)
+    x = 0.4 + 0.3 * rng.standard_normal(d.dim_NLP_variables)
+    x[-2:] = [1.3, 2.1]                                            # v = (mu, tf)
+    y = rng.standard_normal(d.dim_NLP_constraints)
+    md, cref, Jref, fref, gref, Href = _mp_reference(jit_defs.VdpMp(), sch, N, x, y, 0.6)
+    assert (md.nvar, md.ncon) == (d.dim_NLP_variables, d.dim_NLP_constraints)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    c, vals = d.cons_jac(xd)
+    assert relerr(c.cpu().numpy(), cref) <= TOL
+    rows, cols = d.jac_structure()
+    assert relerr(vals.cpu().numpy(), Jref[rows - 1, cols - 1]) <= TOL
+    pat = set(zip(rows - 1, cols - 1))
+    assert all((r, cc) in pat for r, cc in zip(*np.nonzero(Jref)))          # structural pattern holds every true nonzero
+    assert abs(d.obj(xd) - fref) <= TOL * max(1.0, abs(fref))
+    assert relerr(d.grad(xd).cpu().numpy(), gref) <= TOL
+    hr, hc = d.hess_structure()
+    hv = d.hess_coord(xd, yd, 0.6).cpu().numpy()
+    want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
+    assert relerr(hv, want) <= TOL
+    hpat = set(zip(hr - 1, hc - 1))
+    dropped = [k for k, v in Href.items() if v != 0.0 and k not in hpat]
+    assert not dropped, dropped
+    d.close()

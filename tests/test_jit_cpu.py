@@ -1,0 +1,63 @@
+"""CPU tests of the run-time OCP path (ctd_register_ocp): expression parsing and validation, the generated functor, host
+model equality with the registry twin, and that the kernel templates COMPILE for gfx950 with hiprtc (no GPU needed for
+that).  Running them is covered by tests/test_gpu_jit.py."""
+import numpy as np
+import pytest
+
+import ctdirect_jl_amd as ct
+import jit_defs
+
+
+def test_expression_errors_are_reported():
+    for bad, frag in ((["x2 + foo(x1)", "x1"], "unknown function"), (["x3", "x1"], "unknown name 'x3'"), (["x1 +", "x1"], "unexpected end"),
+                      (["x1^-1", "x1"], "integer exponent"), (["(x1", "x1"], "')' expected"), (["x1 x2", "x1"], "trailing"),
+                      (["u1", "x1"], "unknown name 'u1'"), (["xf_1", "x1"], "unknown name")):
+        with pytest.raises(ct.CTDirectError) as e:
+            ct.register_ocp("bad", dynamics=bad)
+        assert e.value.status == ct._lib.CTD_EINVAL and frag in str(e.value), str(e.value)
+    with pytest.raises(ct.CTDirectError):
+        ct.register_ocp("bad", dynamics=["x1"], nv=1, itf=3)
+    with pytest.raises(ct.CTDirectError):
+        ct.register_ocp("bad", dynamics=["x1"], constants={"1a": 2.0})
+
+
+def test_generated_functor_and_traits():
+    name = ct.register_ocp("traits", dynamics=["x2*t", "-x1 + k*u1^3/(1 + v1)"], m=1, nv=1, lagrange="2", mayer="xf_1",
+                           constants=dict(k=0.5))
+    src = ct.ocp_source(name)
+    assert "DYN_T = true" in src and "DYN_V = true" in src and "LAG_T = false" in src and "HAS_LAGRANGE = true" in src
+    assert "d_powi(u[0], 3)" in src and "return T(2.0);" in src and "0.5" in src and "dx[0] = (x[1] * t);" in src
+    # no caller text reaches the compiler except through the parser: identifiers are mapped, numbers re-printed
+    with pytest.raises(ct.CTDirectError):
+        ct.register_ocp("inject", dynamics=["x1; } evil() {"])
+
+
+@pytest.mark.parametrize("prob", sorted(jit_defs.TWINS))
+def test_host_model_equals_registry_twin(prob):
+    """sizes, bounds, patterns (Jacobian: same; Hessian: same, the pattern does not depend on the probe) and the
+    default initial guess of a run-time OCP equal those of the compiled registry entry it restates"""
+    rt = jit_defs.twin(prob)
+    for sch in ("trapeze", "midpoint", "gauss_legendre_2", "gauss_legendre_3_constant_control"):
+        a, b = ct.DOCP(prob, 13, sch, device=-1), ct.DOCP(rt, 13, sch, device=-1)
+        assert (a.dim_NLP_variables, a.dim_NLP_constraints, a.nnzj, a.nnzh) == (b.dim_NLP_variables, b.dim_NLP_constraints, b.nnzj, b.nnzh)
+        for x, y in zip((a.bounds.var_l, a.bounds.var_u, a.bounds.con_l, a.bounds.con_u),
+                        (b.bounds.var_l, b.bounds.var_u, b.bounds.con_l, b.bounds.con_u)):
+            assert np.array_equal(x, y)
+        for f in (ct.DOCP_Jacobian_pattern, ct.DOCP_Hessian_pattern):
+            (c1, r1), (c2, r2) = f(a), f(b)
+            assert np.array_equal(c1, c2) and np.array_equal(r1, r2)
+        assert np.array_equal(ct.initial_guess(a), ct.initial_guess(b))
+
+
+@pytest.mark.parametrize("sch", ["trapeze", "midpoint", "gauss_legendre_1", "gauss_legendre_2", "gauss_legendre_3_constant_control"])
+def test_kernels_compile_for_gfx950_without_a_gpu(sch):
+    ct.jit_check(jit_defs.twin("goddard_all"), sch)
+    name = ct.register_ocp("vdp_cpu", **jit_defs.VDP) if "vdp_cpu" not in ct.PROBLEMS else "vdp_cpu"
+    ct.jit_check(name, sch)
+
+
+def test_compute_without_device_fails_loudly_for_runtime_ocps():
+    d = ct.DOCP(jit_defs.twin("goddard"), 10, "midpoint", device=-1)
+    with pytest.raises(ct.CTDirectError) as e:
+        d.cons(np.full(d.dim_NLP_variables, 0.1))
+    assert e.value.status == ct._lib.CTD_ENODEVICE
