@@ -387,9 +387,9 @@ int32_t ctd_ocp_source(int32_t problem_id, char* buf, int64_t cap) {
 int32_t ctd_jit_check(int32_t problem_id, int32_t scheme) {
     const RtOcp* ro = runtime_ocp(problem_id);
     if (!ro) return fail(nullptr, CTD_EPROBLEM, "ctd_jit_check: not a run-time problem id");
-    if (scheme < 0 || scheme > 6) return fail(nullptr, CTD_ESCHEME, "Unknown discretization method");
-    const int sc = scheme == 0 ? SC_TRAPEZE : (scheme == 1 ? SC_MIDPOINT : SC_IRK);
-    const int s = scheme < 2 ? 0 : (scheme <= 4 ? scheme - 1 : scheme - 3);
+    if (scheme < 0 || scheme > 8) return fail(nullptr, CTD_ESCHEME, "Unknown discretization method");
+    const int sc = scheme == 0 ? SC_TRAPEZE : ((scheme == 1 || scheme >= 7) ? SC_MIDPOINT : SC_IRK);
+    const int s = (scheme < 2 || scheme >= 7) ? 0 : (scheme <= 4 ? scheme - 1 : scheme - 3);
     std::string code, err;
     std::vector<std::string> names;
     int32_t st = jit_compile(*ro, "ctd_kernels.hpp", jit_first_exprs(sc, s), "off", code, names, err);

@@ -68,7 +68,7 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
 
 // ---- 32-bit term code:  value += CP[pair] * rec[di]  of record `slot` ------------------------------------------
 // bits 0-15 di, 16-23 pair id, 24-26 slot.  Inside tile templates slot is relative (0 = the entry's own step,
-// 1 = the previous step); inside the edge lists it is the absolute record id of the edge block.
+// 1 = the previous step, 2 = the next step); inside the edge lists it is the absolute record id of the edge block.
 CTD_HD uint32_t pack_term(int di, int pair, int slot) {
     return (uint32_t)di | ((uint32_t)pair << 16) | ((uint32_t)slot << 24);
 }
@@ -81,7 +81,8 @@ struct HParams {
     Layout L;
     HessRecLayout R;
     const double* tau;          // normalized grid on device (N+1) or nullptr (uniform)
-    int32_t T, HL;              // steps per tile, records a tile needs below its first step (midpoint: 1)
+    int32_t T, HL, HH;          // steps per tile, records a tile needs below its first step (midpoint class: 1) and above its
+                                // last one (implicit Euler with path constraints: 1)
     int32_t ntiles;
     // regular CSC segments of the lower triangle: step i in [reg_first, reg_last) owns
     // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])

@@ -63,7 +63,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     if (block == 0) {
         cx.is_edge = 1;
         cx.nslots = hp.n_edge_slots;
-        cx.in_stride = L.blk + L.n + L.m;
+        cx.in_stride = edge_in_stride(L);
         cx.a = cx.b = cx.lo = 0;
         cx.in = lds;
         cx.ly = cx.in + cx.nslots * cx.in_stride;
@@ -73,7 +73,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.red = cx.rec;
     } else {
         const int tile = block - 1;
-        const int cap = hp.T + hp.HL;
+        const int cap = hp.T + hp.HL + hp.HH;
         if (hess_tables_staged(hp)) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
             cx.tptr = w; w += hp.Lseg + 1;
@@ -90,7 +90,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         (void)last;
         cx.b = cx.a + hp.T < L.N ? cx.a + hp.T : L.N;
         cx.lo = cx.a - hp.HL;
-        cx.nslots = (int)(cx.b - cx.a) + hp.HL;
+        cx.nslots = (int)(cx.b - cx.a) + hp.HL + hp.HH;
         cx.in_stride = L.blk;
         cx.in = lds;
         cx.ly = cx.in + (cap + 1) * L.blk + L.n + L.m;
@@ -104,10 +104,10 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
 
 inline int64_t hess_lds_doubles(const HParams& hp) {
     const Layout& L = hp.L;
-    const int64_t cap = hp.T + hp.HL;
+    const int64_t cap = hp.T + hp.HL + hp.HH;
     const int64_t tile = hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
                          cap * hp.R.stride + (int64_t)hp.nvv * hp.T;
-    const int64_t edge = (int64_t)hp.n_edge_slots * (L.blk + L.n + L.m) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
+    const int64_t edge = (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
                          3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * hp.R.stride;
     return tile > edge ? tile : edge;
 }
@@ -142,7 +142,9 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         const int per = cx.in_stride;
         for (int e = tid; e < cx.nslots * per; e += nthr) {
             const int k = e / per, o = e - k * per;
-            const int64_t g = hp.edge_steps[k] * L.blk + o;
+            int64_t g = hp.edge_steps[k] * L.blk + o;
+            if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
+                g = (hp.edge_steps[k] >= 1 ? hp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
             cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
         }
         for (int e = tid; e < 2 * cx.nslots * L.cb; e += nthr) {
@@ -270,11 +272,15 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
 #pragma unroll
         for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0) + cj * hdb[i];
         t = hess_seed<K>(tA + cj * h, dt_of(p, tau0) + cj * hda, sb);
-    } else if (SC == SC_MIDPOINT) {
+    } else if (SC == SC_MIDPOINT && L.euler == 0) {
 #pragma unroll
         for (int i = 0; i < K; ++i) sb[i] = 0.5 * (dt_of(q[i], tau0) + dt_of(q[i], tau1));
         t = hess_seed<K>(0.5 * (tA + tB), 0.5 * (dt_of(p, tau0) + dt_of(p, tau1)), sb);
-    } else {
+    } else if (SC == SC_MIDPOINT && L.euler == 2) {       // implicit Euler: (t_{i+1}, X_{i+1})
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau1);
+        t = hess_seed<K>(tB, dt_of(p, tau1), sb);
+    } else {                                              // trapeze node, explicit Euler: (t_i, X_i)
 #pragma unroll
         for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0);
         t = hess_seed<K>(tA, dt_of(p, tau0), sb);
@@ -295,7 +301,8 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
         } else {
 #pragma unroll
             for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r);
-            const double xv = (SC == SC_MIDPOINT) ? 0.5 * (base[r] + base[L.blk + r]) : base[r];
+            const double xv = (SC == SC_MIDPOINT && L.euler == 0) ? 0.5 * (base[r] + base[L.blk + r])
+                                                                  : ((SC == SC_MIDPOINT && L.euler == 2) ? base[L.blk + r] : base[r]);
             x[r] = hess_seed<K>(xv, unit(p, r), sb);
         }
     }
@@ -487,7 +494,10 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
             const int64_t s = hslot_step(hp, cx, k);
             if (s >= 0 && s < L.N) {
                 const double* base = cx.in + k * cx.in_stride;
-                hess_eval_path<P, SC, S>(hp, base, base + n, cx.v, hslot_tau(cx, k, 0), hslot_y(hp, cx, k) + L.eqs,
+                const double* ub = base + n;
+                if (L.euler == 2 && s >= 1)     // implicit Euler: u(t_i) = U_{i-1} (euler.jl:59-72)
+                    ub = cx.is_edge ? base + L.blk + n + P::NU : (k >= 1 ? base - L.blk + n : base + n);
+                hess_eval_path<P, SC, S>(hp, base, ub, cx.v, hslot_tau(cx, k, 0), hslot_y(hp, cx, k) + L.eqs,
                                          cx.rec + k * R.stride + R.oHP, code);
             }
         }
@@ -605,7 +615,8 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
 #pragma unroll
         for (int t = 0; t < kMaxTerms; ++t) {
             const uint32_t code = (t < nt) ? cx.terms[t0 + t] : 0u;
-            const int so = (t < nt) ? term_slot(code) * R.stride : 0;
+            const int sl = (t < nt) ? term_slot(code) : 0;
+            const int so = sl == 1 ? R.stride : (sl == 2 ? -R.stride : 0);
             cpo[t] = R.oCP + ((t < nt) ? term_pair(code) : 0) - so;
             dio[t] = ((t < nt) ? term_di(code) : R.oZero) - so;
         }

@@ -23,6 +23,20 @@ static inline void hpush(std::vector<Block>& out, int64_t r0, int64_t r1, int64_
 
 void Model::hess_step_blocks(int64_t i, std::vector<Block>& out) const {
     const int64_t blk = L.blk, vo = i * blk, v0 = L.v_off, v1 = L.nvar;
+    if (L.euler) {                                        // euler.jl:297-326
+        const int64_t x0 = vo, x1 = vo + L.n, u0 = x1, u1 = x1 + L.m, y0 = vo + blk, y1 = y0 + L.n;
+        hpush(out, u0, u1, u0, u1);
+        hpush(out, u0, u1, v0, v1, true);
+        if (L.euler == 2) {                               // implicit: x_{i+1} carries the dynamics' second-order terms
+            hpush(out, y0, y1, y0, y1);
+            hpush(out, y0, y1, u0, u1, true);
+            hpush(out, y0, y1, v0, v1, true);
+        }
+        hpush(out, x0, x1, x0, x1);                       // explicit: dynamics + path; implicit: path part (:321-325)
+        hpush(out, x0, x1, u0, u1, true);
+        hpush(out, x0, x1, v0, v1, true);
+        return;
+    }
     int64_t hi;
     if (L.sc == SC_TRAPEZE) hi = vo + 2 * blk;            // trapeze.jl:262-281  [X_i U_i X_i+1 U_i+1]
     else if (L.sc == SC_MIDPOINT) hi = vo + blk + L.n;    // midpoint.jl:262-281 [X_i U_i X_i+1]
@@ -42,7 +56,7 @@ static void build_hess_tail(Model& mo) {
         if (mo.info.mayer || L.bc > 0) hpush(out, 0, n, xf0, xf1, true);
         return;
     }
-    if (L.sc == SC_MIDPOINT) {                                          // midpoint.jl:284-290
+    if (L.sc == SC_MIDPOINT) {                                          // midpoint.jl:284-290, euler.jl:337-343
         hpush(out, 0, n, xf0, xf1, true);
         return;
     }
@@ -235,7 +249,9 @@ Dir map_stage(const Layout& L, int64_t s, int j, const Var& v) {
         return Dir{true, n + v.c, HC_ONE};
     }
     if (L.sc == SC_MIDPOINT) {
-        if (v.kind == VK_X && (v.s == s || v.s == s + 1)) return Dir{true, v.c, HC_HALF};
+        if (L.euler == 0 && v.kind == VK_X && (v.s == s || v.s == s + 1)) return Dir{true, v.c, HC_HALF};
+        if (L.euler == 1 && v.kind == VK_X && v.s == s) return Dir{true, v.c, HC_ONE};          // f(t_i, X_i, U_i)
+        if (L.euler == 2 && v.kind == VK_X && v.s == s + 1) return Dir{true, v.c, HC_ONE};      // f(t_{i+1}, X_{i+1}, U_i)
         if (v.kind == VK_U && v.s == s) return Dir{true, n + v.c, HC_ONE};
         return Dir{false, 0, 0};
     }
@@ -273,6 +289,7 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
         if (v->kind == VK_V) continue;
         steps.insert(v->s);
         if (L.sc == SC_MIDPOINT && v->kind == VK_X) steps.insert(v->s - 1);
+        if (L.euler == 2 && v->kind == VK_U) steps.insert(v->s + 1);      // path point of node s+1 uses U_s (euler.jl:59-72)
     }
     const int64_t last_pt = (L.sc == SC_TRAPEZE) ? L.N : L.N - 1;
     const bool has_path_pt = L.p > 0 && L.sc != SC_TRAPEZE;
@@ -299,7 +316,8 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
                 out.push_back(Term{PT_LIN, s, R.oYX + kv->c, HC_NBH + 3 * vv->c + kv->l, HC_ONE});
         }
         if (has_path_pt && s < L.N) {
-            const Dir a = map_path(L, s, s, vr), b = map_path(L, s, s, vc);
+            const int64_t us = (L.euler == 2 && s >= 1) ? s - 1 : s;
+            const Dir a = map_path(L, s, us, vr), b = map_path(L, s, us, vc);
             if (a.ok && b.ok && mo.H.need_path[sym_index(R.md, a.d, b.d)])
                 out.push_back(Term{PT_PATH, s, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
         }
@@ -347,11 +365,11 @@ static bool segment_template(Model& mo, int64_t i, SegTmpl& t) {
             collect_terms(mo, row, col, tt);
             for (const Term& x : tt) {
                 if (x.pt == PT_FPATH || x.pt == PT_BND) return false;
-                const int64_t rel = i - x.step;
-                if (rel < 0 || rel > mo.H.HL) return false;
+                const int64_t rel = i - x.step;            // 0 own step, 1 previous, -1 next (slot code 2)
+                if (rel < -mo.H.HH || rel > mo.H.HL) return false;
                 const int pid = pair_id(mo.H, x.c1, x.c2);
                 if (pid < 0) return false;
-                t.terms.push_back(pack_term(x.di, pid, (int)rel));
+                t.terms.push_back(pack_term(x.di, pid, rel < 0 ? 2 : (int)rel));
             }
             if (tt.size() > (size_t)kMaxTerms) return false;
             t.tptr.push_back((uint32_t)t.terms.size());
@@ -369,6 +387,7 @@ int build_hess_model(Model& mo, std::string& err) {
     H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, L.s, L.free_time != 0);
     if (H.R.stride >= 65536) { err = "per-step Hessian record too large for 16-bit data indices"; return ST_EPATTERN; }
     H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
+    H.HH = (L.euler == 2 && L.p > 0) ? 1 : 0;       // implicit Euler: the path point of node i+1 couples X_{i+1} with U_i
     H.pairs.clear();
     pair_id(H, HC_ONE, HC_ONE);           // pair 0
     if (H.R.md > 31 || H.R.mdb > 31 || H.hk > 4) { err = "more than 31 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
@@ -540,7 +559,7 @@ int build_hess_model(Model& mo, std::string& err) {
 int default_hess_tile(const Model& mo) {
     const Layout& L = mo.L;
     const int64_t per_step = (int64_t)(L.blk + L.cb + mo.H.R.stride + 2) * 8;
-    const int64_t fit = (60 * 1024) / per_step - mo.H.HL - 1;
+    const int64_t fit = (60 * 1024) / per_step - mo.H.HL - mo.H.HH - 1;
     int64_t T = 1;
     while (T * 2 <= fit && T * 2 <= 32) T *= 2;
     while (T > 2 && (L.N + T - 1) / T < 256) T /= 2;
@@ -553,6 +572,7 @@ void Model::fill_hparams(HParams& hp, int tile) const {
     hp.R = H.R;
     hp.T = tile;
     hp.HL = H.HL;
+    hp.HH = H.HH;
     hp.ntiles = (int)((L.N + tile - 1) / tile);
     hp.Lseg = H.Lseg;
     hp.nterms = (int)H.terms.size();

@@ -61,6 +61,11 @@ static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
             L.blk = L.n + L.m; L.eqs = L.n;
             L.nvar = N * L.blk + L.n + L.nv;
             break;
+        case 7: case 8:           // Euler explicit / implicit: euler.jl:19-49 (midpoint's layout, evaluation at t_i or t_{i+1})
+            L.sc = SC_MIDPOINT; L.s = 0; L.cu = L.m; L.euler = scheme - 6;
+            L.blk = L.n + L.m; L.eqs = L.n;
+            L.nvar = N * L.blk + L.n + L.nv;
+            break;
         case 2: case 3: case 4:   // Gauss_Legendre_{1,2,3}, constant control: irk.jl:138-160
             L.sc = SC_IRK; L.s = scheme - 1; L.cu = L.m;
             set_butcher(L, L.s);
@@ -74,7 +79,7 @@ static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
             L.nvar = N * L.blk + L.n + L.nv;
             break;
         default:
-            err = "Unknown discretization method (valid: trapeze, midpoint, gauss_legendre_1, gauss_legendre_2/3[_constant_control])";
+            err = "Unknown discretization method (valid: trapeze, midpoint, euler, euler_implicit, gauss_legendre_1, gauss_legendre_2/3[_constant_control])";
             return ST_ESCHEME;
     }
     L.cb = L.eqs + L.p;
@@ -221,7 +226,7 @@ void Model::step_blocks(int64_t i, std::vector<Block>& out) const {
         push_block(out, path0, path1, vo + n, vo + n + m);        // :198
         push_block(out, path0, path1, v0, v1);                    // :203  (path rows only: hazard H1)
         if (pattern_mode == 1) push_block(out, dyn0, dyn1, v0, v1);   // STRUCTURAL: the block the comment at :202 intends
-    } else if (L.sc == SC_MIDPOINT) {                             // midpoint.jl:175-204
+    } else if (L.sc == SC_MIDPOINT) {                             // midpoint.jl:175-204; euler.jl:208-232 lists the same blocks
         push_block(out, co, co + n, vo, vo + blk + n);            // :192-194  x_i, u_i, x_i+1
         push_block(out, co + n, co + cb, vo, vo + n + m);         // :197-199
         push_block(out, co, co + cb, v0, v1);                     // :202
@@ -257,7 +262,8 @@ static void build_tail_blocks(Model& mo) {
     push_block(out, b0, b1, xf0, xf1);
     push_block(out, b0, b1, L.v_off, L.nvar);
     // leftover "lagrange state" entry of the stagewise scheme: irk_stagewise.jl:550-552 (hazard H2)
-    if (L.stagewise && mo.info.lagrange && n > 0) push_block(out, L.ncon - 1, L.ncon, n - 1, n);
+    // (euler.jl:257-259 has the same leftover)
+    if ((L.stagewise || L.euler) && mo.info.lagrange && n > 0) push_block(out, L.ncon - 1, L.ncon, n - 1, n);
 }
 
 void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
@@ -293,7 +299,7 @@ inline bool const_coef(int ci) { return ci == C_ZERO || ci == C_ONE || ci == C_N
 }  // namespace
 
 // d(row lr of a step) / d(local variable q); q in [0,blk): own block, [blk, blk+n): X_{i+1}, then U_{i+1} (trapeze)
-static Loc local_entry(const Model& mo, int lr, int q) {
+static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     const Layout& L = mo.L;
     const RecLayout& R = mo.R;
     const int n = L.n, m = L.m;
@@ -337,10 +343,24 @@ static Loc local_entry(const Model& mo, int lr, int q) {
     if (is_path) {
         const int pq = lr - L.eqs;
         if (kind == 0) return Loc{C_ONE, R.oPx + pq * n + c, 0, false};
-        if (kind == 1) return Loc{C_ONE, R.oPu + pq * m + c, 0, false};
+        // implicit Euler evaluates the path constraints of node i >= 1 with U_{i-1} (euler.jl:59-72): the pattern's
+        // (path_i, U_i) entries are structural zeros there
+        if (kind == 1) return (L.euler == 2 && step >= 1) ? kZero : Loc{C_ONE, R.oPu + pq * m + c, 0, false};
         return kZero;
     }
     const int r = lr;
+    if (L.sc == SC_MIDPOINT && L.euler == 1) {       // x_{i+1} - (x_i + h f(t_i, x_i, u_i)): euler.jl:141-159
+        if (kind == 0) return Loc{C_NH, F(0, r, c), r == c ? 2 : 0, false};
+        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
+        if (kind == 3) return Loc{C_ZERO, 0, r == c ? 1 : 0, false};
+        return kZero;
+    }
+    if (L.sc == SC_MIDPOINT && L.euler == 2) {       // x_{i+1} - (x_i + h f(t_{i+1}, x_{i+1}, u_i))
+        if (kind == 0) return Loc{C_ZERO, 0, r == c ? 2 : 0, false};
+        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
+        if (kind == 3) return Loc{C_NH, F(0, r, c), r == c ? 1 : 0, false};
+        return kZero;
+    }
     if (L.sc == SC_MIDPOINT) {
         if (kind == 0) return Loc{C_NHH, F(0, r, c), r == c ? 2 : 0, false};
         if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
@@ -384,7 +404,7 @@ Model::Entry Model::classify(int64_t row, int64_t col) const {
         if (col >= L.v_off) { set(local_entry_v(*this, lr, (int)(col - L.v_off)), i); return e; }
         const int64_t q = col - i * L.blk;
         if (q < 0 || q >= L.blk + n + m || col >= L.v_off) return e;   // not a local variable of this step: zero
-        set(local_entry(*this, lr, (int)q), i);
+        set(local_entry(*this, lr, (int)q, i), i);
         return e;
     }
     if (row < N * L.cb + L.p) {   // final path row
@@ -596,6 +616,9 @@ static int build_tables(Model& mo, std::string& err) {
     mo.dropped = 0;
     if (mo.pattern_mode == 0 && L.sc == SC_TRAPEZE && L.nv > 0 && (L.free_time || mo.dyn_v))
         mo.dropped = N * (int64_t)L.n * L.nv;
+    // implicit Euler: the path rows of nodes 2..N depend on U_{i-1}, the pattern lists U_i (euler.jl:59-72 vs :231), in
+    // either pattern mode (the periodic emit tables cannot reference the next step's record)
+    if (L.euler == 2 && L.p > 0 && L.m > 0) mo.dropped += (N - 1) * (int64_t)L.p * L.m;
     return ST_OK;
 }
 
@@ -679,7 +702,7 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.fused = mo.nch_dyn == 1 && (ro->info.npath == 0 || mo.nch_path == 1);      // Dirs<P>::FUSED
         mo.H.hk = ro->hk;
     }
-    if (d.scheme < 0 || d.scheme > 6) { err = "Unknown discretization method"; return ST_ESCHEME; }
+    if (d.scheme < 0 || d.scheme > 8) { err = "Unknown discretization method"; return ST_ESCHEME; }
     int64_t N = 0;
     int st = build_time(mo, d, N, err);
     if (st) return st;

@@ -29,7 +29,7 @@ struct HessModel {
     int64_t nnzh = 0;
     std::vector<Block> tail;          // blocks that do not belong to one step (already symmetrised)
     // regular part
-    int Lseg = 0, HL = 0;
+    int Lseg = 0, HL = 0, HH = 0;
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     std::vector<uint32_t> tptr, terms;            // Lseg + 1 offsets, term codes
     std::vector<uint32_t> vptr, vterms;           // V x V contributions of one step

@@ -70,7 +70,7 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     if (kp.has_edge && block == 0) {
         cx.is_edge = 1;
         cx.nslots = kp.n_edge_slots;
-        cx.in_stride = L.blk + L.n + L.m;
+        cx.in_stride = edge_in_stride(L);
         cx.a = cx.b = cx.lo = 0;
         cx.in = lds;
         cx.v = cx.in + cx.nslots * cx.in_stride;
@@ -126,7 +126,7 @@ inline int64_t pipe_lds_doubles(const KParams& kp) {
     const PipeGeom g = pipe_geom(kp);
     const Layout& L = kp.L;
     int64_t pipe = code_doubles(kp) + kMaxNV + 3 * (int64_t)g.in_sz + 3 * g.tau_sz + 2 * (int64_t)g.rec_sz;
-    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
+    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * edge_in_stride(L) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
                    (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
     return pipe > edge ? pipe : edge;
 }
@@ -136,7 +136,7 @@ inline int64_t lds_doubles(const KParams& kp) {
     const Layout& L = kp.L;
     const int64_t cap = kp.T + kp.HL + kp.HH;
     int64_t tile = code_doubles(kp) + (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
-    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * (L.blk + L.n + L.m) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
+    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * edge_in_stride(L) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
                    (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
     return tile > edge ? tile : edge;
 }
@@ -204,7 +204,9 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const int per = cx.in_stride;
         for (int e = tid; e < cx.nslots * per; e += nthr) {
             const int k = e / per, o = e - k * per;
-            const int64_t g = kp.edge_steps[k] * L.blk + o;
+            int64_t g = kp.edge_steps[k] * L.blk + o;
+            if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
+                g = (kp.edge_steps[k] >= 1 ? kp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
             cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
         }
         for (int e = tid; e <= 2 * cx.nslots; e += nthr)
@@ -335,7 +337,8 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
 #pragma unroll
             for (int kk = 0; kk < nv; ++kk) {
                 double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
-                if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (0.5 * (dti[kk] + (dti[kk] + dh[kk])));
+                if (P::DYN_T && FREE)
+                    w = w + ev[R.oft + r] * (L.euler == 0 ? 0.5 * (dti[kk] + (dti[kk] + dh[kk])) : (L.euler == 1 ? dti[kk] : dti[kk] + dh[kk]));
                 ev[R.oW + r * nv + kk] = w;
                 rec[R.oSv + r * nv + kk] = -(dh[kk] * f + h * w);
             }
@@ -449,6 +452,20 @@ template <class P, int S> CTD_HD void node_control(const KParams& kp, const doub
     }
 }
 
+// control of the path constraints of node i held by slot k: node_control, except for implicit Euler where
+// u(t_i) = U_{i-1} for i >= 1 (get_OCP_control_at_time_step, euler.jl:59-72): previous block of a tile / extra field of an edge input
+template <class P, int S> CTD_HD void path_control(const KParams& kp, const BlockCtx& cx, int k, int64_t i, double* u) {
+    const Layout& L = kp.L;
+    const double* base = cx.in + k * cx.in_stride;
+    if (L.euler == 2 && i >= 1 && (cx.is_edge || k >= 1)) {
+        const double* up = cx.is_edge ? base + L.blk + P::NX + P::NU : base - L.blk + P::NX;
+#pragma unroll
+        for (int c = 0; c < P::NU; ++c) u[c] = up[c];
+    } else {
+        node_control<P, S>(kp, base, u);
+    }
+}
+
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
 template <class P, int SC, int S>
 CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q) {
@@ -470,9 +487,16 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
-        t = 0.5 * (ti + time_of<P>(kp, cx.v, slot_tau(cx, k, 1)));
+        const double tip1 = time_of<P>(kp, cx.v, slot_tau(cx, k, 1));
+        if (L.euler == 0) {
+            t = 0.5 * (ti + tip1);
 #pragma unroll
-        for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + base[L.blk + c]);
+            for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + base[L.blk + c]);
+        } else {                                  // Euler: f(t_i, X_i, U_i, v) or f(t_{i+1}, X_{i+1}, U_i, v): euler.jl:86-102
+            t = (L.euler == 1) ? ti : tip1;
+#pragma unroll
+            for (int c = 0; c < n; ++c) xv[c] = (L.euler == 1) ? base[c] : base[L.blk + c];
+        }
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
@@ -607,7 +631,7 @@ CTD_HD void eval_step_path(const KParams& kp, const BlockCtx& cx, int k, int q) 
     if (i < 0 || i >= L.N) return;
     const double* base = cx.in + k * cx.in_stride;
     double uv[m > 0 ? m : 1];
-    node_control<P, S>(kp, base, uv);
+    path_control<P, S>(kp, cx, k, i, uv);
     double xv[n > 0 ? n : 1];
 #pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[c];

@@ -181,10 +181,14 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     }
     const double ti = obj_time<P>(op, v, i), tip1 = obj_time<P>(op, v, i + 1);
     const double h = tip1 - ti;
-    if (SC == SC_MIDPOINT) {           // midpoint.jl:87-97
-        for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+    if (SC == SC_MIDPOINT) {           // midpoint.jl:87-97; Euler (euler.jl:112-134): (t_i, X_i, U_i) or (t_{i+1}, X_{i+1}, U_i)
         for (int c = 0; c < m; ++c) u[c] = base[n + c];
-        return h * P::template lagrange<double>(0.5 * (ti + tip1), x, u, v);
+        if (L.euler == 0) {
+            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+            return h * P::template lagrange<double>(0.5 * (ti + tip1), x, u, v);
+        }
+        for (int c = 0; c < n; ++c) x[c] = (L.euler == 1) ? base[c] : base[L.blk + c];
+        return h * P::template lagrange<double>(L.euler == 1 ? ti : tip1, x, u, v);
     }
     // irk.jl:179-228 / irk_stagewise.jl:344-384
     const double* K = base + n + L.cu;
@@ -374,31 +378,35 @@ __global__ void __launch_bounds__(256) grad_units_kernel(const GradParams gp, co
                 gv[k] = dw * val + w * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * dtime_of<P>(ti, k) : 0.0));
             }
         } else if (SC == SC_MIDPOINT) {
-            // node i gathers step i (x_i, u_i, v) and step i-1 (x_i): h * l(0.5(t_i+t_{i+1}), 0.5(x_i+x_{i+1}), u_i, v)   (midpoint.jl:87-97)
+            // node i gathers step i (x_i, u_i, v) and step i-1 (x_i): h * l(0.5(t_i+t_{i+1}), 0.5(x_i+x_{i+1}), u_i, v)   (midpoint.jl:87-97).
+            // Euler (euler.jl:112-134) evaluates at (t_i, x_i) [explicit: only the own step reaches x_i] or (t_{i+1}, x_{i+1})
+            // [implicit: only the previous step does]; wa / wb are d x_eval / d x_i of the own / previous step's point
+            const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = L.euler == 0 ? 0.5 : (L.euler == 1 ? 0.0 : 1.0);
             double gx[n > 0 ? n : 1];
             for (int c = 0; c < n; ++c) gx[c] = 0.0;
             if (i < L.N) {
                 const double t0 = grad_tau<P>(gp, i), t1 = grad_tau<P>(gp, i + 1);
                 const double ta = grad_time<P>(gp, v, t0), tb = grad_time<P>(gp, v, t1), h = tb - ta;
-                for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (base[c] + base[L.blk + c]) : (L.euler == 1 ? base[c] : base[L.blk + c]);
                 for (int c = 0; c < m; ++c) u[c] = base[n + c];
-                lagrange_partials<P, 0>(0.5 * (ta + tb), x, u, v, val, lx, lu, lt, lv);
-                for (int c = 0; c < n; ++c) gx[c] = h * (0.5 * lx[c]);
+                lagrange_partials<P, 0>(L.euler == 0 ? 0.5 * (ta + tb) : (L.euler == 1 ? ta : tb), x, u, v, val, lx, lu, lt, lv);
+                if (wa != 0.0) for (int c = 0; c < n; ++c) gx[c] = h * (wa * lx[c]);
                 for (int c = 0; c < m; ++c) g[i * L.blk + n + c] = h * lu[c];
                 for (int k = 0; k < nv; ++k) {
                     const double d0 = FREE ? dtime_of<P>(t0, k) : 0.0, d1 = FREE ? dtime_of<P>(t1, k) : 0.0;
-                    gv[k] = (d1 - d0) * val + h * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * (0.5 * (d0 + d1)) : 0.0));
+                    const double dts = L.euler == 0 ? 0.5 * (d0 + d1) : (L.euler == 1 ? d0 : d1);
+                    gv[k] = (d1 - d0) * val + h * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * dts : 0.0));
                 }
             }
-            if (i >= 1) {
+            if (i >= 1 && wb != 0.0) {
                 const double* pb = base - L.blk;
                 const double ta = grad_time<P>(gp, v, grad_tau<P>(gp, i - 1)), tb = grad_time<P>(gp, v, grad_tau<P>(gp, i));
                 const double h = tb - ta;
-                for (int c = 0; c < n; ++c) x[c] = 0.5 * (pb[c] + pb[L.blk + c]);
+                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (pb[c] + pb[L.blk + c]) : pb[L.blk + c];
                 for (int c = 0; c < m; ++c) u[c] = pb[n + c];
                 double val2 = 0.0, lt2 = 0.0, lu2[m > 0 ? m : 1], lv2[nv > 0 ? nv : 1];
-                lagrange_partials<P, 0>(0.5 * (ta + tb), x, u, v, val2, lx, lu2, lt2, lv2);
-                for (int c = 0; c < n; ++c) gx[c] = gx[c] + h * (0.5 * lx[c]);
+                lagrange_partials<P, 0>(L.euler == 0 ? 0.5 * (ta + tb) : tb, x, u, v, val2, lx, lu2, lt2, lv2);
+                for (int c = 0; c < n; ++c) gx[c] = gx[c] + h * (wb * lx[c]);
             }
             for (int c = 0; c < n; ++c) g[i * L.blk + c] = gx[c];
         } else {

@@ -3,6 +3,7 @@
 // Restates the size/offset algebra of the reference's scheme structs:
 //   Trapeze   src/ode/trapeze.jl:14-42      [X_1,U_1, .., X_N+1,U_N+1, V]                (:1-4)
 //   Midpoint  src/ode/midpoint.jl:17-39     [X_1,U_1, .., X_N,U_N, X_N+1, V]             (:1-7)
+//   Euler     src/ode/euler.jl:10-50        same layout as midpoint (explicit and implicit) (:1-8)
 //   GL (cc)   src/ode/irk.jl:138-160        [X_i, U_i, K_i^1..K_i^s].., X_N+1, V         (:1-9)
 //   GL (sw)   src/ode/irk_stagewise.jl:136-163  [X_i, U_i^1..U_i^s, K_i^1..K_i^s].., X_N+1, V  (:6-11)
 // and the constraint layout [C_i^x, C_i^{k,1..s}, G_i].., G_N+1, B (irk_stagewise.jl:13-30).
@@ -35,7 +36,12 @@ struct Layout {
     int64_t v_off;         // nvar - nv : first optimisation variable
     double t0, tf;         // fixed values
     double a[9], b[3], c[3];   // Butcher tables (row-major a), Float64 arithmetic as in irk_stagewise.jl:61-64,103-109
+    int32_t euler;         // SC_MIDPOINT class only: 0 midpoint, 1 explicit Euler, 2 implicit Euler (src/ode/euler.jl:10-50)
+    int32_t pad_;
 };
+
+// doubles per record input of the edge block: own step block | X_{i+1} | U_{i+1} (trapeze) | U_{i-1} (implicit Euler's path control)
+CTD_HD int edge_in_stride(const Layout& L) { return L.blk + L.n + 2 * L.m; }
 
 // ---- per-step LDS record (doubles) -------------------------------------------------------------------
 // [0] = 1.0

@@ -32,7 +32,11 @@ SCHEMES = {
     "gauss_legendre_3_constant_control": 4,
     "gauss_legendre_2": 5,
     "gauss_legendre_3": 6,
+    "euler": 7,
+    "euler_implicit": 8,
 }
+# the reference's aliases (src/DOCP_data.jl:315-320)
+SCHEME_ALIASES = {"euler_explicit": "euler", "euler_forward": "euler", "euler_backward": "euler_implicit"}
 PROBLEMS = {
     "goddard": 0,
     "goddard_all": 1,
@@ -158,6 +162,7 @@ class DOCP:
         self.problem_name = ocp if isinstance(ocp, str) else {v: k for k, v in PROBLEMS.items()}.get(int(ocp), str(ocp))
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
         if isinstance(scheme, str):
+            scheme = SCHEME_ALIASES.get(scheme, scheme)
             if scheme not in SCHEMES:
                 _raise(_lib.CTD_ESCHEME, f"Unknown discretization method: {scheme}")    # src/DOCP_data.jl:342-349
             sid = SCHEMES[scheme]

@@ -59,7 +59,9 @@ enum {
     CTD_SCHEME_GAUSS_LEGENDRE_2_CONSTANT_CONTROL = 3,/* :gauss_legendre_2_constant_control    */
     CTD_SCHEME_GAUSS_LEGENDRE_3_CONSTANT_CONTROL = 4,/* :gauss_legendre_3_constant_control    */
     CTD_SCHEME_GAUSS_LEGENDRE_2 = 5,                 /* :gauss_legendre_2 (stagewise controls) */
-    CTD_SCHEME_GAUSS_LEGENDRE_3 = 6                  /* :gauss_legendre_3 (stagewise controls) */
+    CTD_SCHEME_GAUSS_LEGENDRE_3 = 6,                 /* :gauss_legendre_3 (stagewise controls) */
+    CTD_SCHEME_EULER = 7,                            /* :euler | :euler_explicit | :euler_forward (src/DOCP_data.jl:315-317, src/ode/euler.jl) */
+    CTD_SCHEME_EULER_IMPLICIT = 8                    /* :euler_implicit | :euler_backward (:318-320)                                           */
 };
 
 /* compiled OCP registry (the reference takes arbitrary Julia closures from CTModels; a GPU engine behind a C ABI

@@ -58,6 +58,8 @@ enum Scheme {
     GL3_CC = 4,   // :gauss_legendre_3_constant_control
     GL2_SW = 5,   // :gauss_legendre_2  (stagewise controls)
     GL3_SW = 6,   // :gauss_legendre_3
+    EULER_EXPLICIT = 7,   // :euler | :euler_explicit | :euler_forward      (src/DOCP_data.jl:315-317)
+    EULER_IMPLICIT = 8,   // :euler_implicit | :euler_backward               (src/DOCP_data.jl:318-320)
 };
 
 struct Dims { int NLP_x, NLP_u, NLP_v, path_cons, boundary_cons; };               // DOCP_data.jl:88-94
@@ -70,6 +72,7 @@ struct Disc {                                                                   
     double b[3] = {0};
     double c[3] = {0};
     bool irk = false, stagewise = false;
+    bool euler = false, euler_explicit = true;   // euler.jl:10-50
     int control_block = 0;            // stagewise only
     int step_variables_block = 0;
     int state_stage_eqs_block = 0;
@@ -139,6 +142,14 @@ static void build_scheme(Docp& p, int scheme) {
             d.step_pathcons_block = m.path_cons;
             p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
             break;
+        case EULER_EXPLICIT: case EULER_IMPLICIT:                 // euler.jl:19-49 (same layout as midpoint)
+            d.euler = true;
+            d.euler_explicit = scheme == EULER_EXPLICIT;
+            d.step_variables_block = m.NLP_x + m.NLP_u;
+            d.state_stage_eqs_block = m.NLP_x;
+            d.step_pathcons_block = m.path_cons;
+            p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
+            break;
         case GL1_CC: case GL2_CC: case GL3_CC: {                  // irk.jl:138-160
             int s = scheme - GL1_CC + 1;
             set_butcher(d, s);
@@ -199,6 +210,12 @@ template <class T> static void get_OCP_control(const T* xu, const Docp& p, int64
             const T* uj = get_stagecontrol(xu, p, i, j);
             for (int k = 0; k < m; ++k) ui[k] = ui[k] + p.disc.b[j - 1] * uj[k];
         }
+    } else if (p.disc.euler) {                     // euler.jl:59-72: explicit u(t_N+1) = U_N, implicit u(t_1) = U_1 and u(t_i) = U_{i-1}
+        int64_t blk;
+        if (p.disc.euler_explicit) blk = (i == p.steps + 1 ? p.steps : i) - 1;
+        else blk = (i == 1 ? 2 : i) - 2;
+        const T* u = xu + blk * p.disc.step_variables_block + p.dims.NLP_x;
+        for (int k = 0; k < m; ++k) ui[k] = u[k];
     } else {
         const T* u = get_control_generic(xu, p, i);
         for (int k = 0; k < m; ++k) ui[k] = u[k];
@@ -251,6 +268,14 @@ template <class P, class T> static void constraints(const Docp& p, const T* xu, 
             for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
             P::template dynamics<T>(&work[(i - 1) * n], ts, xs.data(), get_control_generic(xu, p, i), v);
         }
+    } else if (d.euler) {                         // euler.jl:79-105: f at (t_i, x_i, u_i) or (t_i+1, x_i+1, u(t_i+1) = U_i)
+        work.resize((size_t)n * N);
+        std::vector<T> uw(m > 0 ? m : 1);
+        for (int64_t i = 1; i <= N; ++i) {
+            const int64_t index = d.euler_explicit ? i : i + 1;
+            get_OCP_control(xu, p, index, uw.data());
+            P::template dynamics<T>(&work[(i - 1) * n], grid[index - 1], get_state(xu, p, index), uw.data(), v);
+        }
     } else {                                      // irk.jl:167-172, irk_stagewise.jl:235-239: [x_ij ; sum_bk]
         work.resize(2 * (size_t)n);
     }
@@ -273,6 +298,10 @@ template <class P, class T> static void constraints(const Docp& p, const T* xu, 
             }
         } else if (d.scheme == MIDPOINT) {        // midpoint.jl:124-140 (control_steps == 1)
             T hi = (tip1 - ti) / 1.0;
+            const T* fi = &work[(i - 1) * n];
+            for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * fi[k]);
+        } else if (d.euler) {                     // euler.jl:141-159
+            T hi = tip1 - ti;
             const T* fi = &work[(i - 1) * n];
             for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * fi[k]);
         } else {                                  // irk.jl:236-308 / irk_stagewise.jl:394-460
@@ -356,6 +385,14 @@ template <class P, class T> static T objective(const Docp& p, const T* xu) {
                 const T* xip1 = get_state(xu, p, i + 1);
                 for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
                 value = value + hi * P::template lagrange<T>(ts, xs.data(), get_control_generic(xu, p, i), v);
+            }
+        } else if (d.euler) {                     // euler.jl:112-134
+            std::vector<T> uw(m > 0 ? m : 1);
+            for (int64_t i = 1; i <= N; ++i) {
+                const int64_t index = d.euler_explicit ? i : i + 1;
+                get_OCP_control(xu, p, index, uw.data());
+                T hi = grid[i] - grid[i - 1];
+                value = value + hi * P::template lagrange<T>(grid[index - 1], get_state(xu, p, index), uw.data(), v);
             }
         } else {                                  // irk.jl:179-228 / irk_stagewise.jl:344-384
             std::vector<T> work_xij(n);
@@ -576,7 +613,32 @@ static void jacobian_pattern_ij(const Docp& p, IJ& ij) {
         ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
         return;
     }
-    if (d.scheme == MIDPOINT) {                                        // midpoint.jl:163-233
+    if (d.euler) {                                                     // euler.jl:166-263
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t c_block = c_block_step, c_offset = (i - 1) * c_block;
+            int64_t dyn_start = c_offset + 1, dyn_end = c_offset + dm.NLP_x, dyn_lag = c_offset + dm.NLP_x;
+            int64_t path_start = c_offset + dm.NLP_x + 1, path_end = c_offset + c_block;
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1, xi_end = var_offset + dm.NLP_x, li = var_offset + dm.NLP_x;
+            int64_t ui_start = var_offset + dm.NLP_x + 1, ui_end = var_offset + dm.NLP_x + dm.NLP_u;
+            int64_t xip1_end = var_offset + blk + dm.NLP_x, lip1 = var_offset + blk + dm.NLP_x;
+            ij.block(dyn_start, dyn_end, xi_start, xi_end);                                    // :208-210
+            ij.block(dyn_start, dyn_end, ui_start, xip1_end);
+            ij.block(dyn_start, dyn_end, v_start, v_end);
+            if (p.flags.lagrange) {                                                            // :214-226 (stale "lagrange state" entries)
+                if (d.euler_explicit) {
+                    ij.block(dyn_lag, dyn_lag, xi_start, ui_end);
+                    ij.single(dyn_lag, lip1);
+                } else {
+                    ij.block(dyn_lag, dyn_lag, li, lip1);
+                }
+                ij.block(dyn_lag, dyn_lag, v_start, v_end);
+            }
+            ij.block(path_start, path_end, xi_start, xi_end);                                  // :230-232
+            ij.block(path_start, path_end, ui_start, ui_end);
+            ij.block(path_start, path_end, v_start, v_end);
+        }
+    } else if (d.scheme == MIDPOINT) {                                 // midpoint.jl:163-233
         for (int64_t i = 1; i <= N; ++i) {
             int64_t c_block = c_block_step, c_offset = (i - 1) * c_block;
             int64_t var_offset = (i - 1) * blk;
@@ -624,7 +686,7 @@ static void jacobian_pattern_ij(const Docp& p, IJ& ij) {
     ij.block(c_offset + 1, c_offset + c_block, 1, dm.NLP_x);
     ij.block(c_offset + 1, c_offset + c_block, xf_start, xf_end);
     ij.block(c_offset + 1, c_offset + c_block, v_start, v_end);
-    if (d.stagewise && p.flags.lagrange)                               // irk_stagewise.jl:550-552 (hazard H2)
+    if ((d.stagewise || d.euler) && p.flags.lagrange)                  // irk_stagewise.jl:550-552, euler.jl:257-259 (hazard H2)
         ij.single(p.dim_NLP_constraints, dm.NLP_x);
 }
 
@@ -645,6 +707,31 @@ static void hessian_pattern_ij(const Docp& p, IJ& ij) {
             int64_t var_offset = N * blk;
             ij.block(1, dm.NLP_x, var_offset + 1, var_offset + dm.NLP_x, true);
         }
+        return;
+    }
+    if (d.euler) {                                                     // euler.jl:270-355
+        for (int64_t i = 1; i <= N; ++i) {
+            int64_t var_offset = (i - 1) * blk;
+            int64_t xi_start = var_offset + 1, xi_end = var_offset + dm.NLP_x;
+            int64_t xip1_start = var_offset + blk + 1, xip1_end = var_offset + blk + dm.NLP_x;
+            int64_t ui_start = var_offset + dm.NLP_x + 1, ui_end = var_offset + dm.NLP_x + dm.NLP_u;
+            ij.block(ui_start, ui_end, ui_start, ui_end);
+            ij.block(ui_start, ui_end, v_start, v_end, true);
+            if (d.euler_explicit) {
+                ij.block(xi_start, xi_end, xi_start, xi_end);
+                ij.block(xi_start, xi_end, ui_start, ui_end, true);
+                ij.block(xi_start, xi_end, v_start, v_end, true);
+            } else {
+                ij.block(xip1_start, xip1_end, xip1_start, xip1_end);
+                ij.block(xip1_start, xip1_end, ui_start, ui_end, true);
+                ij.block(xip1_start, xip1_end, v_start, v_end, true);
+                ij.block(xi_start, xi_end, xi_start, xi_end);
+                ij.block(xi_start, xi_end, ui_start, ui_end, true);
+                ij.block(xi_start, xi_end, v_start, v_end, true);
+            }
+        }
+        int64_t var_offset = N * blk;
+        ij.block(1, dm.NLP_x, var_offset + 1, var_offset + dm.NLP_x, true);
         return;
     }
     if (d.scheme == MIDPOINT) {                                        // midpoint.jl:240-300
@@ -680,7 +767,7 @@ static void hessian_pattern_ij(const Docp& p, IJ& ij) {
 
 // Greedy distance-1 column colouring in natural order (stand-in for SparseMatrixColorings' column colouring
 // used by ADNLPModels.SparseADJacobian; any valid colouring decompresses to the same values).
-static void color_columns(Docp& p) {
+static void color_columns(Docp& p, const std::vector<int64_t>& colptr, const std::vector<int64_t>& rowval) {
     const int64_t ncol = p.dim_NLP_variables, nrow = p.dim_NLP_constraints;
     std::vector<std::vector<int>> rowcolors(nrow);
     p.color.assign(ncol, -1);
@@ -688,13 +775,13 @@ static void color_columns(Docp& p) {
     std::vector<char> forbidden;
     for (int64_t j = 0; j < ncol; ++j) {
         forbidden.assign(p.ncolors + 1, 0);
-        for (int64_t k = p.colptr[j]; k < p.colptr[j + 1]; ++k)
-            for (int cidx : rowcolors[p.rowval[k]]) forbidden[cidx] = 1;
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k)
+            for (int cidx : rowcolors[rowval[k]]) forbidden[cidx] = 1;
         int cidx = 0;
         while (cidx < p.ncolors && forbidden[cidx]) ++cidx;
         if (cidx == p.ncolors) ++p.ncolors;
         p.color[j] = cidx;
-        for (int64_t k = p.colptr[j]; k < p.colptr[j + 1]; ++k) rowcolors[p.rowval[k]].push_back(cidx);
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) rowcolors[rowval[k]].push_back(cidx);
     }
 }
 
@@ -703,7 +790,21 @@ static void ensure_pattern(Docp& p) {
     IJ ij;
     jacobian_pattern_ij(p, ij);
     to_csc(ij, p.dim_NLP_variables, p.colptr, p.rowval);
-    color_columns(p);
+    // The colouring must see every TRUE structural nonzero or the compressed passes mix columns.  The reference's manual
+    // patterns miss some (hazards: trapeze dynamics x v, trapeze.jl:203; implicit Euler path_i x U_{i-1}, euler.jl:59-72 vs
+    // :231), so the oracle colours on the pattern plus those blocks and reports the exact partials at the pattern's positions.
+    const Disc& d = p.disc;
+    const Dims& dm = p.dims;
+    const int64_t cb = d.state_stage_eqs_block + d.step_pathcons_block, blk = d.step_variables_block;
+    if (d.scheme == TRAPEZE)
+        for (int64_t i = 1; i <= p.steps; ++i)
+            ij.block((i - 1) * cb + 1, (i - 1) * cb + dm.NLP_x, p.dim_NLP_variables - dm.NLP_v + 1, p.dim_NLP_variables);
+    if (d.euler && !d.euler_explicit && dm.path_cons > 0 && dm.NLP_u > 0)
+        for (int64_t i = 2; i <= p.steps; ++i)
+            ij.block((i - 1) * cb + dm.NLP_x + 1, i * cb, (i - 2) * blk + dm.NLP_x + 1, (i - 2) * blk + dm.NLP_x + dm.NLP_u);
+    std::vector<int64_t> ccp, crv;
+    to_csc(ij, p.dim_NLP_variables, ccp, crv);
+    color_columns(p, ccp, crv);
     p.have_pattern = true;
 }
 

@@ -23,6 +23,8 @@ SCHEMES = {
     "gauss_legendre_3_constant_control": 4,
     "gauss_legendre_2": 5,
     "gauss_legendre_3": 6,
+    "euler": 7,
+    "euler_implicit": 8,
 }
 PROBLEMS = {
     "goddard": 0,

@@ -306,6 +306,8 @@ SCHEMES = {
     "gauss_legendre_3_constant_control": ("irk", 3, False),
     "gauss_legendre_2": ("irk", 2, True),
     "gauss_legendre_3": ("irk", 3, True),
+    "euler": ("euler_explicit", 0, False),           # src/ode/euler.jl (explicit=true)
+    "euler_implicit": ("euler_implicit", 0, False),  # src/ode/euler.jl (explicit=false)
 }
 
 
@@ -330,7 +332,7 @@ class Docp:
         if self.kind == "trapeze":
             self.blk, self.eqs, self.final_control = n + m, n, True
             self.nvar = self.N * self.blk + n + nv + m
-        elif self.kind == "midpoint":
+        elif self.kind in ("midpoint", "euler_explicit", "euler_implicit"):
             self.blk, self.eqs, self.final_control = n + m, n, False
             self.nvar = self.N * self.blk + n + nv
         else:
@@ -368,6 +370,12 @@ class Docp:
             for j in range(2, self.s + 1):
                 ui = [a + mpf(self.b[j - 1]) * b for a, b in zip(ui, self.Ustage(xu, i, j))]
             return ui
+        if self.kind == "euler_explicit":                       # euler.jl:59-72
+            return self.Ugen(xu, i)
+        if self.kind == "euler_implicit":                       # u(t_1) = U_1, u(t_i) = U_{i-1}
+            j = (2 if i == 1 else i) - 1
+            o = (j - 1) * self.blk + self.P.n
+            return xu[o:o + self.P.m]
         return self.Ugen(xu, i)
 
     def grid(self, xu):
@@ -388,13 +396,18 @@ class Docp:
                 ts = mpf("0.5") * (T[i - 1] + T[i])
                 xs = [mpf("0.5") * (a + b) for a, b in zip(self.X(xu, i), self.X(xu, i + 1))]
                 work.append(P.dynamics(ts, xs, self.Ugen(xu, i), v))
+        elif self.kind in ("euler_explicit", "euler_implicit"):       # euler.jl:79-105
+            work = []
+            for i in range(1, N + 1):
+                idx = i if self.kind == "euler_explicit" else i + 1
+                work.append(P.dynamics(T[idx - 1], self.X(xu, idx), self.Uctl(xu, idx), v))
         for i in range(1, N + 1):
             ti, tip1 = T[i - 1], T[i]
             xi, xip1 = self.X(xu, i), self.X(xu, i + 1)
             if self.kind == "trapeze":
                 hh = mpf("0.5") * (tip1 - ti)
                 c += [xip1[k] - (xi[k] + hh * (work[i - 1][k] + work[i][k])) for k in range(n)]
-            elif self.kind == "midpoint":
+            elif self.kind in ("midpoint", "euler_explicit", "euler_implicit"):
                 hi = tip1 - ti
                 c += [xip1[k] - (xi[k] + hi * work[i - 1][k]) for k in range(n)]
             else:
@@ -446,6 +459,11 @@ class Docp:
                     ts = mpf("0.5") * (T[i - 1] + T[i])
                     xs = [mpf("0.5") * (a + b) for a, b in zip(self.X(xu, i), self.X(xu, i + 1))]
                     val = val + hi * P.lagr(ts, xs, self.Ugen(xu, i), v)
+            elif self.kind in ("euler_explicit", "euler_implicit"):      # euler.jl:112-134
+                for i in range(1, N + 1):
+                    idx = i if self.kind == "euler_explicit" else i + 1
+                    hi = T[i] - T[i - 1]
+                    val = val + hi * P.lagr(T[idx - 1], self.X(xu, idx), self.Uctl(xu, idx), v)
             else:
                 for i in range(1, N + 1):
                     ti = T[i - 1]
@@ -628,6 +646,15 @@ def main():
     run_case("freet0tf_midpoint_N3", DoubleIntegratorFreeT0Tf(), "midpoint", N=3)
     run_case("freet0tf_gl2_N2", DoubleIntegratorFreeT0Tf(), "gauss_legendre_2", N=2)
     run_case("freet0tf_trapeze_N3", DoubleIntegratorFreeT0Tf(), "trapeze", N=3)
+    run_case("goddard_euler_N4", Goddard(), "euler", N=4)
+    run_case("goddard_all_euler_implicit_N4", GoddardAll(), "euler_implicit", N=4)
+    run_case("goddard_all_euler_nonuniform", GoddardAll(), "euler", time_grid=[0.0, 0.3, 0.5, 0.6, 1.0])
+    run_case("dip_euler_implicit_N3", DoubleIntegratorPath(), "euler_implicit", N=3)
+    run_case("quadrotor_euler_N3", Quadrotor8(), "euler", N=3)
+    run_case("quadrotor_euler_implicit_N2", Quadrotor8(), "euler_implicit", N=2)
+    run_case("lsq_euler_implicit_N3", LeastSquaresConstraint(), "euler_implicit", N=3)
+    run_case("freet0tf_euler_N3", DoubleIntegratorFreeT0Tf(), "euler", N=3)
+    run_case("freet0tf_euler_implicit_N3", DoubleIntegratorFreeT0Tf(), "euler_implicit", N=3)
 
 
 if __name__ == "__main__":

@@ -173,6 +173,14 @@ def main():
         run_case("freet0tf_gl2_N2", gg.DoubleIntegratorFreeT0Tf(), "gauss_legendre_2", N=2)
         run_case("freet0tf_trapeze_N3", gg.DoubleIntegratorFreeT0Tf(), "trapeze", N=3)
         run_case("scalar_gauss_legendre_2_perturbed", gg.StagewiseScalar(), "gauss_legendre_2", time_grid=[0.0, 0.2, 0.6, 1.0])
+        run_case("goddard_euler_N4", gg.Goddard(), "euler", N=4)
+        run_case("goddard_all_euler_implicit_N4", gg.GoddardAll(), "euler_implicit", N=4)
+        run_case("dip_euler_implicit_N3", gg.DoubleIntegratorPath(), "euler_implicit", N=3)
+        run_case("quadrotor_euler_N3", gg.Quadrotor8(), "euler", N=3)
+        run_case("quadrotor_euler_implicit_N2", gg.Quadrotor8(), "euler_implicit", N=2)
+        run_case("lsq_euler_implicit_N3", gg.LeastSquaresConstraint(), "euler_implicit", N=3)
+        run_case("freet0tf_euler_N3", gg.DoubleIntegratorFreeT0Tf(), "euler", N=3)
+        run_case("freet0tf_euler_implicit_N3", gg.DoubleIntegratorFreeT0Tf(), "euler_implicit", N=3)
     finally:
         gg.Du, gg.dexp, gg.dsin, gg.dcos = gg_first_order
 

@@ -73,7 +73,7 @@ def test_error_codes():
     with pytest.raises(ValueError):                                   # ArgumentError, src/DOCP_data.jl:186-189
         ct.DOCP("goddard", scheme="midpoint", time_grid=[0.0, 0.5, 0.5, 1.0], device=-1)
     with pytest.raises(ct.CTDirectError) as e:                        # error(...), src/DOCP_data.jl:342-349
-        ct.DOCP("goddard", 10, "euler", device=-1)
+        ct.DOCP("goddard", 10, "runge_kutta_4", device=-1)
     assert e.value.status == ct._lib.CTD_ESCHEME
     with pytest.raises(ct.CTDirectError) as e:
         ct.DOCP(99, 10, "midpoint", device=-1)

