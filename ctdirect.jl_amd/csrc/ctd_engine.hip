@@ -92,6 +92,7 @@ struct ctd_handle {
     int64_t* d_hedge_idx = nullptr;
     uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
+    unsigned int* d_hcounter = nullptr;
     std::string err;
 };
 
@@ -129,7 +130,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals, (void*)h->d_hcounter})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -807,6 +808,15 @@ static int32_t ensure_hess(ctd_handle* h) {
     hp.edge_idx = h->d_hedge_idx; hp.eptr = h->d_heptr; hp.evptr = h->d_hevptr; hp.eterms = h->d_heterms;
     hp.tasks = h->d_htasks; hp.ptasks = h->d_hptasks; hp.btasks = h->d_hbtasks;
     hp.partials = h->d_hpartials;
+    // V x V partials: added by a second, one-workgroup kernel (default).  CTD_HESS_FINISH=last lets the last workgroup of
+    // the main kernel do it instead -- measured 2-7x SLOWER on MI355X (profiles/r01_hessian_kernel.md): the device-scope
+    // release every workgroup then needs writes the whole XCD L2 back.  Kept as a measured alternative only.
+    const char* fin = std::getenv("CTD_HESS_FINISH");
+    if (fin && std::string(fin) == "last") {
+        HIP_TRY(h, hipMalloc((void**)&h->d_hcounter, sizeof(unsigned int)));
+        HIP_TRY(h, hipMemset(h->d_hcounter, 0, sizeof(unsigned int)));
+        hp.done_counter = h->d_hcounter;
+    }
     hp.debug_stop = env_int("CTD_HESS_STOP", 0);
     h->hess_ready = true;
     return CTD_OK;
@@ -828,7 +838,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
         void* args[] = {&hp, &x_dev, &y_dev};
         e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, timed ? h->ev0 : nullptr,
                        timed ? h->ev1 : nullptr);
-        if (e == hipSuccess && hp.nvv > 0) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
+        if (e == hipSuccess && hp.nvv > 0 && !hp.done_counter) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;

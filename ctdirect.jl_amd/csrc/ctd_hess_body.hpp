@@ -658,7 +658,8 @@ CTD_HD void hess_phase_vvsum(const HParams& hp, const HBlockCtx& cx, int block, 
 // V x V entries: sum of the per-workgroup partials in a fixed order (lane t takes workgroups t, t + nthr, ...; then a tree)
 CTD_HD double hess_finish_partial(const HParams& hp, int e, int tid, int nthr) {
     double acc = 0.0;
-    for (int b = tid; b <= hp.ntiles; b += nthr) acc = acc + hp.partials[(int64_t)b * hp.nvv + e];
+    const volatile double* part = hp.partials;       // written by other workgroups of the same launch (last-workgroup finish)
+    for (int b = tid; b <= hp.ntiles; b += nthr) acc = acc + part[(int64_t)b * hp.nvv + e];
     return acc;
 }
 

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(kHessBlock) void hess_kernel(const HParams hp, cons
     if (hp.nvv > 0) {
         __syncthreads();
         hess_phase_vvsum(hp, cx, blockIdx.x, tid, nthr);
+        if (hp.done_counter) {
+            // V x V entries without a second launch: every workgroup publishes its partial (release at device scope), counts
+            // itself, and the last one to arrive (acquire) adds all partials in the same fixed order as hess_finish_kernel
+            __shared__ int hess_is_last;
+            __shared__ double hess_red[kHessBlock];
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) hess_is_last = (atomicAdd(hp.done_counter, 1u) == gridDim.x - 1) ? 1 : 0;
+            __syncthreads();
+            if (hess_is_last) {
+                __threadfence();
+                for (int e = 0; e < hp.nvv; ++e) {
+                    hess_red[tid] = hess_finish_partial(hp, e, tid, nthr);
+                    __syncthreads();
+                    for (int off = nthr >> 1; off > 0; off >>= 1) {
+                        if (tid < off) hess_red[tid] = hess_red[tid] + hess_red[tid + off];
+                        __syncthreads();
+                    }
+                    if (tid == 0) hp.vals[hp.vv_idx[e]] = hess_red[0];
+                    __syncthreads();
+                }
+                if (tid == 0) *hp.done_counter = 0u;
+            }
+        }
     }
     hess_stamp(hp, 3);
     if (hp.stamps) {             // diagnostics: time until this workgroup's stores have left the CU
@@ -79,7 +103,7 @@ hipError_t launch_hess_variant(const HParams& hp, const double* xu, const double
     const int grid = hp.ntiles + 1;
     if (e0 || e1) hipExtLaunchKernelGGL((hess_kernel<P, SC, S>), dim3(grid), dim3(kHessBlock), lds_bytes, st, e0, e1, 0, hp, xu, y);
     else hess_kernel<P, SC, S><<<grid, kHessBlock, lds_bytes, st>>>(hp, xu, y);
-    if (hp.nvv > 0) hess_finish_kernel<P><<<1, kHessBlock, 0, st>>>(hp);
+    if (hp.nvv > 0 && !hp.done_counter) hess_finish_kernel<P><<<1, kHessBlock, 0, st>>>(hp);
     return hipGetLastError();
 }
 

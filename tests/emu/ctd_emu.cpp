@@ -238,6 +238,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     hp.vals = vals;
     std::vector<double> partials((size_t)(hp.ntiles + 1) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
     hp.partials = partials.data();
+    hp.done_counter = nullptr;     // the emulator steps the separate finish
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {
