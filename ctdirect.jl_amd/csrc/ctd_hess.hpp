@@ -36,12 +36,12 @@ constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3
 //     RK[k*n + a] = h HD[x_a][V_k] + dh/dv_k dPhi/dx_a, the d2/dK dV_k entry up to the factor a_jl)
 // HP[md*md]   path point of the step (Gauss-Legendre / midpoint with path constraints)
 // YX[n]       multipliers of the state-equation rows (Gauss-Legendre with free times: d2/dK^l dV_k of -h b_l y'K^l)
-// CP[kMaxPairs] products C[c1] C[c2] of the chain-rule coefficients, one per pair the term tables use (HParams::pairs)
+// (the products C[c1] C[c2] of the chain-rule coefficients live in a separate LDS table of npairs doubles per slot, cx.cp)
 // The boundary record holds HB[mdb*mdb], mdb = 2n + nv (directions x0 | xf | V); the final-path record uses HP.
 struct HessRecLayout {
     int32_t md, mdb, S;
     int32_t stage_sz, oStage, oRK;   // stage block j at oStage + j * stage_sz: HD at +0, RK at +oRK
-    int32_t oHP, oYX, oZero, oCP;   // rec[oZero] = 0.0: target of padded (absent) terms
+    int32_t oHP, oYX, oZero;        // rec[oZero] = 0.0: target of padded (absent) terms
     int32_t stride;
 };
 
@@ -60,8 +60,7 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
     int end_b = r.mdb * r.mdb;
     int body = end_step > end_b ? end_step : end_b;
     r.oZero = body;
-    r.oCP = body + 1;
-    r.stride = body + 1 + kMaxPairs;
+    r.stride = body + 1;
     if ((r.stride & 1) == 0) r.stride += 1;
     return r;
 }

@@ -36,6 +36,7 @@ struct HBlockCtx {
     double* v;
     double* tau;    // tile: tau[e] = tau_{lo - 1 + e}; edge: 3 per slot (previous, own, next), then tau_N
     double* rec;
+    double* cp;     // coefficient products: npairs per slot (hess_pair), slot k at cp + k * npairs
     double* red;    // tile: nvv * T per-step V x V contributions (summed in step order by hess_phase_vvsum)
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
     const uint32_t *tptr, *terms, *vptr, *vterms;
@@ -70,6 +71,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.v = cx.ly + 2 * cx.nslots * L.cb + L.p + L.bc;
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + 3 * kMaxHessEdgeSlots + 1;
+        cx.cp = cx.rec + (cx.nslots + 2) * hp.R.stride;
         cx.red = cx.rec;
     } else {
         const int tile = block - 1;
@@ -97,7 +99,8 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.v = cx.ly + (cap + 1) * L.cb;
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + cap + 3;
-        cx.red = cx.rec + cap * hp.R.stride;
+        cx.cp = cx.rec + cap * hp.R.stride;
+        cx.red = cx.cp + cap * hp.npairs;
     }
     return cx;
 }
@@ -106,9 +109,9 @@ inline int64_t hess_lds_doubles(const HParams& hp) {
     const Layout& L = hp.L;
     const int64_t cap = hp.T + hp.HL + hp.HH;
     const int64_t tile = hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
-                         cap * hp.R.stride + (int64_t)hp.nvv * hp.T;
+                         cap * (hp.R.stride + hp.npairs) + (int64_t)hp.nvv * hp.T;
     const int64_t edge = (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
-                         3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * hp.R.stride;
+                         3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * (hp.R.stride + hp.npairs);
     return tile > edge ? tile : edge;
 }
 
@@ -210,7 +213,7 @@ CTD_HD void hess_pair(const HParams& hp, const HBlockCtx& cx, int k, int pid) {
     const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
     const double h = htime_of<P>(hp, cx.v, tau1) - htime_of<P>(hp, cx.v, tau0);
     const int code = hp.pairs[pid];
-    rec[R.oCP + pid] = hess_coef_value<P>(L, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(L, code >> 8, h, tau0, tau1);
+    cx.cp[k * hp.npairs + pid] = hess_coef_value<P>(L, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(L, code >> 8, h, tau0, tau1);
     if (pid == 0) rec[R.oZero] = 0.0;
     if (SC == SC_IRK && Dirs<P>::FREE && pid == 0) {
         const double* y = hslot_y(hp, cx, k);
@@ -525,7 +528,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         for (int e = tid; e < 2 * hp.npairs; e += nthr) {
             const int which = e / hp.npairs, pid = e - which * hp.npairs;
             const int code = hp.pairs[pid];
-            cx.rec[(hp.edge_fp + which) * R.stride + R.oCP + pid] =
+            cx.cp[(hp.edge_fp + which) * hp.npairs + pid] =
                 hess_coef_value<P>(L, code & 0xFF, 0.0, 0.0, 0.0) * hess_coef_value<P>(L, code >> 8, 0.0, 0.0, 0.0);
         }
     }
@@ -534,9 +537,8 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
 // ------------------------------------------------------------------------------------------------------
 // phase: emit
 // ------------------------------------------------------------------------------------------------------
-CTD_HD double hess_term(const double* rec, int stride, int oCP, uint32_t code, int slot) {
-    const double* r = rec + slot * stride;
-    return r[oCP + term_pair(code)] * r[term_di(code)];
+CTD_HD double hess_term(const double* rec, int stride, const double* cp, int npairs, uint32_t code, int slot) {
+    return cp[slot * npairs + term_pair(code)] * rec[slot * stride + term_di(code)];
 }
 
 // largest term count among the (up to 64) segment positions w0 .. w0 + nwl - 1 handled by one wave: wave-uniform by
@@ -560,13 +562,14 @@ CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDi
 
 // the steps ibeg, ibeg + G, ... < iend of one segment entry with NT (possibly padded) terms
 template <int NT>
-CTD_HD void hess_emit_steps(const double* rec, int stride, const int* cpo, const int* dio, double* out, int64_t ibeg, int64_t iend,
-                            int G, int64_t lo, int64_t reg_first, int Lseg) {
+CTD_HD void hess_emit_steps(const double* rec, int stride, const double* cp, int npairs, const int* cpo, const int* dio, double* out,
+                            int64_t ibeg, int64_t iend, int G, int64_t lo, int64_t reg_first, int Lseg) {
     for (int64_t i = ibeg; i < iend; i += G) {
         const double* rk = rec + (int)(i - lo) * stride;
+        const double* ck = cp + (int)(i - lo) * npairs;
         double a[NT > 0 ? NT : 1], b[NT > 0 ? NT : 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { a[t] = rk[cpo[t]]; b[t] = rk[dio[t]]; }
+        for (int t = 0; t < NT; ++t) { a[t] = ck[cpo[t]]; b[t] = rk[dio[t]]; }
         double acc = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc = acc + a[t] * b[t];
@@ -582,7 +585,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
             double acc = 0.0;
             for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];
-                acc = acc + hess_term(cx.rec, R.stride, R.oCP, code, term_slot(code));
+                acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, code, term_slot(code));
             }
             hp.vals[hp.edge_idx[e]] = acc;
         }
@@ -590,7 +593,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
             double acc = 0.0;
             for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];
-                acc = acc + hess_term(cx.rec, R.stride, R.oCP, code, term_slot(code));
+                acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, code, term_slot(code));
             }
             hp.partials[e] = acc;
         }
@@ -616,21 +619,21 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
         for (int t = 0; t < kMaxTerms; ++t) {
             const uint32_t code = (t < nt) ? cx.terms[t0 + t] : 0u;
             const int sl = (t < nt) ? term_slot(code) : 0;
-            const int so = sl == 1 ? R.stride : (sl == 2 ? -R.stride : 0);
-            cpo[t] = R.oCP + ((t < nt) ? term_pair(code) : 0) - so;
-            dio[t] = ((t < nt) ? term_di(code) : R.oZero) - so;
+            const int sd = sl == 1 ? 1 : (sl == 2 ? -1 : 0);            // record of the previous / next step
+            cpo[t] = ((t < nt) ? term_pair(code) : 0) - sd * hp.npairs;
+            dio[t] = ((t < nt) ? term_di(code) : R.oZero) - sd * R.stride;
         }
         const int wmax = hess_wave_max(nt, w0, hp.Lseg * G, cx.tptr, hp.div_Lseg, hp.Lseg, nwl);
         double* out = hp.vals + hp.seg_base + e;
         const int64_t ibeg = live ? i0 + g : i1;
         switch (wmax) {
-            case 0: hess_emit_steps<0>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 1: hess_emit_steps<1>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 2: hess_emit_steps<2>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 3: hess_emit_steps<3>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 4: hess_emit_steps<4>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 5: hess_emit_steps<5>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            default: hess_emit_steps<kMaxTerms>(cx.rec, R.stride, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 0: hess_emit_steps<0>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 1: hess_emit_steps<1>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 2: hess_emit_steps<2>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 3: hess_emit_steps<3>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 4: hess_emit_steps<4>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            case 5: hess_emit_steps<5>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+            default: hess_emit_steps<kMaxTerms>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
         }
     }
     // V x V entries: one lane per (step of the tile, entry) adds up that step's terms; hess_phase_vvsum then sums the steps
@@ -639,7 +642,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
         const int si = w / hp.nvv, e = w - si * hp.nvv;
         const int k = si + (int)(cx.a - cx.lo);
         double acc = 0.0;
-        for (uint32_t t = cx.vptr[e]; t < cx.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, R.oCP, cx.vterms[t], k);
+        for (uint32_t t = cx.vptr[e]; t < cx.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, cx.vterms[t], k);
         cx.red[e * hp.T + si] = acc;
     }
 }

@@ -558,7 +558,7 @@ int build_hess_model(Model& mo, std::string& err) {
 
 int default_hess_tile(const Model& mo) {
     const Layout& L = mo.L;
-    const int64_t per_step = (int64_t)(L.blk + L.cb + mo.H.R.stride + 2) * 8;
+    const int64_t per_step = (int64_t)(L.blk + L.cb + mo.H.R.stride + (int64_t)mo.H.pairs.size() + 2) * 8;
     const int64_t fit = (60 * 1024) / per_step - mo.H.HL - mo.H.HH - 1;
     int64_t T = 1;
     while (T * 2 <= fit && T * 2 <= 32) T *= 2;
