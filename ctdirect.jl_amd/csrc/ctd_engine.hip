@@ -771,17 +771,15 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_ready) return CTD_OK;
     const Model& mo = h->model;
     const HessModel& H = mo.H;
-    if (h->step_begin != 0 || h->step_end != mo.L.N)
-        return fail(h, CTD_EINVAL, "the Hessian is evaluated on full-range handles only (its V x V block sums over every step)");
     HIP_TRY(h, hipSetDevice(h->device));
     h->hess_tile = env_int("CTD_HESS_TILE", 0);
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);
-    mo.fill_hparams(h->hp, h->hess_tile);
+    mo.fill_hparams(h->hp, h->hess_tile, h->step_begin, h->step_end);
     h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
     const size_t hess_cap = h->rt ? 64 * 1024 : 96 * 1024;
     while (h->hess_lds_bytes > hess_cap && h->hess_tile > 1) {
         h->hess_tile = (h->hess_tile + 1) / 2;
-        mo.fill_hparams(h->hp, h->hess_tile);
+        mo.fill_hparams(h->hp, h->hess_tile, h->step_begin, h->step_end);
         h->hess_lds_bytes = (size_t)hess_lds_doubles(h->hp) * sizeof(double);
     }
     if (h->hess_lds_bytes > (h->rt ? 64u : 160u) * 1024) return fail(h, CTD_EINVAL, "Hessian records of one step do not fit the LDS");
@@ -908,6 +906,22 @@ int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* 
     }
     (void)hipFree(d_st);
     return st;
+}
+
+// out[0..3 + nvv): vals_main_begin, vals_main_end (contiguous CSC range of the shard's step columns), nvv, then the nvv
+// positions of the V x V entries -- after ctd_hess_coord_dev on a shard they hold the shard's PARTIAL sums and must be
+// added over the shards (one all-reduce of nvv doubles)
+int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    const Model& mo = h->model;
+    const HessModel& H = mo.H;
+    const int64_t a = h->step_begin > H.reg_first ? h->step_begin : H.reg_first;
+    const int64_t b = h->step_end < H.reg_last ? h->step_end : H.reg_last;
+    o[0] = H.seg_base + (a - H.reg_first) * (int64_t)H.Lseg;
+    o[1] = b > a ? H.seg_base + (b - H.reg_first) * (int64_t)H.Lseg : o[0];
+    o[2] = H.nvv;
+    for (int e = 0; e < H.nvv; ++e) o[3 + e] = H.vv_idx[e];
+    return CTD_OK;
 }
 
 int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev, int32_t iters,

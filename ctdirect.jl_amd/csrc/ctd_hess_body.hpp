@@ -87,10 +87,8 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
             lds += hess_table_doubles(hp);
         }
         cx.is_edge = 0;
-        cx.a = (int64_t)tile * hp.T;
-        const int64_t last = (L.sc == SC_TRAPEZE) ? L.N + 1 : L.N;     // trapeze tiles walk nodes 0..N-1, node N is edge
-        (void)last;
-        cx.b = cx.a + hp.T < L.N ? cx.a + hp.T : L.N;
+        cx.a = hp.step_begin + (int64_t)tile * hp.T;                   // (trapeze tiles walk nodes 0..N-1, node N is edge)
+        cx.b = cx.a + hp.T < hp.step_end ? cx.a + hp.T : hp.step_end;
         cx.lo = cx.a - hp.HL;
         cx.nslots = (int)(cx.b - cx.a) + hp.HL + hp.HH;
         cx.in_stride = L.blk;
@@ -581,7 +579,7 @@ template <class P, int SC, int S>
 CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, int tid, int nthr) {
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     if (cx.is_edge) {
-        for (int e = tid; e < hp.n_edge; e += nthr) {
+        for (int e = hp.edge_begin + tid; e < hp.edge_end; e += nthr) {
             double acc = 0.0;
             for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];
@@ -591,10 +589,11 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
         }
         for (int e = tid; e < hp.nvv; e += nthr) {
             double acc = 0.0;
-            for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
-                const uint32_t code = hp.eterms[t];
-                acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, code, term_slot(code));
-            }
+            if (hp.edge_vv)
+                for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
+                    const uint32_t code = hp.eterms[t];
+                    acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, code, term_slot(code));
+                }
             hp.partials[e] = acc;
         }
         return;

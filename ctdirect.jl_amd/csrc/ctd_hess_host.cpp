@@ -473,6 +473,7 @@ int build_hess_model(Model& mo, std::string& err) {
         }
     };
     for (int64_t j = 0; j < head_cols; ++j) scan_col(j);
+    H.edge_split = (int)raws.size();           // entries before: owner of step 0; after: owner of step N-1 (shards)
     for (int64_t j = tail0; j < L.nvar; ++j) scan_col(j);
     if (L.sc == SC_TRAPEZE) need.insert(N);        // node N: its V x V share is summed by the edge block
     if ((int)need.size() > kMaxHessEdgeSlots) { err = "internal: too many edge records (Hessian)"; return ST_EPATTERN; }
@@ -566,14 +567,22 @@ int default_hess_tile(const Model& mo) {
     return (int)T;
 }
 
-void Model::fill_hparams(HParams& hp, int tile) const {
+void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step_end) const {
     hp = HParams{};
     hp.L = L;
     hp.R = H.R;
     hp.T = tile;
     hp.HL = H.HL;
     hp.HH = H.HH;
-    hp.ntiles = (int)((L.N + tile - 1) / tile);
+    if (step_end <= 0) { step_begin = 0; step_end = L.N; }
+    hp.step_begin = step_begin; hp.step_end = step_end;
+    hp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
+    // shards: the owner of step 0 emits the head entries, the owner of step N-1 the tail entries and the V x V share of the
+    // final-path / boundary / last-node points; the other shards have no edge work
+    hp.edge_begin = step_begin == 0 ? 0 : H.edge_split;
+    hp.edge_end = step_end == L.N ? (int)H.edge_idx.size() : H.edge_split;
+    if (hp.edge_end < hp.edge_begin) hp.edge_end = hp.edge_begin;
+    hp.edge_vv = step_end == L.N ? 1 : 0;
     hp.Lseg = H.Lseg;
     hp.nterms = (int)H.terms.size();
     hp.nvterms = (int)H.vterms.size();

@@ -38,6 +38,7 @@ struct HessModel {
     // edge part
     std::vector<int64_t> edge_idx;
     std::vector<uint32_t> eptr, evptr, eterms;
+    int edge_split = 0;               // edge entries [0, edge_split) belong to the head (step 0), the rest to the tail
     int n_edge_slots = 0, edge_fp = 0, edge_b = 0;
     int64_t edge_steps[kMaxHessEdgeSlots] = {0};
     // structural nonzeros of the evaluation points' dense Hessians (row-major md x md / mdb x mdb, upper triangle used)
@@ -99,7 +100,7 @@ struct Model {
     void hess_step_blocks(int64_t i, std::vector<Block>& out) const;
     void hess_gen_column(int64_t j, std::vector<int64_t>& rows) const;   // rows >= j of column j, sorted
     int64_t hess_column_start(int64_t j) const;
-    void fill_hparams(HParams& hp, int tile) const;
+    void fill_hparams(HParams& hp, int tile, int64_t step_begin = 0, int64_t step_end = 0) const;
 };
 
 // builds Model::H (pattern bookkeeping + term tables); called by build_model

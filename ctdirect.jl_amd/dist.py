@@ -55,6 +55,18 @@ def reduce_objective(partial, group=None, device=None):
     return float(t[0])
 
 
+def reduce_hessian_vv(vals, vv_idx, group=None):
+    """Adds the shards' partial sums of the variable x variable Hessian entries (the only entries of hess_coord! that sum
+    over every time step): one all-reduce of nv (nv+1)/2 doubles, in place.  `vv_idx` from DOCP.hess_shard_info()."""
+    if len(vv_idx) == 0:
+        return vals
+    idx = torch.as_tensor(vv_idx, dtype=torch.long, device=vals.device)
+    part = vals.index_select(0, idx)
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    vals.index_copy_(0, idx, part)
+    return vals
+
+
 class ShardedDOCP:
     """One rank's view of a grid-sharded transcription.  `make_docp(steps=(begin, end))` builds the engine handle
     (ctdirect DOCP) for the rank's block of steps."""
@@ -86,6 +98,15 @@ class ShardedDOCP:
             launch()
             stitch_constraints(c, N, cb, world, rank, group)
         return call
+
+    def hess_coord(self, x, y, obj_weight, vals):
+        """This rank's entries of hess_coord!(nlp, x, y, vals; obj_weight) into the full-length `vals` (they stay sharded like
+        the Jacobian values), plus the all-reduced variable x variable entries on every rank."""
+        self.docp.hess_coord(x, y, obj_weight, vals, sync=False)
+        if self.world > 1:
+            self.docp.sync()
+            reduce_hessian_vv(vals, self.docp.hess_shard_info()[2], self.group)
+        return vals
 
     def obj(self, x):
         return reduce_objective(self.docp.obj(x), self.group, device=x.device if hasattr(x, "device") else None)

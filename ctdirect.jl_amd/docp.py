@@ -458,6 +458,13 @@ class DOCP:
                                                   out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
         return out.reshape(grid, 5, 2)
 
+    def hess_shard_info(self):
+        """(vals_main_begin, vals_main_end, positions of the V x V entries): on a sharded handle hess_coord leaves partial
+        sums in the V x V entries, to be added over the shards."""
+        o = np.zeros(13, dtype=np.int64)
+        self._ck(_lib.lib().ctd_hess_shard_info(self._h, _ip(o)))
+        return int(o[0]), int(o[1]), o[3:3 + int(o[2])].copy()
+
     def hess_launch_info(self):
         o = np.zeros(10, dtype=np.int64)
         self._ck(_lib.lib().ctd_hess_launch_info(self._h, _ip(o)))

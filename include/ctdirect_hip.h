@@ -236,7 +236,10 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* out8);
  * block whose add_nonzero_block! call has an empty range in the reference (irk.jl:483 / irk_stagewise.jl:625).
  * Values:  vals[k] = obj_weight * d2 f/dx_i dx_j + sum_r y[r] * d2 c_r/dx_i dx_j  at (i, j) = (rows[k], cols[k]),
  * f = __objective (src/DOCP_functions.jl:23-54), c = __constraints! (:80-115); entries of the pattern that are
- * structurally zero receive 0.0.  Only full-range handles (step_begin = 0, step_end = N) evaluate the Hessian. */
+ * structurally zero receive 0.0.  A sharded handle (step_begin, step_end) writes the entries of its step columns (one
+ * contiguous CSC range), the first / last shard also the irregular first-step / final-state entries, and leaves its PARTIAL
+ * sums in the nv (nv+1)/2 variable x variable entries (they sum over every step): ctd_hess_shard_info names them for the
+ * one all-reduce the caller has to do. */
 /* 1-based (rows[k], cols[k]), k < nnzh, CSC order */
 int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
 /* same pattern as 0-based CSC (colptr[nvar + 1], rowval[nnzh]) */
@@ -254,6 +257,9 @@ int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_de
  * CSC period of the lower triangle (entries per regular step), number of edge entries, second-order eval lanes per
  * stage point / path point / boundary point (after the structural-sparsity probe), terms of the periodic segment */
 int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* out10);
+/* out[0..3 + nvv): vals_main_begin, vals_main_end (0-based contiguous range of the shard's step columns in the CSC value
+ * array), nvv = nv (nv+1)/2, then the 0-based positions of the variable x variable entries (partial sums on a shard) */
+int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* out13);
 /* Diagnostics: one launch of the Hessian kernel with in-kernel phase stamps: per workgroup 5 pairs {100 MHz realtime
  * counter, shader cycle counter} at start, after load, after eval, after emit issue, after the stores drained.
  * cap = capacity of out in uint64 words (needs grid * 10). */

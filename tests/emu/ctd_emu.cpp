@@ -220,14 +220,14 @@ int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const dou
 }
 
 int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
-             const double* x, const double* y, double obj_weight, double* vals) {
+             const double* x, const double* y, double obj_weight, double* vals, int64_t step_begin, int64_t step_end) {
     Model mo;
     HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     if (tile <= 0) tile = default_hess_tile(mo);
     HParams hp;
-    mo.fill_hparams(hp, tile);
+    mo.fill_hparams(hp, tile, step_begin, step_end);
     const HessModel& H = mo.H;
     hp.tau = mo.uniform ? nullptr : mo.tau.data();
     hp.tptr = H.tptr.data(); hp.terms = H.terms.data();

@@ -86,7 +86,7 @@ def hess_csc(problem, scheme, mode, N, time_grid=None):
     return colptr, rowval
 
 
-def hess(problem, scheme, mode, N, x, y, obj_weight=1.0, time_grid=None, tile=0, nthr=64):
+def hess(problem, scheme, mode, N, x, y, obj_weight=1.0, time_grid=None, tile=0, nthr=64, step_begin=0, step_end=0, vals=None):
     nvar, ncon, _, _ = sizes(problem, scheme, mode, N, time_grid)
     tg, n = _tg(time_grid)
     tgp = tg.ctypes.data_as(C.c_void_p) if tg is not None else None
@@ -96,9 +96,11 @@ def hess(problem, scheme, mode, N, x, y, obj_weight=1.0, time_grid=None, tile=0,
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     assert x.size == nvar and y.size == ncon
-    vals = np.full(nnz, 666.666)
+    if vals is None:
+        vals = np.full(nnz, 666.666)
     st = L.emu_hess(problem, scheme, mode, C.c_int64(N or 0), tgp, C.c_int64(n), tile, nthr, x.ctypes.data_as(C.c_void_p),
-                    y.ctypes.data_as(C.c_void_p), C.c_double(obj_weight), vals.ctypes.data_as(C.c_void_p))
+                    y.ctypes.data_as(C.c_void_p), C.c_double(obj_weight), vals.ctypes.data_as(C.c_void_p),
+                    C.c_int64(step_begin), C.c_int64(step_end))
     if st:
         raise RuntimeError(f"emu status {st}: {L.emu_last_error().decode()}")
     return vals

@@ -58,6 +58,18 @@ def _worker(rank, world, port, N, prob, sch, q):
         ctdist.stitch_constraints(c, N, cb, world, rank)
         ok = bool(np.array_equal(c.numpy(), full))
         tot = ctdist.reduce_objective(float(rank + 1))
+        # Hessian: the shards' partial V x V sums (taken from the kernel-logic emulator, tests only) add up to the oracle's
+        from emu import emu
+        y = np.cos(0.3 * np.arange(o.dim_NLP_constraints))
+        hfull = o.hess_coord(x, y, 0.5)
+        sb, se = ctdist.shard_steps(N, world, rank)
+        part = emu.hess(ct.PROBLEMS[prob], ct.SCHEMES[sch], 0, N, x, y, 0.5, step_begin=sb, step_end=se)
+        hv = torch.from_numpy(part.copy())
+        vv = d.hess_shard_info()[2]
+        ctdist.reduce_hessian_vv(hv, vv)
+        lo, hi, _ = d.hess_shard_info()
+        ok = ok and bool(np.allclose(hv.numpy()[vv], hfull[vv], rtol=1e-12, atol=1e-12))
+        ok = ok and bool(np.allclose(hv.numpy()[lo:hi], hfull[lo:hi], rtol=1e-10, atol=1e-10))
         q.put((rank, ok, tot))
     finally:
         dist.destroy_process_group()

@@ -93,10 +93,36 @@ def test_hessian_tile_shapes_and_idempotence(oracle_lib, torch_cuda, monkeypatch
         d.close()
 
 
-def test_hessian_needs_a_full_range_handle(torch_cuda):
-    d = ct.DOCP("goddard", 40, "midpoint", device=0, steps=(0, 20))
-    with pytest.raises(ct.CTDirectError):
-        d.hess_coord(np.full(d.dim_NLP_variables, 0.1), np.zeros(d.dim_NLP_constraints))
+@pytest.mark.parametrize("prob,sch", [("goddard_all", "midpoint"), ("goddard", "gauss_legendre_2"), ("quadrotor", "trapeze"),
+                                      ("double_integrator_freet0tf", "euler_implicit"), ("goddard_all", "gauss_legendre_3_constant_control")])
+def test_hessian_shards_compose_on_gpu(oracle_lib, torch_cuda, prob, sch):
+    """time-step shards (what each rank of a multi-GPU run evaluates): entries outside the V x V block are written by exactly
+    one shard, bit-identical to the full evaluation; the shards' V x V partials add up to the full entries"""
+    torch = torch_cuda
+    N = 301
+    full = ct.DOCP(prob, N, sch, device=0)
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+    y = np.cos(0.37 * np.arange(o.dim_NLP_constraints))
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ref = full.hess_coord(xd, yd, 0.9)
+    vv = torch.as_tensor(full.hess_shard_info()[2], dtype=torch.long, device="cuda")
+    notvv = torch.ones(full.nnzh, dtype=torch.bool, device="cuda")
+    notvv[vv] = False
+    acc = torch.full((full.nnzh,), SENT, dtype=torch.float64, device="cuda")
+    vvsum = torch.zeros(len(vv), dtype=torch.float64, device="cuda")
+    for a, b in ((0, 100), (100, 101), (101, 301)):
+        sh = ct.DOCP(prob, N, sch, device=0, steps=(a, b))
+        part = torch.full((full.nnzh,), SENT, dtype=torch.float64, device="cuda")
+        sh.hess_coord(xd, yd, 0.9, part)
+        wrote = (part != SENT) & notvv
+        assert not bool((wrote & (acc != SENT)).any())
+        acc[wrote] = part[wrote]
+        vvsum += part[vv]
+        sh.close()
+    assert torch.equal(acc[notvv], ref[notvv])
+    assert relerr(vvsum.cpu().numpy(), ref[vv].cpu().numpy()) <= 1e-12
+    assert relerr(ref.cpu().numpy(), o.hess_coord(x, y, 0.9)) <= TOL
 
 
 FULL = [("goddard", "trapeze", 100), ("goddard_all", "trapeze", 100), ("goddard", "gauss_legendre_2", 10000),

@@ -98,3 +98,35 @@ def test_emulated_hessian_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
     o = oracle_lib.OracleDOCP(prob, sch, 7)
     x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
     assert not np.any(emu.hess(pid, sid, 0, 7, x, np.zeros(o.dim_NLP_constraints), 0.0))
+
+
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "quadrotor", "double_integrator_freet0tf", "least_squares_with_constraint"])
+def test_emulated_hessian_shards_compose(prob):
+    """time-step shards (multi-GPU): every entry outside the V x V block is written by exactly one shard with the value of
+    the full evaluation, and the V x V entries of the shards add up to the full ones"""
+    N = 23
+    rng = np.random.default_rng(9)
+    for sch in ct.SCHEMES:
+        d = ct.DOCP(prob, N, sch, device=-1)
+        x = bench_inputs(describe(d, prob, sch), perturb=1e-2)
+        y = rng.standard_normal(d.dim_NLP_constraints)
+        pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+        full = emu.hess(pid, sid, 0, N, x, y, 0.8, tile=4, nthr=64)
+        _, _, vv = d.hess_shard_info()
+        notvv = np.ones(d.nnzh, dtype=bool)
+        notvv[vv] = False
+        for cuts in ([0, 11, 23], [0, 1, 22, 23], [0, 7, 8, 23]):
+            acc = np.full(d.nnzh, 666.666)
+            vvsum = np.zeros(len(vv))
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                part = np.full(d.nnzh, 666.666)
+                emu.hess(pid, sid, 0, N, x, y, 0.8, tile=3, nthr=32, step_begin=a, step_end=b, vals=part)
+                wrote = (part != 666.666) & notvv
+                assert not np.any(wrote & (acc != 666.666))              # disjoint outside the V x V block
+                acc[wrote] = part[wrote]
+                sh = ct.DOCP(prob, N, sch, device=-1, steps=(a, b))
+                lo, hi, _ = sh.hess_shard_info()
+                assert np.all(part[lo:hi] != 666.666)                    # the shard's contiguous CSC range is complete
+                vvsum += part[vv]
+            assert np.array_equal(acc[notvv], full[notvv])
+            assert relerr(vvsum, full[vv]) <= 1e-13
