@@ -2,6 +2,7 @@
 // order (without materialising it for the step-periodic middle) and the term tables the Hessian kernel consumes.
 // See ctd_hess.hpp for the decomposition.
 #include "ctd_host.hpp"
+#include "ctd_jit.hpp"
 
 #include <algorithm>
 #include <map>
@@ -145,10 +146,57 @@ inline SP d_sin(const SP& a) { return sp_nonlin(a); }
 inline SP d_cos(const SP& a) { return sp_nonlin(a); }
 inline SP d_sqr(const SP& a) { return sp_nonlin(a); }
 
-template <class P>
-static void probe_structure(Model& mo) {
-    constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, nb = P::NBC;
+// the OCP functions on dependency masks: compiled registry entry ...
+template <class P> struct RegistryFns {
+    void dynamics(SP* f, const SP& t, const SP* x, const SP* u, const SP* v) const { P::template dynamics<SP>(f, t, x, u, v); }
+    SP lagrange(const SP& t, const SP* x, const SP* u, const SP* v) const { return P::template lagrange<SP>(t, x, u, v); }
+    SP mayer(const SP* x0, const SP* xf, const SP* v) const { return P::template mayer<SP>(x0, xf, v); }
+    void path(SP* r, const SP& t, const SP* x, const SP* u, const SP* v) const { P::template path<SP>(r, t, x, u, v); }
+    void boundary(SP* r, const SP* x0, const SP* xf, const SP* v) const { P::template boundary<SP>(r, x0, xf, v); }
+};
+// ... or the postfix programs of a run-time OCP (ctd_jit.hpp)
+struct RuntimeFns {
+    const RtOcp& ro;
+    static SP run(const RtProgram& prog, const SP* t, const SP* x, const SP* u, const SP* v, const SP* x0, const SP* xf) {
+        std::vector<SP> st;
+        for (const RtOp& o : prog) {
+            switch (o.kind) {
+                case RT_CONST: st.emplace_back(); break;
+                case RT_T: st.push_back(*t); break;
+                case RT_X: st.push_back(x[o.k]); break;
+                case RT_U: st.push_back(u[o.k]); break;
+                case RT_V: st.push_back(v[o.k]); break;
+                case RT_X0: st.push_back(x0[o.k]); break;
+                case RT_XF: st.push_back(xf[o.k]); break;
+                case RT_NEG: break;
+                case RT_NONLIN: st.back() = sp_nonlin(st.back()); break;
+                case RT_POW: if (o.k == 0) st.back() = SP(); else if (o.k >= 2) st.back() = sp_nonlin(st.back()); break;
+                default: {
+                    const SP b = st.back(); st.pop_back();
+                    const SP a = st.back(); st.pop_back();
+                    st.push_back(o.kind == RT_MUL ? a * b : (o.kind == RT_DIV ? a / b : sp_lin(a, b)));
+                }
+            }
+        }
+        return st.empty() ? SP() : st.back();
+    }
+    void dynamics(SP* f, const SP& t, const SP* x, const SP* u, const SP* v) const {
+        for (size_t r = 0; r < ro.p_dynamics.size(); ++r) f[r] = run(ro.p_dynamics[r], &t, x, u, v, nullptr, nullptr);
+    }
+    SP lagrange(const SP& t, const SP* x, const SP* u, const SP* v) const { return run(ro.p_lagrange, &t, x, u, v, nullptr, nullptr); }
+    SP mayer(const SP* x0, const SP* xf, const SP* v) const { return run(ro.p_mayer, nullptr, nullptr, nullptr, v, x0, xf); }
+    void path(SP* r, const SP& t, const SP* x, const SP* u, const SP* v) const {
+        for (size_t q = 0; q < ro.p_path.size(); ++q) r[q] = run(ro.p_path[q], &t, x, u, v, nullptr, nullptr);
+    }
+    void boundary(SP* r, const SP* x0, const SP* xf, const SP* v) const {
+        for (size_t q = 0; q < ro.p_boundary.size(); ++q) r[q] = run(ro.p_boundary[q], nullptr, nullptr, nullptr, v, x0, xf);
+    }
+};
+
+template <class F>
+static void probe_structure(Model& mo, const F& fn) {
     const Layout& L = mo.L;
+    const int n = L.n, m = L.m, nv = L.nv, np = L.p, nb = L.bc;
     HessModel& H = mo.H;
     const int md = H.R.md, mdb = H.R.mdb, vd = n + m;
     const bool free_time = L.free_time != 0;
@@ -162,20 +210,20 @@ static void probe_structure(Model& mo) {
                 if ((phi.m2[p] >> q & 1u) || (phi.m2[q] >> p & 1u)) out[p * dim + q] = 1;
     };
     const SP hh = SP::dir(TV), t = SP::dir(TV);
-    SP x[n > 0 ? n : 1], u[m > 0 ? m : 1], v[nv > 0 ? nv : 1];
+    std::vector<SP> x(n > 0 ? n : 1), u(m > 0 ? m : 1), v(nv > 0 ? nv : 1);
     for (int r = 0; r < n; ++r) x[r] = SP::dir((1u << r) | ((L.sc == SC_IRK && free_time) ? TV : 0u));
     for (int b = 0; b < m; ++b) u[b] = SP::dir(1u << (n + b));
     for (int k = 0; k < nv; ++k) v[k] = SP::dir(1u << (vd + k));
     // stage-type point
     {
-        SP f[n > 0 ? n : 1];
-        P::template dynamics<SP>(f, t, x, u, v);
+        std::vector<SP> f(n > 0 ? n : 1);
+        fn.dynamics(f.data(), t, x.data(), u.data(), v.data());
         SP phi;
         for (int r = 0; r < n; ++r) phi = phi + f[r] * (L.sc == SC_IRK ? SP() : hh);
-        if (P::HAS_LAGRANGE) phi = phi + hh * P::template lagrange<SP>(t, x, u, v);
+        if (mo.info.lagrange) phi = phi + hh * fn.lagrange(t, x.data(), u.data(), v.data());
         if (L.sc == SC_TRAPEZE && np > 0) {
-            SP g[np > 0 ? np : 1];
-            P::template path<SP>(g, t, x, u, v);
+            std::vector<SP> g(np);
+            fn.path(g.data(), t, x.data(), u.data(), v.data());
             for (int r = 0; r < np; ++r) phi = phi + g[r];
         }
         fill(phi, md, H.need_stage);
@@ -190,10 +238,9 @@ static void probe_structure(Model& mo) {
     // path point (x = X_i exactly: no dependence on the time grid through the state)
     H.need_path.assign((size_t)md * md, 0);
     if (np > 0 && L.sc != SC_TRAPEZE) {
-        SP xp[n > 0 ? n : 1];
+        std::vector<SP> xp(n > 0 ? n : 1), g(np);
         for (int r = 0; r < n; ++r) xp[r] = SP::dir(1u << r);
-        SP g[np > 0 ? np : 1];
-        P::template path<SP>(g, t, xp, u, v);
+        fn.path(g.data(), t, xp.data(), u.data(), v.data());
         SP phi;
         for (int r = 0; r < np; ++r) phi = phi + g[r];
         fill(phi, md, H.need_path);
@@ -201,16 +248,16 @@ static void probe_structure(Model& mo) {
     // boundary + Mayer point
     H.need_bnd.assign((size_t)mdb * mdb, 0);
     {
-        SP x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], vb[nv > 0 ? nv : 1];
+        std::vector<SP> x0(n > 0 ? n : 1), xf(n > 0 ? n : 1), vb(nv > 0 ? nv : 1);
         for (int r = 0; r < n; ++r) { x0[r] = SP::dir(1u << r); xf[r] = SP::dir(1u << (n + r)); }
         for (int k = 0; k < nv; ++k) vb[k] = SP::dir(1u << (2 * n + k));
         SP phi;
         if (nb > 0) {
-            SP r_[nb > 0 ? nb : 1];
-            P::template boundary<SP>(r_, x0, xf, vb);
+            std::vector<SP> r_(nb);
+            fn.boundary(r_.data(), x0.data(), xf.data(), vb.data());
             for (int r = 0; r < nb; ++r) phi = phi + r_[r];
         }
-        if (P::HAS_MAYER) phi = phi + P::template mayer<SP>(x0, xf, vb);
+        if (mo.info.mayer) phi = phi + fn.mayer(x0.data(), xf.data(), vb.data());
         fill(phi, mdb, H.need_bnd);
     }
 }
@@ -391,12 +438,10 @@ int build_hess_model(Model& mo, std::string& err) {
     H.pairs.clear();
     pair_id(H, HC_ONE, HC_ONE);           // pair 0
     if (H.R.md > 31 || H.R.mdb > 31 || H.hk > 4) { err = "more than 31 Hessian directions per evaluation point are not supported"; return ST_EPATTERN; }
-    if (!for_problem(mo.problem, [&](auto tag) { probe_structure<typename decltype(tag)::type>(mo); })) {
-        // run-time defined OCP: its functor only exists as device code, assume every pair of directions is coupled
-        H.need_stage.assign((size_t)H.R.md * H.R.md, 1);
-        H.need_path.assign((size_t)H.R.md * H.R.md, (L.p > 0 && L.sc != SC_TRAPEZE) ? 1 : 0);
-        H.need_bnd.assign((size_t)H.R.mdb * H.R.mdb, 1);
-        H.need_rk.assign((size_t)(L.nv > 0 ? L.nv : 1) * L.n, (L.sc == SC_IRK && L.free_time) ? 1 : 0);
+    if (!for_problem(mo.problem, [&](auto tag) { probe_structure(mo, RegistryFns<typename decltype(tag)::type>{}); })) {
+        const RtOcp* ro = runtime_ocp(mo.problem);       // run-time OCP: the probe walks its postfix programs
+        if (!ro) { err = "problem id not in the registry"; return ST_EPATTERN; }
+        probe_structure(mo, RuntimeFns{*ro});
     }
     build_hess_tail(mo);
 

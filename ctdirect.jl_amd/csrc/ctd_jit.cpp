@@ -25,6 +25,8 @@ struct Parser {
     size_t pos = 0;
     bool uses_t = false, uses_v = false;
     std::string err;
+    RtProgram rpn;
+    void op(uint8_t kind, int k = 0) { rpn.push_back(RtOp{kind, (int16_t)k}); }
     struct Val { std::string code; bool is_const; };
 
     Parser(const std::string& s_, const ExprCtx& cx_) : s(s_), cx(cx_) {}
@@ -53,6 +55,7 @@ struct Parser {
                 if (!term(r)) return false;
                 out.code = "(" + out.code + " " + op + " " + r.code + ")";
                 out.is_const = out.is_const && r.is_const;
+                this->op(op == '+' ? RT_ADD : RT_SUB);
             } else return true;
         }
     }
@@ -66,6 +69,7 @@ struct Parser {
                 if (!unary(r)) return false;
                 out.code = "(" + out.code + " " + op + " " + r.code + ")";
                 out.is_const = out.is_const && r.is_const;
+                this->op(op == '*' ? RT_MUL : RT_DIV);
             } else return true;
         }
     }
@@ -77,6 +81,7 @@ struct Parser {
             if (!unary(r)) return false;
             out.code = "(-" + r.code + ")";
             out.is_const = r.is_const;
+            op(RT_NEG);
             return true;
         }
         if (pos < s.size() && s[pos] == '+') { ++pos; return unary(out); }
@@ -95,6 +100,7 @@ struct Parser {
             if (k == 0) { out.code = "1.0"; out.is_const = true; }
             else if (k == 2) out.code = "d_sqr(" + out.code + ")";
             else if (k > 2) out.code = "d_powi(" + out.code + ", " + std::to_string(k) + ")";
+            op(RT_POW, k);
         }
         return true;
     }
@@ -116,6 +122,7 @@ struct Parser {
             if (end == s.c_str() + pos) return fail("malformed number");
             pos = (size_t)(end - s.c_str());
             out.code = num(v); out.is_const = true;
+            op(RT_CONST);
             return true;
         }
         if (std::isalpha((unsigned char)c) || c == '_') {
@@ -136,21 +143,22 @@ struct Parser {
                 ++pos;
                 out.code = std::string(target) + "(" + a.code + ")";
                 out.is_const = a.is_const;
+                op(RT_NONLIN);
                 return true;
             }
             int k = 0;
             out.is_const = false;
             if (cx.kind == 0) {
-                if (name == "t") { uses_t = true; out.code = "t"; return true; }
-                if (name[0] == 'x' && index_of(name, 1, cx.n, k)) { out.code = "x[" + std::to_string(k - 1) + "]"; return true; }
-                if (name[0] == 'u' && index_of(name, 1, cx.m, k)) { out.code = "u[" + std::to_string(k - 1) + "]"; return true; }
+                if (name == "t") { uses_t = true; out.code = "t"; op(RT_T); return true; }
+                if (name[0] == 'x' && index_of(name, 1, cx.n, k)) { out.code = "x[" + std::to_string(k - 1) + "]"; op(RT_X, k - 1); return true; }
+                if (name[0] == 'u' && index_of(name, 1, cx.m, k)) { out.code = "u[" + std::to_string(k - 1) + "]"; op(RT_U, k - 1); return true; }
             } else {
-                if (name.rfind("x0_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "x0[" + std::to_string(k - 1) + "]"; return true; }
-                if (name.rfind("xf_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "xf[" + std::to_string(k - 1) + "]"; return true; }
+                if (name.rfind("x0_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "x0[" + std::to_string(k - 1) + "]"; op(RT_X0, k - 1); return true; }
+                if (name.rfind("xf_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "xf[" + std::to_string(k - 1) + "]"; op(RT_XF, k - 1); return true; }
             }
-            if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; return true; }
+            if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; op(RT_V, k - 1); return true; }
             auto it = cx.constants.find(name);
-            if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; return true; }
+            if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; op(RT_CONST); return true; }
             return fail("unknown name '" + name + "'");
         }
         return fail(std::string("unexpected character '") + c + "'");
@@ -190,13 +198,14 @@ std::vector<std::unique_ptr<RtOcp>> g_ocps;
 }  // namespace
 
 bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
-                 std::string& err) {
+                 std::string& err, RtProgram* prog) {
     Parser p(expr, cx);
     Parser::Val v;
     if (!p.expr(v)) { err = p.err; return false; }
     p.skip();
     if (p.pos != expr.size()) { p.fail("unexpected trailing input"); err = p.err; return false; }
     out = v.code; is_const = v.is_const; uses_t = p.uses_t; uses_v = p.uses_v;
+    if (prog) *prog = p.rpn;
     return true;
 }
 
@@ -221,25 +230,27 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     c1.constants = c0.constants;
     o->dyn_t = o->dyn_v = o->path_t = o->path_v = o->lag_t = o->lag_v = false;
     std::string body_dyn, body_lag, body_may, body_path, body_bnd;
-    auto emit = [&](const char* text, const ExprCtx& cx, const std::string& lhs, std::string& body, bool& ut, bool& uv, const char* what, int idx) {
+    auto emit = [&](const char* text, const ExprCtx& cx, const std::string& lhs, std::string& body, bool& ut, bool& uv, const char* what, int idx,
+                    RtProgram& prog) {
         if (!text) { err = std::string(what) + " expression " + std::to_string(idx + 1) + " is null"; return false; }
         std::string code, e;
         bool isc = false, t_ = false, v_ = false;
-        if (!expr_to_cpp(text, cx, code, isc, t_, v_, e)) { err = std::string(what) + " " + std::to_string(idx + 1) + ": " + e; return false; }
+        if (!expr_to_cpp(text, cx, code, isc, t_, v_, e, &prog)) { err = std::string(what) + " " + std::to_string(idx + 1) + ": " + e; return false; }
         ut = ut || t_; uv = uv || v_;
         body += "        " + lhs + (isc ? " T(" + code + ");\n" : " " + code + ";\n");
         return true;
     };
     bool dummy_t = false, dummy_v = false;
+    o->p_dynamics.resize(d->n); o->p_path.resize(d->npath); o->p_boundary.resize(d->nbc);
     for (int r = 0; r < d->n; ++r)
-        if (!emit(d->dynamics[r], c0, "dx[" + std::to_string(r) + "] =", body_dyn, o->dyn_t, o->dyn_v, "dynamics", r)) return CTD_EINVAL;
+        if (!emit(d->dynamics[r], c0, "dx[" + std::to_string(r) + "] =", body_dyn, o->dyn_t, o->dyn_v, "dynamics", r, o->p_dynamics[r])) return CTD_EINVAL;
     const bool has_lag = d->lagrange && *d->lagrange, has_may = d->mayer && *d->mayer;
-    if (has_lag && !emit(d->lagrange, c0, "return", body_lag, o->lag_t, o->lag_v, "lagrange", 0)) return CTD_EINVAL;
-    if (has_may && !emit(d->mayer, c1, "return", body_may, dummy_t, dummy_v, "mayer", 0)) return CTD_EINVAL;
+    if (has_lag && !emit(d->lagrange, c0, "return", body_lag, o->lag_t, o->lag_v, "lagrange", 0, o->p_lagrange)) return CTD_EINVAL;
+    if (has_may && !emit(d->mayer, c1, "return", body_may, dummy_t, dummy_v, "mayer", 0, o->p_mayer)) return CTD_EINVAL;
     for (int r = 0; r < d->npath; ++r)
-        if (!emit(d->path[r], c0, "r[" + std::to_string(r) + "] =", body_path, o->path_t, o->path_v, "path", r)) return CTD_EINVAL;
+        if (!emit(d->path[r], c0, "r[" + std::to_string(r) + "] =", body_path, o->path_t, o->path_v, "path", r, o->p_path[r])) return CTD_EINVAL;
     for (int r = 0; r < d->nbc; ++r)
-        if (!emit(d->boundary[r], c1, "r[" + std::to_string(r) + "] =", body_bnd, dummy_t, dummy_v, "boundary", r)) return CTD_EINVAL;
+        if (!emit(d->boundary[r], c1, "r[" + std::to_string(r) + "] =", body_bnd, dummy_t, dummy_v, "boundary", r, o->p_boundary[r])) return CTD_EINVAL;
     if (!has_lag) body_lag = "        return T(0.0);\n";
     if (!has_may) body_may = "        return T(0.0);\n";
     o->dc = 4;

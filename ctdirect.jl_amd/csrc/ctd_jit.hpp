@@ -21,12 +21,20 @@ namespace ctd {
 
 constexpr int kRuntimeIdBase = 1000;
 
+// postfix form of one expression, kept for analyses that need the functions on the HOST (the structural-sparsity probe
+// of the Hessian tables, ctd_hess_host.cpp); the numbers themselves are only ever computed by the compiled kernels
+enum RtOpKind : uint8_t { RT_CONST, RT_T, RT_X, RT_U, RT_V, RT_X0, RT_XF, RT_ADD, RT_SUB, RT_MUL, RT_DIV, RT_NEG, RT_NONLIN, RT_POW };
+struct RtOp { uint8_t kind; int16_t k; };
+using RtProgram = std::vector<RtOp>;
+
 struct RtOcp {
     std::string name;
     ProblemInfo info;                  // info.name points into `name`
     bool dyn_t, dyn_v, path_t, path_v, lag_t, lag_v;
     int dc, hk, maxb;
     std::string functor_src;           // namespace ctd { struct UserOCP { ... }; }
+    std::vector<RtProgram> p_dynamics, p_path, p_boundary;
+    RtProgram p_lagrange, p_mayer;     // empty: absent
 };
 
 inline bool is_runtime_problem(int id) { return id >= kRuntimeIdBase; }
@@ -42,6 +50,6 @@ struct ExprCtx {
     std::map<std::string, double> constants;
 };
 bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
-                 std::string& err);
+                 std::string& err, RtProgram* prog = nullptr);
 
 }  // namespace ctd
