@@ -603,12 +603,19 @@ int build_hess_model(Model& mo, std::string& err) {
 }
 
 int default_hess_tile(const Model& mo) {
+    // The eval phase runs (steps per tile) x (lanes per step) second-order tasks on 256 lanes: tiles are sized so that the
+    // tasks fill whole passes (MI355X sweeps, profiles/r01_hessian_kernel.md): one full pass when that gives a tile of >= 24
+    // steps (trapeze / midpoint / Euler / light Gauss-Legendre problems), else two passes; clamped to ~60 KiB of LDS, and
+    // halved while the grid would not give every CU at least one workgroup
     const Layout& L = mo.L;
-    const int64_t per_step = (int64_t)(L.blk + L.cb + mo.H.R.stride + (int64_t)mo.H.pairs.size() + 2) * 8;
-    const int64_t fit = (60 * 1024) / per_step - mo.H.HL - mo.H.HH - 1;
-    int64_t T = 1;
-    while (T * 2 <= fit && T * 2 <= 32) T *= 2;
-    while (T > 2 && (L.N + T - 1) / T < 256) T /= 2;
+    const HessModel& H = mo.H;
+    const int tps = std::max(1, H.R.S * (int)H.tasks.size() + (int)H.ptasks.size());
+    const int64_t per_step = (int64_t)(L.blk + L.cb + H.R.stride + (int64_t)H.pairs.size() + 2) * 8;
+    const int64_t fit = std::max<int64_t>(1, (60 * 1024) / per_step - H.HL - H.HH - 1);
+    int64_t T = 256 / tps;
+    if (T < 24) T = 512 / tps;
+    T = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(T, 128), fit));
+    while (T > 4 && (L.N + T - 1) / T < 256) T = (T + 1) / 2;
     return (int)T;
 }
 
