@@ -19,9 +19,24 @@ namespace ctd {
 // names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants; functions exp sin cos sqrt
 // ------------------------------------------------------------------------------------------------------
 namespace {
+// common sub-expression pool of one generated function: every distinct non-constant call of exp / sin / cos / sqrt is
+// computed once into a temporary shared by all outputs of the function (hand-written functors do the same)
+struct CsePool {
+    std::vector<std::pair<std::string, std::string>> seen;   // (expression text, temporary)
+    std::string decls;
+    std::string intern(const std::string& code) {
+        for (auto& e : seen) if (e.first == code) return e.second;
+        const std::string name = "e" + std::to_string(seen.size());
+        decls += "        const T " + name + " = " + code + ";\n";
+        seen.emplace_back(code, name);
+        return name;
+    }
+};
+
 struct Parser {
     const std::string& s;
     const ExprCtx& cx;
+    CsePool* cse = nullptr;
     size_t pos = 0;
     bool uses_t = false, uses_v = false;
     std::string err;
@@ -143,6 +158,7 @@ struct Parser {
                 ++pos;
                 out.code = std::string(target) + "(" + a.code + ")";
                 out.is_const = a.is_const;
+                if (cse && !a.is_const) out.code = cse->intern(out.code);
                 op(RT_NONLIN);
                 return true;
             }
@@ -197,9 +213,18 @@ std::mutex g_mu;
 std::vector<std::unique_ptr<RtOcp>> g_ocps;
 }  // namespace
 
+static bool expr_to_cpp_cse(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
+                            std::string& err, RtProgram* prog, CsePool* cse);
+
 bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
                  std::string& err, RtProgram* prog) {
+    return expr_to_cpp_cse(expr, cx, out, is_const, uses_t, uses_v, err, prog, nullptr);
+}
+
+static bool expr_to_cpp_cse(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
+                            std::string& err, RtProgram* prog, CsePool* cse) {
     Parser p(expr, cx);
+    p.cse = cse;
     Parser::Val v;
     if (!p.expr(v)) { err = p.err; return false; }
     p.skip();
@@ -230,12 +255,13 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     c1.constants = c0.constants;
     o->dyn_t = o->dyn_v = o->path_t = o->path_v = o->lag_t = o->lag_v = false;
     std::string body_dyn, body_lag, body_may, body_path, body_bnd;
+    CsePool pool_dyn, pool_lag, pool_may, pool_path, pool_bnd;
     auto emit = [&](const char* text, const ExprCtx& cx, const std::string& lhs, std::string& body, bool& ut, bool& uv, const char* what, int idx,
-                    RtProgram& prog) {
+                    RtProgram& prog, CsePool& pool) {
         if (!text) { err = std::string(what) + " expression " + std::to_string(idx + 1) + " is null"; return false; }
         std::string code, e;
         bool isc = false, t_ = false, v_ = false;
-        if (!expr_to_cpp(text, cx, code, isc, t_, v_, e, &prog)) { err = std::string(what) + " " + std::to_string(idx + 1) + ": " + e; return false; }
+        if (!expr_to_cpp_cse(text, cx, code, isc, t_, v_, e, &prog, &pool)) { err = std::string(what) + " " + std::to_string(idx + 1) + ": " + e; return false; }
         ut = ut || t_; uv = uv || v_;
         body += "        " + lhs + (isc ? " T(" + code + ");\n" : " " + code + ";\n");
         return true;
@@ -243,14 +269,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     bool dummy_t = false, dummy_v = false;
     o->p_dynamics.resize(d->n); o->p_path.resize(d->npath); o->p_boundary.resize(d->nbc);
     for (int r = 0; r < d->n; ++r)
-        if (!emit(d->dynamics[r], c0, "dx[" + std::to_string(r) + "] =", body_dyn, o->dyn_t, o->dyn_v, "dynamics", r, o->p_dynamics[r])) return CTD_EINVAL;
+        if (!emit(d->dynamics[r], c0, "dx[" + std::to_string(r) + "] =", body_dyn, o->dyn_t, o->dyn_v, "dynamics", r, o->p_dynamics[r], pool_dyn)) return CTD_EINVAL;
     const bool has_lag = d->lagrange && *d->lagrange, has_may = d->mayer && *d->mayer;
-    if (has_lag && !emit(d->lagrange, c0, "return", body_lag, o->lag_t, o->lag_v, "lagrange", 0, o->p_lagrange)) return CTD_EINVAL;
-    if (has_may && !emit(d->mayer, c1, "return", body_may, dummy_t, dummy_v, "mayer", 0, o->p_mayer)) return CTD_EINVAL;
+    if (has_lag && !emit(d->lagrange, c0, "return", body_lag, o->lag_t, o->lag_v, "lagrange", 0, o->p_lagrange, pool_lag)) return CTD_EINVAL;
+    if (has_may && !emit(d->mayer, c1, "return", body_may, dummy_t, dummy_v, "mayer", 0, o->p_mayer, pool_may)) return CTD_EINVAL;
     for (int r = 0; r < d->npath; ++r)
-        if (!emit(d->path[r], c0, "r[" + std::to_string(r) + "] =", body_path, o->path_t, o->path_v, "path", r, o->p_path[r])) return CTD_EINVAL;
+        if (!emit(d->path[r], c0, "r[" + std::to_string(r) + "] =", body_path, o->path_t, o->path_v, "path", r, o->p_path[r], pool_path)) return CTD_EINVAL;
     for (int r = 0; r < d->nbc; ++r)
-        if (!emit(d->boundary[r], c1, "r[" + std::to_string(r) + "] =", body_bnd, dummy_t, dummy_v, "boundary", r, o->p_boundary[r])) return CTD_EINVAL;
+        if (!emit(d->boundary[r], c1, "r[" + std::to_string(r) + "] =", body_bnd, dummy_t, dummy_v, "boundary", r, o->p_boundary[r], pool_bnd)) return CTD_EINVAL;
     if (!has_lag) body_lag = "        return T(0.0);\n";
     if (!has_may) body_may = "        return T(0.0);\n";
     o->dc = 4;
@@ -266,11 +292,11 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     s += std::string("    static constexpr bool DYN_T = ") + B(o->dyn_t) + ", DYN_V = " + B(o->dyn_v) + ", PATH_T = " + B(o->path_t) +
          ", PATH_V = " + B(o->path_v) + ", LAG_T = " + B(o->lag_t) + ", LAG_V = " + B(o->lag_v) + ";\n";
     s += "    static constexpr int DC = " + std::to_string(o->dc) + ", MAXB = " + std::to_string(o->maxb) + ";\n";
-    s += "    template <class T> CTD_HD static void dynamics(T* dx, const T& t, const T* x, const T* u, const T* v) {\n" + body_dyn + "    }\n";
-    s += "    template <class T> CTD_HD static T lagrange(const T& t, const T* x, const T* u, const T* v) {\n" + body_lag + "    }\n";
-    s += "    template <class T> CTD_HD static T mayer(const T* x0, const T* xf, const T* v) {\n" + body_may + "    }\n";
-    s += "    template <class T> CTD_HD static void path(T* r, const T& t, const T* x, const T* u, const T* v) {\n" + body_path + "    }\n";
-    s += "    template <class T> CTD_HD static void boundary(T* r, const T* x0, const T* xf, const T* v) {\n" + body_bnd + "    }\n";
+    s += "    template <class T> CTD_HD static void dynamics(T* dx, const T& t, const T* x, const T* u, const T* v) {\n" + pool_dyn.decls + body_dyn + "    }\n";
+    s += "    template <class T> CTD_HD static T lagrange(const T& t, const T* x, const T* u, const T* v) {\n" + pool_lag.decls + body_lag + "    }\n";
+    s += "    template <class T> CTD_HD static T mayer(const T* x0, const T* xf, const T* v) {\n" + pool_may.decls + body_may + "    }\n";
+    s += "    template <class T> CTD_HD static void path(T* r, const T& t, const T* x, const T* u, const T* v) {\n" + pool_path.decls + body_path + "    }\n";
+    s += "    template <class T> CTD_HD static void boundary(T* r, const T* x0, const T* xf, const T* v) {\n" + pool_bnd.decls + body_bnd + "    }\n";
     s += "};\n}  // namespace ctd\n";
 
     ProblemInfo& pi = o->info;
