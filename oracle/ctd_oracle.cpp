@@ -21,6 +21,12 @@
 //   bounds / initial guess          src/DOCP_functions.jl:163-191 ; src/DOCP_variables.jl:21-145 ; irk_stagewise.jl:250-335
 //   Jacobian / Hessian patterns     trapeze.jl:149-303 ; midpoint.jl:163-300 ; irk.jl:315-496 ; irk_stagewise.jl:468-638 ;
 //                                   add_nonzero_block! src/ode/common.jl:285-312
+//   Euler explicit / implicit       src/ode/euler.jl:10-50 (struct), :59-72 (control getter), :79-159 (work array, integral,
+//                                   step constraints), :166-355 (patterns)
+//   Hessian values                  third-party in the reference (ADNLPModels sparse Hessian backend over the closures,
+//                                   src/collocation.jl:121-125): restated as a sparse second-order forward sweep over the
+//                                   same objective / constraints templates (dual2.hpp), on the lower triangle of
+//                                   DOCP_Hessian_pattern
 //   Jacobian values                 third-party in the reference (ADNLPModels.SparseADJacobian, not under
 //                                   /root/reference): column-colour the pattern, one pass of c!(Dual) per colour,
 //                                   decompress into CSC order.  Restated here from the reference's own description
@@ -31,8 +37,8 @@
 // objective 4/3 (test/ci/test_discretization_stagewise.jl:53-100,176-198), nnzj 6028 / nnzh 6519
 // (test/ci/test_modeler_solver.jl:37), zero-control dims 24 / 23 (test/ci/test_zero_control_allocations.jl:31,138),
 // goddard_all trapeze 4005/6007, 40005/60007 (test/archives/AD_backend.md:59-60), and by 50-digit mpmath fixtures
-// (tests/golden/).  Jacobian VALUES have no golden in the reference ("parity unpinned" for values; pinned by the
-// build's own mpmath derivative fixtures and finite differences).
+// (tests/golden/).  Jacobian and Hessian VALUES have no golden in the reference ("parity unpinned" for values; pinned by
+// the build's own first- and second-order mpmath derivative fixtures and finite differences).
 // =================================================================================================
 #include <algorithm>
 #include <cmath>
