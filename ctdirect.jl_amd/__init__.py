@@ -5,10 +5,11 @@ is the thin host-side mirror of the reference's DOCP interface plus the multi-GP
 """
 from . import _lib
 from .docp import (DOCP, PATTERN_MODES, PROBLEMS, SCHEMES, CTDirectError, DOCP_Hessian_pattern, DOCP_Jacobian_pattern, constraints,
-                   constraints_bounds, gradient, initial_guess, jit_check, objective, ocp_source, register_ocp, variables_bounds)
+                   constraints_bounds, get_time_grid, gradient, initial_guess, jit_check, objective, ocp_source, register_ocp,
+                   unpack_solution, variables_bounds)
 
 __all__ = ["DOCP", "PROBLEMS", "SCHEMES", "PATTERN_MODES", "CTDirectError", "DOCP_Hessian_pattern", "DOCP_Jacobian_pattern", "constraints",
-           "constraints_bounds", "gradient", "initial_guess", "jit_check", "objective", "ocp_source", "register_ocp",
+           "constraints_bounds", "get_time_grid", "unpack_solution", "gradient", "initial_guess", "jit_check", "objective", "ocp_source", "register_ocp",
            "variables_bounds", "build"]
 
 

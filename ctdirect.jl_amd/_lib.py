@@ -49,6 +49,7 @@ SYMBOLS = {
     "ctd_sizes": (C.c_int32, [_vp, _ip, _ip, _ip, _ip]),
     "ctd_dims": (C.c_int32, [_vp, _ip]),
     "ctd_time_grid": (C.c_int32, [_vp, _dp, _dp]),
+    "ctd_time_grid_at": (C.c_int32, [_vp, _dp, _dp]),
     "ctd_butcher": (C.c_int32, [_vp, _dp, _dp, _dp]),
     "ctd_bounds": (C.c_int32, [_vp, _dp, _dp, _dp, _dp]),
     "ctd_initial_guess": (C.c_int32, [_vp, _dp, C.POINTER(ctd_init)]),

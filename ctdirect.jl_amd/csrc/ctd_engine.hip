@@ -433,6 +433,17 @@ int32_t ctd_time_grid(const ctd_handle* h, double* normalized, double* fixed) {
     return CTD_OK;
 }
 
+// get_time_grid(xu, docp), src/DOCP_data.jl:437-458 (host arithmetic on the tail of x: post-processing, not the hot path)
+int32_t ctd_time_grid_at(const ctd_handle* h, const double* x, double* grid) {
+    if (!h || !x || !grid) return CTD_EINVAL;
+    const Model& mo = h->model;
+    const Layout& L = mo.L;
+    const double t0 = L.it0 >= 0 ? x[L.v_off + L.it0] : L.t0;
+    const double tf = L.itf >= 0 ? x[L.v_off + L.itf] : L.tf;
+    for (int64_t i = 0; i <= L.N; ++i) grid[i] = L.free_time ? t0 + mo.tau[i] * (tf - t0) : mo.fixed_grid[i];
+    return CTD_OK;
+}
+
 int32_t ctd_butcher(const ctd_handle* h, double* a, double* b, double* c) {
     if (!h) return CTD_EINVAL;
     const Layout& L = h->model.L;

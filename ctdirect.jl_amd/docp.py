@@ -542,8 +542,42 @@ def DOCP_Hessian_pattern(docp):
 
 
 def get_time_grid(xu, docp):
-    """`CTDirect.get_time_grid(xu, docp)` (src/DOCP_data.jl:437-458); cheap host-side helper for post-processing."""
-    # t0/tf live in v for free-time problems; ids follow the registry (0-based position inside v)
-    if not (docp.flags.freet0 or docp.flags.freetf):
-        return docp.time.fixed_grid.copy()
-    raise NotImplementedError("free-time grids are evaluated on the device inside the callbacks")
+    """`CTDirect.get_time_grid(xu, docp)` (src/DOCP_data.jl:437-458): t_i = t0 + tau_i (tf - t0), t0 / tf fixed or entries of v."""
+    xu = np.ascontiguousarray(xu.detach().cpu().numpy() if _is_tensor(xu) else xu, dtype=np.float64)
+    grid = np.zeros(docp.time.steps + 1)
+    docp._ck(_lib.lib().ctd_time_grid_at(docp._h, _dp(xu), _dp(grid)))
+    return grid
+
+
+def unpack_solution(docp, x, multipliers=None):
+    """The arrays `CTDirect.build_OCP_solution` hands to CTModels (src/DOCP_data.jl:514-633) from an NLP solution, with the
+    reference's getter conventions (src/ode/common.jl:7-104): X[N+1, n], U[N+1, m] (control of the scheme at every node,
+    final control duplicated when the scheme has none), v, and from the constraint multipliers the costate P[N, n] (the
+    multipliers of the state-equation rows), the path-constraint duals divided by the step length and the boundary duals."""
+    x = np.ascontiguousarray(x.detach().cpu().numpy() if _is_tensor(x) else x, dtype=np.float64)
+    n, m, nv = docp.dims.NLP_x, docp.dims.NLP_u, docp.dims.NLP_v
+    N, blk = docp.time.steps, docp.discretization._step_variables_block
+    T = get_time_grid(x, docp)
+    X = np.stack([x[i * blk:i * blk + n] for i in range(N + 1)])
+    stage = docp.discretization.stage
+    stagewise = docp.scheme in ("gauss_legendre_2", "gauss_legendre_3")
+    U = np.zeros((N + 1, m))
+    if m:
+        b = docp.discretization.butcher_b if stagewise else None
+        for i in range(N + 1):
+            j = i if (i < N or docp.discretization._final_control) else N - 1     # u(t_f) = U_N convention
+            if docp.scheme == "euler_implicit":
+                j = max(i - 1, 0) if i > 0 else 0                                # u(t_i) = U_{i-1}, u(t_0) = U_0
+            o = j * blk + n
+            U[i] = sum(b[s] * x[o + s * m:o + (s + 1) * m] for s in range(stage)) if stagewise else x[o:o + m]
+    out = dict(T=T, X=X, U=U, v=x[len(x) - nv:].copy())
+    if multipliers is not None:
+        y = np.ascontiguousarray(multipliers, dtype=np.float64)
+        eqs, p, bc = docp.discretization._state_stage_eqs_block, docp.dims.path_cons, docp.dims.boundary_cons
+        cb = eqs + p
+        out["P"] = np.stack([y[i * cb:i * cb + n] for i in range(N)])
+        h = np.diff(T)
+        raw = np.stack([y[i * cb + eqs:i * cb + eqs + p] for i in range(N)] + [y[N * cb:N * cb + p]]) if p else np.zeros((N + 1, 0))
+        out["path_constraints_dual"] = raw / np.concatenate([h, h[-1:]])[:, None]
+        out["boundary_constraints_dual"] = y[N * cb + p:N * cb + p + bc].copy()
+    return out

@@ -165,6 +165,9 @@ int32_t ctd_sizes(const ctd_handle* h, int64_t* nvar, int64_t* ncon, int64_t* nn
 int32_t ctd_dims(const ctd_handle* h, int64_t* out16);
 /* docp.time.normalized_grid / fixed_grid (src/DOCP_data.jl:147-152), each N+1 */
 int32_t ctd_time_grid(const ctd_handle* h, double* normalized, double* fixed);
+/* get_time_grid(xu, docp), src/DOCP_data.jl:437-458: grid[i] = t0 + tau_i (tf - t0) with t0 / tf fixed or read from the
+ * tail of x (host pointers; post-processing helper for the solution rebuild, src/DOCP_data.jl:514-633) */
+int32_t ctd_time_grid_at(const ctd_handle* h, const double* x, double* grid);
 /* Butcher tables of the scheme struct (row-major a[stage*stage], b[stage], c[stage]), src/ode/irk_stagewise.jl:61-64,103-109 */
 int32_t ctd_butcher(const ctd_handle* h, double* a, double* b, double* c);
 /* docp.bounds.var_l/var_u/con_l/con_u : __variables_bounds! (src/DOCP_variables.jl:21-63, irk_stagewise.jl:250-300)

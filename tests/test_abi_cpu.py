@@ -135,3 +135,33 @@ def test_shard_info():
     assert (b.shard.c_row_begin, b.shard.c_row_end) == (20 * cb, 40 * cb)
     assert a.shard.vals_main_end == b.shard.vals_main_begin
     assert a.shard.owns_first and not a.shard.owns_last and b.shard.owns_last and not b.shard.owns_first
+
+
+def test_solution_unpacking_follows_the_reference_getter():
+    """unpack_solution mirrors getter / build_OCP_solution (src/ode/common.jl:7-104, src/DOCP_data.jl:514-633): layouts of
+    X, U, v, costate = state-equation multipliers, path duals divided by the step length, final control duplicated"""
+    for sch in ("midpoint", "trapeze", "gauss_legendre_2", "gauss_legendre_3_constant_control", "euler_implicit"):
+        d = ct.DOCP("goddard_all", 6, sch, device=-1)
+        n, m, blk = 3, 1, d.discretization._step_variables_block
+        x = np.arange(d.dim_NLP_variables, dtype=float) * 0.01
+        x[-1] = 0.3                                               # tf
+        y = np.arange(d.dim_NLP_constraints, dtype=float) + 1.0
+        s = ct.unpack_solution(d, x, y)
+        assert np.allclose(s["T"], np.linspace(0, 0.3, 7)) and np.array_equal(ct.get_time_grid(x, d), s["T"])
+        assert s["X"].shape == (7, 3) and np.array_equal(s["X"][2], x[2 * blk:2 * blk + 3]) and s["v"][0] == 0.3
+        cb = d.discretization._state_stage_eqs_block + 3
+        assert np.array_equal(s["P"][4], y[4 * cb:4 * cb + 3])
+        eqs = d.discretization._state_stage_eqs_block
+        assert np.allclose(s["path_constraints_dual"][1], y[cb + eqs:cb + eqs + 3] / 0.05)
+        assert np.allclose(s["path_constraints_dual"][6], y[6 * cb:6 * cb + 3] / 0.05)
+        assert np.array_equal(s["boundary_constraints_dual"], y[6 * cb + 3:])
+        if sch == "trapeze":
+            assert s["U"][6, 0] == x[6 * blk + n]                 # U_{N+1} exists
+        elif sch == "gauss_legendre_2":
+            b = d.discretization.butcher_b
+            assert np.isclose(s["U"][2, 0], b[0] * x[2 * blk + n] + b[1] * x[2 * blk + n + 1])
+            assert s["U"][6, 0] == s["U"][5, 0]
+        elif sch == "euler_implicit":
+            assert s["U"][3, 0] == x[2 * blk + n] and s["U"][0, 0] == x[n]
+        else:
+            assert s["U"][6, 0] == x[5 * blk + n] and s["U"][2, 0] == x[2 * blk + n]

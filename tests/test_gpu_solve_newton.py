@@ -51,6 +51,19 @@ def test_newton_kkt_step_solves_the_quadratic_program():
     assert abs(d.obj(x1) - 1.5) <= 1e-6
     c1 = d.cons(x1)
     assert np.all(c1 <= uc + 1e-9)                     # q + 0.1 w^2 <= 1.05 indeed inactive
+    # solution rebuild with the reference's conventions (src/ode/common.jl:7-104, src/DOCP_data.jl:514-633) against the analytic
+    # extremal of min int u^2 on [0, 2]: u = 1.5 - 1.5 t, q = 0.75 t^2 - 0.25 t^3, w = 1.5 t - 0.75 t^2, costate (3, 3 - 3 t);
+    # same check and tolerance as test/ci/test_modeler_solver.jl:49-65
+    sol = ct.unpack_solution(d, x1, y1)
+    T = sol["T"]
+    assert np.allclose(T, np.linspace(0.0, 2.0, N + 1))
+    assert np.allclose(sol["X"], np.stack([0.75 * T ** 2 - 0.25 * T ** 3, 1.5 * T - 0.75 * T ** 2], axis=1), atol=1e-2)
+    assert np.allclose(sol["U"][:-1, 0], 1.5 - 1.5 * (T[:-1] + T[1:]) / 2, atol=2e-2)         # b-weighted stage average ~ midpoint value
+    # the multipliers of the state-equation rows of step i are the discrete costate at the END of the step (exactly, for this
+    # QP); the reference compares them with p(t_i) in norm at rtol 1e-2 on its 250-step grid, where the O(h) shift is below that
+    assert np.allclose(sol["P"], np.stack([np.full(N, 3.0), 3.0 - 3.0 * T[1:]], axis=1), atol=1e-7)
+    assert sol["path_constraints_dual"].shape == (N + 1, 1) and np.allclose(sol["path_constraints_dual"], 0.0)
+    assert sol["boundary_constraints_dual"].shape == (4,)
     # the Hessian of this problem does not depend on x (checked at the solution, with the new multipliers)
     assert np.max(np.abs(d.hess_coord(x1, y1, 1.0) - d.hess_coord(x, y1, 1.0))) <= 1e-12
 
