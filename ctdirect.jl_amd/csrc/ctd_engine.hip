@@ -288,7 +288,14 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     for_problem(mo.problem, [&](auto tag) { maxb = decltype(tag)::type::MAXB; });
     h->rt = runtime_ocp(mo.problem);
     if (h->rt) maxb = h->rt->maxb;
-    h->block = env_int("CTD_BLOCK", 256);
+    h->block = env_int("CTD_BLOCK", 0);
+    if (h->block <= 0) {
+        // 256 lanes, or 320 on small grids (everything resident at once) when a fifth wave lets the emit phase hold one more
+        // replica of the CSC period: 10 000-step Goddard / GL2, period 102: 3 x 102 = 306 of 320 lanes, 7.5 us vs 7.8 us
+        h->block = 256;
+        const int64_t ntl = (mo.L.N + h->tile - 1) / h->tile;
+        if (ntl <= 512 && mo.Lseg > 0 && 320 / mo.Lseg > 256 / mo.Lseg && mo.Lseg * (320 / mo.Lseg) * 10 >= 320 * 9) h->block = 320;
+    }
     if (h->block < 64 || (h->block % 64)) h->block = 256;
     if (h->block > maxb) h->block = maxb;
     mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
