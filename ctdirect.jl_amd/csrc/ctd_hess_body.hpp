@@ -20,7 +20,12 @@
 
 namespace ctd {
 
+// inner directions per second-order eval lane (-DCTD_HESSK_OVERRIDE=k for tuning experiments)
+#ifdef CTD_HESSK_OVERRIDE
+template <class P> struct HessK { static constexpr int value = CTD_HESSK_OVERRIDE; };
+#else
 template <class P> struct HessK { static constexpr int value = (P::NX >= 8) ? 2 : 4; };
+#endif
 
 template <class P, int SC, int S> struct HRL {
     static constexpr HessRecLayout R =

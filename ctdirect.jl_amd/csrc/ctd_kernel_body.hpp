@@ -219,11 +219,30 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const double* __restrict__ src = xu + g0;
         double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
         const int cnt = (int)(g1 - g0);
-        for (int e = tid; e < cnt; e += nthr) dst[e] = src[e];
+        // A lane first ISSUES its global loads of every stream (two elements of the xu slice, its optimisation variable, its
+        // share of the emit templates), then stores them to LDS: one exposed memory latency instead of one per copy loop
+        const bool codes = LOAD_V && codes_staged(kp);
+        const int nvc = kp.L.nv * kp.vr;
+        const double x0 = tid < cnt ? src[tid] : 0.0;
+        const double x1 = tid + nthr < cnt ? src[tid + nthr] : 0.0;
+        const double vv = (LOAD_V && tid < P::NV) ? xu[L.v_off + tid] : 0.0;
+        const uint32_t c0 = (codes && tid < kp.Lseg) ? kp.tmpl[tid] : 0u;
+        const uint32_t c1 = (codes && tid < nvc) ? kp.vtmpl[tid] : 0u;
+        if (tid < cnt) dst[tid] = x0;
+        if (tid + nthr < cnt) dst[tid + nthr] = x1;
+        if (LOAD_V && tid < kMaxNV) cx.v[tid] = vv;
+        if (codes) {
+            uint32_t* cd = const_cast<uint32_t*>(cx.codes);
+            if (tid < kp.Lseg) cd[tid] = c0;
+            if (tid < nvc) cd[kp.Lseg + tid] = c1;
+            for (int e = tid + nthr; e < kp.Lseg; e += nthr) cd[e] = kp.tmpl[e];
+            for (int e = tid + nthr; e < nvc; e += nthr) cd[kp.Lseg + e] = kp.vtmpl[e];
+        }
+        for (int e = tid + 2 * nthr; e < cnt; e += nthr) dst[e] = src[e];
         for (int e = tid; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
+        return;
     }
     if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
-    if (LOAD_V && !cx.is_edge) load_codes(kp, cx, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------------------------
