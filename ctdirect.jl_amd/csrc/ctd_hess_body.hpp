@@ -167,25 +167,38 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         const double* __restrict__ src = xu + g0;
         double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
         const int cnt = (int)(g1 - g0);
-        for (int e = tid; e < cnt; e += nthr) dst[e] = src[e];
         // rows of steps lo-1 .. lo+nslots-1 are contiguous in y; tiles never hold node N (its rows sit after N * cb)
         const int ny = (cx.nslots + 1) * L.cb;
         const int64_t yb = (cx.lo - 1) * (int64_t)L.cb, ylim = L.N * (int64_t)L.cb;
-        for (int e = tid; e < ny; e += nthr) {
-            const int64_t g = yb + e;
-            cx.ly[e] = (g >= 0 && g < ylim) ? y[g] : 0.0;
-        }
-        for (int e = tid; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
-        if (hess_tables_staged(hp)) {
+        auto yval = [&](int e) -> double { const int64_t g = yb + e; return (g >= 0 && g < ylim) ? y[g] : 0.0; };
+        // A lane first ISSUES its global loads of every stream (xu slice, multipliers, variable, term / task tables), then
+        // stores them to LDS: one exposed memory latency instead of one per copy loop
+        const bool st = hess_tables_staged(hp);
+        const double x0 = tid < cnt ? src[tid] : 0.0, x1 = tid + nthr < cnt ? src[tid + nthr] : 0.0;
+        const double y0 = tid < ny ? yval(tid) : 0.0, y1 = tid + nthr < ny ? yval(tid + nthr) : 0.0;
+        const double vv = tid < P::NV ? xu[L.v_off + tid] : 0.0;
+        const uint32_t w0 = (st && tid <= hp.Lseg) ? hp.tptr[tid] : 0u, w1 = (st && tid < hp.nterms) ? hp.terms[tid] : 0u;
+        const uint32_t w2 = (st && tid <= hp.nvv) ? hp.vptr[tid] : 0u, w3 = (st && tid < hp.nvterms) ? hp.vterms[tid] : 0u;
+        const uint32_t w4 = (st && tid < hp.ntask) ? hp.tasks[tid] : 0u, w5 = (st && tid < hp.nptask) ? hp.ptasks[tid] : 0u;
+        if (tid < cnt) dst[tid] = x0;
+        if (tid + nthr < cnt) dst[tid + nthr] = x1;
+        if (tid < ny) cx.ly[tid] = y0;
+        if (tid + nthr < ny) cx.ly[tid + nthr] = y1;
+        if (tid < kMaxNV) cx.v[tid] = vv;
+        if (st) {
             uint32_t* d;
-            d = const_cast<uint32_t*>(cx.tptr);   for (int e = tid; e <= hp.Lseg; e += nthr) d[e] = hp.tptr[e];
-            d = const_cast<uint32_t*>(cx.terms);  for (int e = tid; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
-            d = const_cast<uint32_t*>(cx.vptr);   for (int e = tid; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
-            d = const_cast<uint32_t*>(cx.vterms); for (int e = tid; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
-            uint32_t* q = const_cast<uint32_t*>(cx.tasks);
-            for (int e = tid; e < hp.ntask; e += nthr) q[e] = hp.tasks[e];
-            for (int e = tid; e < hp.nptask; e += nthr) q[hp.ntask + e] = hp.ptasks[e];
+            d = const_cast<uint32_t*>(cx.tptr);   if (tid <= hp.Lseg) d[tid] = w0;   for (int e = tid + nthr; e <= hp.Lseg; e += nthr) d[e] = hp.tptr[e];
+            d = const_cast<uint32_t*>(cx.terms);  if (tid < hp.nterms) d[tid] = w1;  for (int e = tid + nthr; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
+            d = const_cast<uint32_t*>(cx.vptr);   if (tid <= hp.nvv) d[tid] = w2;    for (int e = tid + nthr; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
+            d = const_cast<uint32_t*>(cx.vterms); if (tid < hp.nvterms) d[tid] = w3; for (int e = tid + nthr; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
+            d = const_cast<uint32_t*>(cx.tasks);  if (tid < hp.ntask) d[tid] = w4;   for (int e = tid + nthr; e < hp.ntask; e += nthr) d[e] = hp.tasks[e];
+            if (tid < hp.nptask) d[hp.ntask + tid] = w5;
+            for (int e = tid + nthr; e < hp.nptask; e += nthr) d[hp.ntask + e] = hp.ptasks[e];
         }
+        for (int e = tid + 2 * nthr; e < cnt; e += nthr) dst[e] = src[e];
+        for (int e = tid + 2 * nthr; e < ny; e += nthr) cx.ly[e] = yval(e);
+        for (int e = tid; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
+        return;
     }
     if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
 }
