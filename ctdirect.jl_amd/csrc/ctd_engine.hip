@@ -283,7 +283,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     if (h->step_begin < 0 || h->step_end > mo.L.N || h->step_begin >= h->step_end)
         return fail(nullptr, CTD_EINVAL, "ctd_create: shard [step_begin, step_end) is not inside [0, N)");
     h->tile = env_int("CTD_TILE", 0);
-    if (h->tile <= 0) h->tile = default_tile(mo);
+    if (h->tile <= 0) h->tile = default_tile(mo, h->step_end - h->step_begin);
     int maxb = 256;
     for_problem(mo.problem, [&](auto tag) { maxb = decltype(tag)::type::MAXB; });
     h->rt = runtime_ocp(mo.problem);
@@ -293,7 +293,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         // 256 lanes, or 320 on small grids (everything resident at once) when a fifth wave lets the emit phase hold one more
         // replica of the CSC period: 10 000-step Goddard / GL2, period 102: 3 x 102 = 306 of 320 lanes, 7.5 us vs 7.8 us
         h->block = 256;
-        const int64_t ntl = (mo.L.N + h->tile - 1) / h->tile;
+        const int64_t ntl = (h->step_end - h->step_begin + h->tile - 1) / h->tile;
         if (ntl <= 512 && mo.Lseg > 0 && 320 / mo.Lseg > 256 / mo.Lseg && mo.Lseg * (320 / mo.Lseg) * 10 >= 320 * 9) h->block = 320;
     }
     if (h->block < 64 || (h->block % 64)) h->block = 256;

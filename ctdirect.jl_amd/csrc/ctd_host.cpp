@@ -622,7 +622,7 @@ static int build_tables(Model& mo, std::string& err) {
     return ST_OK;
 }
 
-int default_tile(const Model& mo) {
+int default_tile(const Model& mo, int64_t nsteps) {
     // steps per 256-lane workgroup, from the MI355X tuning sweeps (profiles/): the largest power of two whose tile fits
     // ~60 KiB of LDS (two workgroups per CU stay resident), at most 32 for the Gauss-Legendre schemes and 64 for
     // trapeze / midpoint (small records).  Small grids: when that would give fewer than ~480 workgroups the tile shrinks
@@ -634,7 +634,8 @@ int default_tile(const Model& mo) {
     const int64_t cap = (L.sc == SC_IRK) ? 32 : 64;
     int64_t T = 1;
     while (T * 2 <= fit && T * 2 <= cap) T *= 2;
-    if ((L.N + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (L.N + 479) / 480));
+    if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
+    if ((nsteps + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (nsteps + 479) / 480));
     return (int)T;
 }
 

@@ -111,7 +111,7 @@ int default_hess_tile(const Model& m);
 int build_model(const HostDesc& d, Model& m, std::string& err);
 void model_initial_guess(const Model& m, double* x0, bool use_problem_default, const double* state, const double* control,
                          const double* variable);
-int default_tile(const Model& m);
+int default_tile(const Model& m, int64_t nsteps = 0);
 // sub-tile length of the pipelined driver: the producer is ONE wave, so Ts * (lanes per step) <= 64, and the three input
 // + two record buffers must fit ~60 KiB of LDS
 int default_pipe_tile(const Model& m);
