@@ -613,10 +613,10 @@ int32_t ctd_cons_jac(ctd_handle* h, const double* x, double* c, double* vals) {
     return host_cons_jac(h, x, c, vals);
 }
 
-int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
+static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
-    if (!x_dev || !f_host) return fail(h, CTD_EINVAL, "null argument");
+    if (!x_dev || !f_dev) return fail(h, CTD_EINVAL, "null argument");
     HIP_TRY(h, hipSetDevice(h->device));
     const Layout& L = h->model.L;
     ObjParams op;
@@ -629,7 +629,7 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
     op.unit_end = (L.sc == SC_TRAPEZE && last) ? L.N + 1 : h->step_end;
     op.add_mayer = last ? 1 : 0;
     op.partial = h->d_partial;
-    op.out = h->d_obj;
+    op.out = f_dev;
     const int64_t units = op.unit_end - op.unit_begin;
     int blocks = (int)((units + 255) / 256);
     if (blocks > h->obj_blocks) blocks = h->obj_blocks;
@@ -646,12 +646,30 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
         e = launch_obj<P>(L.sc, op, x_dev, blocks, 256, h->stream);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return CTD_OK;
+}
+
+int32_t ctd_obj_dev_async(ctd_handle* h, const double* x_dev, double* f_dev) { return enqueue_obj(h, x_dev, f_dev); }
+
+int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
+    if (h && !f_host) return fail(h, CTD_EINVAL, "null argument");
+    int32_t st = enqueue_obj(h, x_dev, h ? h->d_obj : nullptr);
+    if (st) return st;
     HIP_TRY(h, hipMemcpyAsync(f_host, h->d_obj, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTD_OK;
 }
 
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev);
+int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev) { return enqueue_grad(h, x_dev, g_dev); }
 int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
+    int32_t st = enqueue_grad(h, x_dev, g_dev);
+    if (st) return st;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
@@ -684,7 +702,6 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
         e = launch_grad<P>(L.sc, L.s, gp, x_dev, blocks, h->stream);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTD_OK;
 }
 

@@ -373,7 +373,13 @@ class DOCP:
             self._ck(L.ctd_obj(self._h, _dp(x), C.byref(f)))
         return f.value
 
-    def grad(self, x, g=None):
+    def obj_async(self, x, f):
+        """Enqueue obj(nlp, x) with the value written to the 1-element device tensor `f` (no host copy, no wait)."""
+        self._check_x(x)
+        self._ck(_lib.lib().ctd_obj_dev_async(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), self._dev_ptr(f, 1, "f")))
+        return f
+
+    def grad(self, x, g=None, sync=True):
         """grad!(nlp, x, g): gradient of __objective (ReverseDiff over the closure in the reference, src/collocation.jl:127)."""
         L = _lib.lib()
         self._check_x(x)
@@ -381,8 +387,8 @@ class DOCP:
             import torch
             if g is None:
                 g = torch.empty(self.dim_NLP_variables, dtype=torch.float64, device=x.device)
-            self._ck(L.ctd_grad_dev(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
-                                    self._dev_ptr(g, self.dim_NLP_variables, "g")))
+            fn = L.ctd_grad_dev if sync else L.ctd_grad_dev_async
+            self._ck(fn(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), self._dev_ptr(g, self.dim_NLP_variables, "g")))
             return g
         x = np.ascontiguousarray(x, dtype=np.float64)
         if g is None:

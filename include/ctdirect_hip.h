@@ -206,6 +206,10 @@ int32_t ctd_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, doub
 int32_t ctd_cons_jac_dev_async(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev);
 int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host);
 int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev);
+/* enqueue-only variants for device-resident solver loops: the objective goes to f_dev[0] (device memory), nothing is
+ * copied to the host and nothing waits; ctd_sync (or any later work on the handle's stream) orders the results */
+int32_t ctd_obj_dev_async(ctd_handle* h, const double* x_dev, double* f_dev);
+int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_sync(ctd_handle* h);
 
 /* ---- multi-GPU shards (time-step partition) ------------------------------------------ */

@@ -315,3 +315,31 @@ def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch
             assert np.array_equal(rows[cp[jg]:cp[jg + 1]] - 1 - s0 * cb, rvw[cpw[jl]:cpw[jl + 1]])
             assert relerr(seg_g, seg_w) <= 1e-9
     d.close()
+
+
+def test_device_resident_iteration_without_host_syncs(oracle_lib, torch_cuda):
+    """all five callbacks of one solver iteration enqueued on the stream with no host synchronisation in between
+    (ctd_*_dev_async), results read back once at the end -- the call pattern of a device-resident solver loop"""
+    torch = torch_cuda
+    prob, sch, N = "goddard_all", "gauss_legendre_2", 500
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    o.set_pattern_mode(1)
+    d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+    y = np.cos(0.41 * np.arange(o.dim_NLP_constraints))
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    f = torch.full((1,), SENT, dtype=torch.float64, device="cuda")
+    g = torch.full((d.dim_NLP_variables,), SENT, dtype=torch.float64, device="cuda")
+    c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
+    v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
+    hv = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        d.obj_async(xd, f)
+        d.grad(xd, g, sync=False)
+        d.cons_jac(xd, c, v, sync=False)
+        d.hess_coord(xd, yd, 1.0, hv, sync=False)
+    d.sync()
+    assert _rel(float(f[0]), o.objective(x)) <= TOL
+    assert relerr(g.cpu().numpy(), o.gradient(x)) <= TOL
+    assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+    assert relerr(hv.cpu().numpy(), o.hess_coord(x, y, 1.0)) <= TOL
