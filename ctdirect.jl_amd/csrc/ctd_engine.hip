@@ -562,6 +562,17 @@ int32_t ctd_cons_jac_dev_async(ctd_handle* h, const double* x_dev, double* c_dev
     return enqueue_cons_jac(h, x_dev, c_dev, vals_dev);
 }
 
+// Launch on another stream from now on (e.g. the capturing stream while the caller records a HIP graph of a whole solver
+// iteration).  The handle never owns a stream passed this way.
+int32_t ctd_set_stream(ctd_handle* h, void* stream) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+    return CTD_OK;
+}
+
 int32_t ctd_sync(ctd_handle* h) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
@@ -634,16 +645,17 @@ static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     int blocks = (int)((units + 255) / 256);
     if (blocks > h->obj_blocks) blocks = h->obj_blocks;
     if (blocks < 1) blocks = 1;
-    op.nblocks = blocks;
+    const bool lagrange = h->model.info.lagrange;      // Mayer-only cost: no quadrature pass, the finish kernel alone
+    op.nblocks = lagrange ? blocks : 0;
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
         void* args[] = {&op, &x_dev};
-        e = jit_launch(h->f_obj_partial, blocks, 256, 0, h->stream, args);
+        e = lagrange ? jit_launch(h->f_obj_partial, blocks, 256, 0, h->stream, args) : hipSuccess;
         if (e == hipSuccess) e = jit_launch(h->f_obj_finish, 1, 64, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
-        e = launch_obj<P>(L.sc, op, x_dev, blocks, 256, h->stream);
+        e = launch_obj<P>(L.sc, op, x_dev, lagrange ? blocks : 0, 256, h->stream);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;
@@ -690,16 +702,22 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev) {
     gp.g = g_dev;
     gp.partial = h->d_gpartial;
     gp.nblocks = blocks;
-    HIP_TRY(h, hipMemsetAsync(g_dev, 0, sizeof(double) * L.nvar, h->stream));
+    // With a Lagrange cost the per-step kernel writes every entry of the step blocks (owner computes), only the tail
+    // (final state, variables) needs zeroing before the finish kernel adds the Mayer part; a Mayer-only gradient is zero
+    // except at x_0, x_f, v: one memset and the finish kernel
+    const bool lagrange = h->model.info.lagrange;
+    if (lagrange) HIP_TRY(h, hipMemsetAsync(g_dev + L.N * (int64_t)L.blk, 0, sizeof(double) * (L.nvar - L.N * (int64_t)L.blk), h->stream));
+    else HIP_TRY(h, hipMemsetAsync(g_dev, 0, sizeof(double) * L.nvar, h->stream));
+    gp.nblocks = lagrange ? blocks : 0;
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
         void* args[] = {&gp, &x_dev};
-        e = jit_launch(h->f_grad_units, blocks, 256, 0, h->stream, args);
+        e = lagrange ? jit_launch(h->f_grad_units, blocks, 256, 0, h->stream, args) : hipSuccess;
         if (e == hipSuccess) e = jit_launch(h->f_grad_finish, 1, 64, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
-        e = launch_grad<P>(L.sc, L.s, gp, x_dev, blocks, h->stream);
+        e = launch_grad<P>(L.sc, L.s, gp, x_dev, lagrange ? blocks : 0, h->stream);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;

@@ -499,7 +499,8 @@ __global__ void grad_finish_kernel(const GradParams gp, const double* __restrict
 #if !defined(__HIPCC_RTC__)
 template <class P>
 hipError_t launch_grad(int sc, int s, const GradParams& gp, const double* xu, int grid, hipStream_t st) {
-    if (sc == SC_TRAPEZE) grad_units_kernel<P, SC_TRAPEZE, 1><<<grid, 256, 0, st>>>(gp, xu);
+    if (grid <= 0) {}      // Mayer-only cost: nothing to integrate
+    else if (sc == SC_TRAPEZE) grad_units_kernel<P, SC_TRAPEZE, 1><<<grid, 256, 0, st>>>(gp, xu);
     else if (sc == SC_MIDPOINT) grad_units_kernel<P, SC_MIDPOINT, 1><<<grid, 256, 0, st>>>(gp, xu);
     else if (s == 1) grad_units_kernel<P, SC_IRK, 1><<<grid, 256, 0, st>>>(gp, xu);
     else if (s == 2) grad_units_kernel<P, SC_IRK, 2><<<grid, 256, 0, st>>>(gp, xu);
@@ -571,7 +572,8 @@ hipError_t launch_cons_jac(int sc, const KParams& kp, const double* xu, int grid
 
 template <class P>
 hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st) {
-    if (sc == SC_TRAPEZE) obj_partial_kernel<P, SC_TRAPEZE><<<grid, block, 0, st>>>(op, xu);
+    if (grid <= 0) {}      // Mayer-only cost: nothing to integrate
+    else if (sc == SC_TRAPEZE) obj_partial_kernel<P, SC_TRAPEZE><<<grid, block, 0, st>>>(op, xu);
     else if (sc == SC_MIDPOINT) obj_partial_kernel<P, SC_MIDPOINT><<<grid, block, 0, st>>>(op, xu);
     else obj_partial_kernel<P, SC_IRK><<<grid, block, 0, st>>>(op, xu);
     obj_finish_kernel<P><<<1, 64, 0, st>>>(op, xu);

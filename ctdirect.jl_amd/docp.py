@@ -399,6 +399,15 @@ class DOCP:
     def sync(self):
         self._ck(_lib.lib().ctd_sync(self._h))
 
+    def set_stream(self, stream=None):
+        """Launch on `stream` from now on (a torch.cuda.Stream, a raw hipStream_t or None = torch's current stream), e.g.
+        inside `torch.cuda.graph(...)` to record a whole solver iteration into one HIP graph."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device)
+        raw = getattr(stream, "cuda_stream", stream)
+        self._ck(_lib.lib().ctd_set_stream(self._h, C.c_void_p(int(raw))))
+
     def time_cons_jac(self, x, c, vals, iters=20):
         """Mean duration (ms) of one fused-kernel launch, from HIP events recorded by each dispatch on the handle's stream."""
         ms = C.c_double()

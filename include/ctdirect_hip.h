@@ -208,6 +208,11 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host);
 int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev);
 /* enqueue-only variants for device-resident solver loops: the objective goes to f_dev[0] (device memory), nothing is
  * copied to the host and nothing waits; ctd_sync (or any later work on the handle's stream) orders the results */
+/* Launch on `stream` (a hipStream_t, NULL = the device's default stream) from now on, e.g. the capturing stream while the
+ * caller records a HIP graph of a whole solver iteration: every *_dev_async entry point only enqueues kernels (and one
+ * memset) and is capturable.  Handles of run-time OCPs and the first Hessian call compile / upload on first use: call
+ * each entry point once before capturing. */
+int32_t ctd_set_stream(ctd_handle* h, void* stream);
 int32_t ctd_obj_dev_async(ctd_handle* h, const double* x_dev, double* f_dev);
 int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_sync(ctd_handle* h);

@@ -343,3 +343,44 @@ def test_device_resident_iteration_without_host_syncs(oracle_lib, torch_cuda):
     assert relerr(g.cpu().numpy(), o.gradient(x)) <= TOL
     assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
     assert relerr(hv.cpu().numpy(), o.hess_coord(x, y, 1.0)) <= TOL
+
+
+def test_whole_iteration_as_one_hip_graph(oracle_lib, torch_cuda):
+    """the five callbacks of an iteration recorded once into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed on new
+    iterates: one graph launch instead of eight kernel launches"""
+    torch = torch_cuda
+    prob, sch, N = "goddard", "gauss_legendre_2", 2000
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    d = ct.DOCP(prob, N, sch, device=0)
+    x0 = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+    y = np.cos(0.41 * np.arange(o.dim_NLP_constraints))
+    xd, yd = torch.from_numpy(x0).cuda(), torch.from_numpy(y).cuda()
+    f = torch.zeros(1, dtype=torch.float64, device="cuda")
+    g = torch.zeros(d.dim_NLP_variables, dtype=torch.float64, device="cuda")
+    c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
+    v = torch.zeros(d.nnzj, dtype=torch.float64, device="cuda")
+    hv = torch.zeros(d.nnzh, dtype=torch.float64, device="cuda")
+
+    def iteration():
+        d.obj_async(xd, f)
+        d.grad(xd, g, sync=False)
+        d.cons_jac(xd, c, v, sync=False)
+        d.hess_coord(xd, yd, 1.0, hv, sync=False)
+
+    iteration()                       # first use: uploads the Hessian tables (not capturable)
+    d.sync()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        d.set_stream(side)
+        iteration()
+    d.set_stream(None)
+    rng = np.random.default_rng(3)
+    for _ in range(3):                # new iterate in the same buffers, one graph launch
+        x = x0 + 1e-3 * rng.standard_normal(x0.size)
+        xd.copy_(torch.from_numpy(x))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert _rel(float(f[0]), o.objective(x)) <= TOL and relerr(g.cpu().numpy(), o.gradient(x)) <= TOL
+        assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+        assert relerr(hv.cpu().numpy(), o.hess_coord(x, y, 1.0)) <= TOL
