@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <cstdlib>
@@ -535,7 +536,8 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
 
 // ---- hot path ------------------------------------------------------------------------------------------------
 
-static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, bool timed = false) {
+static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, hipEvent_t te0 = nullptr,
+                                hipEvent_t te1 = nullptr) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev) return fail(h, CTD_EINVAL, "x is null");
@@ -547,12 +549,11 @@ static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_de
     const int sc = h->model.L.sc;
     if (h->rt) {
         void* args[] = {&kp, &x_dev};
-        e = jit_launch(h->f_cons_jac, h->grid, h->block, h->lds_bytes, h->stream, args, timed ? h->ev0 : nullptr, timed ? h->ev1 : nullptr);
+        e = jit_launch(h->f_cons_jac, h->grid, h->block, h->lds_bytes, h->stream, args, te0, te1);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
-        e = launch_cons_jac<P>(sc, kp, x_dev, h->grid, h->block, h->lds_bytes, h->stream, timed ? h->ev0 : nullptr,
-                               timed ? h->ev1 : nullptr);
+        e = launch_cons_jac<P>(sc, kp, x_dev, h->grid, h->block, h->lds_bytes, h->stream, te0, te1);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;
@@ -772,24 +773,41 @@ int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, doub
     return st;
 }
 
-int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, int32_t iters, double* mean_ms) {
-    if (!h || !mean_ms || iters < 1) return CTD_EINVAL;
-    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
-    int32_t st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);   // warm
+// Mean duration of one dispatch of a kernel, measured the way the timed region of bench.py runs it: the launches are
+// enqueued back to back in batches (the GPU stays busy, clocks stay up), every launch carries its own pair of dispatch
+// events (start / stop timestamps taken by the dispatch of THAT kernel on the handle's stream), one synchronisation per batch
+static int32_t time_dispatches(ctd_handle* h, int32_t iters, double* mean_ms,
+                               const std::function<int32_t(hipEvent_t, hipEvent_t)>& launch) {
+    constexpr int kBatch = 32;
+    static thread_local hipEvent_t ev[2 * kBatch] = {nullptr};
+    for (hipEvent_t& e : ev)
+        if (!e) HIP_TRY(h, hipEventCreate(&e));
+    int32_t st = launch(nullptr, nullptr);   // warm
     if (st) return st;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    // per-dispatch events: the start/stop timestamps are taken by the dispatch of THIS kernel on the handle's stream
     double total = 0.0;
-    for (int i = 0; i < iters; ++i) {
-        st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev, true);
-        if (st) return st;
-        HIP_TRY(h, hipEventSynchronize(h->ev1));
-        float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        total += (double)ms;
+    for (int done = 0; done < iters;) {
+        const int nb = iters - done < kBatch ? iters - done : kBatch;
+        for (int i = 0; i < nb; ++i) {
+            st = launch(ev[2 * i], ev[2 * i + 1]);
+            if (st) return st;
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < nb; ++i) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            total += (double)ms;
+        }
+        done += nb;
     }
     *mean_ms = total / iters;
     return CTD_OK;
+}
+
+int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, int32_t iters, double* mean_ms) {
+    if (!h || !mean_ms || iters < 1) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    return time_dispatches(h, iters, mean_ms, [&](hipEvent_t a, hipEvent_t b) { return enqueue_cons_jac(h, x_dev, c_dev, vals_dev, a, b); });
 }
 
 // ---- Hessian of the Lagrangian ----------------------------------------------------------------------------------------
@@ -874,7 +892,7 @@ static int32_t ensure_hess(ctd_handle* h) {
 }
 
 static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
-                            bool timed = false) {
+                            hipEvent_t te0 = nullptr, hipEvent_t te1 = nullptr) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !y_dev || !vals_dev) return fail(h, CTD_EINVAL, "null argument");
@@ -887,13 +905,12 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
         void* args[] = {&hp, &x_dev, &y_dev};
-        e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, timed ? h->ev0 : nullptr,
-                       timed ? h->ev1 : nullptr);
+        e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, te0, te1);
         if (e == hipSuccess && hp.nvv > 0 && !hp.done_counter) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
-        e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, timed ? h->ev0 : nullptr, timed ? h->ev1 : nullptr);
+        e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, te0, te1);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;
@@ -980,20 +997,8 @@ int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* o) {
 int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev, int32_t iters,
                           double* mean_ms) {
     if (!h || !mean_ms || iters < 1) return CTD_EINVAL;
-    int32_t st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);   // warm
-    if (st) return st;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    double total = 0.0;
-    for (int i = 0; i < iters; ++i) {
-        st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev, true);
-        if (st) return st;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        float ms = 0.f;
-        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        total += (double)ms;
-    }
-    *mean_ms = total / iters;
-    return CTD_OK;
+    return time_dispatches(h, iters, mean_ms,
+                           [&](hipEvent_t a, hipEvent_t b) { return enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev, a, b); });
 }
 
 }  // extern "C"
