@@ -46,7 +46,14 @@ struct HBlockCtx {
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
     const uint32_t *tptr, *terms, *vptr, *vterms;
     const uint32_t *tasks, *ptasks;
+    // LDS copies of the Butcher tables (a[9] | b[3] | c[3]) and of the coefficient-pair codes: both sit in the kernel
+    // arguments, where a lane-dependent index would cost a global load per use
+    const double* abc;
+    const uint32_t* pairs;
 };
+
+// doubles at the head of every workgroup's LDS: abc (15, padded to 16) | pair codes (kMaxPairs words)
+constexpr int kHessCoefDoubles = 16 + kMaxPairs / 2;
 
 // words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks | ptasks
 constexpr int kMaxStagedHessWords = 3072;
@@ -66,6 +73,9 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     const Layout& L = hp.L;
     cx.tptr = hp.tptr; cx.terms = hp.terms; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
     cx.tasks = hp.tasks; cx.ptasks = hp.ptasks;
+    cx.abc = lds;
+    cx.pairs = reinterpret_cast<const uint32_t*>(lds + 16);
+    lds += kHessCoefDoubles;
     if (block == 0) {
         cx.is_edge = 1;
         cx.nslots = hp.n_edge_slots;
@@ -111,9 +121,9 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
 inline int64_t hess_lds_doubles(const HParams& hp) {
     const Layout& L = hp.L;
     const int64_t cap = hp.T + hp.HL + hp.HH;
-    const int64_t tile = hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
+    const int64_t tile = kHessCoefDoubles + hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
                          cap * (hp.R.stride + hp.npairs) + (int64_t)hp.nvv * hp.T;
-    const int64_t edge = (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
+    const int64_t edge = kHessCoefDoubles + (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
                          3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * (hp.R.stride + hp.npairs);
     return tile > edge ? tile : edge;
 }
@@ -140,11 +150,27 @@ CTD_HD double hess_y_of(const HParams& hp, const double* __restrict__ y, int64_t
 // ------------------------------------------------------------------------------------------------------
 // phase: load
 // ------------------------------------------------------------------------------------------------------
+CTD_HD double hess_butcher_entry(const Layout& L, int e) {
+    return e < 9 ? L.a[e < 9 ? e : 0] : (e < 12 ? L.b[e < 12 ? e - 9 : 0] : (e < 15 ? L.c[e - 12] : 0.0));
+}
+// cf / pc: entry `tid` of the two tables, loaded by the caller ahead of its other copies (workgroups narrower than the
+// tables, which only the emulator uses, fetch the rest here)
+CTD_HD void hess_stage_coefs(const HParams& hp, const HBlockCtx& cx, double cf, uint32_t pc, int tid, int nthr) {
+    if (tid < 16) const_cast<double*>(cx.abc)[tid] = cf;
+    if (tid < kMaxPairs) const_cast<uint32_t*>(cx.pairs)[tid] = pc;
+    for (int e = tid + nthr; e < 16; e += nthr) const_cast<double*>(cx.abc)[e] = hess_butcher_entry(hp.L, e);
+    for (int e = tid + nthr; e < hp.npairs; e += nthr) const_cast<uint32_t*>(cx.pairs)[e] = hp.pairs[e];
+}
+
 template <class P>
 CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double* __restrict__ xu,
                             const double* __restrict__ y, int tid, int nthr) {
     const Layout& L = hp.L;
+    // Butcher tables and pair codes (issued first: their latency overlaps the copies below)
+    const double cf = hess_butcher_entry(L, tid);
+    const uint32_t pc = tid < hp.npairs ? hp.pairs[tid] : 0u;
     if (cx.is_edge) {
+        hess_stage_coefs(hp, cx, cf, pc, tid, nthr);
         const int per = cx.in_stride;
         for (int e = tid; e < cx.nslots * per; e += nthr) {
             const int k = e / per, o = e - k * per;
@@ -185,6 +211,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         if (tid < ny) cx.ly[tid] = y0;
         if (tid + nthr < ny) cx.ly[tid + nthr] = y1;
         if (tid < kMaxNV) cx.v[tid] = vv;
+        hess_stage_coefs(hp, cx, cf, pc, tid, nthr);
         if (st) {
             uint32_t* d;
             d = const_cast<uint32_t*>(cx.tptr);   if (tid <= hp.Lseg) d[tid] = w0;   for (int e = tid + nthr; e <= hp.Lseg; e += nthr) d[e] = hp.tptr[e];
@@ -208,15 +235,15 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
 // ------------------------------------------------------------------------------------------------------
 // value of chain-rule coefficient ci for a step of length h (dh[k] = dh/dv_k); see the HC_* enum
 template <class P>
-CTD_HD double hess_coef_value(const Layout& L, int ci, double h, double tau0, double tau1) {
+CTD_HD double hess_coef_value(const double* abc, int ci, double h, double tau0, double tau1) {
     if (ci == HC_ONE) return 1.0;
     if (ci == HC_HALF) return 0.5;
-    if (ci < HC_A) return h * L.a[ci - HC_HA];
-    if (ci < HC_B) return L.a[ci - HC_A];
-    if (ci < HC_NBH) return L.b[ci - HC_B];
+    if (ci < HC_A) return h * abc[ci - HC_HA];
+    if (ci < HC_B) return abc[ci - HC_A];
+    if (ci < HC_NBH) return abc[9 + ci - HC_B];
     const int k = (ci - HC_NBH) / 3, l = (ci - HC_NBH) - 3 * k;
     const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, k) - dtime_of<P>(tau0, k) : 0.0;
-    return -(L.b[l] * dh);
+    return -(abc[9 + l] * dh);
 }
 
 // coefficient products of one record (slot k, pair id) + the state-equation multipliers the K x V terms need
@@ -228,8 +255,8 @@ CTD_HD void hess_pair(const HParams& hp, const HBlockCtx& cx, int k, int pid) {
     double* rec = cx.rec + k * R.stride;
     const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
     const double h = htime_of<P>(hp, cx.v, tau1) - htime_of<P>(hp, cx.v, tau0);
-    const int code = hp.pairs[pid];
-    cx.cp[k * hp.npairs + pid] = hess_coef_value<P>(L, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(L, code >> 8, h, tau0, tau1);
+    const int code = (int)cx.pairs[pid];
+    cx.cp[k * hp.npairs + pid] = hess_coef_value<P>(cx.abc, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(cx.abc, code >> 8, h, tau0, tau1);
     if (pid == 0) rec[R.oZero] = 0.0;
     if (SC == SC_IRK && Dirs<P>::FREE && pid == 0) {
         const double* y = hslot_y(hp, cx, k);
@@ -287,7 +314,7 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     // evaluation time
     T t;
     if (SC == SC_IRK) {
-        const double cj = L.c[j];
+        const double cj = butcher_c<S>(L, j);
 #pragma unroll
         for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0) + cj * hdb[i];
         t = hess_seed<K>(tA + cj * h, dt_of(p, tau0) + cj * hda, sb);
@@ -313,7 +340,7 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
             const double* Kv = base + n + L.cu;
             double kap = 0.0;
 #pragma unroll
-            for (int l = 0; l < S; ++l) kap = kap + L.a[3 * j + l] * Kv[l * n + r];
+            for (int l = 0; l < S; ++l) kap = kap + butcher_a<S>(L, j, l) * Kv[l * n + r];
 #pragma unroll
             for (int i = 0; i < K; ++i) sb[i] = unit(q[i], r) + hdb[i] * kap;
             x[r] = hess_seed<K>(base[r] + h * kap, unit(p, r) + hda * kap, sb);
@@ -347,7 +374,7 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     if (SC == SC_IRK) {
 #pragma unroll
         for (int r = 0; r < n; ++r) phi = phi + f[r] * (-y[n + j * n + r]);
-        if (P::HAS_LAGRANGE) phi = phi + (hh * P::template lagrange<T>(t, x, u, v)) * (hp.obj_weight * L.b[j]);
+        if (P::HAS_LAGRANGE) phi = phi + (hh * P::template lagrange<T>(t, x, u, v)) * (hp.obj_weight * butcher_b<S>(L, j));
     } else if (SC == SC_MIDPOINT) {
         T inner(0.0);
 #pragma unroll
@@ -543,9 +570,9 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         // coefficient products of the two extra records: no step length (only ONE, HALF and the b_l can occur)
         for (int e = tid; e < 2 * hp.npairs; e += nthr) {
             const int which = e / hp.npairs, pid = e - which * hp.npairs;
-            const int code = hp.pairs[pid];
+            const int code = (int)cx.pairs[pid];
             cx.cp[(hp.edge_fp + which) * hp.npairs + pid] =
-                hess_coef_value<P>(L, code & 0xFF, 0.0, 0.0, 0.0) * hess_coef_value<P>(L, code >> 8, 0.0, 0.0, 0.0);
+                hess_coef_value<P>(cx.abc, code & 0xFF, 0.0, 0.0, 0.0) * hess_coef_value<P>(cx.abc, code >> 8, 0.0, 0.0, 0.0);
         }
     }
 }

@@ -332,10 +332,10 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
             for (int c = 0; c < n; ++c) {
                 double acc = 0.0;
 #pragma unroll
-                for (int l = 0; l < S; ++l) acc = acc + (dh[kk] * L.a[3 * j + l]) * K[l * n + c];
+                for (int l = 0; l < S; ++l) acc = acc + (dh[kk] * butcher_a<S>(L, j, l)) * K[l * n + c];
                 dx[c] = acc;
             }
-            const double dtij = dti[kk] + L.c[j] * dh[kk];
+            const double dtij = dti[kk] + butcher_c<S>(L, j) * dh[kk];
 #pragma unroll
             for (int r = 0; r < n; ++r) {
                 double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
@@ -394,13 +394,13 @@ CTD_HD void fin_stage_row(const KParams& kp, const BlockCtx& cx, int k, int j, i
         const double dti = FREE ? dtime_of<P>(tau0, kk) : 0.0;
         const double dh = FREE ? dtime_of<P>(tau1, kk) - dti : 0.0;
         double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
-        if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (dti + L.c[j] * dh);
+        if (P::DYN_T && FREE) w = w + ev[R.oft + r] * (dti + butcher_c<S>(L, j) * dh);
         if (FREE) {
 #pragma unroll
             for (int c = 0; c < n; ++c) {
                 double acc = 0.0;
 #pragma unroll
-                for (int l = 0; l < S; ++l) acc = acc + (dh * L.a[3 * j + l]) * K[l * n + c];
+                for (int l = 0; l < S; ++l) acc = acc + (dh * butcher_a<S>(L, j, l)) * K[l * n + c];
                 w = w + ev[R.oF + r * n + c] * acc;
             }
         }
@@ -520,13 +520,13 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
         const double h = time_of<P>(kp, cx.v, slot_tau(cx, k, 1)) - ti;
-        t = ti + L.c[j] * h;
+        t = ti + butcher_c<S>(L, j) * h;
         const double* K = base + n + L.cu;
 #pragma unroll
         for (int c = 0; c < n; ++c) {
             double x = base[c];
 #pragma unroll
-            for (int l = 0; l < S; ++l) x = x + h * L.a[3 * j + l] * K[l * n + c];
+            for (int l = 0; l < S; ++l) x = x + h * butcher_a<S>(L, j, l) * K[l * n + c];
             xv[c] = x;
         }
         const double* U = base + n + (L.stagewise ? j * m : 0);

@@ -40,6 +40,19 @@ struct Layout {
     int32_t pad_;
 };
 
+// Butcher entries for a stage index j that differs between the lanes of a wave.  The tables sit in the kernel arguments:
+// indexed with a vector register they cost a global load (and a full memory latency) per use, selected from the S scalar
+// values they stay in scalar registers.  Same values, so the arithmetic is unchanged.
+template <int S> CTD_HD double butcher_pick(const double* t, int j, int stride, int off) {
+    const double t0 = t[off], t1 = t[(S > 1 ? stride : 0) + off], t2 = t[(S > 2 ? 2 * stride : 0) + off];   // uniform loads first
+    if (S <= 1) return t0;
+    if (S == 2) return j == 0 ? t0 : t1;
+    return j == 0 ? t0 : (j == 1 ? t1 : t2);
+}
+template <int S> CTD_HD double butcher_a(const Layout& L, int j, int l) { return butcher_pick<S>(L.a, j, 3, l); }
+template <int S> CTD_HD double butcher_b(const Layout& L, int j) { return butcher_pick<S>(L.b, j, 1, 0); }
+template <int S> CTD_HD double butcher_c(const Layout& L, int j) { return butcher_pick<S>(L.c, j, 1, 0); }
+
 // doubles per record input of the edge block: own step block | X_{i+1} | U_{i+1} (trapeze) | U_{i-1} (implicit Euler's path control)
 CTD_HD int edge_in_stride(const Layout& L) { return L.blk + L.n + 2 * L.m; }
 

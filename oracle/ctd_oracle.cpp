@@ -40,6 +40,8 @@
 // (tests/golden/).  Jacobian and Hessian VALUES have no golden in the reference ("parity unpinned" for values; pinned by
 // the build's own first- and second-order mpmath derivative fixtures and finite differences).
 // =================================================================================================
+#include <malloc.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -828,6 +830,34 @@ template <class P> static void jacobian_colored(Docp& p, const double* xu, doubl
     }
 }
 
+// The same coloured passes spread over host threads (OpenMP, one colour at a time per thread; every pass is independent and
+// writes its own columns' entries): the multi-core CPU baseline bench.py reports beside the single-thread one.
+template <class P> static void jacobian_colored_mt(Docp& p, const double* xu, double* vals, int nthreads) {
+    ensure_pattern(p);
+    const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > p.ncolors) nthreads = p.ncolors;
+    // every pass allocates its time grid / work arrays (as the reference does); keep those in the per-thread malloc arenas:
+    // one mmap + munmap per pass would serialise the threads on the address-space lock and its TLB shoot-downs
+    static const int arena_ok = mallopt(M_MMAP_THRESHOLD, 32 << 20) + mallopt(M_TRIM_THRESHOLD, 512 << 20);
+    (void)arena_ok;
+    const Docp& cp = p;
+    // OpenMP keeps its worker threads (and their malloc arenas and warm buffers) between calls
+#pragma omp parallel num_threads(nthreads)
+    {
+        static thread_local std::vector<D1> z, cz;
+        z.resize(nvar); cz.resize(ncon);
+#pragma omp for schedule(static, 1)
+        for (int col = 0; col < cp.ncolors; ++col) {
+            for (int64_t j = 0; j < nvar; ++j) z[j] = D1(xu[j], cp.color[j] == col ? 1.0 : 0.0);
+            constraints<P, D1>(cp, z.data(), cz.data());
+            for (int64_t j = 0; j < nvar; ++j)
+                if (cp.color[j] == col)
+                    for (int64_t k = cp.colptr[j]; k < cp.colptr[j + 1]; ++k) vals[k] = cz[cp.rowval[k]].d;
+        }
+    }
+}
+
 // one full column of the dense Jacobian (independent of any pattern)
 template <class P> static void jacobian_column(const Docp& p, const double* xu, int64_t col, double* out) {
     const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
@@ -1042,6 +1072,10 @@ void orc_jac_pattern(void* h, int64_t* colptr, int64_t* rowval) {
 void orc_jac_coord(void* h, const double* xu, double* vals) {
     Docp& p = *(Docp*)h;
     orc::dispatch(p.problem, [&](auto tag) { orc::jacobian_colored<typename decltype(tag)::type>(p, xu, vals); });
+}
+void orc_jac_coord_mt(void* h, const double* xu, double* vals, int nthreads) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::jacobian_colored_mt<typename decltype(tag)::type>(p, xu, vals, nthreads); });
 }
 void orc_jac_column(void* h, const double* xu, int64_t col, double* out) {
     Docp& p = *(Docp*)h;

@@ -82,6 +82,7 @@ def lib():
         L.orc_jac_ncolors.restype = C.c_int
         L.orc_jac_pattern.argtypes = [C.c_void_p, ip, ip]
         L.orc_jac_coord.argtypes = [C.c_void_p, dp, dp]
+        L.orc_jac_coord_mt.argtypes = [C.c_void_p, dp, dp, C.c_int]
         L.orc_jac_column.argtypes = [C.c_void_p, dp, C.c_int64, dp]
         L.orc_hess_nnz.argtypes = [C.c_void_p, ip, ip]
         L.orc_hess_lower_nnz.argtypes = [C.c_void_p]
@@ -202,6 +203,13 @@ class OracleDOCP:
         xu = np.ascontiguousarray(xu, dtype=np.float64)
         vals = np.zeros(self.jac_nnz())
         lib().orc_jac_coord(self._h, _dp(xu), _dp(vals))
+        return vals
+
+    def jac_coord_mt(self, xu, nthreads):
+        """jac_coord with the colours spread over `nthreads` host threads (same values; multi-core baseline)."""
+        xu = np.ascontiguousarray(xu, dtype=np.float64)
+        vals = np.zeros(self.jac_nnz())
+        lib().orc_jac_coord_mt(self._h, _dp(xu), _dp(vals), int(nthreads))
         return vals
 
     def jac_dense(self, xu):

@@ -205,3 +205,14 @@ def test_G2_hessian_pattern_nnzh(oracle_lib):
     d = oracle_lib.OracleDOCP("goddard", "midpoint", 250)
     colptr, rowval = d.hess_pattern()
     assert len(rowval) == 6519 and colptr[-1] == 6519
+
+
+@pytest.mark.parametrize("problem, scheme, N", [("goddard", "gauss_legendre_2", 200), ("goddard_all", "trapeze", 64),
+                                                ("quadrotor", "gauss_legendre_3", 9)])
+def test_threaded_coloured_jacobian_equals_serial(oracle_lib, problem, scheme, N):
+    """the multi-core CPU baseline of bench.py runs the same coloured passes: bit-identical values for any thread count"""
+    o = oracle_lib.OracleDOCP(problem, scheme, N)
+    x = 0.1 + 0.05 * np.sin(1.3 * np.arange(o.dim_NLP_variables))
+    want = o.jac_coord(x)
+    for nt in (1, 3, 64):
+        assert np.array_equal(o.jac_coord_mt(x, nt), want)
