@@ -564,16 +564,12 @@ def get_time_grid(xu, docp):
     return grid
 
 
-def unpack_solution(docp, x, multipliers=None):
-    """The arrays `CTDirect.build_OCP_solution` hands to CTModels (src/DOCP_data.jl:514-633) from an NLP solution, with the
-    reference's getter conventions (src/ode/common.jl:7-104): X[N+1, n], U[N+1, m] (control of the scheme at every node,
-    final control duplicated when the scheme has none), v, and from the constraint multipliers the costate P[N, n] (the
-    multipliers of the state-equation rows), the path-constraint duals divided by the step length and the boundary duals."""
-    x = np.ascontiguousarray(x.detach().cpu().numpy() if _is_tensor(x) else x, dtype=np.float64)
+def _state_control_variable(docp, data):
+    """X[N+1, n], U[N+1, m], v read from any vector with the NLP variable layout (the primal iterate or a vector of bound
+    multipliers) with the reference's getters (`getter(...; val=:state | :control | :variable)`, src/ode/common.jl:50-84)"""
     n, m, nv = docp.dims.NLP_x, docp.dims.NLP_u, docp.dims.NLP_v
     N, blk = docp.time.steps, docp.discretization._step_variables_block
-    T = get_time_grid(x, docp)
-    X = np.stack([x[i * blk:i * blk + n] for i in range(N + 1)])
+    X = np.stack([data[i * blk:i * blk + n] for i in range(N + 1)])
     stage = docp.discretization.stage
     stagewise = docp.scheme in ("gauss_legendre_2", "gauss_legendre_3")
     U = np.zeros((N + 1, m))
@@ -584,10 +580,30 @@ def unpack_solution(docp, x, multipliers=None):
             if docp.scheme == "euler_implicit":
                 j = max(i - 1, 0) if i > 0 else 0                                # u(t_i) = U_{i-1}, u(t_0) = U_0
             o = j * blk + n
-            U[i] = sum(b[s] * x[o + s * m:o + (s + 1) * m] for s in range(stage)) if stagewise else x[o:o + m]
-    out = dict(T=T, X=X, U=U, v=x[len(x) - nv:].copy())
+            U[i] = sum(b[s] * data[o + s * m:o + (s + 1) * m] for s in range(stage)) if stagewise else data[o:o + m]
+    return X, U, data[len(data) - nv:].copy()
+
+
+def unpack_solution(docp, x, multipliers=None, multipliers_L=None, multipliers_U=None):
+    """The arrays `CTDirect.build_OCP_solution` hands to CTModels (src/DOCP_data.jl:514-633) from an NLP solution, with the
+    reference's getter conventions (src/ode/common.jl:7-104): X[N+1, n], U[N+1, m] (control of the scheme at every node,
+    final control duplicated when the scheme has none), v, and from the constraint multipliers the costate P[N, n] (the
+    multipliers of the state-equation rows), the path-constraint duals divided by the step length and the boundary duals;
+    from the bound multipliers (`multipliers_L`, `multipliers_U`, nvar entries each) the state / control / variable box
+    duals, read with the same getters as the primal arrays."""
+    x = np.ascontiguousarray(x.detach().cpu().numpy() if _is_tensor(x) else x, dtype=np.float64)
+    N = docp.time.steps
+    T = get_time_grid(x, docp)
+    X, U, v = _state_control_variable(docp, x)
+    out = dict(T=T, X=X, U=U, v=v)
+    for z, tag in ((multipliers_L, "lb"), (multipliers_U, "ub")):
+        zz = np.zeros_like(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
+        ZX, ZU, Zv = _state_control_variable(docp, zz)
+        out["state_constraints_%s_dual" % tag], out["control_constraints_%s_dual" % tag] = ZX, ZU
+        out["variable_constraints_%s_dual" % tag] = Zv
     if multipliers is not None:
         y = np.ascontiguousarray(multipliers, dtype=np.float64)
+        n = docp.dims.NLP_x
         eqs, p, bc = docp.discretization._state_stage_eqs_block, docp.dims.path_cons, docp.dims.boundary_cons
         cb = eqs + p
         out["P"] = np.stack([y[i * cb:i * cb + n] for i in range(N)])

@@ -165,3 +165,11 @@ def test_solution_unpacking_follows_the_reference_getter():
             assert s["U"][3, 0] == x[2 * blk + n] and s["U"][0, 0] == x[n]
         else:
             assert s["U"][6, 0] == x[5 * blk + n] and s["U"][2, 0] == x[2 * blk + n]
+        # bound multipliers go through the same getters (src/DOCP_data.jl:567-579); absent ones unpack as zeros
+        zl = np.arange(d.dim_NLP_variables, dtype=float) + 0.5
+        s2 = ct.unpack_solution(d, x, y, multipliers_L=zl)
+        assert np.array_equal(s2["state_constraints_lb_dual"][3], zl[3 * blk:3 * blk + 3])
+        assert s2["control_constraints_lb_dual"].shape == (7, 1) and s2["variable_constraints_lb_dual"][0] == zl[-1]
+        assert not s2["state_constraints_ub_dual"].any() and not s2["control_constraints_ub_dual"].any()
+        if sch == "midpoint":
+            assert s2["control_constraints_lb_dual"][6, 0] == zl[5 * blk + n]
