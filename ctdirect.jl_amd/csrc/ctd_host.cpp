@@ -303,8 +303,8 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     const Layout& L = mo.L;
     const RecLayout& R = mo.R;
     const int n = L.n, m = L.m;
-    auto F = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oF + r * n + c; };
-    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * m + c; };
+    auto F = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oF + r * R.ldx + c; };
+    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * R.ldu + c; };
     const bool is_path = lr >= L.eqs;
     if (L.sc == SC_IRK) {
         // column kind
@@ -316,8 +316,8 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
         else kind = 4;
         if (is_path) {
             const int pq = lr - L.eqs;
-            if (kind == 0) return Loc{C_ONE, R.oPx + pq * n + c, 0, false};
-            if (kind == 1) return Loc{L.stagewise ? C_B + l : C_ONE, R.oPu + pq * m + c, 0, false};
+            if (kind == 0) return Loc{C_ONE, R.oPx + pq * R.ldx + c, 0, false};
+            if (kind == 1) return Loc{L.stagewise ? C_B + l : C_ONE, R.oPu + pq * R.ldu + c, 0, false};
             return kZero;
         }
         if (lr < n) {   // state equation row
@@ -342,10 +342,10 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     else kind = 4;
     if (is_path) {
         const int pq = lr - L.eqs;
-        if (kind == 0) return Loc{C_ONE, R.oPx + pq * n + c, 0, false};
+        if (kind == 0) return Loc{C_ONE, R.oPx + pq * R.ldx + c, 0, false};
         // implicit Euler evaluates the path constraints of node i >= 1 with U_{i-1} (euler.jl:59-72): the pattern's
         // (path_i, U_i) entries are structural zeros there
-        if (kind == 1) return (L.euler == 2 && step >= 1) ? kZero : Loc{C_ONE, R.oPu + pq * m + c, 0, false};
+        if (kind == 1) return (L.euler == 2 && step >= 1) ? kZero : Loc{C_ONE, R.oPu + pq * R.ldu + c, 0, false};
         return kZero;
     }
     const int r = lr;
@@ -412,16 +412,16 @@ Model::Entry Model::classify(int64_t row, int64_t col) const {
         e.kind = 1;
         if (col >= L.v_off) { e.ci = C_ONE; e.di = Rr.oPv + pq * nv + (int)(col - L.v_off); return e; }
         const int64_t xf0 = N * L.blk;
-        if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oPx + pq * n + (int)(col - xf0); return e; }
+        if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oPx + pq * Rr.ldx + (int)(col - xf0); return e; }
         if (L.sc == SC_TRAPEZE) {
-            if (col >= xf0 + n && col < xf0 + n + m) { e.ci = C_ONE; e.di = Rr.oPu + pq * m + (int)(col - xf0 - n); }
+            if (col >= xf0 + n && col < xf0 + n + m) { e.ci = C_ONE; e.di = Rr.oPu + pq * Rr.ldu + (int)(col - xf0 - n); }
             return e;
         }
         const int64_t u0 = (N - 1) * L.blk + n;
         if (col >= u0 && col < u0 + L.cu) {
             const int o = (int)(col - u0);
-            if (L.stagewise) { e.ci = C_B + o / m; e.di = Rr.oPu + pq * m + o % m; }
-            else { e.ci = C_ONE; e.di = Rr.oPu + pq * m + o; }
+            if (L.stagewise) { e.ci = C_B + o / m; e.di = Rr.oPu + pq * Rr.ldu + o % m; }
+            else { e.ci = C_ONE; e.di = Rr.oPu + pq * Rr.ldu + o; }
         }
         return e;
     }
@@ -430,8 +430,8 @@ Model::Entry Model::classify(int64_t row, int64_t col) const {
     e.kind = 2;
     const int64_t xf0 = N * L.blk;
     if (col >= L.v_off) { e.ci = C_ONE; e.di = Rr.oBv + r * nv + (int)(col - L.v_off); return e; }
-    if (col < n) { e.ci = C_ONE; e.di = Rr.oB0 + r * n + (int)col; return e; }
-    if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oBf + r * n + (int)(col - xf0); return e; }
+    if (col < n) { e.ci = C_ONE; e.di = Rr.oB0 + r * Rr.ldx + (int)col; return e; }
+    if (col >= xf0 && col < xf0 + n) { e.ci = C_ONE; e.di = Rr.oBf + r * Rr.ldx + (int)(col - xf0); return e; }
     return e;
 }
 

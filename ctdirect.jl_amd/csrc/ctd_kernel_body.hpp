@@ -342,7 +342,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
                 if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dtij;
                 if (FREE) {
 #pragma unroll
-                    for (int c = 0; c < n; ++c) w = w + ev[R.oF + r * n + c] * dx[c];
+                    for (int c = 0; c < n; ++c) w = w + ev[R.oF + r * R.ldx + c] * dx[c];
                 }
                 ev[R.oW + r * nv + kk] = w;
             }
@@ -401,7 +401,7 @@ CTD_HD void fin_stage_row(const KParams& kp, const BlockCtx& cx, int k, int j, i
                 double acc = 0.0;
 #pragma unroll
                 for (int l = 0; l < S; ++l) acc = acc + (dh * butcher_a<S>(L, j, l)) * K[l * n + c];
-                w = w + ev[R.oF + r * n + c] * acc;
+                w = w + ev[R.oF + r * R.ldx + c] * acc;
             }
         }
         ev[R.oW + r * nv + kk] = w;
@@ -566,10 +566,10 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         const int g = g0 + d;
         if (g < n) {
 #pragma unroll
-            for (int r = 0; r < n; ++r) ev[R.oF + r * n + g] = out[r].d[d];
+            for (int r = 0; r < n; ++r) ev[R.oF + r * R.ldx + g] = out[r].d[d];
         } else if (g < n + m) {
 #pragma unroll
-            for (int r = 0; r < n; ++r) ev[R.oG + r * m + (g - n)] = out[r].d[d];
+            for (int r = 0; r < n; ++r) ev[R.oG + r * R.ldu + (g - n)] = out[r].d[d];
         } else if (P::DYN_T && g == n + m) {
 #pragma unroll
             for (int r = 0; r < n; ++r) ev[R.oft + r] = out[r].d[d];
@@ -622,10 +622,10 @@ CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv
         const int g = g0 + d;
         if (g < n) {
 #pragma unroll
-            for (int r = 0; r < np; ++r) rec[R.oPx + r * n + g] = out[r].d[d];
+            for (int r = 0; r < np; ++r) rec[R.oPx + r * R.ldx + g] = out[r].d[d];
         } else if (g < n + m) {
 #pragma unroll
-            for (int r = 0; r < np; ++r) rec[R.oPu + r * m + (g - n)] = out[r].d[d];
+            for (int r = 0; r < np; ++r) rec[R.oPu + r * R.ldu + (g - n)] = out[r].d[d];
         } else if (P::PATH_T && g == n + m) {
 #pragma unroll
             for (int r = 0; r < np; ++r) rec[R.oPt + r] = out[r].d[d];
@@ -714,10 +714,10 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
         const int g = g0 + d;
         if (g < n) {
 #pragma unroll
-            for (int r = 0; r < nb; ++r) rec[R.oB0 + r * n + g] = out[r].d[d];
+            for (int r = 0; r < nb; ++r) rec[R.oB0 + r * R.ldx + g] = out[r].d[d];
         } else if (g < 2 * n) {
 #pragma unroll
-            for (int r = 0; r < nb; ++r) rec[R.oBf + r * n + (g - n)] = out[r].d[d];
+            for (int r = 0; r < nb; ++r) rec[R.oBf + r * R.ldx + (g - n)] = out[r].d[d];
         } else if (g < 2 * n + nv) {
 #pragma unroll
             for (int r = 0; r < nb; ++r) rec[R.oBv + r * nv + (g - 2 * n)] = out[r].d[d];

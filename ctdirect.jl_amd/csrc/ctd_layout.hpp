@@ -72,6 +72,9 @@ enum { C_ZERO = 0, C_ONE = 1, C_NEG1 = 2, C_HA = 3 /* -h a_jl at 3+3j+l */, C_HB
 
 struct RecLayout {
     int32_t S, eval_sz;
+    int32_t ldx, ldu;                     // row pitch of the (rows x n) and (rows x m) derivative blocks: n, m rounded up to odd.
+                                          // The CSC emission walks DOWN a column (fixed c, consecutive rows r): with an even
+                                          // pitch the lanes of a wave hit a few LDS banks only (8-way conflicts for n = 8)
     int32_t oF, oG, oW, of, oft;          // inside an eval block
     int32_t oEval;                        // first eval block
     int32_t oSv, oPx, oPu, oPv, oPt, oR, oC;
@@ -82,17 +85,18 @@ struct RecLayout {
 constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
     RecLayout r{};
     r.S = s > 0 ? s : 1;
-    r.oF = 0; r.oG = n * n; r.oW = r.oG + n * m; r.of = r.oW + n * nv; r.oft = r.of + n;
+    r.ldx = n | 1; r.ldu = m | 1;
+    r.oF = 0; r.oG = n * r.ldx; r.oW = r.oG + n * r.ldu; r.of = r.oW + n * nv; r.oft = r.of + n;
     r.eval_sz = r.oft + n;
     r.oEval = 1;
     r.oSv = r.oEval + r.S * r.eval_sz;
     r.oPx = r.oSv + n * nv;
-    r.oPu = r.oPx + p * n;
-    r.oPv = r.oPu + p * m;
+    r.oPu = r.oPx + p * r.ldx;
+    r.oPv = r.oPu + p * r.ldu;
     r.oPt = r.oPv + p * nv;
     r.oR = r.oPt + p;
     int end_step = r.oR + cb;
-    r.oB0 = 1; r.oBf = r.oB0 + bc * n; r.oBv = r.oBf + bc * n; r.oBval = r.oBv + bc * nv;
+    r.oB0 = 1; r.oBf = r.oB0 + bc * r.ldx; r.oBv = r.oBf + bc * r.ldx; r.oBval = r.oBv + bc * nv;
     int end_b = r.oBval + bc;
     int body = end_step > end_b ? end_step : end_b;
     r.oC = body;
