@@ -99,3 +99,22 @@ def dsqrt(x):
     if hasattr(x, "chain"):
         return x.chain(s, 1 / (2 * s), -1 / (4 * s * x.v))
     return gg.Du(s, [a / (2 * s) for a in x.d])
+
+
+# ---- a Lagrange problem with NO boundary and NO path rows: the case in which the leftover block of the stagewise / Euler
+# Jacobian patterns (irk_stagewise.jl:550-552, euler.jl:257-259: last row x column n, hazard H2 of SURVEY.md section 8) is
+# a real extra entry instead of being merged into the boundary rows
+PENDULUM = dict(dynamics=["x2", "-sin(x1) + u1 - 0.05*x2"], m=1, lagrange="x1^2 + 0.2*x2^2 + 0.1*u1^2", t0=0.0, tf=1.5,
+                control_box=([-3], [3]))
+
+
+class PendulumMp(gg.Problem):
+    name = "pendulum_rt"
+    n, m, nv, p, bc = 2, 1, 0, 0, 0
+    lagrange = True
+
+    def tf(self, v): return gg.Du(mpf("1.5"))
+
+    def dynamics(self, t, x, u, v): return [x[1] + 0, -gg.dsin(x[0]) + u[0] - mpf("0.05") * x[1]]
+
+    def lagr(self, t, x, u, v): return x[0] ** 2 + mpf("0.2") * x[1] ** 2 + mpf("0.1") * u[0] ** 2

@@ -123,3 +123,38 @@ def test_expression_only_problem_against_mpmath(torch_cuda, sch):
     dropped = [k for k, v in Href.items() if v != 0.0 and k not in hpat]
     assert euler or not dropped, dropped
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sch", ["gauss_legendre_2", "gauss_legendre_3", "euler", "euler_implicit", "midpoint", "trapeze",
+                                 "gauss_legendre_2_constant_control"])
+def test_lagrange_problem_without_boundary_rows(torch_cuda, sch):
+    """bc = 0, p = 0, Lagrange cost: the leftover block of the stagewise / Euler patterns (hazard H2) is then a REAL extra
+    entry (last row, column n) of the reference pattern; the engine lists it (bug-compatible pattern) and writes the exact
+    partial there -- 0 unless the last row really depends on X_1 -- beside the true values everywhere else"""
+    torch = torch_cuda
+    name = "pendulum_rt" if "pendulum_rt" in ct.PROBLEMS else ct.register_ocp("pendulum_rt", **jit_defs.PENDULUM)
+    for N in (1, 4):
+        d = ct.DOCP(name, N, sch, device=0)                            # reference (manual) pattern
+        rng = np.random.default_rng(5)
+        x = 0.3 + 0.4 * rng.standard_normal(d.dim_NLP_variables)
+        y = rng.standard_normal(d.dim_NLP_constraints)
+        md, cref, Jref, fref, gref, Href = _mp_reference(jit_defs.PendulumMp(), sch, N, x, y, 0.9)
+        assert (md.nvar, md.ncon) == (d.dim_NLP_variables, d.dim_NLP_constraints)
+        rows, cols = d.jac_structure()
+        pat = set(zip(rows - 1, cols - 1))
+        leftover = (d.dim_NLP_constraints - 1, 1)                      # 0-based (ncon, n)
+        has = sch in ("gauss_legendre_2", "gauss_legendre_3", "euler", "euler_implicit")
+        assert (leftover in pat) == (has or Jref[leftover] != 0.0), (sch, N)
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        c, vals = d.cons_jac(xd)
+        assert relerr(c.cpu().numpy(), cref) <= TOL
+        assert relerr(vals.cpu().numpy(), Jref[rows - 1, cols - 1]) <= TOL
+        assert all((r, cc) in pat for r, cc in zip(*np.nonzero(Jref))) or sch == "euler_implicit"
+        assert abs(d.obj(xd) - fref) <= TOL * max(1.0, abs(fref))
+        assert relerr(d.grad(xd).cpu().numpy(), gref) <= TOL
+        hr, hc = d.hess_structure()
+        hv = d.hess_coord(xd, yd, 0.9).cpu().numpy()
+        want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
+        assert relerr(hv, want) <= TOL
+        d.close()
