@@ -84,7 +84,8 @@ struct HParams {
                                 // last one (implicit Euler with path constraints: 1)
     int32_t ntiles;
     int64_t step_begin, step_end;   // shard of the time grid this launch evaluates (tiles cover [step_begin, step_end))
-    int32_t edge_begin, edge_end;   // edge entries this shard emits
+    int32_t edge_begin, edge_end;   // edge entries this shard emits: irregular leading columns of its own steps ...
+    int32_t edge2_begin, edge2_end; // ... and the trailing columns (owner of step N-1)
     int32_t edge_vv;                // 1: this shard adds the V x V terms of the final-path / boundary / last-node points
     // regular CSC segments of the lower triangle: step i in [reg_first, reg_last) owns
     // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])

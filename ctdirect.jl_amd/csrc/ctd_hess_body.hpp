@@ -624,7 +624,9 @@ template <class P, int SC, int S>
 CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, int tid, int nthr) {
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     if (cx.is_edge) {
-        for (int e = hp.edge_begin + tid; e < hp.edge_end; e += nthr) {
+        const int n1 = hp.edge_end - hp.edge_begin, ntot = n1 + (hp.edge2_end - hp.edge2_begin);
+        for (int w = tid; w < ntot; w += nthr) {
+            const int e = w < n1 ? hp.edge_begin + w : hp.edge2_begin + (w - n1);
             double acc = 0.0;
             for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
                 const uint32_t code = hp.eterms[t];

@@ -517,8 +517,13 @@ int build_hess_model(Model& mo, std::string& err) {
             raws.push_back(Raw{base + (int64_t)t, tt});
         }
     };
-    for (int64_t j = 0; j < head_cols; ++j) scan_col(j);
-    H.edge_split = (int)raws.size();           // entries before: owner of step 0; after: owner of step N-1 (shards)
+    H.head_ptr.assign(H.reg_first + 1, 0);     // head entries grouped by step (see Model::head_ptr)
+    for (int64_t j = 0; j < head_cols; ++j) {
+        if (j % L.blk == 0) H.head_ptr[j / L.blk] = (int)raws.size();
+        scan_col(j);
+    }
+    H.head_ptr[H.reg_first] = (int)raws.size();
+    H.edge_split = (int)raws.size();           // entries before: owners of the leading steps; after: owner of step N-1 (shards)
     for (int64_t j = tail0; j < L.nvar; ++j) scan_col(j);
     if (L.sc == SC_TRAPEZE) need.insert(N);        // node N: its V x V share is summed by the edge block
     if ((int)need.size() > kMaxHessEdgeSlots) { err = "internal: too many edge records (Hessian)"; return ST_EPATTERN; }
@@ -629,11 +634,12 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     if (step_end <= 0) { step_begin = 0; step_end = L.N; }
     hp.step_begin = step_begin; hp.step_end = step_end;
     hp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
-    // shards: the owner of step 0 emits the head entries, the owner of step N-1 the tail entries and the V x V share of the
+    // shards: the owners of the leading irregular steps emit their head entries, the owner of step N-1 the tail entries and the V x V share of the
     // final-path / boundary / last-node points; the other shards have no edge work
-    hp.edge_begin = step_begin == 0 ? 0 : H.edge_split;
-    hp.edge_end = step_end == L.N ? (int)H.edge_idx.size() : H.edge_split;
-    if (hp.edge_end < hp.edge_begin) hp.edge_end = hp.edge_begin;
+    hp.edge_begin = H.head_ptr[std::min<int64_t>(step_begin, H.reg_first)];
+    hp.edge_end = H.head_ptr[std::min<int64_t>(step_end, H.reg_first)];
+    hp.edge2_begin = H.edge_split;
+    hp.edge2_end = step_end == L.N ? (int)H.edge_idx.size() : H.edge_split;
     hp.edge_vv = step_end == L.N ? 1 : 0;
     hp.Lseg = H.Lseg;
     hp.nterms = (int)H.terms.size();

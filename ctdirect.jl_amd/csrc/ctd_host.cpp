@@ -573,7 +573,14 @@ static int build_tables(Model& mo, std::string& err) {
             dst.push_back(Raw{base + (int64_t)t, e});
         }
     };
-    for (int64_t j = 0; j < head_cols; ++j) scan_col(j, first);
+    // head entries in column order, i.e. grouped by step: head_ptr[s] = entries before the columns of step s (a shard emits
+    // the groups of its own steps -- for N < 5 every step column is irregular and sits here)
+    mo.head_ptr.assign(mo.reg_first + 1, 0);
+    for (int64_t j = 0; j < head_cols; ++j) {
+        if (j % L.blk == 0) mo.head_ptr[j / L.blk] = (int)first.size();
+        scan_col(j, first);
+    }
+    mo.head_ptr[mo.reg_first] = (int)first.size();
     for (int64_t j = tail0; j < L.nvar; ++j) scan_col(j, last);
     if ((int)need.size() > kMaxEdgeSlots) { err = "internal: too many edge records"; return ST_EPATTERN; }
     std::map<int64_t, int> slot_of;
@@ -667,11 +674,12 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.div_vr = make_fastdiv((uint32_t)(vr > 0 ? vr : 1));
     kp.seg_base = seg_base; kp.reg_first = reg_first; kp.reg_last = reg_last;
     for (int k = 0; k < kMaxNV; ++k) kp.vcol_base[k] = vcol_base[k];
-    const bool owns_first = step_begin == 0, owns_last = step_end == L.N;
-    kp.edge_begin = owns_first ? 0 : edge_split;
-    kp.edge_end = owns_last ? (int)edge_idx.size() : edge_split2;
-    if (kp.edge_end < kp.edge_begin) kp.edge_end = kp.edge_begin;
-    kp.has_edge = kp.edge_end > kp.edge_begin ? 1 : 0;
+    const bool owns_last = step_end == L.N;
+    kp.edge_begin = head_ptr[std::min<int64_t>(step_begin, reg_first)];
+    kp.edge_end = head_ptr[std::min<int64_t>(step_end, reg_first)];
+    kp.edge2_begin = edge_split;                       // tail rows of c (every shard), then the trailing columns (last shard)
+    kp.edge2_end = owns_last ? (int)edge_idx.size() : edge_split2;
+    kp.has_edge = (kp.edge_end > kp.edge_begin || kp.edge2_end > kp.edge2_begin) ? 1 : 0;
     kp.n_edge_slots = n_edge_slots;
     kp.edge_fp = edge_fp; kp.edge_b = edge_b;
     kp.edge_slot_first = edge_slot_first; kp.edge_slot_last = edge_slot_last;

@@ -38,7 +38,8 @@ struct HessModel {
     // edge part
     std::vector<int64_t> edge_idx;
     std::vector<uint32_t> eptr, evptr, eterms;
-    int edge_split = 0;               // edge entries [0, edge_split) belong to the head (step 0), the rest to the tail
+    int edge_split = 0;               // edge entries [0, edge_split): head (leading irregular steps), the rest: tail
+    std::vector<int> head_ptr;        // [reg_first + 1]: first head entry of every leading irregular step
     int n_edge_slots = 0, edge_fp = 0, edge_b = 0;
     int64_t edge_steps[kMaxHessEdgeSlots] = {0};
     // structural nonzeros of the evaluation points' dense Hessians (row-major md x md / mdb x mdb, upper triangle used)
@@ -76,12 +77,14 @@ struct Model {
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     int64_t vcol_base[kMaxNV] = {0, 0, 0, 0};
     int HL = 0, HH = 0;
-    // edge part: entries [0, edge_split) belong to the shard that owns step 0, [edge_split, edge_split2) are the tail rows
+    // edge part: entries [0, edge_split) belong to the shards that own the leading irregular steps (step 0; every step when
+    // N < 5: head_ptr), [edge_split, edge_split2) are the tail rows
     // of c (final-time path + boundary values: every shard computes them, x is replicated), the rest belongs to the owner
     // of step N-1
     std::vector<int64_t> edge_idx;
     std::vector<uint32_t> edge_code;
     int edge_split = 0, edge_split2 = 0;
+    std::vector<int> head_ptr;        // [reg_first + 1]: first head entry of every leading irregular step (shard ownership)
     int n_edge_slots = 0, edge_fp = 0, edge_b = 0, edge_slot_first = 0, edge_slot_last = 0;
     int64_t edge_steps[kMaxEdgeSlots] = {0};
     // CSC column starts without materialising the pattern: explicit for the head columns [0, reg_first*blk) and the

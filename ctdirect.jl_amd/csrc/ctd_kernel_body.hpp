@@ -914,7 +914,9 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
     if (cx.is_edge) {
-        for (int e = kp.edge_begin + tid; e < kp.edge_end; e += nthr) {
+        const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
+        for (int w = tid; w < ntot; w += nthr) {
+            const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
             const uint32_t code = kp.edge_code[e];
             const int64_t idx = kp.edge_idx[e];
             const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);

@@ -150,7 +150,8 @@ struct KParams {
     // edge entries (first step, last step, final block, tails): explicit (index, code) list
     const int64_t* edge_idx;
     const uint32_t* edge_code;
-    int32_t edge_begin, edge_end;
+    int32_t edge_begin, edge_end;       // edge entries this shard emits: [edge_begin, edge_end) (irregular leading columns of its
+    int32_t edge2_begin, edge2_end;     // own steps) and [edge2_begin, edge2_end) (tail rows of c; trailing columns: last shard)
     int32_t n_edge_slots;
     int32_t edge_fp, edge_b;            // record ids of the final-path and boundary records
     int32_t edge_slot_first, edge_slot_last;   // slots holding step 0 and step N-1

@@ -77,3 +77,40 @@ def test_emulated_shards_compose_exactly(prob):
                 c = np.where(c2 != 666.666, c2, c)
                 v = np.where(v2 != 666.666, v2, v)
             assert np.array_equal(c, cf) and np.array_equal(v, vf)
+
+
+@pytest.mark.parametrize("prob, sch", [("goddard", "gauss_legendre_3"), ("goddard_all", "trapeze"),
+                                       ("double_integrator_freet0tf", "euler_implicit"),
+                                       ("least_squares_with_constraint", "gauss_legendre_2_constant_control")])
+def test_every_split_of_a_tiny_grid_composes(oracle_lib, prob, sch):
+    """Grids of fewer than 5 steps have no step-periodic part: every step column is an explicit edge entry.  Each of them
+    must still be written by exactly the shard that owns its step, for every way of cutting [0, N) into up to three
+    shards -- constraints, Jacobian values and Hessian values (V x V entries: partial sums that add up)."""
+    SENT = 777.25
+    pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+    for N in (2, 3, 4, 5):
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        x = 0.35 + 0.25 * np.random.default_rng(0).random(o.dim_NLP_variables)
+        if o.nv:
+            x[-o.nv:] = np.sort(x[-o.nv:])
+        y = 0.5 + np.random.default_rng(1).random(o.dim_NLP_constraints)
+        cref, vref, href = o.constraints(x), o.jac_coord(x), o.hess_coord(x, y, 0.8)
+        cuts = [(0, a, N) for a in range(1, N)] + [(0, a, b, N) for a in range(1, N) for b in range(a + 1, N)]
+        for cut in cuts:
+            c, v = np.full(len(cref), SENT), np.full(len(vref), SENT)
+            h, hw = np.zeros(len(href)), np.zeros(len(href), bool)
+            for a, b in zip(cut[:-1], cut[1:]):
+                emu.cons_jac(pid, sid, 0, N, x, step_begin=a, step_end=b, c=c, vals=v)
+                hv = np.full(len(href), SENT)
+                emu.hess(pid, sid, 0, N, x, y, 0.8, step_begin=a, step_end=b, vals=hv)
+                d = ct.DOCP(prob, N, sch, device=-1, steps=(a, b))
+                isvv = np.zeros(len(href), bool)
+                isvv[np.array(d.hess_shard_info()[2], dtype=int)] = True
+                d.close()
+                w = hv != SENT
+                assert not (hw & w & ~isvv).any(), (N, cut, "Hessian entry written by two shards")
+                h[w & ~isvv] = hv[w & ~isvv]
+                h[isvv] += hv[isvv]
+                hw |= w
+            assert hw.all() and not np.any(c == SENT) and not np.any(v == SENT), (N, cut)
+            assert relerr(c, cref) <= TOL and relerr(v, vref) <= TOL and relerr(h, href) <= 1e-9, (N, cut)
