@@ -14,6 +14,9 @@ import ctdirect_jl_amd as ct
 from oracle.oracle import OracleDOCP
 from helpers import relerr, TOL, bench_inputs, describe
 budget, seed = float(sys.argv[1]), int(sys.argv[2])
+JIT = len(sys.argv) > 3 and sys.argv[3] == "jit"      # also draw the expression twins of the registry problems (hiprtc)
+if JIT:
+    import jit_defs
 rng = np.random.default_rng(seed)
 probs, schemes = list(ct.PROBLEMS), list(ct.SCHEMES)
 t_end = time.time() + budget
@@ -34,10 +37,14 @@ while time.time() < t_end:
     if rng.random() < 0.35 and N >= 2:
         a = int(rng.integers(0, N)); b = int(rng.integers(a + 1, N + 1)); steps = (a, b)
     os.environ["CTD_TILE"] = str(tile) if tile else ""; os.environ["CTD_HESS_TILE"] = str(htile) if htile else ""
-    desc = f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps}"
+    pipe = rng.random() < 0.15; os.environ["CTD_PIPE"] = "1" if pipe else ""
+    fin_last = rng.random() < 0.15; os.environ["CTD_HESS_FINISH"] = "last" if fin_last else ""
+    use_twin = JIT and prob in jit_defs.TWINS and rng.random() < 0.2
+    api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
+    desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
+            f"pipe={int(pipe)} finlast={int(fin_last)} twin={int(use_twin)} api={api}")
     try:
-        d = ct.DOCP(prob, N if tg is None else None, sch, time_grid=tg, pattern=mode, device=0, steps=steps) if tg is None else \
-            ct.DOCP(prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps)
+        d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps)
         o = OracleDOCP(prob, sch, N, time_grid=tg) if tg is not None else OracleDOCP(prob, sch, N)
         if mode == "structural": o.set_pattern_mode(1)
         nvar, ncon = d.dim_NLP_variables, d.dim_NLP_constraints
@@ -53,8 +60,14 @@ while time.time() < t_end:
         xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
         SENT = 777.25
         c = torch.full((ncon,), SENT, dtype=torch.float64, device="cuda"); v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
-        d.cons_jac(xd, c, v); torch.cuda.synchronize()
-        c, v = c.cpu().numpy(), v.cpu().numpy()
+        if api == 0 or steps is not None:
+            d.cons_jac(xd, c, v); torch.cuda.synchronize()
+            c, v = c.cpu().numpy(), v.cpu().numpy()
+        elif api == 1:
+            d.cons(xd, c); d.jac_coord(xd, v); torch.cuda.synchronize()
+            c, v = c.cpu().numpy(), v.cpu().numpy()
+        else:
+            c, v = d.cons_jac(x)
         cref, vref = o.constraints(x), o.jac_coord(x)
         errs = {}
         if steps is None:
