@@ -24,7 +24,9 @@ class ctd_desc(C.Structure):
 
 class ctd_init(C.Structure):
     _fields_ = [("use_problem_default", C.c_int32), ("state", C.POINTER(C.c_double)),
-                ("control", C.POINTER(C.c_double)), ("variable", C.POINTER(C.c_double))]
+                ("control", C.POINTER(C.c_double)), ("variable", C.POINTER(C.c_double)),
+                ("n_samples", C.c_int64), ("t_samples", C.POINTER(C.c_double)),
+                ("state_samples", C.POINTER(C.c_double)), ("control_samples", C.POINTER(C.c_double))]
 
 
 class ctd_ocp_def(C.Structure):

@@ -475,7 +475,17 @@ int32_t ctd_bounds(const ctd_handle* h, double* lvar, double* uvar, double* lcon
 
 int32_t ctd_initial_guess(const ctd_handle* h, double* x0, const ctd_init* init) {
     if (!h || !x0) return CTD_EINVAL;
-    if (init) model_initial_guess(h->model, x0, init->use_problem_default != 0, init->state, init->control, init->variable);
+    if (init) {
+        InitSamples sm;
+        if (init->n_samples > 0) {
+            if (!init->t_samples) return fail(const_cast<ctd_handle*>(h), CTD_EINVAL, "ctd_initial_guess: t_samples is NULL");
+            for (int64_t k = 1; k < init->n_samples; ++k)
+                if (!(init->t_samples[k] > init->t_samples[k - 1]))
+                    return fail(const_cast<ctd_handle*>(h), CTD_EGRID, "ctd_initial_guess: t_samples must be strictly increasing");
+            sm.n = init->n_samples; sm.t = init->t_samples; sm.state = init->state_samples; sm.control = init->control_samples;
+        }
+        model_initial_guess(h->model, x0, init->use_problem_default != 0, init->state, init->control, init->variable, sm);
+    }
     else model_initial_guess(h->model, x0, false, nullptr, nullptr, nullptr);
     return CTD_OK;
 }

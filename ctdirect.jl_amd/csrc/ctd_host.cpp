@@ -167,8 +167,18 @@ static void build_bounds(Model& mo) {
 }
 
 // __initial_guess: DOCP_variables.jl:122-145, irk_stagewise.jl:302-335
+// trajectory sampled at increasing times, evaluated by linear interpolation (end values held outside the span)
+static void sample_at(const InitSamples& sm, const double* data, int dim, double t, double* out) {
+    const int64_t K = sm.n;
+    if (K == 1 || t <= sm.t[0]) { for (int k = 0; k < dim; ++k) out[k] = data[k]; return; }
+    if (t >= sm.t[K - 1]) { for (int k = 0; k < dim; ++k) out[k] = data[(K - 1) * dim + k]; return; }
+    const int64_t hi = std::upper_bound(sm.t, sm.t + K, t) - sm.t, lo = hi - 1;      // t[lo] <= t < t[hi]
+    const double w = (t - sm.t[lo]) / (sm.t[hi] - sm.t[lo]);
+    for (int k = 0; k < dim; ++k) out[k] = data[lo * dim + k] + w * (data[hi * dim + k] - data[lo * dim + k]);
+}
+
 void model_initial_guess(const Model& mo, double* X, bool use_default, const double* state, const double* control,
-                         const double* variable) {
+                         const double* variable, const InitSamples& sm) {
     const Layout& L = mo.L;
     const ProblemInfo& pi = mo.info;
     for (int64_t k = 0; k < L.nvar; ++k) X[k] = 0.1;
@@ -182,10 +192,12 @@ void model_initial_guess(const Model& mo, double* X, bool use_default, const dou
     const double tf = L.itf >= 0 ? X[L.v_off + L.itf] : L.tf;
     auto grid = [&](int64_t i) { return t0 + mo.tau[i] * (tf - t0); };
     auto get_state = [&](double t, double* out) -> bool {
+        if (sm.n > 0 && sm.state) { sample_at(sm, sm.state, L.n, t, out); return true; }
         if (state) { for (int k = 0; k < L.n; ++k) out[k] = state[k]; return true; }
         return use_default && pi.init_state(t, out);
     };
     auto get_control = [&](double t, double* out) -> bool {
+        if (sm.n > 0 && sm.control) { sample_at(sm, sm.control, L.m, t, out); return true; }
         if (control) { for (int k = 0; k < L.m; ++k) out[k] = control[k]; return true; }
         return use_default && pi.init_control(t, out);
     };

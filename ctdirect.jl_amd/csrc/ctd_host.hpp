@@ -112,8 +112,9 @@ int default_hess_tile(const Model& m);
 
 // status codes are those of include/ctdirect_hip.h; err receives a message on failure
 int build_model(const HostDesc& d, Model& m, std::string& err);
+struct InitSamples { int64_t n = 0; const double* t = nullptr; const double* state = nullptr; const double* control = nullptr; };
 void model_initial_guess(const Model& m, double* x0, bool use_problem_default, const double* state, const double* control,
-                         const double* variable);
+                         const double* variable, const InitSamples& samples = InitSamples{});
 int default_tile(const Model& m, int64_t nsteps = 0);
 // sub-tile length of the pipelined driver: the producer is ONE wave, so Ts * (lanes per step) <= 64, and the three input
 // + two record buffers must fit ~60 KiB of LDS

@@ -523,12 +523,28 @@ def constraints_bounds(docp):
 
 def initial_guess(docp, init=None):
     """`CTDirect.__initial_guess(docp, init)`.  init: None (everything 0.1), "problem" (the problem file's init
-    tuple) or a dict with optional constant `state`, `control`, `variable` entries."""
+    tuple) or a dict with optional constant `state`, `control`, `variable` entries; with a `time` entry (K increasing
+    times) `state` [K, n] and `control` [K, m] are trajectories -- the interpolated / warm-start guesses of the reference
+    (test/ci/test_initial_guess.jl), e.g. the T, X, U of `unpack_solution` -- interpolated linearly at the node (and stage)
+    times."""
     x0 = np.zeros(docp.dim_NLP_variables)
     ci = _lib.ctd_init()
     keep = []
     if init == "problem":
         ci.use_problem_default = 1
+    elif isinstance(init, dict) and init.get("time") is not None:
+        t = np.ascontiguousarray(init["time"], dtype=np.float64)
+        keep.append(t)
+        ci.n_samples, ci.t_samples = len(t), _dp(t)
+        for key, dim in (("state", docp.dims.NLP_x), ("control", docp.dims.NLP_u)):
+            if init.get(key) is not None and dim > 0:
+                a = np.ascontiguousarray(init[key], dtype=np.float64).reshape(len(t), dim)
+                keep.append(a)
+                setattr(ci, key + "_samples", _dp(a))
+        if init.get("variable") is not None:
+            a = np.ascontiguousarray(init["variable"], dtype=np.float64)
+            keep.append(a)
+            ci.variable = _dp(a)
     elif isinstance(init, dict):
         for key in ("state", "control", "variable"):
             if init.get(key) is not None:

@@ -112,6 +112,15 @@ typedef struct ctd_init {
     const double* state;         /* constant state guess  [n]  or NULL                                      */
     const double* control;       /* constant control guess [m] or NULL                                      */
     const double* variable;      /* variable guess [nv] or NULL                                             */
+    /* time-dependent guesses -- the functional / interpolated / warm-start forms of CTModels' init.state(t), init.control(t)
+     * (test/ci/test_initial_guess.jl): n_samples > 0 gives trajectories sampled at the increasing times t_samples[k];
+     * state_samples is row-major [n_samples][n], control_samples [n_samples][m] (either may be NULL).  They are evaluated
+     * where the reference evaluates the functions (node times t_i; stage times t_ij for stagewise controls) by linear
+     * interpolation, end values held outside the sampled span, and take precedence over the constant entries above. */
+    int64_t n_samples;
+    const double* t_samples;
+    const double* state_samples;
+    const double* control_samples;
 } ctd_init;
 
 /* ---- OCPs defined at run time ----------------------------------------------------------------------------------

@@ -540,6 +540,45 @@ template <class P> static void initial_guess(const Docp& p, bool use_problem_ini
     }
 }
 
+// __initial_guess with time-dependent init.state(t) / init.control(t) given as sampled trajectories (the interpolated and
+// warm-start guesses of test/ci/test_initial_guess.jl): same loops as above (src/DOCP_variables.jl:122-145,
+// irk_stagewise.jl:302-335), the init functions being piecewise-linear interpolants with held end values.
+static void interp_row(int64_t K, const double* T, const double* data, int dim, double t, double* out) {
+    int64_t lo = 0;
+    if (K == 1 || t <= T[0]) { for (int k = 0; k < dim; ++k) out[k] = data[k]; return; }
+    if (t >= T[K - 1]) { for (int k = 0; k < dim; ++k) out[k] = data[(K - 1) * dim + k]; return; }
+    while (lo + 1 < K && T[lo + 1] <= t) ++lo;
+    const double w = (t - T[lo]) / (T[lo + 1] - T[lo]);
+    for (int k = 0; k < dim; ++k) out[k] = data[lo * dim + k] + w * (data[(lo + 1) * dim + k] - data[lo * dim + k]);
+}
+template <class P> static void initial_guess_sampled(const Docp& p, int64_t K, const double* T, const double* Xs, const double* Us,
+                                                      const double* v, double* X) {
+    const int n = p.dims.NLP_x, m = p.dims.NLP_u, nv = p.dims.NLP_v;
+    const int64_t N = p.steps;
+    const Disc& d = p.disc;
+    for (int64_t k = 0; k < p.dim_NLP_variables; ++k) X[k] = 0.1;
+    if (v) for (int k = 0; k < nv; ++k) X[p.dim_NLP_variables - nv + k] = v[k];
+    std::vector<double> grid, tmp(std::max(std::max(n, m), 1));
+    get_time_grid<P, double>(X, p, grid);
+    for (int64_t i = 1; i <= N + 1; ++i) {
+        const double ti = grid[i - 1];
+        const int64_t off = (i - 1) * d.step_variables_block;
+        if (Xs) { interp_row(K, T, Xs, n, ti, tmp.data()); for (int k = 0; k < n; ++k) X[off + k] = tmp[k]; }
+        if (Us && m > 0 && !d.stagewise && (i <= N || d.final_control)) {
+            interp_row(K, T, Us, m, ti, tmp.data());
+            for (int k = 0; k < m; ++k) X[off + n + k] = tmp[k];
+        }
+    }
+    if (Us && m > 0 && d.stagewise)
+        for (int64_t i = 1; i <= N; ++i) {
+            const double ti = grid[i - 1], hi = grid[i] - ti;
+            for (int j = 1; j <= d.stage; ++j) {
+                interp_row(K, T, Us, m, ti + d.c[j - 1] * hi, tmp.data());
+                for (int k = 0; k < m; ++k) X[(i - 1) * d.step_variables_block + n + (j - 1) * m + k] = tmp[k];
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sparsity patterns: literal (Is, Js) pushes + SparseArrays.sparse semantics
 // ---------------------------------------------------------------------------------------------
@@ -1033,6 +1072,10 @@ void orc_bounds(void* h, double* lvar, double* uvar, double* lcon, double* ucon)
 void orc_initial_guess(void* h, int use_problem_init, double* x0) {
     Docp& p = *(Docp*)h;
     orc::dispatch(p.problem, [&](auto tag) { orc::initial_guess<typename decltype(tag)::type>(p, use_problem_init != 0, x0); });
+}
+void orc_initial_guess_sampled(void* h, int64_t K, const double* T, const double* Xs, const double* Us, const double* v, double* x0) {
+    Docp& p = *(Docp*)h;
+    orc::dispatch(p.problem, [&](auto tag) { orc::initial_guess_sampled<typename decltype(tag)::type>(p, K, T, Xs, Us, v, x0); });
 }
 void orc_constraints(void* h, const double* xu, double* c) {
     Docp& p = *(Docp*)h;

@@ -71,6 +71,7 @@ def lib():
         L.orc_grids.argtypes = [C.c_void_p, dp, dp]
         L.orc_bounds.argtypes = [C.c_void_p, dp, dp, dp, dp]
         L.orc_initial_guess.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_initial_guess_sampled.argtypes = [C.c_void_p, C.c_int64, dp, dp, dp, dp, dp]
         L.orc_constraints.argtypes = [C.c_void_p, dp, dp]
         L.orc_objective.argtypes = [C.c_void_p, dp]
         L.orc_objective.restype = C.c_double
@@ -154,6 +155,15 @@ class OracleDOCP:
         lc = np.zeros(self.dim_NLP_constraints); uc = np.zeros(self.dim_NLP_constraints)
         lib().orc_bounds(self._h, _dp(lv), _dp(uv), _dp(lc), _dp(uc))
         return lv, uv, lc, uc
+
+    def initial_guess_sampled(self, T, X=None, U=None, v=None):
+        """__initial_guess with init.state / init.control given as trajectories sampled at the times T (linear
+        interpolation, end values held): X [K, n], U [K, m], v [nv], each optional."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (X, U, v)]
+        x0 = np.zeros(self.dim_NLP_variables)
+        lib().orc_initial_guess_sampled(self._h, len(T), _dp(T), *[None if a is None else _dp(a) for a in arrs], _dp(x0))
+        return x0
 
     def initial_guess(self, use_problem_init=True):
         x0 = np.zeros(self.dim_NLP_variables)

@@ -173,3 +173,54 @@ def test_solution_unpacking_follows_the_reference_getter():
         assert not s2["state_constraints_ub_dual"].any() and not s2["control_constraints_ub_dual"].any()
         if sch == "midpoint":
             assert s2["control_constraints_lb_dual"][6, 0] == zl[5 * blk + n]
+
+
+@pytest.mark.parametrize("prob, sch", [("goddard", "gauss_legendre_2"), ("goddard", "gauss_legendre_3_constant_control"),
+                                       ("goddard_all", "trapeze"), ("quadrotor", "midpoint"),
+                                       ("double_integrator_freet0tf", "euler_implicit"), ("estimate_initial_condition", "gauss_legendre_2")])
+def test_time_dependent_initial_guess(oracle_lib, prob, sch):
+    """init.state(t) / init.control(t) as sampled trajectories (the functional / interpolated / warm-start guesses of
+    test/ci/test_initial_guess.jl): state at the node times, control at the node times -- at the stage times t_ij for the
+    stagewise schemes (irk_stagewise.jl:320-331) -- on the grid of the guessed free times; stage variables stay at 0.1"""
+    N = 7
+    d = ct.DOCP(prob, N, sch, device=-1)
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    n, m, nv = d.dims.NLP_x, d.dims.NLP_u, d.dims.NLP_v
+    rng = np.random.default_rng(3)
+    T = np.concatenate([[0.0], np.cumsum(0.1 + rng.random(11))]) * 0.2
+    X, U = rng.standard_normal((len(T), n)), rng.standard_normal((len(T), max(m, 1)))[:, :m]
+    v = np.sort(0.4 + rng.random(nv)) if nv else None
+    x0 = ct.initial_guess(d, dict(time=T, state=X, control=U if m else None, variable=v))
+    assert np.array_equal(x0, o.initial_guess_sampled(T, X, U if m else None, v))
+    # state and (non-stagewise) control rows are the interpolant at the node times of the guessed grid
+    tg = ct.get_time_grid(x0, d)
+    blk = d.discretization._step_variables_block
+    for i in (0, 3, N):
+        want = np.array([np.interp(tg[i], T, X[:, k]) for k in range(n)])
+        assert np.allclose(x0[i * blk:i * blk + n], want, rtol=0, atol=1e-14)
+    if sch == "gauss_legendre_2" and m:
+        c = d.discretization.butcher_c
+        t12 = tg[1] + c[1] * (tg[2] - tg[1])
+        assert np.isclose(x0[blk + n + m], np.interp(t12, T, U[:, 0]), rtol=0, atol=1e-14)
+    # only state / control / variable slots are touched
+    touched = np.zeros(d.dim_NLP_variables, bool)
+    cu = (d.discretization.stage if sch in ("gauss_legendre_2", "gauss_legendre_3") else 1) * m
+    for i in range(N + 1):
+        touched[i * blk:i * blk + n] = True
+        if i < N or d.discretization._final_control:
+            touched[i * blk + n:i * blk + n + cu] = True
+    if nv:
+        touched[-nv:] = True
+    assert np.all(x0[~touched] == 0.1)
+
+
+def test_warm_start_round_trip_and_sample_errors():
+    """a previous solution unpacked with unpack_solution is a valid time-dependent guess: on the same grid it reproduces the
+    states (and the controls of the non-stagewise schemes) exactly; unsorted sample times are refused"""
+    d = ct.DOCP("goddard", 9, "midpoint", device=-1)
+    x = 0.3 + 0.01 * np.arange(d.dim_NLP_variables)
+    s = ct.unpack_solution(d, x)
+    x0 = ct.initial_guess(d, dict(time=s["T"], state=s["X"], control=s["U"], variable=s["v"]))
+    assert np.allclose(x0, x, rtol=0, atol=1e-15)
+    with pytest.raises(ValueError):          # grid errors are ArgumentError in the reference (src/DOCP_data.jl:186-189)
+        ct.initial_guess(d, dict(time=[0.0, 0.2, 0.1], state=np.zeros((3, 3))))
