@@ -118,3 +118,47 @@ class PendulumMp(gg.Problem):
     def dynamics(self, t, x, u, v): return [x[1] + 0, -gg.dsin(x[0]) + u[0] - mpf("0.05") * x[1]]
 
     def lagr(self, t, x, u, v): return x[0] ** 2 + mpf("0.2") * x[1] ** 2 + mpf("0.1") * u[0] ** 2
+
+
+# ---- problems of the reference's solve catalogue (test/ci/test_all_ocp.jl, test/problems/*.jl) restated as expressions, with the
+# catalogued objective of each problem file: solved end to end through the callbacks in tests/test_gpu_solve_catalogue.py
+CATALOGUE = {
+    # test/problems/beam.jl:4-18
+    "beam": (dict(dynamics=["x2", "u1"], m=1, lagrange="u1^2", boundary=["x0_1", "x0_2", "xf_1", "xf_2"], t0=0.0, tf=1.0,
+                  state_box=([0, -INF], [0.1, INF]), control_box=([-10], [10]), boundary_bounds=([0, 1, 0, -1], [0, 1, 0, -1])),
+             8.898598),
+    # test/problems/fuller.jl:4-15
+    "fuller": (dict(dynamics=["x2", "u1"], m=1, lagrange="x1^2", boundary=["x0_1", "x0_2", "xf_1", "xf_2"], t0=0.0, tf=3.5,
+                    control_box=([-1], [1]), boundary_bounds=([0, 1, 0, 0], [0, 1, 0, 0])), 2.683944e-1),
+    # test/problems/jackson.jl:4-26
+    "jackson": (dict(dynamics=["-u1*(k1*x1 - k2*x2)", "u1*(k1*x1 - k2*x2) - (1 - u1)*k3*x2", "(1 - u1)*k3*x2"], m=1, mayer="xf_3",
+                     maximize=True, boundary=["x0_1", "x0_2", "x0_3"], constants=dict(k1=1, k2=10, k3=1), t0=0.0, tf=4.0,
+                     state_box=([0, 0, 0], [1.1, 1.1, 1.1]), control_box=([0], [1]), boundary_bounds=([1, 0, 0], [1, 0, 0])),
+                0.192011),
+    # test/problems/vanderpol.jl:4-18
+    "vanderpol": (dict(dynamics=["x2", "epsilon*omega*(1 - x1^2)*x2 - omega^2*x1 + u1"], m=1,
+                       lagrange="0.5*(x1^2 + x2^2 + u1^2)", boundary=["x0_1", "x0_2"], constants=dict(omega=1, epsilon=1),
+                       t0=0.0, tf=2.0, boundary_bounds=([1, 0], [1, 0])), 1.047921),
+    # test/problems/simple_integrator.jl:5-16
+    "simple_integrator": (dict(dynamics=["-x1 - u1 + u2"], m=2, lagrange="(u1 + u2)^2", boundary=["x0_1", "xf_1"], t0=0.0, tf=1.0,
+                               control_box=([0, 0], [INF, INF]), boundary_bounds=([-1, 0], [-1, 0])), 3.13e-1),
+    # test/problems/bolza.jl:4-17
+    "bolza_freetf": (dict(dynamics=["v1*u1"], m=1, nv=1, lagrange="0.5*u1^2", mayer="v1", boundary=["x0_1", "xf_1"], itf=0,
+                          state_box=([0], [INF]), variable_box=([0.1], [INF]), boundary_bounds=([0, 1], [0, 1])), 1.476),
+    # test/problems/robbins.jl:4-20
+    "robbins": (dict(dynamics=["x2", "x3", "u1"], m=1, lagrange="alpha*x1 + beta*x1^2 + gamma*u1^2",
+                     boundary=["x0_1", "x0_2", "x0_3", "xf_1", "xf_2", "xf_3"], constants=dict(alpha=3, beta=0, gamma=0.5),
+                     t0=0.0, tf=10.0, state_box=([0, -INF, -INF], [INF, INF, INF]),
+                     boundary_bounds=([1, -2, 0, 0, 0, 0], [1, -2, 0, 0, 0, 0])), 19.4),
+    # test/problems/double_integrator.jl:4-18
+    "double_integrator_tf": (dict(dynamics=["x2", "u1"], m=1, nv=1, mayer="v1", boundary=["x0_1", "x0_2", "xf_1", "xf_2"], itf=0,
+                                  control_box=([-1], [1]), variable_box=([0.05], [INF]),
+                                  boundary_bounds=([0, 0, 1, 0], [0, 0, 1, 0])), 2.0),
+}
+
+
+def catalogue(name):
+    key = name + "_cat"
+    if key not in _registered:
+        _registered[key] = ct.register_ocp(key, **CATALOGUE[name][0])
+    return _registered[key], CATALOGUE[name][1]
