@@ -154,11 +154,20 @@ CATALOGUE = {
     "double_integrator_tf": (dict(dynamics=["x2", "u1"], m=1, nv=1, mayer="v1", boundary=["x0_1", "x0_2", "xf_1", "xf_2"], itf=0,
                                   control_box=([-1], [1]), variable_box=([0.05], [INF]),
                                   boundary_bounds=([0, 0, 1, 0], [0, 0, 1, 0])), 2.0),
+    # test/problems/moonlander.jl:7-82 (the problem the reference's "quadrotor" testset actually solves, test_all_ocp.jl:90-92);
+    # F_tot = R(theta) [0, F1 + F2]: ddp1 = -sin(theta) (F1 + F2) / m, ddp2 = cos(theta) (F1 + F2) / m - g
+    "moonlander": (dict(dynamics=["x3", "x4", "-sin(x5)*(u1 + u2)/mass", "cos(x5)*(u1 + u2)/mass - g", "x6", "(1/I)*(D/2)*(u2 - u1)"],
+                        m=2, nv=1, mayer="v1", itf=0, constants=dict(mass=1.0, g=9.81, I=0.1, D=1.0),
+                        boundary=[f"x0_{i}" for i in range(1, 7)] + ["xf_1", "xf_2", "xf_3", "xf_4"],
+                        control_box=([0, 0], [2 * 9.81, 2 * 9.81]), variable_box=([0.1], [INF]),
+                        boundary_bounds=([0] * 6 + [5, 5, 0, 0], [0] * 6 + [5, 5, 0, 0])), 9.62e-1, dict(control=[5.0, 5.0])),
 }
 
 
 def catalogue(name):
+    """(run-time problem name, catalogued objective, init of the problem file or None)"""
     key = name + "_cat"
+    entry = CATALOGUE[name]
     if key not in _registered:
-        _registered[key] = ct.register_ocp(key, **CATALOGUE[name][0])
-    return _registered[key], CATALOGUE[name][1]
+        _registered[key] = ct.register_ocp(key, **entry[0])
+    return _registered[key], entry[1], (entry[2] if len(entry) > 2 else None)

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _solve(name, scheme, N, maxiter=400):
-    prob, want = jit_defs.catalogue(name)
+    prob, want, init = jit_defs.catalogue(name)
     d = ct.DOCP(prob, N, scheme, pattern="structural", device=0)
     nvar, ncon = d.dim_NLP_variables, d.dim_NLP_constraints
     lc, uc = ct.constraints_bounds(d)
     lv, uv = ct.variables_bounds(d)
-    x0 = np.clip(ct.initial_guess(d), lv, uv)
+    x0 = np.clip(ct.initial_guess(d, init), lv, uv)
     colptr, rowval = ct.DOCP_Jacobian_pattern(d)
     hr, hc = d.hess_structure()
     sign = -1.0 if d.flags.max else 1.0                # minimize = !docp.flags.max (src/collocation.jl:145)
@@ -47,7 +47,7 @@ def _solve(name, scheme, N, maxiter=400):
     ("beam", "midpoint", 60), ("beam", "gauss_legendre_2", 30), ("fuller", "midpoint", 100), ("jackson", "midpoint", 60),
     ("vanderpol", "gauss_legendre_3", 20), ("vanderpol", "trapeze", 60), ("simple_integrator", "midpoint", 40),
     ("bolza_freetf", "gauss_legendre_2", 30), ("bolza_freetf", "euler_implicit", 100), ("robbins", "midpoint", 250),
-    ("double_integrator_tf", "trapeze", 50),
+    ("double_integrator_tf", "trapeze", 50), ("moonlander", "midpoint", 50), ("moonlander", "gauss_legendre_2", 25),
 ])
 def test_catalogued_objective(name, scheme, N):
     obj, want, viol, res = _solve(name, scheme, N)
