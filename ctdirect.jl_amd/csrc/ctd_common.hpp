@@ -144,6 +144,24 @@ template <int K> CTD_HD Dual<K> d_sqrt(const Dual<K>& a) {
     for (int i = 0; i < K; ++i) r.d[i] = w * a.d[i];
     return r;
 }
+// further unary functions of run-time defined OCPs (ctd_jit.cpp): value f0 and derivative f1 at a.v
+template <int K> CTD_HD Dual<K> d1_chain(const Dual<K>& a, double f0, double f1) {
+    Dual<K> r; r.v = f0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r.d[i] = f1 * a.d[i];
+    return r;
+}
+CTD_HD double d_log(double x) { return ::log(x); }
+CTD_HD double d_tan(double x) { return ::tan(x); }
+CTD_HD double d_atan(double x) { return ::atan(x); }
+CTD_HD double d_tanh(double x) { return ::tanh(x); }
+CTD_HD double d_abs(double x) { return ::fabs(x); }
+CTD_HD double d_sgn(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+template <int K> CTD_HD Dual<K> d_log(const Dual<K>& a) { return d1_chain(a, ::log(a.v), 1.0 / a.v); }
+template <int K> CTD_HD Dual<K> d_tan(const Dual<K>& a) { const double t = ::tan(a.v); return d1_chain(a, t, 1.0 + t * t); }
+template <int K> CTD_HD Dual<K> d_atan(const Dual<K>& a) { return d1_chain(a, ::atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+template <int K> CTD_HD Dual<K> d_tanh(const Dual<K>& a) { const double t = ::tanh(a.v); return d1_chain(a, t, 1.0 - t * t); }
+template <int K> CTD_HD Dual<K> d_abs(const Dual<K>& a) { return d1_chain(a, ::fabs(a.v), d_sgn(a.v)); }
 // x^k for a small non-negative integer k by repeated multiplication (run-time defined OCPs, ctd_jit.cpp)
 template <class T> CTD_HD T d_powi(const T& x, int k) {
     T r = x;
@@ -227,6 +245,11 @@ template <int K> CTD_HD Dual2<K> d_sin(const Dual2<K>& x) { const double s = ::s
 template <int K> CTD_HD Dual2<K> d_cos(const Dual2<K>& x) { const double s = ::sin(x.v), c = ::cos(x.v); return d2_chain(x, c, -s, -c); }
 template <int K> CTD_HD Dual2<K> d_sqr(const Dual2<K>& x) { return d2_chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
 template <int K> CTD_HD Dual2<K> d_sqrt(const Dual2<K>& x) { const double s = ::sqrt(x.v); return d2_chain(x, s, 0.5 / s, -0.25 / (s * x.v)); }
+template <int K> CTD_HD Dual2<K> d_log(const Dual2<K>& x) { const double q = 1.0 / x.v; return d2_chain(x, ::log(x.v), q, -(q * q)); }
+template <int K> CTD_HD Dual2<K> d_tan(const Dual2<K>& x) { const double t = ::tan(x.v), s = 1.0 + t * t; return d2_chain(x, t, s, 2.0 * t * s); }
+template <int K> CTD_HD Dual2<K> d_atan(const Dual2<K>& x) { const double q = 1.0 / (1.0 + x.v * x.v); return d2_chain(x, ::atan(x.v), q, -2.0 * x.v * (q * q)); }
+template <int K> CTD_HD Dual2<K> d_tanh(const Dual2<K>& x) { const double t = ::tanh(x.v), s = 1.0 - t * t; return d2_chain(x, t, s, -2.0 * t * s); }
+template <int K> CTD_HD Dual2<K> d_abs(const Dual2<K>& x) { return d2_chain(x, ::fabs(x.v), d_sgn(x.v), 0.0); }
 template <int K> CTD_HD double d_val(const Dual2<K>& x) { return x.v; }
 
 }  // namespace ctd

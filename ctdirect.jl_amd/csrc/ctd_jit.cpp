@@ -16,10 +16,10 @@ namespace ctd {
 // ------------------------------------------------------------------------------------------------------
 // expressions:  expr := term (('+'|'-') term)* ; term := unary (('*'|'/') unary)* ; unary := '-' unary | power ;
 //               power := atom ('^' integer)? ; atom := number | name | func '(' expr ')' | '(' expr ')'
-// names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants; functions exp sin cos sqrt
+// names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants; functions exp log sin cos tan atan tanh sqrt abs
 // ------------------------------------------------------------------------------------------------------
 namespace {
-// common sub-expression pool of one generated function: every distinct non-constant call of exp / sin / cos / sqrt is
+// common sub-expression pool of one generated function: every distinct non-constant function call (exp, sin, ...) is
 // computed once into a temporary shared by all outputs of the function (hand-written functors do the same)
 struct CsePool {
     std::vector<std::pair<std::string, std::string>> seen;   // (expression text, temporary)
@@ -146,10 +146,11 @@ struct Parser {
             const std::string name = s.substr(b, pos - b);
             skip();
             if (pos < s.size() && s[pos] == '(') {          // function call
-                static const char* fn[][2] = {{"exp", "d_exp"}, {"sin", "d_sin"}, {"cos", "d_cos"}, {"sqrt", "d_sqrt"}};
+                static const char* fn[][2] = {{"exp", "d_exp"}, {"sin", "d_sin"}, {"cos", "d_cos"}, {"sqrt", "d_sqrt"}, {"log", "d_log"},
+                                              {"tan", "d_tan"}, {"atan", "d_atan"}, {"tanh", "d_tanh"}, {"abs", "d_abs"}};
                 const char* target = nullptr;
                 for (auto& f : fn) if (name == f[0]) target = f[1];
-                if (!target) return fail("unknown function '" + name + "' (available: exp, sin, cos, sqrt)");
+                if (!target) return fail("unknown function '" + name + "' (available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs)");
                 ++pos;
                 Val a;
                 if (!expr(a)) return false;

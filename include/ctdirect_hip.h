@@ -128,7 +128,7 @@ typedef struct ctd_init {
  * at src/ode/trapeze.jl:66, midpoint.jl:64, irk.jl:291, irk_stagewise.jl:441; lagrange / mayer src/DOCP_functions.jl:35-48;
  * path / boundary constraints :108-110,136-138).  A closure cannot cross a C ABI, so an OCP that is not in the compiled
  * registry is handed over as TEXT: one arithmetic expression per output.  Grammar: + - * / ^(integer) parentheses, numbers,
- * exp sin cos sqrt, the names t, x1..xn, u1..um, v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer,
+ * exp log sin cos tan atan tanh sqrt abs, the names t, x1..xn, u1..um, v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer,
  * boundary), and the constants declared in `constants` ("Cd=310; beta=500").  No C++ is accepted.  ctd_register_ocp parses
  * the expressions, generates a functor of the registry's shape and returns a problem id (>= 1000) for ctd_desc.problem;
  * ctd_create then compiles the SAME kernel templates for it with hiprtc (gfx950) -- same code path as a built-in problem.

@@ -171,3 +171,70 @@ def catalogue(name):
     if key not in _registered:
         _registered[key] = ct.register_ocp(key, **entry[0])
     return _registered[key], entry[1], (entry[2] if len(entry) > 2 else None)
+
+
+# ---- every function of the expression grammar in one problem (log, tan, atan, tanh, abs beside exp / sin / cos / sqrt)
+FUNCS = dict(
+    dynamics=["x2 + log(1 + x1^2) - 0.3*tan(0.5*u1)", "atan(x1*x2) - tanh(v1*x2) + u1 + 0.1*abs(x1 - 0.2)"], m=1, nv=1,
+    lagrange="log(2 + u1^2) + tanh(x1)^2 + 0.05*abs(x2)", mayer="atan(xf_1) + v1*tan(0.3*xf_2)",
+    path=["tan(0.4*x1) + abs(u1 + 0.7)"], boundary=["x0_1", "log(1 + x0_2^2)", "tanh(xf_1) + xf_2"], t0=0.0, tf=1.2,
+    path_bounds=([-INF], [3.0]), boundary_bounds=([0.5, 0.0, 0.0], [0.5, 0.5, 1.0]))
+
+
+def _mp_unary(x, f0, f1, f2):
+    """unary function for whichever dual type gen_golden currently uses (first order Du or the second-order Du2)"""
+    if hasattr(x, "chain"):
+        return x.chain(f0, f1, f2)
+    return gg.Du(f0, [a * f1 for a in x.d])
+
+
+def dlog(x):
+    from mpmath import mp
+    x = gg.Du.lift(x)
+    return _mp_unary(x, mp.log(x.v), 1 / x.v, -1 / x.v ** 2)
+
+
+def dtan(x):
+    from mpmath import mp
+    x = gg.Du.lift(x)
+    t = mp.tan(x.v)
+    return _mp_unary(x, t, 1 + t * t, 2 * t * (1 + t * t))
+
+
+def datan(x):
+    from mpmath import mp
+    x = gg.Du.lift(x)
+    q = 1 / (1 + x.v ** 2)
+    return _mp_unary(x, mp.atan(x.v), q, -2 * x.v * q * q)
+
+
+def dtanh(x):
+    from mpmath import mp
+    x = gg.Du.lift(x)
+    t = mp.tanh(x.v)
+    return _mp_unary(x, t, 1 - t * t, -2 * t * (1 - t * t))
+
+
+def dabs(x):
+    x = gg.Du.lift(x)
+    return _mp_unary(x, abs(x.v), mpf(1) if x.v > 0 else (mpf(-1) if x.v < 0 else mpf(0)), mpf(0))
+
+
+class FuncsMp(gg.Problem):
+    name = "funcs_rt"
+    n, m, nv, p, bc = 2, 1, 1, 1, 3
+    lagrange, mayer = True, True
+
+    def tf(self, v): return gg.Du(mpf("1.2"))
+
+    def dynamics(self, t, x, u, v):
+        return [x[1] + dlog(1 + x[0] ** 2) - mpf("0.3") * dtan(mpf("0.5") * u[0]),
+                datan(x[0] * x[1]) - dtanh(v[0] * x[1]) + u[0] + mpf("0.1") * dabs(x[0] - mpf("0.2"))]
+
+    def lagr(self, t, x, u, v): return dlog(2 + u[0] ** 2) + dtanh(x[0]) ** 2 + mpf("0.05") * dabs(x[1])
+
+    def may(self, x0, xf, v): return datan(xf[0]) + v[0] * dtan(mpf("0.3") * xf[1])
+
+    def path(self, t, x, u, v): return [dtan(mpf("0.4") * x[0]) + dabs(u[0] + mpf("0.7"))]
+
+    def boundary(self, x0, xf, v): return [x0[0] + 0, dlog(1 + x0[1] ** 2), dtanh(xf[0]) + xf[1]]

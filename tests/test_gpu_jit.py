@@ -158,3 +158,29 @@ def test_lagrange_problem_without_boundary_rows(torch_cuda, sch):
         want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
         assert relerr(hv, want) <= TOL
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sch", ["gauss_legendre_2", "midpoint", "trapeze", "euler_implicit"])
+def test_every_function_of_the_grammar_against_mpmath(torch_cuda, sch):
+    """log, tan, atan, tanh and abs (value, first and second derivative) through the generated functor, in dynamics, both
+    costs, a path row and boundary rows, against the 50-digit evaluation"""
+    torch = torch_cuda
+    name = "funcs_rt" if "funcs_rt" in ct.PROBLEMS else ct.register_ocp("funcs_rt", **jit_defs.FUNCS)
+    N = 4
+    d = ct.DOCP(name, N, sch, pattern="structural", device=0)
+    rng = np.random.default_rng(12)
+    x = 0.3 * rng.standard_normal(d.dim_NLP_variables)
+    x[-1] = 0.8
+    y = rng.standard_normal(d.dim_NLP_constraints)
+    md, cref, Jref, fref, gref, Href = _mp_reference(jit_defs.FuncsMp(), sch, N, x, y, 0.7)
+    assert (md.nvar, md.ncon) == (d.dim_NLP_variables, d.dim_NLP_constraints)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    c, vals = d.cons_jac(xd)
+    rows, cols = d.jac_structure()
+    assert relerr(c.cpu().numpy(), cref) <= TOL and relerr(vals.cpu().numpy(), Jref[rows - 1, cols - 1]) <= TOL
+    assert abs(d.obj(xd) - fref) <= TOL * max(1.0, abs(fref)) and relerr(d.grad(xd).cpu().numpy(), gref) <= TOL
+    hr, hc = d.hess_structure()
+    want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
+    assert relerr(d.hess_coord(xd, yd, 0.7).cpu().numpy(), want) <= TOL
+    d.close()

@@ -61,3 +61,16 @@ def test_compute_without_device_fails_loudly_for_runtime_ocps():
     with pytest.raises(ct.CTDirectError) as e:
         d.cons(np.full(d.dim_NLP_variables, 0.1))
     assert e.value.status == ct._lib.CTD_ENODEVICE
+
+
+def test_all_grammar_functions_parse_and_compile():
+    """log / tan / atan / tanh / abs are accepted beside exp / sin / cos / sqrt, appear in the generated functor and the kernel
+    templates compile for gfx950 with them (first- and second-order number types)"""
+    name = "funcs_rt" if "funcs_rt" in ct.PROBLEMS else ct.register_ocp("funcs_rt", **jit_defs.FUNCS)
+    src = ct.ocp_source(name)
+    for fn in ("d_log(", "d_tan(", "d_atan(", "d_tanh(", "d_abs("):
+        assert fn in src, fn
+    ct.jit_check(name, "gauss_legendre_2")
+    with pytest.raises(ct.CTDirectError) as e:
+        ct.register_ocp("bad", dynamics=["asinh(x1)"])
+    assert "available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs" in str(e.value)
