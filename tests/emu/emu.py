@@ -14,7 +14,9 @@ def lib():
     global _lib
     if _lib is None:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
-        L = C.CDLL(_LIB)
+        # CTD_EMU_LIB: an instrumented build of the same source (e.g. -fsanitize=address,undefined; run pytest with the
+        # sanitizer runtime preloaded)
+        L = C.CDLL(os.environ.get("CTD_EMU_LIB") or _LIB)
         L.emu_last_error.restype = C.c_char_p
         _lib = L
     return _lib
