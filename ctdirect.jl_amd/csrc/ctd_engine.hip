@@ -310,6 +310,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     }
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
     h->kp.debug_stop = debug_stop;
+    h->kp.xcd_remap = env_int("CTD_XCD", 0);          // 1: every XCD walks one contiguous run of tiles (measured neutral)
     h->device = desc->device;
     // 0 classic driver (default: on MI355X the pipelined driver measured within 1 us of it, profiles/r01_pipeline.md),
     // 1 pipelined driver, -1 automatic choice (pipelined for Gauss-Legendre grids with >= 3 sub-tiles per workgroup)
@@ -897,6 +898,7 @@ static int32_t ensure_hess(ctd_handle* h) {
         hp.done_counter = h->d_hcounter;
     }
     hp.debug_stop = env_int("CTD_HESS_STOP", 0);
+    hp.xcd_remap = env_int("CTD_XCD", 0);
     h->hess_ready = true;
     return CTD_OK;
 }

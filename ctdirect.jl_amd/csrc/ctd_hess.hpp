@@ -84,6 +84,7 @@ struct HParams {
                                 // last one (implicit Euler with path constraints: 1)
     int32_t ntiles;
     int64_t step_begin, step_end;   // shard of the time grid this launch evaluates (tiles cover [step_begin, step_end))
+    int32_t xcd_remap;              // tiles follow xcd_tile(block - 1) (ctd_layout.hpp)
     int32_t edge_begin, edge_end;   // edge entries this shard emits: irregular leading columns of its own steps ...
     int32_t edge2_begin, edge2_end; // ... and the trailing columns (owner of step N-1)
     int32_t edge_vv;                // 1: this shard adds the V x V terms of the final-path / boundary / last-node points

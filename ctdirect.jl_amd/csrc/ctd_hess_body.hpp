@@ -89,7 +89,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.cp = cx.rec + (cx.nslots + 2) * hp.R.stride;
         cx.red = cx.rec;
     } else {
-        const int tile = block - 1;
+        const int tile = hp.xcd_remap ? xcd_tile(block - 1, hp.ntiles) : block - 1;
         const int cap = hp.T + hp.HL + hp.HH;
         if (hess_tables_staged(hp)) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);

@@ -634,6 +634,7 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     if (step_end <= 0) { step_begin = 0; step_end = L.N; }
     hp.step_begin = step_begin; hp.step_end = step_end;
     hp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
+    hp.xcd_remap = 0;
     // shards: the owners of the leading irregular steps emit their head entries, the owner of step N-1 the tail entries and the V x V share of the
     // final-path / boundary / last-node points; the other shards have no edge work
     hp.edge_begin = H.head_ptr[std::min<int64_t>(step_begin, H.reg_first)];

@@ -680,6 +680,7 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.HL = HL; kp.HH = HH;
     kp.step_begin = step_begin; kp.step_end = step_end;
     kp.ntiles = (int)((step_end - step_begin + tile - 1) / tile);
+    kp.xcd_remap = 0;
     kp.Lseg = Lseg; kp.vr = vr;
     kp.div_cb = make_fastdiv((uint32_t)L.cb);
     kp.div_Lseg = make_fastdiv((uint32_t)(Lseg > 0 ? Lseg : 1));

@@ -77,7 +77,8 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + 2 * kMaxEdgeSlots + 2;
     } else {
-        const int tile = block - (kp.has_edge ? 1 : 0);
+        const int tb = block - (kp.has_edge ? 1 : 0);
+        const int tile = kp.xcd_remap ? xcd_tile(tb, kp.ntiles) : tb;
         const int cap = kp.T + kp.HL + kp.HH;
         cx.is_edge = 0;
         cx.a = kp.step_begin + (int64_t)tile * kp.T;

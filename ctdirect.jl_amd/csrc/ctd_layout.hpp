@@ -53,6 +53,14 @@ template <int S> CTD_HD double butcher_a(const Layout& L, int j, int l) { return
 template <int S> CTD_HD double butcher_b(const Layout& L, int j) { return butcher_pick<S>(L.b, j, 1, 0); }
 template <int S> CTD_HD double butcher_c(const Layout& L, int j) { return butcher_pick<S>(L.c, j, 1, 0); }
 
+// Workgroups whose ids are congruent modulo 8 share an XCD (and its L2) on MI355X.  With this bijective remap every XCD
+// walks one contiguous run of tiles, so a tile's halo step and the cache line its output segment shares with the next tile
+// stay inside one L2 (the id is a group label only; nothing depends on it for correctness).
+CTD_HD int xcd_tile(int b, int nt) {
+    const int q = nt / 8, r = nt % 8, k = b % 8;
+    return (k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q) + b / 8;
+}
+
 // doubles per record input of the edge block: own step block | X_{i+1} | U_{i+1} (trapeze) | U_{i-1} (implicit Euler's path control)
 CTD_HD int edge_in_stride(const Layout& L) { return L.blk + L.n + 2 * L.m; }
 
@@ -136,6 +144,7 @@ struct KParams {
     int32_t HL, HH;             // extra records a tile needs below / above its steps (midpoint: 1,0; trapeze: 0,1)
     int32_t ntiles;
     int32_t has_edge;           // block 0 is the edge block
+    int32_t xcd_remap;          // tiles follow xcd_tile(block) instead of the block id
     int64_t step_begin, step_end;
     // regular CSC segments: step i in [reg_first, reg_last) owns vals[seg_base + (i - reg_first) * Lseg, +Lseg)
     const uint32_t* tmpl;

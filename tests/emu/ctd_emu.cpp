@@ -8,6 +8,7 @@
 // parity tests (-m gpu) never use it.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <string>
 #include <vector>
@@ -153,6 +154,7 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     if (tile <= 0) tile = default_tile(mo);
     KParams kp;
     mo.fill_kparams(kp, step_begin, step_end, tile);
+    if (const char* e = std::getenv("CTD_XCD")) kp.xcd_remap = std::atoi(e);      // same ablation knob as the engine
     kp.tau = mo.uniform ? nullptr : mo.tau.data();
     kp.tmpl = mo.tmpl.data();
     kp.vtmpl = mo.vtmpl.data();
@@ -228,6 +230,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     if (tile <= 0) tile = default_hess_tile(mo);
     HParams hp;
     mo.fill_hparams(hp, tile, step_begin, step_end);
+    if (const char* e = std::getenv("CTD_XCD")) hp.xcd_remap = std::atoi(e);
     const HessModel& H = mo.H;
     hp.tau = mo.uniform ? nullptr : mo.tau.data();
     hp.tptr = H.tptr.data(); hp.terms = H.terms.data();

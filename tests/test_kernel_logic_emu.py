@@ -114,3 +114,25 @@ def test_every_split_of_a_tiny_grid_composes(oracle_lib, prob, sch):
                 hw |= w
             assert hw.all() and not np.any(c == SENT) and not np.any(v == SENT), (N, cut)
             assert relerr(c, cref) <= TOL and relerr(v, vref) <= TOL and relerr(h, href) <= 1e-9, (N, cut)
+
+
+def test_xcd_tile_order_is_a_pure_permutation(monkeypatch):
+    """CTD_XCD=1 hands every XCD one contiguous run of tiles (ctd_layout.hpp xcd_tile): a bijection of the tile indices, so
+    every output is still written once and the values do not change (the V x V Hessian entries: same terms, other order)"""
+    pid, sid = ct.PROBLEMS["goddard_all"], ct.SCHEMES["gauss_legendre_2"]
+    for N, tile in ((37, 2), (64, 3), (7, 1)):
+        d = ct.DOCP("goddard_all", N, "gauss_legendre_2", device=-1)
+        rng = np.random.default_rng(2)
+        x = 0.4 + 0.2 * rng.random(d.dim_NLP_variables)
+        y = rng.standard_normal(d.dim_NLP_constraints)
+        monkeypatch.setenv("CTD_XCD", "0")
+        c0, v0 = emu.cons_jac(pid, sid, 0, N, x, tile=tile)
+        h0 = emu.hess(pid, sid, 0, N, x, y, 0.6, tile=tile)
+        monkeypatch.setenv("CTD_XCD", "1")
+        c1, v1 = emu.cons_jac(pid, sid, 0, N, x, tile=tile)
+        h1 = emu.hess(pid, sid, 0, N, x, y, 0.6, tile=tile)
+        assert np.array_equal(c0, c1) and np.array_equal(v0, v1)
+        vv = np.zeros(len(h0), bool)
+        vv[np.array(d.hess_shard_info()[2], dtype=int)] = True
+        assert np.array_equal(h0[~vv], h1[~vv]) and np.allclose(h0[vv], h1[vv], rtol=1e-13, atol=0)
+        d.close()
