@@ -5,12 +5,12 @@ is the thin host-side mirror of the reference's DOCP interface plus the multi-GP
 """
 from . import _lib
 from .docp import (DOCP, PATTERN_MODES, PROBLEMS, SCHEMES, CTDirectError, DOCP_Hessian_pattern, DOCP_Jacobian_pattern, constraints,
-                   constraints_bounds, get_time_grid, gradient, initial_guess, jit_check, objective, ocp_source, register_ocp,
-                   unpack_solution, variables_bounds)
+                   constraints_bounds, get_time_grid, gradient, initial_guess, jit_check, objective, ocp_source, pinned_empty,
+                   register_ocp, unpack_solution, variables_bounds)
 
 __all__ = ["DOCP", "PROBLEMS", "SCHEMES", "PATTERN_MODES", "CTDirectError", "DOCP_Hessian_pattern", "DOCP_Jacobian_pattern", "constraints",
            "constraints_bounds", "get_time_grid", "unpack_solution", "gradient", "initial_guess", "jit_check", "objective", "ocp_source", "register_ocp",
-           "variables_bounds", "build"]
+           "variables_bounds", "pinned_empty", "build"]
 
 
 def build(jobs=8):

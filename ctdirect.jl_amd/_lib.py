@@ -48,6 +48,8 @@ SYMBOLS = {
     "ctd_destroy": (C.c_int32, [_vp]),
     "ctd_last_error": (C.c_char_p, [_vp]),
     "ctd_strerror": (C.c_char_p, [C.c_int32]),
+    "ctd_host_alloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "ctd_host_free": (C.c_int32, [C.c_void_p]),
     "ctd_sizes": (C.c_int32, [_vp, _ip, _ip, _ip, _ip]),
     "ctd_dims": (C.c_int32, [_vp, _ip]),
     "ctd_time_grid": (C.c_int32, [_vp, _dp, _dp]),

@@ -623,6 +623,18 @@ static int32_t host_cons_jac(ctd_handle* h, const double* x, double* c, double* 
     return CTD_OK;
 }
 
+int32_t ctd_host_alloc(void** ptr, size_t bytes) {
+    if (!ptr) return CTD_EINVAL;
+    *ptr = nullptr;
+    const hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_host_alloc: ") + hipGetErrorString(e); return CTD_EHIP; }
+    return CTD_OK;
+}
+int32_t ctd_host_free(void* ptr) {
+    if (!ptr) return CTD_OK;
+    return hipHostFree(ptr) == hipSuccess ? CTD_OK : CTD_EHIP;
+}
+
 int32_t ctd_cons(ctd_handle* h, const double* x, double* c) {
     if (h && !c) return fail(h, CTD_EINVAL, "c is null");
     return host_cons_jac(h, x, c, nullptr);

@@ -521,6 +521,38 @@ def constraints_bounds(docp):
     return docp.bounds.con_l, docp.bounds.con_u
 
 
+class _Pinned:
+    """owner of one ctd_host_alloc block (freed when the last array viewing it goes away)"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        st = _lib.lib().ctd_host_alloc(C.byref(self.ptr), nbytes)
+        if st:
+            _raise(st, _lib.lib().ctd_last_error(None).decode())
+
+    def __del__(self):
+        try:
+            _lib.lib().ctd_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(n, dtype=np.float64):
+    """NumPy array in page-locked host memory (`ctd_host_alloc`): passing such arrays to the host-pointer calls
+    (`docp.cons_jac(x, c, vals)` with NumPy arguments, ...) lets the copies run as direct DMA at PCIe rate."""
+    dtype = np.dtype(dtype)
+    own = _Pinned(int(n) * dtype.itemsize)
+    buf = (C.c_char * (int(n) * dtype.itemsize)).from_address(own.ptr.value)
+    a = np.frombuffer(buf, dtype=dtype, count=int(n))
+    _pinned_owners[a.__array_interface__["data"][0]] = own      # keeps the block alive as long as the module does ...
+    import weakref
+    weakref.finalize(a, _pinned_owners.pop, a.__array_interface__["data"][0], None)   # ... or until the array is collected
+    return a
+
+
+_pinned_owners = {}
+
+
 def initial_guess(docp, init=None):
     """`CTDirect.__initial_guess(docp, init)`.  init: None (everything 0.1), "problem" (the problem file's init
     tuple) or a dict with optional constant `state`, `control`, `variable` entries; with a `time` entry (K increasing

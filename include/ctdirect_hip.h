@@ -28,6 +28,7 @@
 #ifndef CTDIRECT_HIP_H
 #define CTDIRECT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -161,6 +162,12 @@ int32_t ctd_jit_check(int32_t problem_id, int32_t scheme);
 int32_t ctd_create(const ctd_desc* desc, ctd_handle** out);
 int32_t ctd_destroy(ctd_handle* h);
 const char* ctd_last_error(const ctd_handle* h);   /* h may be NULL: error of the last failed ctd_create */
+/* Page-locked host memory for the vectors a caller hands to the host-pointer entry points (x, c, vals, g, y ...): the
+ * copies then run as direct DMA at PCIe rate instead of through the runtime's bounce buffers.  Optional -- any host pointer
+ * is accepted everywhere -- and independent of handles.  The reference's vectors are plain Julia arrays owned by the solver
+ * (src/collocation.jl:137-149); a shim would wrap these with unsafe_wrap. */
+int32_t ctd_host_alloc(void** ptr, size_t bytes);
+int32_t ctd_host_free(void* ptr);
 const char* ctd_strerror(int32_t status);
 
 /* ---- sizes and static data (host) ------------------------------------------------------------------------ */

@@ -384,3 +384,20 @@ def test_whole_iteration_as_one_hip_graph(oracle_lib, torch_cuda):
         assert _rel(float(f[0]), o.objective(x)) <= TOL and relerr(g.cpu().numpy(), o.gradient(x)) <= TOL
         assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
         assert relerr(hv.cpu().numpy(), o.hess_coord(x, y, 1.0)) <= TOL
+
+
+@pytest.mark.gpu
+def test_page_locked_host_arrays_take_the_same_path(torch_cuda):
+    """ctd_host_alloc memory (ct.pinned_empty) through the host-pointer entry points: same values as pageable arrays"""
+    d = ct.DOCP("goddard", 300, "gauss_legendre_2", device=0)
+    x = bench_inputs(describe(d, "goddard", "gauss_legendre_2"), perturb=1e-3)
+    c, v = d.cons_jac(x)
+    xp, cp, vp = ct.pinned_empty(x.size), ct.pinned_empty(c.size), ct.pinned_empty(v.size)
+    xp[:] = x
+    cp[:] = vp[:] = 777.0
+    d.cons_jac(xp, cp, vp)
+    assert np.array_equal(cp, c) and np.array_equal(vp, v)
+    g = ct.pinned_empty(x.size)
+    assert np.array_equal(d.grad(xp, g), d.grad(x))
+    del xp, cp, vp, g
+    d.close()
