@@ -24,7 +24,10 @@ namespace ctd {
 #ifdef CTD_HESSK_OVERRIDE
 template <class P> struct HessK { static constexpr int value = CTD_HESSK_OVERRIDE; };
 #else
-template <class P> struct HessK { static constexpr int value = (P::NX >= 8) ? 2 : 4; };
+// Four for small OCPs; one for state dimension >= 8, where every further inner direction costs 2 doubles for each of the
+// ~3 n + m second-order numbers a lane holds: with two, the 12-state quadrotor needed 356 registers per lane (one wave per
+// SIMD) and ran 1.6x slower than with one (216 registers, two waves per SIMD); the 8-state one gains 4 %.
+template <class P> struct HessK { static constexpr int value = (P::NX >= 8) ? 1 : 4; };
 #endif
 
 template <class P, int SC, int S> struct HRL {

@@ -281,7 +281,7 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if (!has_lag) body_lag = "        return T(0.0);\n";
     if (!has_may) body_may = "        return T(0.0);\n";
     o->dc = 4;
-    o->hk = d->n >= 8 ? 2 : 4;
+    o->hk = d->n >= 8 ? 1 : 4;          // ctd::HessK (ctd_hess_body.hpp)
     o->maxb = 256;
     auto B = [](bool b) { return b ? "true" : "false"; };
     std::string& s = o->functor_src;
