@@ -231,9 +231,13 @@ __global__ void __launch_bounds__(256) obj_partial_kernel(const ObjParams op, co
 
 template <class P>
 __global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__ xu) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    // one wave: lane l adds the partials l, l + 64, ... in index order, then a fixed shuffle tree (deterministic; the
+    // loads of the 64 lanes are in flight together instead of one dependent chain of nblocks loads)
     double s = 0.0;
-    for (int b = 0; b < op.nblocks; ++b) s += op.partial[b];
+    for (int b = threadIdx.x; b < op.nblocks; b += 64) s += op.partial[b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x != 0) return;
     double mayer = 0.0;
     if (P::HAS_MAYER && op.add_mayer) {
         constexpr int n = P::NX, nv = P::NV;
@@ -476,15 +480,17 @@ __global__ void __launch_bounds__(256) grad_units_kernel(const GradParams gp, co
 
 template <class P>
 __global__ void grad_finish_kernel(const GradParams gp, const double* __restrict__ xu) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     constexpr int n = P::NX, nv = P::NV;
     const Layout& L = gp.L;
     double gvs[nv > 0 ? nv : 1];
-    for (int k = 0; k < nv; ++k) {
+    for (int k = 0; k < nv; ++k) {          // one wave, fixed order (see obj_finish_kernel)
         double sacc = 0.0;
-        for (int b = 0; b < gp.nblocks; ++b) sacc += gp.partial[(size_t)b * kMaxNV + k];
+        for (int b = threadIdx.x; b < gp.nblocks; b += 64) sacc += gp.partial[(size_t)b * kMaxNV + k];
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
         gvs[k] = sacc;
     }
+    if (threadIdx.x != 0) return;
     if (P::HAS_MAYER) {
         double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1], g0x[n > 0 ? n : 1], gfx[n > 0 ? n : 1], gmv[nv > 0 ? nv : 1];
         for (int c = 0; c < n; ++c) { x0[c] = xu[c]; xf[c] = xu[L.N * (int64_t)L.blk + c]; g0x[c] = 0.0; gfx[c] = 0.0; }
