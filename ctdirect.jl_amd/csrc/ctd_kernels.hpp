@@ -352,7 +352,7 @@ template <class P> __device__ __forceinline__ double grad_time(const GradParams&
 }
 
 template <class P, int SC, int S>
-__global__ void __launch_bounds__(256) grad_units_kernel(const GradParams gp, const double* __restrict__ xu) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) grad_units_kernel(const GradParams gp, const double* __restrict__ xu) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV;
     constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
     __shared__ double wsum[4][kMaxNV];
@@ -422,7 +422,9 @@ __global__ void __launch_bounds__(256) grad_units_kernel(const GradParams gp, co
             for (int c = 0; c < n; ++c) { gx[c] = 0.0; for (int l = 0; l < S; ++l) gK[l][c] = 0.0; }
             for (int c = 0; c < m; ++c) gu[c] = 0.0;
             double sum_bl = 0.0;
-#pragma unroll
+            // not unrolled: with the stages unrolled the compiler keeps every stage's x_ij, sum a K and l_x live at once
+            // (364 registers per lane for the 12-state quadrotor at S = 3, one wave per SIMD); j is wave-uniform
+#pragma unroll 1
             for (int j = 0; j < S; ++j) {
                 double sa[n > 0 ? n : 1];              // sum_l a_jl K^l (for d x_ij / d v)
                 for (int c = 0; c < n; ++c) {
