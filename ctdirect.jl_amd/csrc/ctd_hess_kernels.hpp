@@ -22,8 +22,14 @@ __device__ __forceinline__ void hess_stamp(const HParams& hp, int slot) {
     }
 }
 
+// at least two waves per SIMD: an instance a few registers over 256 per lane spills them instead of halving its occupancy
+#ifdef CTD_HESS_NO_CAP          // ablation
+#define CTD_HESS_CAP
+#else
+#define CTD_HESS_CAP __attribute__((amdgpu_waves_per_eu(2)))
+#endif
 template <class P, int SC, int S>
-__global__ __launch_bounds__(kHessBlock) void hess_kernel(const HParams hp, const double* __restrict__ xu,
+__global__ __launch_bounds__(kHessBlock) CTD_HESS_CAP void hess_kernel(const HParams hp, const double* __restrict__ xu,
                                                           const double* __restrict__ y) {
     extern __shared__ double hess_lds[];
     const int tid = threadIdx.x, nthr = blockDim.x;
