@@ -182,7 +182,7 @@ def main():
     if world == 1:
         import numpy as np
         for prob, sch, n in ((PROBLEM, SCHEME, STEPS_PER_GPU), ("goddard", "gauss_legendre_3", 80000),
-                             ("quadrotor", "gauss_legendre_3", 20000)):
+                             ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000)):
             d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch")
             x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
             y2 = torch.from_numpy(0.6 + 0.4 * np.sin(0.7 * np.arange(d2.dim_NLP_constraints) + 0.3)).to(dev)
