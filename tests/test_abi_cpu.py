@@ -224,3 +224,25 @@ def test_warm_start_round_trip_and_sample_errors():
     assert np.allclose(x0, x, rtol=0, atol=1e-15)
     with pytest.raises(ValueError):          # grid errors are ArgumentError in the reference (src/DOCP_data.jl:186-189)
         ct.initial_guess(d, dict(time=[0.0, 0.2, 0.1], state=np.zeros((3, 3))))
+
+
+def _build_c_demo(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_demo")
+    libdir = os.path.join(root, "ctdirect.jl_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "cabi_demo.c"), "-o", exe, "-L", libdir, "-lctdirect_hip",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/ctdirect_hip.h compiles as C99 (-pedantic -Werror) and examples/cabi_demo.c -- what a foreign-function binding
+    does -- links against the shared library and runs its host-only part; compute on a host-only handle is refused"""
+    import subprocess
+    ct._lib.lib()
+    out = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "nvar 1104 ncon 904 nnzj 11128 nnzh 7722" in out.stdout and "no CPU fallback" in out.stdout

@@ -401,3 +401,17 @@ def test_page_locked_host_arrays_take_the_same_path(torch_cuda):
     assert np.array_equal(d.grad(xp, g), d.grad(x))
     del xp, cp, vp, g
     d.close()
+
+
+@pytest.mark.gpu
+def test_c_program_evaluates_on_the_gpu(torch_cuda, tmp_path):
+    """examples/cabi_demo.c (plain C against the ABI) runs one fused evaluation on device 0; same numbers as the Python mirror"""
+    import subprocess
+    from test_abi_cpu import _build_c_demo
+    out = subprocess.run([_build_c_demo(tmp_path), "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    d = ct.DOCP("goddard", 100, "gauss_legendre_2", device=0)
+    x0 = ct.initial_guess(d)
+    c, v = d.cons_jac(x0)
+    assert f"objective {d.obj(x0):.6f}  c[0] {c[0]:.6e}  vals[0] {v[0]:.6e}" in out.stdout, out.stdout
+    d.close()
