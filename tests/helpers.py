@@ -1,7 +1,6 @@
 """Shared helpers for the test-suite: golden-fixture loading and deterministic input fills."""
 import glob
 import json
-import math
 import os
 
 import numpy as np

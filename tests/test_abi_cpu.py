@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 
 import ctdirect_jl_amd as ct
-from helpers import golden_files, load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ALL = [(p, s) for p in ct.PROBLEMS for s in ct.SCHEMES]
