@@ -415,3 +415,42 @@ def test_c_program_evaluates_on_the_gpu(torch_cuda, tmp_path):
     c, v = d.cons_jac(x0)
     assert f"objective {d.obj(x0):.6f}  c[0] {c[0]:.6e}  vals[0] {v[0]:.6e}" in out.stdout, out.stdout
     d.close()
+
+
+@pytest.mark.gpu
+def test_distinct_handles_are_usable_from_concurrent_threads(torch_cuda):
+    """"handle is not thread-safe, distinct handles are" (include/ctdirect_hip.h): four host threads, each with its own handle
+    (own stream) -- two of them created concurrently for a run-time OCP, i.e. through the hiprtc cache -- evaluate at the
+    same time through the host-pointer entry points and get the single-threaded results"""
+    import threading
+    import jit_defs
+    jobs = [("goddard", "gauss_legendre_2", 400), ("quadrotor", "midpoint", 150), (jit_defs.twin("goddard"), "trapeze", 300),
+            (jit_defs.twin("goddard"), "gauss_legendre_3", 200)]
+    want, got, errs = {}, {}, []
+    for k, (prob, sch, N) in enumerate(jobs):
+        d = ct.DOCP(prob, N, sch, device=0, stream="own")
+        x = 0.4 + 0.1 * np.sin(np.arange(d.dim_NLP_variables))
+        y = np.cos(0.3 * np.arange(d.dim_NLP_constraints))
+        want[k] = (x, y, d.cons_jac(x), d.grad(x), d.hess_coord(x, y, 0.5))
+        d.close()
+
+    def work(k):
+        try:
+            prob, sch, N = jobs[k]
+            d = ct.DOCP(prob, N, sch, device=0, stream="own")
+            x, y = want[k][0], want[k][1]
+            for _ in range(40):
+                out = (d.cons_jac(x), d.grad(x), d.hess_coord(x, y, 0.5))
+            got[k] = out
+            d.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(len(jobs)):
+        (c0, v0), g0, h0 = want[k][2], want[k][3], want[k][4]
+        (c1, v1), g1, h1 = got[k]
+        assert np.array_equal(c0, c1) and np.array_equal(v0, v1) and np.array_equal(g0, g1) and np.array_equal(h0, h1), k
