@@ -97,7 +97,7 @@ struct ctd_handle {
     std::string err;
 };
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;      // error of this thread's last failed handle-less call (ctd_last_error(NULL))
 
 static int32_t fail(ctd_handle* h, int32_t code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -127,6 +127,7 @@ static int env_int(const char* name, int dflt) {
 static void free_device(ctd_handle* h) {
     if (h->device < 0) return;
     (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);      // enqueue-only calls may still be running on the tables freed below
     for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
@@ -378,6 +379,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
 }
 
 int32_t ctd_register_ocp(const ctd_ocp_def* def, int32_t* problem_id) {
+    if (!def || !problem_id) return fail(nullptr, CTD_EINVAL, "ctd_register_ocp: null argument");
     std::string err;
     int id = -1;
     const int st = register_runtime_ocp(def, &id, err);
