@@ -65,6 +65,19 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
     return r;
 }
 
+// ---- parameters of the symbolically differentiated stage functions of a run-time OCP (ctd_sym.hpp, ctd_jit.cpp) -----
+// The evaluation point as a function of the differentiation variables d = (dx[n], du[m], dv[nv]), all zero at the point:
+//   t = T0 + sum_k TD_k dv_k      h = H0 + sum_k HD_k dv_k      x_r = X0_r + dx_r + sum_k HD_k KAP_r dv_k   (KAP: IRK only)
+//   u_b = U0_b + du_b             v_k = V0_k + dv_k
+//   Phi = sum_r W_r f_r + CL h l  (Gauss-Legendre stage)        Phi = h (sum_r W_r f_r + CL l)  (midpoint / Euler point)
+struct SymPrm { int T0, H0, CL, TD, HD, X0, KAP, U0, V0, W, count; };
+constexpr SymPrm sym_prm(int n, int m, int nv) {
+    SymPrm p{};
+    p.T0 = 0; p.H0 = 1; p.CL = 2; p.TD = 3; p.HD = 3 + nv; p.X0 = 3 + 2 * nv; p.KAP = p.X0 + n; p.U0 = p.KAP + n;
+    p.V0 = p.U0 + m; p.W = p.V0 + nv; p.count = p.W + n;
+    return p;
+}
+
 // ---- 32-bit term code:  value += CP[pair] * rec[di]  of record `slot` ------------------------------------------
 // bits 0-15 di, 16-23 pair id, 24-26 slot.  Inside tile templates slot is relative (0 = the entry's own step,
 // 1 = the previous step, 2 = the next step); inside the edge lists it is the absolute record id of the edge block.

@@ -415,6 +415,72 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     }
 }
 
+// The same stage-type point for an OCP that carries symbolically differentiated stage functions (run-time OCPs,
+// ctd_sym.hpp / ctd_jit.cpp): ONE lane fills the parameters of the point (SymPrm, ctd_hess.hpp) and the generated
+// straight-line code writes every second derivative of the record (and the RK block) -- no second-order number types.
+template <class P, int SC, int S>
+CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, int j) {
+    if constexpr (P::HAS_SYM) {
+        constexpr int n = P::NX, m = P::NU, nv = P::NV;
+        constexpr bool FREE = Dirs<P>::FREE;
+        constexpr HessRecLayout R = HRL<P, SC, S>::R;
+        constexpr SymPrm Q = sym_prm(n, m, nv);
+        const Layout& L = hp.L;
+        const int64_t s = hslot_step(hp, cx, k);
+        if (s < 0 || s >= L.N) return;
+        const double* base = cx.in + k * cx.in_stride;
+        const double* y = hslot_y(hp, cx, k);
+        double* HD = cx.rec + k * R.stride + R.oStage + j * R.stage_sz;
+        const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
+        const double tA = htime_of<P>(hp, cx.v, tau0), tB = htime_of<P>(hp, cx.v, tau1), h = tB - tA;
+        double prm[Q.count];
+        double d0[nv > 0 ? nv : 1], d1[nv > 0 ? nv : 1];
+#pragma unroll
+        for (int kk = 0; kk < nv; ++kk) {
+            d0[kk] = FREE ? dtime_of<P>(tau0, kk) : 0.0;
+            d1[kk] = FREE ? dtime_of<P>(tau1, kk) : 0.0;
+            prm[Q.HD + kk] = d1[kk] - d0[kk];
+            prm[Q.V0 + kk] = cx.v[kk];
+        }
+        prm[Q.H0] = h;
+        if (SC == SC_IRK) {
+            const double cj = butcher_c<S>(L, j);
+            prm[Q.T0] = tA + cj * h;
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) prm[Q.TD + kk] = d0[kk] + cj * (d1[kk] - d0[kk]);
+            const double* Kv = base + n + L.cu;
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                double kap = 0.0;
+#pragma unroll
+                for (int l = 0; l < S; ++l) kap = kap + butcher_a<S>(L, j, l) * Kv[l * n + r];
+                prm[Q.X0 + r] = base[r] + h * kap;
+                prm[Q.KAP + r] = kap;
+                prm[Q.W + r] = -y[n + j * n + r];
+            }
+#pragma unroll
+            for (int b = 0; b < m; ++b) prm[Q.U0 + b] = L.stagewise ? base[n + j * m + b] : base[n + b];
+            prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight * butcher_b<S>(L, j) : 0.0;
+            P::stage_sym_irk(prm, HD);
+        } else {
+            const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = 1.0 - wa;   // weights of (t_i, X_i) / (t_i+1, X_i+1)
+            prm[Q.T0] = wa * tA + wb * tB;
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) prm[Q.TD + kk] = wa * d0[kk] + wb * d1[kk];
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                prm[Q.X0 + r] = L.euler == 0 ? 0.5 * (base[r] + base[L.blk + r]) : (L.euler == 1 ? base[r] : base[L.blk + r]);
+                prm[Q.KAP + r] = 0.0;
+                prm[Q.W + r] = -y[r];
+            }
+#pragma unroll
+            for (int b = 0; b < m; ++b) prm[Q.U0 + b] = base[n + b];
+            prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight : 0.0;
+            P::stage_sym_mid(prm, HD);
+        }
+    }
+}
+
 // path point: x = X_s (or X_N), u = control of the step (stagewise: sum_l b_l U^l), t = t_s; `yrow` = multipliers of the rows
 template <class P, int SC, int S>
 CTD_HD void hess_eval_path(const HParams& hp, const double* xs, const double* ub, const double* vv, double tau,
@@ -537,7 +603,8 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int r = w - k * hp.slot_tasks;
         if (r < R.S * hp.ntask) {
             const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-            hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
+            if constexpr (P::HAS_SYM && SC != SC_TRAPEZE) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
+            else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
         } else if (PATH_PT) {
             const uint32_t code = cx.ptasks[r - R.S * hp.ntask];
             const int64_t s = hslot_step(hp, cx, k);

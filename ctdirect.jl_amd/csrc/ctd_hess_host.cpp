@@ -602,6 +602,13 @@ int build_hess_model(Model& mo, std::string& err) {
         }
     };
     make_tasks(H.R.md, H.need_stage, L.sc == SC_IRK && L.free_time, H.tasks);
+    // run-time OCP with symbolically differentiated stage functions: one lane per stage point writes every second
+    // derivative of the point (hess_eval_stage_sym); the direction-pair tasks are only used by trapeze nodes
+    {
+        const RtOcp* ro = runtime_ocp(mo.problem);
+        H.sym_stage = ro && ro->has_sym && L.sc != SC_TRAPEZE;
+        if (H.sym_stage) H.tasks.assign(1, 0u);
+    }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);
     make_tasks(H.R.mdb, H.need_bnd, false, H.btasks);
     return ST_OK;
@@ -617,6 +624,15 @@ int default_hess_tile(const Model& mo) {
     const int tps = std::max(1, H.R.S * (int)H.tasks.size() + (int)H.ptasks.size());
     const int64_t per_step = (int64_t)(L.blk + L.cb + H.R.stride + (int64_t)H.pairs.size() + 2) * 8;
     const int64_t fit = std::max<int64_t>(1, (60 * 1024) / per_step - H.HL - H.HH - 1);
+    if (H.sym_stage) {
+        // symbolic stage functions (run-time OCPs): the eval phase is one short pass, so the tile is set by the other
+        // phases -- MI355X sweeps (profiles/r01_hessian_symbolic.md): ~27 KiB of LDS per workgroup for light steps (five to six
+        // workgroups per CU), ~48 KiB for steps of 2 KiB and more (the CSC period is then several wave passes per step)
+        const int64_t budget = per_step >= 2048 ? 48 * 1024 : 27 * 1024;
+        int64_t Ts = std::max<int64_t>(1, std::min<int64_t>(128, budget / per_step - H.HL - H.HH - 1));
+        while (Ts > 4 && (L.N + Ts - 1) / Ts < 512) Ts = (Ts + 1) / 2;      // small grids: about two workgroups per CU
+        return (int)Ts;
+    }
     int64_t T = 256 / tps;
     if (T < 24) T = 512 / tps;
     T = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(T, 128), fit));

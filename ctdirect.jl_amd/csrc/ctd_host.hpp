@@ -26,6 +26,7 @@ struct Block { int64_t r0, r1, c0, c1; };   // rows [r0,r1) x cols [c0,c1), 0-ba
 struct HessModel {
     HessRecLayout R;
     int hk = 4;                       // inner directions per eval lane (ctd::HessK<P>)
+    bool sym_stage = false;           // stage points use the OCP's symbolic second derivatives (run-time OCPs, ctd_sym.hpp)
     int64_t nnzh = 0;
     std::vector<Block> tail;          // blocks that do not belong to one step (already symmetrised)
     // regular part

@@ -10,6 +10,8 @@
 #include <mutex>
 
 #include "../../include/ctdirect_hip.h"
+#include "ctd_hess.hpp"
+#include "ctd_sym.hpp"
 
 namespace ctd {
 
@@ -42,7 +44,11 @@ struct Parser {
     std::string err;
     RtProgram rpn;
     void op(uint8_t kind, int k = 0) { rpn.push_back(RtOp{kind, (int16_t)k}); }
-    struct Val { std::string code; bool is_const; };
+    struct Val { std::string code; bool is_const; int node = -1; };
+    // optional symbolic build (kind 0 expressions): the names t / x<k> / u<k> / v<k> are bound to these DAG nodes
+    sym::Graph* g = nullptr;
+    int g_t = -1;
+    const int *g_x = nullptr, *g_u = nullptr, *g_v = nullptr;
 
     Parser(const std::string& s_, const ExprCtx& cx_) : s(s_), cx(cx_) {}
     void skip() { while (pos < s.size() && std::isspace((unsigned char)s[pos])) ++pos; }
@@ -70,6 +76,7 @@ struct Parser {
                 if (!term(r)) return false;
                 out.code = "(" + out.code + " " + op + " " + r.code + ")";
                 out.is_const = out.is_const && r.is_const;
+                if (g) out.node = op == '+' ? g->add(out.node, r.node) : g->sub(out.node, r.node);
                 this->op(op == '+' ? RT_ADD : RT_SUB);
             } else return true;
         }
@@ -84,6 +91,7 @@ struct Parser {
                 if (!unary(r)) return false;
                 out.code = "(" + out.code + " " + op + " " + r.code + ")";
                 out.is_const = out.is_const && r.is_const;
+                if (g) out.node = op == '*' ? g->mul(out.node, r.node) : g->div(out.node, r.node);
                 this->op(op == '*' ? RT_MUL : RT_DIV);
             } else return true;
         }
@@ -96,6 +104,7 @@ struct Parser {
             if (!unary(r)) return false;
             out.code = "(-" + r.code + ")";
             out.is_const = r.is_const;
+            if (g) out.node = g->neg(r.node);
             op(RT_NEG);
             return true;
         }
@@ -115,6 +124,7 @@ struct Parser {
             if (k == 0) { out.code = "1.0"; out.is_const = true; }
             else if (k == 2) out.code = "d_sqr(" + out.code + ")";
             else if (k > 2) out.code = "d_powi(" + out.code + ", " + std::to_string(k) + ")";
+            if (g) out.node = g->powi(out.node, k);
             op(RT_POW, k);
         }
         return true;
@@ -137,6 +147,7 @@ struct Parser {
             if (end == s.c_str() + pos) return fail("malformed number");
             pos = (size_t)(end - s.c_str());
             out.code = num(v); out.is_const = true;
+            if (g) out.node = g->constant(v);
             op(RT_CONST);
             return true;
         }
@@ -148,8 +159,10 @@ struct Parser {
             if (pos < s.size() && s[pos] == '(') {          // function call
                 static const char* fn[][2] = {{"exp", "d_exp"}, {"sin", "d_sin"}, {"cos", "d_cos"}, {"sqrt", "d_sqrt"}, {"log", "d_log"},
                                               {"tan", "d_tan"}, {"atan", "d_atan"}, {"tanh", "d_tanh"}, {"abs", "d_abs"}};
+                static const sym::Fn fid[] = {sym::F_EXP, sym::F_SIN, sym::F_COS, sym::F_SQRT, sym::F_LOG, sym::F_TAN, sym::F_ATAN, sym::F_TANH, sym::F_ABS};
                 const char* target = nullptr;
-                for (auto& f : fn) if (name == f[0]) target = f[1];
+                int fidx = -1;
+                for (int i = 0; i < (int)(sizeof(fn) / sizeof(fn[0])); ++i) if (name == fn[i][0]) { target = fn[i][1]; fidx = i; }
                 if (!target) return fail("unknown function '" + name + "' (available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs)");
                 ++pos;
                 Val a;
@@ -159,6 +172,7 @@ struct Parser {
                 ++pos;
                 out.code = std::string(target) + "(" + a.code + ")";
                 out.is_const = a.is_const;
+                if (g) out.node = g->fn(fid[fidx], a.node);
                 if (cse && !a.is_const) out.code = cse->intern(out.code);
                 op(RT_NONLIN);
                 return true;
@@ -166,16 +180,16 @@ struct Parser {
             int k = 0;
             out.is_const = false;
             if (cx.kind == 0) {
-                if (name == "t") { uses_t = true; out.code = "t"; op(RT_T); return true; }
-                if (name[0] == 'x' && index_of(name, 1, cx.n, k)) { out.code = "x[" + std::to_string(k - 1) + "]"; op(RT_X, k - 1); return true; }
-                if (name[0] == 'u' && index_of(name, 1, cx.m, k)) { out.code = "u[" + std::to_string(k - 1) + "]"; op(RT_U, k - 1); return true; }
+                if (name == "t") { uses_t = true; out.code = "t"; if (g) out.node = g_t; op(RT_T); return true; }
+                if (name[0] == 'x' && index_of(name, 1, cx.n, k)) { out.code = "x[" + std::to_string(k - 1) + "]"; if (g) out.node = g_x[k - 1]; op(RT_X, k - 1); return true; }
+                if (name[0] == 'u' && index_of(name, 1, cx.m, k)) { out.code = "u[" + std::to_string(k - 1) + "]"; if (g) out.node = g_u[k - 1]; op(RT_U, k - 1); return true; }
             } else {
                 if (name.rfind("x0_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "x0[" + std::to_string(k - 1) + "]"; op(RT_X0, k - 1); return true; }
                 if (name.rfind("xf_", 0) == 0 && index_of(name, 3, cx.n, k)) { out.code = "xf[" + std::to_string(k - 1) + "]"; op(RT_XF, k - 1); return true; }
             }
-            if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; op(RT_V, k - 1); return true; }
+            if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; if (g) out.node = g_v[k - 1]; op(RT_V, k - 1); return true; }
             auto it = cx.constants.find(name);
-            if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; op(RT_CONST); return true; }
+            if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; if (g) out.node = g->constant(it->second); op(RT_CONST); return true; }
             return fail("unknown name '" + name + "'");
         }
         return fail(std::string("unexpected character '") + c + "'");
@@ -241,6 +255,64 @@ const RtOcp* runtime_ocp(int id) {
     return (k >= 0 && k < (int)g_ocps.size()) ? g_ocps[k].get() : nullptr;
 }
 
+// Symbolic second derivatives of the scalar a stage-type point contributes to the Lagrangian (ctd_sym.hpp, SymPrm in
+// ctd_hess.hpp): returns the bodies of UserOCP::stage_sym_irk / stage_sym_mid, which write the md x md upper triangle of the
+// point's record (and, for Gauss-Legendre stages with free times, the RK helper block behind it).
+static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag, bool irk, std::string& body, std::string& err) {
+    const int n = d->n, m = d->m, nv = d->nv, md = n + m + nv;
+    const SymPrm P = sym_prm(n, m, nv);
+    const bool free_time = d->it0 >= 0 || d->itf >= 0;
+    sym::Graph g;
+    std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    int t = g.param(P.T0), h = g.param(P.H0);
+    for (int k = 0; k < nv; ++k) {
+        t = g.add(t, g.mul(g.param(P.TD + k), g.var(n + m + k)));
+        h = g.add(h, g.mul(g.param(P.HD + k), g.var(n + m + k)));
+    }
+    for (int r = 0; r < n; ++r) {
+        int x = g.add(g.param(P.X0 + r), g.var(r));
+        if (irk) for (int k = 0; k < nv; ++k) x = g.add(x, g.mul(g.mul(g.param(P.HD + k), g.param(P.KAP + r)), g.var(n + m + k)));
+        X[r] = x;
+    }
+    for (int b = 0; b < m; ++b) U[b] = g.add(g.param(P.U0 + b), g.var(n + b));
+    for (int k = 0; k < nv; ++k) V[k] = g.add(g.param(P.V0 + k), g.var(n + m + k));
+    auto parse = [&](const char* text, int& node) {
+        const std::string str(text);
+        Parser ps(str, c0);
+        ps.g = &g; ps.g_t = t; ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+        Parser::Val v;
+        if (!ps.expr(v)) { err = ps.err; return false; }
+        node = v.node;
+        return true;
+    };
+    int F = g.constant(0.0);
+    for (int r = 0; r < n; ++r) {
+        int fr = -1;
+        if (!parse(d->dynamics[r], fr)) return false;
+        F = g.add(F, g.mul(g.param(P.W + r), fr));
+    }
+    int L = g.constant(0.0);
+    if (has_lag && !parse(d->lagrange, L)) return false;
+    const int Phi = irk ? g.add(F, g.mul(g.param(P.CL), g.mul(h, L))) : g.mul(h, g.add(F, g.mul(g.param(P.CL), L)));
+    std::vector<std::pair<std::string, int>> outs;
+    std::vector<int> d1(md);
+    for (int p = 0; p < md; ++p) d1[p] = g.diff(Phi, p);
+    for (int p = 0; p < md; ++p)
+        for (int q = p; q < md; ++q)
+            outs.emplace_back("HD[" + std::to_string(p * md + q) + "]", g.at_zero(g.diff(d1[p], q)));
+    if (irk && free_time) {      // RK[k][a] = h d2Phi/dx_a dV_k + dh/dv_k dPhi/dx_a   (hess_eval_stage)
+        const int oRK = md * md;
+        for (int k = 0; k < nv; ++k)
+            for (int a = 0; a < n; ++a)
+                outs.emplace_back("HD[" + std::to_string(oRK + k * n + a) + "]",
+                                  g.add(g.mul(g.param(P.H0), g.at_zero(g.diff(d1[a], n + m + k))),
+                                        g.mul(g.param(P.HD + k), g.at_zero(d1[a]))));
+    }
+    if (g.nodes.size() > 200000) { err = "symbolic derivatives too large"; return false; }
+    body = g.codegen(outs, "p", "        ");
+    return true;
+}
+
 int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if (!d || !id) { err = "null argument"; return CTD_EINVAL; }
     if (d->n < 1 || d->n > 24 || d->m < 0 || d->m > 12 || d->nv < 0 || d->nv > kMaxNV || d->npath < 0 || d->npath > 16 ||
@@ -298,6 +370,18 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     s += "    template <class T> CTD_HD static T mayer(const T* x0, const T* xf, const T* v) {\n" + pool_may.decls + body_may + "    }\n";
     s += "    template <class T> CTD_HD static void path(T* r, const T& t, const T* x, const T* u, const T* v) {\n" + pool_path.decls + body_path + "    }\n";
     s += "    template <class T> CTD_HD static void boundary(T* r, const T* x0, const T* xf, const T* v) {\n" + pool_bnd.decls + body_bnd + "    }\n";
+    // symbolically differentiated stage functions for the Hessian kernel (opt-out: CTD_HESS_SYM=0 at registration)
+    {
+        const char* env = std::getenv("CTD_HESS_SYM");
+        std::string b_irk, b_mid, e2;
+        o->has_sym = !(env && std::string(env) == "0") && gen_sym_stage(d, c0, has_lag, true, b_irk, e2) &&
+                     gen_sym_stage(d, c0, has_lag, false, b_mid, e2);
+        s += std::string("    static constexpr bool HAS_SYM = ") + B(o->has_sym) + ";\n";
+        if (o->has_sym) {
+            s += "    CTD_HD static void stage_sym_irk(const double* p, double* HD) {\n" + b_irk + "    }\n";
+            s += "    CTD_HD static void stage_sym_mid(const double* p, double* HD) {\n" + b_mid + "    }\n";
+        }
+    }
     s += "};\n}  // namespace ctd\n";
 
     ProblemInfo& pi = o->info;

@@ -32,6 +32,7 @@ struct RtOcp {
     ProblemInfo info;                  // info.name points into `name`
     bool dyn_t, dyn_v, path_t, path_v, lag_t, lag_v;
     int dc, hk, maxb;
+    bool has_sym = false;              // the functor carries symbolically differentiated stage functions (ctd_sym.hpp)
     std::string functor_src;           // namespace ctd { struct UserOCP { ... }; }
     std::vector<RtProgram> p_dynamics, p_path, p_boundary;
     RtProgram p_lagrange, p_mayer;     // empty: absent

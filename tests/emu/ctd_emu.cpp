@@ -257,4 +257,40 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     return ok ? 0 : 5;
 }
 
+// Symbolic engine check (ctd_sym.hpp, test infrastructure): parses `expr` (kind-0 grammar) with t, x, u, v bound to the
+// differentiation variables 0 .. n+m+nv (t first), differentiates it twice symbolically and compares every second
+// derivative, evaluated at `point`, with central differences of the symbolic first derivatives.  Returns the largest
+// difference relative to max(1, |value|) in *max_err and the number of DAG nodes in *nnodes.
+int emu_sym_check(const char* expr, int n, int m, int nv, const double* point, double* max_err, int64_t* nnodes) {
+    const int nz = 1 + n + m + nv;
+    sym::Graph g;
+    std::vector<int> X(n > 0 ? n : 1), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    for (int r = 0; r < n; ++r) X[r] = g.var(1 + r);
+    for (int b = 0; b < m; ++b) U[b] = g.var(1 + n + b);
+    for (int k = 0; k < nv; ++k) V[k] = g.var(1 + n + m + k);
+    ExprCtx cx{n, m, nv, 0, {}};
+    const std::string text(expr);
+    Parser ps(text, cx);
+    ps.g = &g; ps.g_t = g.var(0); ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+    Parser::Val val;
+    if (!ps.expr(val)) { g_err = ps.err; return 1; }
+    const std::vector<double> prm;
+    std::vector<double> z(point, point + nz);
+    double worst = 0.0;
+    for (int i = 0; i < nz; ++i) {
+        const int di = g.diff(val.node, i);
+        for (int j = 0; j < nz; ++j) {
+            const double s = g.eval(g.diff(di, j), prm, z);
+            const double hstep = 1e-6 * std::max(1.0, std::fabs(z[j]));
+            std::vector<double> zp = z, zm = z;
+            zp[j] += hstep; zm[j] -= hstep;
+            const double fd = (g.eval(di, prm, zp) - g.eval(di, prm, zm)) / (2.0 * hstep);
+            worst = std::max(worst, std::fabs(s - fd) / std::max(1.0, std::fabs(s)));
+        }
+    }
+    *max_err = worst;
+    *nnodes = (int64_t)g.nodes.size();
+    return 0;
+}
+
 }  // extern "C"

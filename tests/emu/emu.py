@@ -106,3 +106,15 @@ def hess(problem, scheme, mode, N, x, y, obj_weight=1.0, time_grid=None, tile=0,
     if st:
         raise RuntimeError(f"emu status {st}: {L.emu_last_error().decode()}")
     return vals
+
+
+def sym_check(expr, n, m, nv, point):
+    """(largest difference between the symbolic second derivatives of `expr` and central differences of its symbolic first
+    derivatives at `point` = (t, x, u, v), number of DAG nodes): ctd_sym.hpp"""
+    point = np.ascontiguousarray(point, dtype=np.float64)
+    assert point.size == 1 + n + m + nv
+    err, nn = C.c_double(), C.c_int64()
+    st = lib().emu_sym_check(expr.encode(), n, m, nv, point.ctypes.data_as(C.c_void_p), C.byref(err), C.byref(nn))
+    if st:
+        raise RuntimeError(lib().emu_last_error().decode())
+    return err.value, nn.value

@@ -74,3 +74,21 @@ def test_all_grammar_functions_parse_and_compile():
     with pytest.raises(ct.CTDirectError) as e:
         ct.register_ocp("bad", dynamics=["asinh(x1)"])
     assert "available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs" in str(e.value)
+
+
+@pytest.mark.parametrize("expr", [
+    "x1*x2*u1 + t*v1^3 - x1/(1 + x2^2)", "exp(-2*x1)*sin(x2 + t) - cos(u1*v1)/(2 + x1^2)",
+    "log(1 + x1^2 + u1^2)*tanh(x2 - v1) + atan(x1*x2) + tan(0.3*u1)", "sqrt(1 + x1^2 + x2^2)*abs(u1 - 0.3) + (x1 - x2)^4/(1 + t)",
+    "-Cd*x2^2*exp(-beta*(x1 - 1))/x3 - 1/x1^2 + u1*Tmax/x3".replace("Cd", "310").replace("beta", "5").replace("Tmax", "3.5"),
+    "((x1 + 2*x2)*(3 - u1))/((1 + v1)*(2 + t)) - -x1", "2^3 + x1*0 + 0*u1 + x2^1 + x1^0",
+])
+def test_symbolic_second_derivatives_match_finite_differences(expr):
+    """the symbolic engine behind the stage functions of run-time OCPs (ctd_sym.hpp): every operator and function of the
+    grammar, second derivatives against central differences of the symbolic first derivatives"""
+    from emu import emu
+    n, m, nv = 3, 1, 1
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        point = 0.5 + 0.4 * rng.random(1 + n + m + nv)
+        err, nnodes = emu.sym_check(expr, n, m, nv, point)
+        assert err <= 1e-6 and nnodes < 5000, (expr, err, nnodes)
