@@ -70,11 +70,15 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
 //   t = T0 + sum_k TD_k dv_k      h = H0 + sum_k HD_k dv_k      x_r = X0_r + dx_r + sum_k HD_k KAP_r dv_k   (KAP: IRK only)
 //   u_b = U0_b + du_b             v_k = V0_k + dv_k
 //   Phi = sum_r W_r f_r + CL h l  (Gauss-Legendre stage)        Phi = h (sum_r W_r f_r + CL l)  (midpoint / Euler point)
-struct SymPrm { int T0, H0, CL, TD, HD, X0, KAP, U0, V0, W, count; };
-constexpr SymPrm sym_prm(int n, int m, int nv) {
+//   trapeze node (shared by the steps before and after it, lengths hm and h; W = multipliers of the step after, WP of the
+//   step before, WG of the node's path rows):
+//   hm = HM0 + sum_k HMD_k dv_k     Phi = -1/2 sum_r f_r (hm WP_r + h W_r) + CL (hm + h) l + sum_r WG_r g_r
+struct SymPrm { int T0, H0, CL, TD, HD, X0, KAP, U0, V0, W, HM0, HMD, WP, WG, count; };
+constexpr SymPrm sym_prm(int n, int m, int nv, int np = 0) {
     SymPrm p{};
     p.T0 = 0; p.H0 = 1; p.CL = 2; p.TD = 3; p.HD = 3 + nv; p.X0 = 3 + 2 * nv; p.KAP = p.X0 + n; p.U0 = p.KAP + n;
-    p.V0 = p.U0 + m; p.W = p.V0 + nv; p.count = p.W + n;
+    p.V0 = p.U0 + m; p.W = p.V0 + nv; p.HM0 = p.W + n; p.HMD = p.HM0 + 1; p.WP = p.HMD + nv; p.WG = p.WP + n;
+    p.count = p.WG + np;
     return p;
 }
 

@@ -424,10 +424,10 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
         constexpr int n = P::NX, m = P::NU, nv = P::NV;
         constexpr bool FREE = Dirs<P>::FREE;
         constexpr HessRecLayout R = HRL<P, SC, S>::R;
-        constexpr SymPrm Q = sym_prm(n, m, nv);
+        constexpr SymPrm Q = sym_prm(n, m, nv, P::NPATH);
         const Layout& L = hp.L;
         const int64_t s = hslot_step(hp, cx, k);
-        if (s < 0 || s >= L.N) return;
+        if (s < 0 || (SC == SC_TRAPEZE ? s > L.N : s >= L.N)) return;
         const double* base = cx.in + k * cx.in_stride;
         const double* y = hslot_y(hp, cx, k);
         double* HD = cx.rec + k * R.stride + R.oStage + j * R.stage_sz;
@@ -462,6 +462,31 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
             for (int b = 0; b < m; ++b) prm[Q.U0 + b] = L.stagewise ? base[n + j * m + b] : base[n + b];
             prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight * butcher_b<S>(L, j) : 0.0;
             P::stage_sym_irk(prm, HD);
+        } else if (SC == SC_TRAPEZE) {
+            // node s between step s-1 (length hm) and step s (length h); the clamped tau makes the missing one 0
+            const double taum = hslot_tau(cx, k, -1);
+            const double tM = htime_of<P>(hp, cx.v, taum);
+            const double* yp = hslot_yprev(hp, cx, k);
+            prm[Q.T0] = tA;
+            prm[Q.HM0] = tA - tM;
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                prm[Q.TD + kk] = d0[kk];
+                prm[Q.HMD + kk] = d0[kk] - (FREE ? dtime_of<P>(taum, kk) : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                prm[Q.X0 + r] = base[r];
+                prm[Q.KAP + r] = 0.0;
+                prm[Q.W + r] = y[r];
+                prm[Q.WP + r] = yp[r];
+            }
+#pragma unroll
+            for (int b = 0; b < m; ++b) prm[Q.U0 + b] = base[n + b];
+#pragma unroll
+            for (int r = 0; r < P::NPATH; ++r) prm[Q.WG + r] = y[L.eqs + r];
+            prm[Q.CL] = P::HAS_LAGRANGE ? 0.5 * hp.obj_weight : 0.0;
+            P::stage_sym_trap(prm, HD);
         } else {
             const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = 1.0 - wa;   // weights of (t_i, X_i) / (t_i+1, X_i+1)
             prm[Q.T0] = wa * tA + wb * tB;
@@ -603,7 +628,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int r = w - k * hp.slot_tasks;
         if (r < R.S * hp.ntask) {
             const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-            if constexpr (P::HAS_SYM && SC != SC_TRAPEZE) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
+            if constexpr (P::HAS_SYM) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
             else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
         } else if (PATH_PT) {
             const uint32_t code = cx.ptasks[r - R.S * hp.ntask];

@@ -603,10 +603,10 @@ int build_hess_model(Model& mo, std::string& err) {
     };
     make_tasks(H.R.md, H.need_stage, L.sc == SC_IRK && L.free_time, H.tasks);
     // run-time OCP with symbolically differentiated stage functions: one lane per stage point writes every second
-    // derivative of the point (hess_eval_stage_sym); the direction-pair tasks are only used by trapeze nodes
+    // derivative of the point (hess_eval_stage_sym)
     {
         const RtOcp* ro = runtime_ocp(mo.problem);
-        H.sym_stage = ro && ro->has_sym && L.sc != SC_TRAPEZE;
+        H.sym_stage = ro && ro->has_sym;
         if (H.sym_stage) H.tasks.assign(1, 0u);
     }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);

@@ -258,9 +258,10 @@ const RtOcp* runtime_ocp(int id) {
 // Symbolic second derivatives of the scalar a stage-type point contributes to the Lagrangian (ctd_sym.hpp, SymPrm in
 // ctd_hess.hpp): returns the bodies of UserOCP::stage_sym_irk / stage_sym_mid, which write the md x md upper triangle of the
 // point's record (and, for Gauss-Legendre stages with free times, the RK helper block behind it).
-static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag, bool irk, std::string& body, std::string& err) {
+static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag, int kind, std::string& body, std::string& err) {
+    const bool irk = kind == 0, trap = kind == 2;
     const int n = d->n, m = d->m, nv = d->nv, md = n + m + nv;
-    const SymPrm P = sym_prm(n, m, nv);
+    const SymPrm P = sym_prm(n, m, nv, d->npath);
     const bool free_time = d->it0 >= 0 || d->itf >= 0;
     sym::Graph g;
     std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
@@ -285,15 +286,28 @@ static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag,
         node = v.node;
         return true;
     };
+    int hm = g.param(P.HM0);
+    for (int k = 0; k < nv; ++k) hm = g.add(hm, g.mul(g.param(P.HMD + k), g.var(n + m + k)));
     int F = g.constant(0.0);
     for (int r = 0; r < n; ++r) {
         int fr = -1;
         if (!parse(d->dynamics[r], fr)) return false;
-        F = g.add(F, g.mul(g.param(P.W + r), fr));
+        const int w = trap ? g.mul(g.constant(-0.5), g.add(g.mul(hm, g.param(P.WP + r)), g.mul(h, g.param(P.W + r)))) : g.param(P.W + r);
+        F = g.add(F, g.mul(w, fr));
     }
     int L = g.constant(0.0);
     if (has_lag && !parse(d->lagrange, L)) return false;
-    const int Phi = irk ? g.add(F, g.mul(g.param(P.CL), g.mul(h, L))) : g.mul(h, g.add(F, g.mul(g.param(P.CL), L)));
+    int Phi;
+    if (irk) Phi = g.add(F, g.mul(g.param(P.CL), g.mul(h, L)));
+    else if (!trap) Phi = g.mul(h, g.add(F, g.mul(g.param(P.CL), L)));
+    else {
+        Phi = g.add(F, g.mul(g.param(P.CL), g.mul(g.add(hm, h), L)));
+        for (int r = 0; r < d->npath; ++r) {
+            int gr = -1;
+            if (!parse(d->path[r], gr)) return false;
+            Phi = g.add(Phi, g.mul(g.param(P.WG + r), gr));
+        }
+    }
     std::vector<std::pair<std::string, int>> outs;
     std::vector<int> d1(md);
     for (int p = 0; p < md; ++p) d1[p] = g.diff(Phi, p);
@@ -373,13 +387,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     // symbolically differentiated stage functions for the Hessian kernel (opt-out: CTD_HESS_SYM=0 at registration)
     {
         const char* env = std::getenv("CTD_HESS_SYM");
-        std::string b_irk, b_mid, e2;
-        o->has_sym = !(env && std::string(env) == "0") && gen_sym_stage(d, c0, has_lag, true, b_irk, e2) &&
-                     gen_sym_stage(d, c0, has_lag, false, b_mid, e2);
+        std::string b_irk, b_mid, b_trap, e2;
+        o->has_sym = !(env && std::string(env) == "0") && gen_sym_stage(d, c0, has_lag, 0, b_irk, e2) &&
+                     gen_sym_stage(d, c0, has_lag, 1, b_mid, e2) && gen_sym_stage(d, c0, has_lag, 2, b_trap, e2);
         s += std::string("    static constexpr bool HAS_SYM = ") + B(o->has_sym) + ";\n";
         if (o->has_sym) {
             s += "    CTD_HD static void stage_sym_irk(const double* p, double* HD) {\n" + b_irk + "    }\n";
             s += "    CTD_HD static void stage_sym_mid(const double* p, double* HD) {\n" + b_mid + "    }\n";
+            s += "    CTD_HD static void stage_sym_trap(const double* p, double* HD) {\n" + b_trap + "    }\n";
         }
     }
     s += "};\n}  // namespace ctd\n";

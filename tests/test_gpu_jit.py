@@ -53,10 +53,10 @@ def test_runtime_twin_matches_registry_and_oracle(oracle_lib, torch_cuda, prob, 
         hb = b.hess_coord(xd, yd, 0.7).cpu().numpy()
         # the structural-sparsity probe walks the expressions of a run-time OCP and the functor of a registry entry: same
         # nonzero structure, hence the same number of terms and of second-order eval lanes -- except at stage points, where
-        # a run-time OCP runs its symbolically differentiated stage function on ONE lane (trapeze nodes: lanes as before)
+        # a run-time OCP runs its symbolically differentiated stage function on ONE lane
         ia, ib = a.hess_launch_info(), b.hess_launch_info()
         assert all(ia[k] == ib[k] for k in ("path_lanes", "boundary_lanes", "segment_terms", "edge_entries")), (ia, ib)
-        assert ib["stage_lanes"] == (ia["stage_lanes"] if sch == "trapeze" else 1), (ia, ib)
+        assert ib["stage_lanes"] == 1, (ia, ib)
         assert relerr(hb, a.hess_coord(xd, yd, 0.7).cpu().numpy()) <= TOL
         assert relerr(hb, o.hess_coord(x, y, 0.7)) <= TOL
         # host-pointer entry points take the same path
