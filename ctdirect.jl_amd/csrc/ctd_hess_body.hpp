@@ -415,12 +415,27 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     }
 }
 
+// Symbolically differentiated stage functions of an OCP: members of the generated functor for run-time OCPs (HAS_SYM,
+// ctd_jit.cpp), explicit specialisations generated at build time for the registry problems (ctd_sym_registry.hpp)
+template <class P> struct SymStage {
+    static constexpr bool value = P::HAS_SYM;
+    CTD_HD static void irk(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_irk(p, HD); }
+    CTD_HD static void mid(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_mid(p, HD); }
+    CTD_HD static void trap(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_trap(p, HD); }
+};
+#if !defined(__HIPCC_RTC__)
+}  // namespace ctd
+#include "ctd_problems.hpp"
+#include "ctd_sym_registry.hpp"
+namespace ctd {
+#endif
+
 // The same stage-type point for an OCP that carries symbolically differentiated stage functions (run-time OCPs,
 // ctd_sym.hpp / ctd_jit.cpp): ONE lane fills the parameters of the point (SymPrm, ctd_hess.hpp) and the generated
 // straight-line code writes every second derivative of the record (and the RK block) -- no second-order number types.
 template <class P, int SC, int S>
 CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, int j) {
-    if constexpr (P::HAS_SYM) {
+    if constexpr (SymStage<P>::value) {
         constexpr int n = P::NX, m = P::NU, nv = P::NV;
         constexpr bool FREE = Dirs<P>::FREE;
         constexpr HessRecLayout R = HRL<P, SC, S>::R;
@@ -461,7 +476,7 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
 #pragma unroll
             for (int b = 0; b < m; ++b) prm[Q.U0 + b] = L.stagewise ? base[n + j * m + b] : base[n + b];
             prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight * butcher_b<S>(L, j) : 0.0;
-            P::stage_sym_irk(prm, HD);
+            SymStage<P>::irk(prm, HD);
         } else if (SC == SC_TRAPEZE) {
             // node s between step s-1 (length hm) and step s (length h); the clamped tau makes the missing one 0
             const double taum = hslot_tau(cx, k, -1);
@@ -486,7 +501,7 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
 #pragma unroll
             for (int r = 0; r < P::NPATH; ++r) prm[Q.WG + r] = y[L.eqs + r];
             prm[Q.CL] = P::HAS_LAGRANGE ? 0.5 * hp.obj_weight : 0.0;
-            P::stage_sym_trap(prm, HD);
+            SymStage<P>::trap(prm, HD);
         } else {
             const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = 1.0 - wa;   // weights of (t_i, X_i) / (t_i+1, X_i+1)
             prm[Q.T0] = wa * tA + wb * tB;
@@ -501,7 +516,7 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
 #pragma unroll
             for (int b = 0; b < m; ++b) prm[Q.U0 + b] = base[n + b];
             prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight : 0.0;
-            P::stage_sym_mid(prm, HD);
+            SymStage<P>::mid(prm, HD);
         }
     }
 }
@@ -628,7 +643,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int r = w - k * hp.slot_tasks;
         if (r < R.S * hp.ntask) {
             const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-            if constexpr (P::HAS_SYM) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
+            if constexpr (SymStage<P>::value) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
             else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
         } else if (PATH_PT) {
             const uint32_t code = cx.ptasks[r - R.S * hp.ntask];

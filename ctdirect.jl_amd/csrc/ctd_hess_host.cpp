@@ -3,6 +3,7 @@
 // See ctd_hess.hpp for the decomposition.
 #include "ctd_host.hpp"
 #include "ctd_jit.hpp"
+#include "ctd_hess_body.hpp"
 
 #include <algorithm>
 #include <map>
@@ -606,7 +607,7 @@ int build_hess_model(Model& mo, std::string& err) {
     // derivative of the point (hess_eval_stage_sym)
     {
         const RtOcp* ro = runtime_ocp(mo.problem);
-        H.sym_stage = ro && ro->has_sym;
+        H.sym_stage = (ro && ro->has_sym) || registry_has_sym(mo.problem);
         if (H.sym_stage) H.tasks.assign(1, 0u);
     }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);
@@ -630,6 +631,9 @@ int default_hess_tile(const Model& mo) {
         // workgroups per CU), ~48 KiB for steps of 2 KiB and more (the CSC period is then several wave passes per step)
         const int64_t budget = per_step >= 2048 ? 48 * 1024 : 27 * 1024;
         int64_t Ts = std::max<int64_t>(1, std::min<int64_t>(128, budget / per_step - H.HL - H.HH - 1));
+        // very heavy steps (the 12-state quadrotor, 11 KiB per step): up to 6 steps as long as two workgroups still share a
+        // CU's LDS (6 steps = 77 KiB: 151 us; 3 steps: 258 us; 7 steps = one workgroup per CU: 249 us)
+        if (Ts < 6) Ts = std::max<int64_t>(Ts, std::min<int64_t>(6, (78 * 1024) / per_step - H.HL - H.HH - 1));
         while (Ts > 4 && (L.N + Ts - 1) / Ts < 512) Ts = (Ts + 1) / 2;      // small grids: about two workgroups per CU
         return (int)Ts;
     }
