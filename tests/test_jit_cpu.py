@@ -92,3 +92,15 @@ def test_symbolic_second_derivatives_match_finite_differences(expr):
         point = 0.5 + 0.4 * rng.random(1 + n + m + nv)
         err, nnodes = emu.sym_check(expr, n, m, nv, point)
         assert err <= 1e-6 and nnodes < 5000, (expr, err, nnodes)
+
+
+def test_committed_registry_stage_functions_are_what_the_generator_writes(tmp_path):
+    """ctd_sym_registry.hpp is generated (csrc/ctd_gen_sym.cpp: expression form of the registry problems -> symbolic stage
+    functions) and committed: rebuilding the tool and running it reproduces the committed file byte for byte"""
+    import os
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ctdirect.jl_amd", "csrc")
+    exe = str(tmp_path / "ctd_gen_sym")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-o", exe, os.path.join(csrc, "ctd_gen_sym.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(csrc, "ctd_sym_registry.hpp")).read()
