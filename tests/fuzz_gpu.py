@@ -22,7 +22,11 @@ probs, schemes = list(ct.PROBLEMS), list(ct.SCHEMES)
 t_end = time.time() + budget
 ncase = nfail = 0
 worst = {}
+t_note = time.time() + 60.0
 while time.time() < t_end:
+    if time.time() >= t_note:          # progress line (long runs behind a quiet pipe look hung to gpurun)
+        print(f"... {ncase} cases, {nfail} failures", flush=True)
+        t_note += 60.0
     prob, sch = probs[rng.integers(len(probs))], schemes[rng.integers(len(schemes))]
     big = rng.random() < 0.25
     N = int(rng.integers(1, 2500 if big else 90))
