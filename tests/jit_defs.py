@@ -238,3 +238,33 @@ class FuncsMp(gg.Problem):
     def path(self, t, x, u, v): return [dtan(mpf("0.4") * x[0]) + dabs(u[0] + mpf("0.7"))]
 
     def boundary(self, x0, xf, v): return [x0[0] + 0, dlog(1 + x0[1] ** 2), dtanh(xf[0]) + xf[1]]
+
+
+# ---- four optimisation variables, both times free and NOT at the ends of v (it0 = 2, itf = 1): every V x V entry, the
+# composite time directions and the K x V terms of the Hessian at once
+FOURV = dict(
+    dynamics=["x2*v1 + 0.2*sin(t)", "-x1*(1 + v4^2) + u1*v1 - 0.1*x2^3"], m=1, nv=4, it0=2, itf=1,
+    lagrange="0.5*u1^2 + v4*x1^2 + 0.1*t*x2", mayer="xf_1^2 + v1*v4 + 0.5*(v2 - v3)^2",
+    path=["x1*u1 + v4*t"], boundary=["x0_1", "x0_2 - v1", "xf_1*xf_2", "v2 - v3"],
+    variable_box=([0.1, 0.5, -1.0, -2.0], [3.0, 6.0, 0.4, 2.0]), control_box=([-2], [2]),
+    path_bounds=([-INF], [2.0]), boundary_bounds=([1, 0, 0, 0.2], [1, 0, 0.5, INF]))
+
+
+class FourVMp(gg.Problem):
+    name = "fourv_rt"
+    n, m, nv, p, bc = 2, 1, 4, 1, 4
+    freet0, freetf, lagrange, mayer = True, True, True, True
+
+    def t0(self, v): return v[2]
+    def tf(self, v): return v[1]
+
+    def dynamics(self, t, x, u, v):
+        return [x[1] * v[0] + mpf("0.2") * gg.dsin(gg.Du.lift(t)), -x[0] * (1 + v[3] ** 2) + u[0] * v[0] - mpf("0.1") * x[1] ** 2 * x[1]]
+
+    def lagr(self, t, x, u, v): return mpf("0.5") * u[0] ** 2 + v[3] * x[0] ** 2 + mpf("0.1") * t * x[1]
+
+    def may(self, x0, xf, v): return xf[0] ** 2 + v[0] * v[3] + mpf("0.5") * (v[1] - v[2]) ** 2
+
+    def path(self, t, x, u, v): return [x[0] * u[0] + v[3] * t]
+
+    def boundary(self, x0, xf, v): return [x0[0] + 0, x0[1] - v[0], xf[0] * xf[1], v[1] - v[2]]

@@ -186,3 +186,45 @@ def test_every_function_of_the_grammar_against_mpmath(torch_cuda, sch):
     want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
     assert relerr(d.hess_coord(xd, yd, 0.7).cpu().numpy(), want) <= TOL
     d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sch", ["gauss_legendre_3", "gauss_legendre_2_constant_control", "midpoint", "trapeze", "euler"])
+def test_four_optimisation_variables_with_both_times_free(torch_cuda, sch):
+    """nv = 4 (the ABI's maximum), t0 = v3 and tf = v2: all ten V x V Hessian entries, the composite time directions and the
+    K x V terms, against the 50-digit evaluation"""
+    torch = torch_cuda
+    name = "fourv_rt" if "fourv_rt" in ct.PROBLEMS else ct.register_ocp("fourv_rt", **jit_defs.FOURV)
+    for N in (3, 26):
+        d = ct.DOCP(name, N, sch, pattern="structural", device=0)
+        rng = np.random.default_rng(8)
+        x = 0.4 + 0.3 * rng.standard_normal(d.dim_NLP_variables)
+        x[-4:] = [1.2, 1.9, 0.15, 0.7]                              # v = (a, tf, t0, b)
+        y = rng.standard_normal(d.dim_NLP_constraints)
+        if N == 3:
+            md, cref, Jref, fref, gref, Href = _mp_reference(jit_defs.FourVMp(), sch, N, x, y, 0.8)
+            assert (md.nvar, md.ncon) == (d.dim_NLP_variables, d.dim_NLP_constraints)
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        c, vals = d.cons_jac(xd)
+        rows, cols = d.jac_structure()
+        hr, hc = d.hess_structure()
+        hv = d.hess_coord(xd, yd, 0.8).cpu().numpy()
+        if N == 3:
+            assert relerr(c.cpu().numpy(), cref) <= TOL and relerr(vals.cpu().numpy(), Jref[rows - 1, cols - 1]) <= TOL
+            assert abs(d.obj(xd) - fref) <= TOL * max(1.0, abs(fref)) and relerr(d.grad(xd).cpu().numpy(), gref) <= TOL
+            want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
+            assert relerr(hv, want) <= TOL
+            assert sum(1 for r, cc in zip(hr, hc) if r > d.dim_NLP_variables - 4 and cc > d.dim_NLP_variables - 4) == 10
+        else:
+            # larger grid: the symbolic stage functions against the second-order forward numbers of the generic path
+            import os
+            os.environ["CTD_HESS_SYM"] = "0"
+            try:
+                name0 = "fourv_rt0" if "fourv_rt0" in ct.PROBLEMS else ct.register_ocp("fourv_rt0", **jit_defs.FOURV)
+            finally:
+                os.environ.pop("CTD_HESS_SYM", None)
+            d0 = ct.DOCP(name0, N, sch, pattern="structural", device=0)
+            assert d0.hess_launch_info()["stage_lanes"] > 1 and d.hess_launch_info()["stage_lanes"] == 1
+            assert relerr(hv, d0.hess_coord(xd, yd, 0.8).cpu().numpy()) <= TOL
+            d0.close()
+        d.close()
