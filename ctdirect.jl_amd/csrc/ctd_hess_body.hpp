@@ -423,12 +423,6 @@ template <class P> struct SymStage {
     CTD_HD static void mid(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_mid(p, HD); }
     CTD_HD static void trap(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_trap(p, HD); }
 };
-#if !defined(__HIPCC_RTC__)
-}  // namespace ctd
-#include "ctd_problems.hpp"
-#include "ctd_sym_registry.hpp"
-namespace ctd {
-#endif
 
 // The same stage-type point for an OCP that carries symbolically differentiated stage functions (run-time OCPs,
 // ctd_sym.hpp / ctd_jit.cpp): ONE lane fills the parameters of the point (SymPrm, ctd_hess.hpp) and the generated

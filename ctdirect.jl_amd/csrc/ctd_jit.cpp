@@ -327,6 +327,43 @@ static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag,
     return true;
 }
 
+// First derivatives of the dynamics at an evaluation point, written straight into an eval block of the step record of the
+// constraint / Jacobian kernel (ctd_layout.hpp: F[n x ldx] | G[n x ldu] | W[n x nv] | f[n] | ft[n]): body of
+// UserOCP::dyn_sym(t, x, u, v, ev).  Every entry of F and G is written (structural zeros as 0.0); ft / W only when the
+// dynamics depend on t / v explicitly, as eval_dynamics does.
+static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err) {
+    const int n = d->n, m = d->m, nv = d->nv;
+    const RecLayout R = make_rec_layout(n, m, nv, d->npath, d->nbc, 0, n + d->npath);     // eval-block offsets depend on n, m, nv only
+    sym::Graph g;
+    // parameters: p[0] = t, then x[n], u[m], v[nv]; variables: the same positions
+    std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    const int t = g.add(g.param(0), g.var(0));
+    for (int r = 0; r < n; ++r) X[r] = g.add(g.param(1 + r), g.var(1 + r));
+    for (int b = 0; b < m; ++b) U[b] = g.add(g.param(1 + n + b), g.var(1 + n + b));
+    for (int k = 0; k < nv; ++k) V[k] = g.add(g.param(1 + n + m + k), g.var(1 + n + m + k));
+    std::vector<int> f(n);
+    dyn_t = dyn_v = false;
+    for (int r = 0; r < n; ++r) {
+        const std::string str(d->dynamics[r]);
+        Parser ps(str, c0);
+        ps.g = &g; ps.g_t = t; ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+        Parser::Val v;
+        if (!ps.expr(v)) { err = ps.err; return false; }
+        f[r] = v.node;
+        dyn_t = dyn_t || ps.uses_t; dyn_v = dyn_v || ps.uses_v;
+    }
+    std::vector<std::pair<std::string, int>> outs;
+    for (int r = 0; r < n; ++r) {
+        for (int c = 0; c < n; ++c) outs.emplace_back("ev[" + std::to_string(R.oF + r * R.ldx + c) + "]", g.at_zero(g.diff(f[r], 1 + c)));
+        for (int b = 0; b < m; ++b) outs.emplace_back("ev[" + std::to_string(R.oG + r * R.ldu + b) + "]", g.at_zero(g.diff(f[r], 1 + n + b)));
+        if (dyn_t) outs.emplace_back("ev[" + std::to_string(R.oft + r) + "]", g.at_zero(g.diff(f[r], 0)));
+        if (dyn_v) for (int k = 0; k < nv; ++k) outs.emplace_back("ev[" + std::to_string(R.oW + r * nv + k) + "]", g.at_zero(g.diff(f[r], 1 + n + m + k)));
+        outs.emplace_back("ev[" + std::to_string(R.of + r) + "]", g.at_zero(f[r]));
+    }
+    body = g.codegen(outs, "p", "        ");
+    return true;
+}
+
 int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if (!d || !id) { err = "null argument"; return CTD_EINVAL; }
     if (d->n < 1 || d->n > 24 || d->m < 0 || d->m > 12 || d->nv < 0 || d->nv > kMaxNV || d->npath < 0 || d->npath > 16 ||
@@ -396,6 +433,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
             s += "    CTD_HD static void stage_sym_mid(const double* p, double* HD) {\n" + b_mid + "    }\n";
             s += "    CTD_HD static void stage_sym_trap(const double* p, double* HD) {\n" + b_trap + "    }\n";
         }
+    }
+    {   // symbolic first derivatives of the dynamics for the constraint / Jacobian kernel (opt-out: CTD_DYN_SYM=0)
+        const char* env = std::getenv("CTD_DYN_SYM");
+        std::string b_dyn, e2;
+        bool dt = false, dv = false;
+        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2);
+        s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
+        if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
     }
     s += "};\n}  // namespace ctd\n";
 

@@ -486,6 +486,14 @@ template <class P, int S> CTD_HD void path_control(const KParams& kp, const Bloc
     }
 }
 
+// Symbolic first derivatives of the dynamics (ctd_sym.hpp): member of the generated functor of a run-time OCP, explicit
+// specialisation generated at build time for a registry problem (ctd_sym_registry.hpp, included at the end of this header)
+template <class P> struct SymDyn {
+    static constexpr bool value = P::HAS_SYM_DYN;
+    CTD_HD static void eval(const double* p, double* ev) { if constexpr (P::HAS_SYM_DYN) P::dyn_sym(p, ev); }
+};
+template <class P> struct SymStage;
+
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
 template <class P, int SC, int S>
 CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q) {
@@ -533,6 +541,20 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         const double* U = base + n + (L.stagewise ? j * m : 0);
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = U[c];
+    }
+    if constexpr (SymDyn<P>::value) {
+        // every partial of the point by the generated straight-line code, on the lane of the first direction chunk
+        if (q != 0) return;
+        double prm[1 + n + m + nv];
+        prm[0] = t;
+#pragma unroll
+        for (int c = 0; c < n; ++c) prm[1 + c] = xv[c];
+#pragma unroll
+        for (int c = 0; c < m; ++c) prm[1 + n + c] = uv[c];
+#pragma unroll
+        for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = cx.v[c];
+        SymDyn<P>::eval(prm, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+        return;
     }
     // seed directions [x | u | t | v] of this chunk
     // (compare-and-select seeding keeps the dual arrays in registers: no runtime-indexed private arrays)
@@ -1074,3 +1096,9 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
 }
 
 }  // namespace ctd
+
+// symbolic functions of the registry problems (generated at build time; run-time OCPs carry theirs in the functor)
+#if !defined(__HIPCC_RTC__)
+#include "ctd_problems.hpp"
+#include "ctd_sym_registry.hpp"
+#endif
