@@ -364,6 +364,42 @@ static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bo
     return true;
 }
 
+// The same for the path constraints g(t, x, u, v): Px[np x ldx] | Pu[np x ldu] | Pv[np x nv] | Pt[np] of the step record and
+// the values into `val` (eval_path): body of UserOCP::path_sym(p, rec, val).
+static bool gen_sym_path(const ctd_ocp_def* d, const ExprCtx& c0, std::string& body, std::string& err) {
+    const int n = d->n, m = d->m, nv = d->nv, np = d->npath;
+    const int ldx = n | 1, ldu = m | 1;
+    sym::Graph g;
+    std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    const int t = g.add(g.param(0), g.var(0));
+    for (int r = 0; r < n; ++r) X[r] = g.add(g.param(1 + r), g.var(1 + r));
+    for (int b = 0; b < m; ++b) U[b] = g.add(g.param(1 + n + b), g.var(1 + n + b));
+    for (int k = 0; k < nv; ++k) V[k] = g.add(g.param(1 + n + m + k), g.var(1 + n + m + k));
+    std::vector<int> f(np > 0 ? np : 1);
+    bool pt = false, pv = false;
+    for (int r = 0; r < np; ++r) {
+        const std::string str(d->path[r]);
+        Parser ps(str, c0);
+        ps.g = &g; ps.g_t = t; ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+        Parser::Val v;
+        if (!ps.expr(v)) { err = ps.err; return false; }
+        f[r] = v.node;
+        pt = pt || ps.uses_t; pv = pv || ps.uses_v;
+    }
+    // offsets relative to oPx (the caller passes rec + R.oPx): Px | Pu | Pv | Pt, as in make_rec_layout
+    const int oPu = np * ldx, oPv = oPu + np * ldu, oPt = oPv + np * nv;
+    std::vector<std::pair<std::string, int>> outs;
+    for (int r = 0; r < np; ++r) {
+        for (int c = 0; c < n; ++c) outs.emplace_back("px[" + std::to_string(r * ldx + c) + "]", g.at_zero(g.diff(f[r], 1 + c)));
+        for (int b = 0; b < m; ++b) outs.emplace_back("px[" + std::to_string(oPu + r * ldu + b) + "]", g.at_zero(g.diff(f[r], 1 + n + b)));
+        if (pt) outs.emplace_back("px[" + std::to_string(oPt + r) + "]", g.at_zero(g.diff(f[r], 0)));
+        if (pv) for (int k = 0; k < nv; ++k) outs.emplace_back("px[" + std::to_string(oPv + r * nv + k) + "]", g.at_zero(g.diff(f[r], 1 + n + m + k)));
+        outs.emplace_back("val[" + std::to_string(r) + "]", g.at_zero(f[r]));
+    }
+    body = g.codegen(outs, "p", "        ");
+    return true;
+}
+
 int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if (!d || !id) { err = "null argument"; return CTD_EINVAL; }
     if (d->n < 1 || d->n > 24 || d->m < 0 || d->m > 12 || d->nv < 0 || d->nv > kMaxNV || d->npath < 0 || d->npath > 16 ||
@@ -441,6 +477,10 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2);
         s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
+        std::string b_path;
+        const bool okp = ok && d->npath > 0 && gen_sym_path(d, c0, b_path, e2);
+        s += std::string("    static constexpr bool HAS_SYM_PATH = ") + B(okp) + ";\n";
+        if (okp) s += "    CTD_HD static void path_sym(const double* p, double* px, double* val) {\n" + b_path + "    }\n";
     }
     s += "};\n}  // namespace ctd\n";
 

@@ -492,6 +492,10 @@ template <class P> struct SymDyn {
     static constexpr bool value = P::HAS_SYM_DYN;
     CTD_HD static void eval(const double* p, double* ev) { if constexpr (P::HAS_SYM_DYN) P::dyn_sym(p, ev); }
 };
+template <class P> struct SymPath {
+    static constexpr bool value = P::HAS_SYM_PATH;
+    CTD_HD static void eval(const double* p, double* px, double* val) { if constexpr (P::HAS_SYM_PATH) P::path_sym(p, px, val); }
+};
 template <class P> struct SymStage;
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
@@ -615,6 +619,19 @@ CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv
     constexpr int n = P::NX, m = P::NU, nv = P::NV, np = P::NPATH, DC = P::DC;
     using D = Dual<DC>;
     constexpr RecLayout R = RL<P, SC, S>::R;
+    if constexpr (SymPath<P>::value) {
+        if (q != 0) return;
+        double prm[1 + n + m + nv];
+        prm[0] = t;
+#pragma unroll
+        for (int c = 0; c < n; ++c) prm[1 + c] = xv[c];
+#pragma unroll
+        for (int c = 0; c < m; ++c) prm[1 + n + c] = uv[c];
+#pragma unroll
+        for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = vv[c];
+        SymPath<P>::eval(prm, rec + R.oPx, rec + value_off);
+        return;
+    }
     D X[n > 0 ? n : 1], U[m > 0 ? m : 1], V[nv > 0 ? nv : 1], Tt, out[np > 0 ? np : 1];
     const int g0 = q * DC;
     constexpr int gT = n + m, gV = n + m + (P::PATH_T ? 1 : 0);
