@@ -217,14 +217,19 @@ def test_four_optimisation_variables_with_both_times_free(torch_cuda, sch):
             assert sum(1 for r, cc in zip(hr, hc) if r > d.dim_NLP_variables - 4 and cc > d.dim_NLP_variables - 4) == 10
         else:
             # larger grid: the symbolic stage functions against the second-order forward numbers of the generic path
+            # (and the symbolic first derivatives of the constraint / Jacobian kernel against the forward duals)
             import os
-            os.environ["CTD_HESS_SYM"] = "0"
+            os.environ["CTD_HESS_SYM"] = os.environ["CTD_DYN_SYM"] = "0"
             try:
                 name0 = "fourv_rt0" if "fourv_rt0" in ct.PROBLEMS else ct.register_ocp("fourv_rt0", **jit_defs.FOURV)
             finally:
                 os.environ.pop("CTD_HESS_SYM", None)
+                os.environ.pop("CTD_DYN_SYM", None)
+            assert "HAS_SYM_DYN = false" in ct.ocp_source(name0) and "HAS_SYM_DYN = true" in ct.ocp_source(name)
             d0 = ct.DOCP(name0, N, sch, pattern="structural", device=0)
             assert d0.hess_launch_info()["stage_lanes"] > 1 and d.hess_launch_info()["stage_lanes"] == 1
             assert relerr(hv, d0.hess_coord(xd, yd, 0.8).cpu().numpy()) <= TOL
+            c0, v0 = d0.cons_jac(xd)
+            assert relerr(c.cpu().numpy(), c0.cpu().numpy()) <= TOL and relerr(vals.cpu().numpy(), v0.cpu().numpy()) <= TOL
             d0.close()
         d.close()
