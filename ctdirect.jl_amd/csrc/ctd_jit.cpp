@@ -400,6 +400,31 @@ static bool gen_sym_path(const ctd_ocp_def* d, const ExprCtx& c0, std::string& b
     return true;
 }
 
+// Value and first derivatives of the Lagrange cost l(t, x, u, v) for the gradient kernel (lagrange_partials, ctd_kernels.hpp):
+// body of UserOCP::lag_sym(p, out), out = [value | l_x[n] | l_u[m] | l_t | l_v[nv]].
+static bool gen_sym_lag(const ctd_ocp_def* d, const ExprCtx& c0, std::string& body, std::string& err) {
+    const int n = d->n, m = d->m, nv = d->nv;
+    sym::Graph g;
+    std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    const int t = g.add(g.param(0), g.var(0));
+    for (int r = 0; r < n; ++r) X[r] = g.add(g.param(1 + r), g.var(1 + r));
+    for (int b = 0; b < m; ++b) U[b] = g.add(g.param(1 + n + b), g.var(1 + n + b));
+    for (int k = 0; k < nv; ++k) V[k] = g.add(g.param(1 + n + m + k), g.var(1 + n + m + k));
+    const std::string str(d->lagrange);
+    Parser ps(str, c0);
+    ps.g = &g; ps.g_t = t; ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+    Parser::Val v;
+    if (!ps.expr(v)) { err = ps.err; return false; }
+    std::vector<std::pair<std::string, int>> outs;
+    outs.emplace_back("out[0]", g.at_zero(v.node));
+    for (int c = 0; c < n; ++c) outs.emplace_back("out[" + std::to_string(1 + c) + "]", g.at_zero(g.diff(v.node, 1 + c)));
+    for (int b = 0; b < m; ++b) outs.emplace_back("out[" + std::to_string(1 + n + b) + "]", g.at_zero(g.diff(v.node, 1 + n + b)));
+    outs.emplace_back("out[" + std::to_string(1 + n + m) + "]", g.at_zero(g.diff(v.node, 0)));
+    for (int k = 0; k < nv; ++k) outs.emplace_back("out[" + std::to_string(2 + n + m + k) + "]", g.at_zero(g.diff(v.node, 1 + n + m + k)));
+    body = g.codegen(outs, "p", "        ");
+    return true;
+}
+
 int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if (!d || !id) { err = "null argument"; return CTD_EINVAL; }
     if (d->n < 1 || d->n > 24 || d->m < 0 || d->m > 12 || d->nv < 0 || d->nv > kMaxNV || d->npath < 0 || d->npath > 16 ||
@@ -479,6 +504,10 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
         std::string b_path;
         const bool okp = ok && d->npath > 0 && gen_sym_path(d, c0, b_path, e2);
+        std::string b_lag;
+        const bool okl = ok && has_lag && gen_sym_lag(d, c0, b_lag, e2);
+        s += std::string("    static constexpr bool HAS_SYM_LAG = ") + B(okl) + ";\n";
+        if (okl) s += "    CTD_HD static void lag_sym(const double* p, double* out) {\n" + b_lag + "    }\n";
         s += std::string("    static constexpr bool HAS_SYM_PATH = ") + B(okp) + ";\n";
         if (okp) s += "    CTD_HD static void path_sym(const double* p, double* px, double* val) {\n" + b_path + "    }\n";
     }

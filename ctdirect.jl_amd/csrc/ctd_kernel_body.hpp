@@ -496,6 +496,10 @@ template <class P> struct SymPath {
     static constexpr bool value = P::HAS_SYM_PATH;
     CTD_HD static void eval(const double* p, double* px, double* val) { if constexpr (P::HAS_SYM_PATH) P::path_sym(p, px, val); }
 };
+template <class P> struct SymLag {       // Lagrange cost: out = [value | l_x | l_u | l_t | l_v]
+    static constexpr bool value = P::HAS_SYM_LAG;
+    CTD_HD static void eval(const double* p, double* out) { if constexpr (P::HAS_SYM_LAG) P::lag_sym(p, out); }
+};
 template <class P> struct SymStage;
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q

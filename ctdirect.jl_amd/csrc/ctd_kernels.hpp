@@ -275,6 +275,28 @@ template <class P, int Q>
 __device__ __forceinline__ void lagrange_partials(double t, const double* x, const double* u, const double* v, double& val,
                                                   double* lx, double* lu, double& lt, double* lv) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
+    if constexpr (SymLag<P>::value) {          // generated straight-line code (symbolic first derivatives, ctd_sym.hpp)
+        double prm[1 + n + m + nv], out[2 + n + m + nv];
+        prm[0] = t;
+#pragma unroll
+        for (int c = 0; c < n; ++c) prm[1 + c] = x[c];
+#pragma unroll
+        for (int c = 0; c < m; ++c) prm[1 + n + c] = u[c];
+#pragma unroll
+        for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = v[c];
+        SymLag<P>::eval(prm, out);
+        val = out[0];
+#pragma unroll
+        for (int c = 0; c < n; ++c) lx[c] = out[1 + c];
+#pragma unroll
+        for (int c = 0; c < m; ++c) lu[c] = out[1 + n + c];
+        if (P::LAG_T) lt = out[1 + n + m];
+        if (P::LAG_V) {
+#pragma unroll
+            for (int c = 0; c < nv; ++c) lv[c] = out[2 + n + m + c];
+        }
+        return;
+    }
     using D = Dual<DC>;
     constexpr int g0 = Q * DC, gT = n + m, gV = n + m + (P::LAG_T ? 1 : 0);
     D X[n > 0 ? n : 1], U[m > 0 ? m : 1], V[nv > 0 ? nv : 1], Tt;

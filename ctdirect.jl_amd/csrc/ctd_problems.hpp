@@ -58,7 +58,7 @@ struct GoddardOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);                     // dual directions per pass
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     // xdot = F0(x) + u F1(x)   (goddard.jl:7-16, :44)
@@ -97,7 +97,7 @@ struct GoddardAllOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // f! :127-132
@@ -139,7 +139,7 @@ struct DoubleIntegratorPathOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 2.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -173,7 +173,7 @@ struct QuadrotorOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {  // :20-40
@@ -232,7 +232,7 @@ struct Quadrotor12OCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
     static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) {
@@ -296,7 +296,7 @@ struct StagewiseScalarOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T*, const T* u, const T*) { dx[0] = u[0]; }
@@ -322,7 +322,7 @@ struct EstimateInitialConditionOCP {                                            
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 3.14159265358979323846 / 2; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -345,7 +345,7 @@ struct EstimateRotationRateOCP {                                                
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T* v) {
@@ -373,7 +373,7 @@ struct LeastSquaresConstraintOCP {                                              
     static constexpr bool LAG_T = true, LAG_V = false;       // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(2);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 1.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T*, const T*) { dx[0] = -x[1]; dx[1] = x[0]; }
@@ -402,7 +402,7 @@ struct DoubleIntegratorFreeT0TfOCP {
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(3);
     static constexpr int MAXB = 1024;                       // largest workgroup the kernels are compiled for (register budget)
-    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
+    static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
     template <class T> CTD_HD static void dynamics(T* dx, const T&, const T* x, const T* u, const T*) { dx[0] = x[1]; dx[1] = u[0]; }
