@@ -56,7 +56,6 @@ struct ctd_handle {
     bool own_stream = false;
     int64_t step_begin = 0, step_end = 0;
     int tile = 0, block = 256;
-    int pipe_mode = -1, pipe_occ = 0;
     KParams kp;                 // device pointers filled in, outputs set per call
     size_t lds_bytes = 0;
     int grid = 0;
@@ -111,6 +110,22 @@ static int32_t fail(ctd_handle* h, int32_t code, const std::string& msg) {
             return fail(h, CTD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// Every entry point that touches the device runs on the handle's device and leaves the caller's current device as it found
+// it (a process driving several GPUs keeps its own notion of "current"); hipGetDevice is a thread-local read, and the
+// hipSetDevice pair is only paid when the two differ.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = (err == hipSuccess); }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 template <class T> static hipError_t upload(T** dst, const std::vector<T>& src) {
     *dst = nullptr;
     if (src.empty()) return hipSuccess;
@@ -126,7 +141,7 @@ static int env_int(const char* name, int dflt) {
 
 static void free_device(ctd_handle* h) {
     if (h->device < 0) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dg_(h->device);
     (void)hipStreamSynchronize(h->stream);      // enqueue-only calls may still be running on the tables freed below
     for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
@@ -206,7 +221,7 @@ int32_t jit_compile(const RtOcp& ro, const char* header, const std::vector<std::
 
 std::vector<std::string> jit_first_exprs(int sc, int s) {
     const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
-    return {"ctd::cons_jac_kernel<" + P + ", " + a + ", " + b + ">", "ctd::obj_partial_kernel<" + P + ", " + a + ">",
+    return {"ctd::cons_jac_kernel<" + P + ", " + a + ", " + b + ", false>", "ctd::obj_partial_kernel<" + P + ", " + a + ">",
             "ctd::obj_finish_kernel<" + P + ">", "ctd::grad_units_kernel<" + P + ", " + a + ", " + b + ">",
             "ctd::grad_finish_kernel<" + P + ">"};
 }
@@ -313,20 +328,20 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     h->kp.debug_stop = debug_stop;
     h->kp.xcd_remap = env_int("CTD_XCD", 0);          // 1: every XCD walks one contiguous run of tiles (measured neutral)
     h->device = desc->device;
-    // 0 classic driver (default: on MI355X the pipelined driver measured within 1 us of it, profiles/r01_pipeline.md),
-    // 1 pipelined driver, -1 automatic choice (pipelined for Gauss-Legendre grids with >= 3 sub-tiles per workgroup)
-    h->pipe_mode = env_int("CTD_PIPE", 0);
-    if (h->rt) h->pipe_mode = 0;
     if (h->device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || h->device >= ndev)
             return fail(nullptr, CTD_ENODEVICE, "ctd_create: HIP device not available");
         ctd_handle* hp = h.get();
         if (h->lds_bytes > 160 * 1024) return fail(nullptr, CTD_EINVAL, "ctd_create: tile does not fit the 160 KiB LDS");
-        HIP_TRY(nullptr, hipSetDevice(hp->device));
+        DeviceGuard dg_(hp->device); HIP_TRY(nullptr, dg_.err);
         if (desc->stream_mode == CTD_STREAM_GIVEN) { hp->stream = (hipStream_t)desc->stream; hp->own_stream = false; }
         else { HIP_TRY(nullptr, hipStreamCreateWithFlags(&hp->stream, hipStreamNonBlocking)); hp->own_stream = true; }
-        if (!mo.uniform) HIP_TRY(nullptr, upload(&hp->d_tau, mo.tau));
+        // The normalized grid is always read from this table (N + 1 doubles, L2-resident): for a uniform grid the kernels
+        // could compute tau_i = i / N themselves, but an FP64 division is ~35 dependent instructions on the evaluating lane's
+        // critical path while the table load is issued together with the loads of x (the values are identical: the host
+        // fills the table with the same division).
+        HIP_TRY(nullptr, upload(&hp->d_tau, mo.tau));
         HIP_TRY(nullptr, upload(&hp->d_tmpl, mo.tmpl));
         HIP_TRY(nullptr, upload(&hp->d_vtmpl, mo.vtmpl));
         HIP_TRY(nullptr, upload(&hp->d_edge_idx, mo.edge_idx));
@@ -345,33 +360,6 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             if (hp->lds_bytes > 64 * 1024) return fail(nullptr, CTD_EINVAL, "ctd_create: one step of this run-time OCP does not fit 64 KiB of LDS");
             int32_t jst = jit_load_first(hp);
             if (jst) return jst;
-        }
-        // pipelined driver: sub-tiles of Ts steps, as many chunks as workgroups are resident at once
-        if (hp->pipe_mode != 0 && hp->block >= 128) {
-            KParams pk = hp->kp;
-            pk.pipe_Ts = env_int("CTD_PIPE_TS", 0);
-            if (pk.pipe_Ts <= 0) pk.pipe_Ts = default_pipe_tile(mo);
-            const size_t plds = (size_t)pipe_lds_doubles(pk) * sizeof(double);
-            int occ = 0, ncu = 0;
-            for_problem(mo.problem, [&](auto tag) { occ = pipe_occupancy<typename decltype(tag)::type>(mo.L.sc, mo.L.s, hp->block, plds); });
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, hp->device) == hipSuccess) ncu = prop.multiProcessorCount;
-            const int64_t nsteps = hp->step_end - hp->step_begin;
-            const int64_t nsub = (nsteps + pk.pipe_Ts - 1) / pk.pipe_Ts;
-            int64_t capacity = (int64_t)occ * ncu;
-            if (capacity < 1) capacity = 1;
-            const int64_t nchunks0 = nsub < capacity ? nsub : capacity;
-            const int64_t subs_per_chunk = (nsub + nchunks0 - 1) / nchunks0;
-            pk.pipe_chunk = (int32_t)(subs_per_chunk * pk.pipe_Ts);
-            const int64_t nchunks = (nsteps + pk.pipe_chunk - 1) / pk.pipe_chunk;
-            const bool want = hp->pipe_mode == 1 || (hp->pipe_mode < 0 && mo.L.sc == SC_IRK && subs_per_chunk >= 3);
-            if (want && plds <= 160 * 1024 && occ > 0) {
-                hp->kp.pipe_Ts = pk.pipe_Ts;
-                hp->kp.pipe_chunk = pk.pipe_chunk;
-                hp->lds_bytes = plds;
-                hp->grid = (int)nchunks + (hp->kp.has_edge ? 1 : 0);
-                hp->pipe_occ = occ;
-            }
         }
     }
     *out = h.release();
@@ -543,7 +531,8 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
     if (!h || !o) return CTD_EINVAL;
     o[0] = h->grid; o[1] = h->block; o[2] = (int64_t)h->lds_bytes; o[3] = h->tile; o[4] = h->model.Lseg;
     o[5] = (int64_t)h->model.edge_idx.size();
-    o[6] = h->kp.pipe_Ts; o[7] = h->kp.pipe_chunk;
+    o[6] = (h->model.fused && h->model.L.sc != SC_TRAPEZE) ? 1 : 0;      // DirectTile<P, SC>
+    o[7] = 0;
     return CTD_OK;
 }
 
@@ -554,7 +543,7 @@ static int32_t enqueue_cons_jac(ctd_handle* h, const double* x_dev, double* c_de
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev) return fail(h, CTD_EINVAL, "x is null");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     KParams kp = h->kp;
     kp.c = c_dev;
     kp.vals = vals_dev;
@@ -602,7 +591,7 @@ int32_t ctd_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev, doub
 
 static int32_t ensure_staging(ctd_handle* h, bool need_c, bool need_vals) {
     const Model& mo = h->model;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     if (!h->d_x) HIP_TRY(h, hipMalloc((void**)&h->d_x, sizeof(double) * mo.L.nvar));
     if (need_c && !h->d_c) HIP_TRY(h, hipMalloc((void**)&h->d_c, sizeof(double) * mo.L.ncon));
     if (need_vals && !h->d_vals) HIP_TRY(h, hipMalloc((void**)&h->d_vals, sizeof(double) * (mo.nnzj > 0 ? mo.nnzj : 1)));
@@ -654,7 +643,7 @@ static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !f_dev) return fail(h, CTD_EINVAL, "null argument");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
     ObjParams op;
     std::memset(&op, 0, sizeof(op));
@@ -711,7 +700,7 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
     const int64_t units = (L.sc == SC_IRK) ? L.N : L.N + 1;
     const int blocks = (int)((units + 255) / 256);
@@ -777,9 +766,10 @@ int32_t ctd_obj(ctd_handle* h, const double* x, double* f) {
 int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, uint64_t* out, int64_t cap) {
     if (!h || !out) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
-    const int64_t words = (int64_t)h->grid * 12;
+    int64_t words = (int64_t)h->grid * 12;
     if (cap < words) return fail(h, CTD_EINVAL, "stamp buffer too small");
-    HIP_TRY(h, hipSetDevice(h->device));
+    if (cap >= (int64_t)h->grid * 28) words = (int64_t)h->grid * 28;      // + sub-stamps of experiment builds (CTD_SUBSTAMPS)
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     unsigned long long* d_st = nullptr;
     HIP_TRY(h, hipMalloc((void**)&d_st, sizeof(unsigned long long) * words));
     HIP_TRY(h, hipMemsetAsync(d_st, 0, sizeof(unsigned long long) * words, h->stream));
@@ -804,7 +794,10 @@ int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, doub
 static int32_t time_dispatches(ctd_handle* h, int32_t iters, double* mean_ms,
                                const std::function<int32_t(hipEvent_t, hipEvent_t)>& launch) {
     constexpr int kBatch = 32;
-    static thread_local hipEvent_t ev[2 * kBatch] = {nullptr};
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
+    static thread_local std::map<int, std::vector<hipEvent_t>> ev_by_device;    // events belong to the device they were created on
+    std::vector<hipEvent_t>& ev = ev_by_device[h->device];
+    if (ev.empty()) ev.assign(2 * kBatch, nullptr);
     for (hipEvent_t& e : ev)
         if (!e) HIP_TRY(h, hipEventCreate(&e));
     int32_t st = launch(nullptr, nullptr);   // warm
@@ -867,7 +860,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_ready) return CTD_OK;
     const Model& mo = h->model;
     const HessModel& H = mo.H;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     h->hess_tile = env_int("CTD_HESS_TILE", 0);
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);
     mo.fill_hparams(h->hp, h->hess_tile, h->step_begin, h->step_end);
@@ -924,7 +917,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     if (!x_dev || !y_dev || !vals_dev) return fail(h, CTD_EINVAL, "null argument");
     int32_t st = ensure_hess(h);
     if (st) return st;
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     HParams hp = h->hp;
     hp.obj_weight = obj_weight;
     hp.vals = vals_dev;

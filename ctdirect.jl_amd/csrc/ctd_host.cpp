@@ -658,20 +658,6 @@ int default_tile(const Model& mo, int64_t nsteps) {
     return (int)T;
 }
 
-int default_pipe_tile(const Model& mo) {
-    const Layout& L = mo.L;
-    const int S = L.s > 0 ? L.s : 1;
-    const int lanes_per_step = S * mo.nch_dyn + mo.nch_path + (mo.fused ? 1 : 0);
-    int Ts = 1;
-    while (Ts * 2 <= 16 && (Ts * 2 + mo.HL + mo.HH) * lanes_per_step <= 64) Ts *= 2;
-    auto lds = [&](int t) {
-        const int64_t cap = t + mo.HL + mo.HH;
-        return (int64_t)8 * (kMaxNV + 3 * ((cap + 1) * L.blk + L.n + L.m) + 3 * (cap + 2) + 2 * cap * mo.R.stride);
-    };
-    while (Ts > 1 && lds(Ts) > 60 * 1024) Ts /= 2;
-    return Ts;
-}
-
 void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const {
     std::memset(&kp, 0, sizeof(kp));
     kp.L = L;

@@ -117,8 +117,5 @@ struct InitSamples { int64_t n = 0; const double* t = nullptr; const double* sta
 void model_initial_guess(const Model& m, double* x0, bool use_problem_default, const double* state, const double* control,
                          const double* variable, const InitSamples& samples = InitSamples{});
 int default_tile(const Model& m, int64_t nsteps = 0);
-// sub-tile length of the pipelined driver: the producer is ONE wave, so Ts * (lanes per step) <= 64, and the three input
-// + two record buffers must fit ~60 KiB of LDS
-int default_pipe_tile(const Model& m);
 
 }  // namespace ctd

@@ -37,8 +37,25 @@
 
 namespace ctd {
 
+// Experiment builds only (make EXTRA=-DCTD_SUBSTAMPS): cycle stamps INSIDE the evaluation phase, taken by lane 0 of waves 0
+// and 1 after draining the wave's memory counters (so each segment is timed serialised: an upper bound of its share).
+// Words [grid * 12, grid * 28) of the ctd_debug_stamps buffer; never compiled into the shipped library.
+#if defined(CTD_SUBSTAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define CTD_SUB(kp, id)                                                                                              \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_waitcnt(0);                                                                               \
+        if ((kp).stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 128)                                             \
+            (kp).stamps[(size_t)gridDim.x * 12 + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (id)] = clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#else
+#define CTD_SUB(kp, id) do { } while (0)
+#endif
+
 struct BlockCtx {
     int is_edge;
+    int direct;        // 1: in / v point into xu (global memory), tau is null (make_direct_ctx)
     int nslots;        // records held by this block (step / node records)
     int in_stride;     // doubles between the inputs of consecutive slots
     int64_t a, b;      // steps [a, b) whose outputs this tile emits
@@ -63,6 +80,7 @@ CTD_HD int64_t slot_index(const KParams& kp, const BlockCtx& cx, int k) {
 
 CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     BlockCtx cx;
+    cx.direct = 0;
     const Layout& L = kp.L;
     cx.codes = codes_staged(kp) ? reinterpret_cast<const uint32_t*>(lds) : kp.tmpl;
     cx.vcodes = codes_staged(kp) ? cx.codes + kp.Lseg : kp.vtmpl;
@@ -94,42 +112,45 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     return cx;
 }
 
-// ---- pipelined driver: LDS = v | 3 input buffers | 3 tau buffers | 2 record buffers --------------------------------
-struct PipeGeom { int cap, in_sz, tau_sz, rec_sz; };
-CTD_HD PipeGeom pipe_geom(const KParams& kp) {
-    PipeGeom g;
-    g.cap = kp.pipe_Ts + kp.HL + kp.HH;
-    g.in_sz = (g.cap + 1) * kp.L.blk + kp.L.n + kp.L.m;
-    g.tau_sz = g.cap + 2;
-    g.rec_sz = g.cap * kp.R.stride;
-    return g;
-}
-// sub-tile q of the chunk [A, B): steps [A + q Ts, min(A + (q+1) Ts, B)), input buffer q % 3, record buffer q % 2
-CTD_HD BlockCtx make_sub_ctx(const KParams& kp, double* lds, int64_t A, int64_t B, int q) {
-    const PipeGeom g = pipe_geom(kp);
+// Direct tiles: OCPs whose functions are differentiated in one pass (Dirs<P>::FUSED) on the one-point schemes and the
+// Gauss-Legendre schemes skip the staging of xu in LDS.  An evaluating lane reads the handful of doubles of its own step
+// straight from global memory (L2-resident: x was just written by the solver) into registers, so the load -> barrier ->
+// evaluate hop of the staged driver disappears; the only workgroup barrier left sits between the evaluation and the emission.
+// `in`, `v` point into xu (global address space: this context is built on a code path of its own so the compiler emits
+// global loads, not flat ones), `tau` is null: slot_tau computes the times of the lane's own grid points.
+CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const double* xu) {
     BlockCtx cx;
-    cx.codes = codes_staged(kp) ? reinterpret_cast<const uint32_t*>(lds) : kp.tmpl;
-    cx.vcodes = codes_staged(kp) ? cx.codes + kp.Lseg : kp.vtmpl;
-    lds += code_doubles(kp);
+    const Layout& L = kp.L;
+    cx.direct = 1;
+    cx.codes = kp.tmpl;
+    cx.vcodes = kp.vtmpl;
+    cx.in_stride = L.blk;
+    cx.v = const_cast<double*>(xu) + L.v_off;
+    cx.tau = nullptr;
+    cx.rec = lds + code_doubles(kp);
+    if (kp.has_edge && block == 0) {
+        // edge block: slot k holds step kp.edge_steps[k] (slot_base); X_{i+1} (and U_{i-1} for implicit Euler) are where
+        // the global layout has them
+        cx.is_edge = 1;
+        cx.nslots = kp.n_edge_slots;
+        cx.a = cx.b = cx.lo = 0;
+        cx.in = const_cast<double*>(xu);
+        return cx;
+    }
+    const int tile = block - (kp.has_edge ? 1 : 0);      // (the XCD-aware tile order of the staged driver measured neutral: not offered here)
     cx.is_edge = 0;
-    cx.a = A + (int64_t)q * kp.pipe_Ts;
-    cx.b = cx.a + kp.pipe_Ts < B ? cx.a + kp.pipe_Ts : B;
+    cx.a = kp.step_begin + (int64_t)tile * kp.T;
+    cx.b = cx.a + kp.T < kp.step_end ? cx.a + kp.T : kp.step_end;
     cx.lo = cx.a - kp.HL;
     cx.nslots = (int)(cx.b - cx.a) + kp.HL + kp.HH;
-    cx.in_stride = kp.L.blk;
-    cx.v = lds;
-    cx.in = lds + kMaxNV + (q % 3) * g.in_sz;
-    cx.tau = lds + kMaxNV + 3 * g.in_sz + (q % 3) * g.tau_sz;
-    cx.rec = lds + kMaxNV + 3 * g.in_sz + 3 * g.tau_sz + (q & 1) * g.rec_sz;
+    cx.in = const_cast<double*>(xu) + cx.lo * (int64_t)L.blk;
     return cx;
 }
-inline int64_t pipe_lds_doubles(const KParams& kp) {
-    const PipeGeom g = pipe_geom(kp);
-    const Layout& L = kp.L;
-    int64_t pipe = code_doubles(kp) + kMaxNV + 3 * (int64_t)g.in_sz + 3 * g.tau_sz + 2 * (int64_t)g.rec_sz;
-    int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * edge_in_stride(L) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
-                   (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
-    return pipe > edge ? pipe : edge;
+
+// inputs of slot k: staged copy in LDS, or (direct) the step's own block of xu
+CTD_HD const double* slot_base(const KParams& kp, const BlockCtx& cx, int k) {
+    if (cx.direct && cx.is_edge) return cx.in + kp.edge_steps[k] * (int64_t)cx.in_stride;
+    return cx.in + k * cx.in_stride;
 }
 
 // LDS doubles a block needs (host uses this to size the launch)
@@ -149,8 +170,14 @@ CTD_HD double tau_global(const KParams& kp, int64_t i) {
     if (i > kp.L.N) i = kp.L.N;
     return kp.tau ? kp.tau[i] : (double)i / (double)kp.L.N;
 }
-CTD_HD double slot_tau(const BlockCtx& cx, int k, int d) { return cx.is_edge ? cx.tau[2 * k + d] : cx.tau[k + d]; }
-CTD_HD double final_tau(const BlockCtx& cx) { return cx.tau[2 * cx.nslots]; }   // edge block only
+// direct blocks hold no staged times: the lane reads (or computes) tau of its own grid points
+CTD_HD double slot_tau(const KParams& kp, const BlockCtx& cx, int k, int d) {
+    if (cx.direct) return tau_global(kp, slot_index(kp, cx, k) + d);
+    return cx.is_edge ? cx.tau[2 * k + d] : cx.tau[k + d];
+}
+CTD_HD double final_tau(const KParams& kp, const BlockCtx& cx) {       // edge block only
+    return cx.direct ? tau_global(kp, kp.L.N) : cx.tau[2 * cx.nslots];
+}
 
 // get_time_grid (src/DOCP_data.jl:437-458): t_i = t0 + tau_i (tf - t0), t0/tf fixed or components of v
 template <class P> CTD_HD double time_of(const KParams& kp, const double* v, double tau) {
@@ -184,6 +211,10 @@ template <class P> struct Dirs {
     static constexpr bool FUSED = (NCH_DYN == 1) && (P::NPATH == 0 || NCH_PATH == 1);
     static constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
 };
+
+// tiles of this (OCP, scheme class) run the direct driver (make_direct_ctx); the trapeze residual needs the records of two
+// nodes (phase_fin2) and keeps the staged one
+template <class P, int SC> struct DirectTile { static constexpr bool value = Dirs<P>::FUSED && SC != SC_TRAPEZE; };
 
 // ------------------------------------------------------------------------------------------------------
 // phase: load
@@ -268,10 +299,10 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
     double* C = rec + R.oC;
     fill_const_coefs<P>(kp, C);
     if (i < 0 || i >= L.N) return;
-    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     const double h = time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0);
     if (SC == SC_IRK) {
-        const double* base = cx.in + k * cx.in_stride;
+        const double* base = slot_base(kp, cx, k);
         const double* K = base + n + L.cu;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
@@ -301,8 +332,9 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
 }
 
 // the part of the chain rule that needs all partials of one eval point
+// `ev`: the eval block of (slot k, point j) -- its place in the LDS record, or a register copy the caller stores afterwards
 template <class P, int SC, int S>
-CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
+CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, double* ev) {
     constexpr int n = P::NX, nv = P::NV;
     constexpr bool FREE = Dirs<P>::FREE;
     const Layout& L = kp.L;
@@ -311,9 +343,8 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j) {
     if (i < 0) return;
     if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
     double* rec = cx.rec + k * R.stride;
-    double* ev = rec + R.oEval + j * R.eval_sz;
-    const double* base = cx.in + k * cx.in_stride;
-    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double* base = slot_base(kp, cx, k);
+    const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     double dti[nv > 0 ? nv : 1], dh[nv > 0 ? nv : 1];
 #pragma unroll
     for (int kk = 0; kk < nv; ++kk) {
@@ -387,8 +418,8 @@ CTD_HD void fin_stage_row(const KParams& kp, const BlockCtx& cx, int k, int j, i
     if (i < 0 || i >= L.N) return;
     double* rec = cx.rec + k * R.stride;
     double* ev = rec + R.oEval + j * R.eval_sz;
-    const double* K = cx.in + k * cx.in_stride + n + L.cu;
-    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double* K = slot_base(kp, cx, k) + n + L.cu;
+    const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     rec[R.oR + n + j * n + r] = K[j * n + r] - ev[R.of + r];
 #pragma unroll
     for (int kk = 0; kk < nv; ++kk) {
@@ -435,8 +466,8 @@ CTD_HD void fin_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
     if (slot_index(kp, cx, k + 1) != i + 1) return;
     double* rec = cx.rec + k * R.stride;
     const double* nxt = rec + R.stride;
-    const double* base = cx.in + k * cx.in_stride;
-    const double tau0 = slot_tau(cx, k, 0), tau1 = slot_tau(cx, k, 1);
+    const double* base = slot_base(kp, cx, k);
+    const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     const double half_h = 0.5 * (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0));
     const double* e0 = rec + R.oEval;
     const double* e1 = nxt + R.oEval;
@@ -476,9 +507,9 @@ template <class P, int S> CTD_HD void node_control(const KParams& kp, const doub
 // u(t_i) = U_{i-1} for i >= 1 (get_OCP_control_at_time_step, euler.jl:59-72): previous block of a tile / extra field of an edge input
 template <class P, int S> CTD_HD void path_control(const KParams& kp, const BlockCtx& cx, int k, int64_t i, double* u) {
     const Layout& L = kp.L;
-    const double* base = cx.in + k * cx.in_stride;
+    const double* base = slot_base(kp, cx, k);
     if (L.euler == 2 && i >= 1 && (cx.is_edge || k >= 1)) {
-        const double* up = cx.is_edge ? base + L.blk + P::NX + P::NU : base - L.blk + P::NX;
+        const double* up = (cx.is_edge && !cx.direct) ? base + L.blk + P::NX + P::NU : base - L.blk + P::NX;
 #pragma unroll
         for (int c = 0; c < P::NU; ++c) u[c] = up[c];
     } else {
@@ -504,7 +535,7 @@ template <class P> struct SymStage;
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
 template <class P, int SC, int S>
-CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q) {
+CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q, double* ev) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
     using D = Dual<DC>;
     const Layout& L = kp.L;
@@ -512,8 +543,8 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0) return;
     if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
-    const double* base = cx.in + k * cx.in_stride;
-    const double ti = time_of<P>(kp, cx.v, slot_tau(cx, k, 0));
+    const double* base = slot_base(kp, cx, k);
+    const double ti = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 0));
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
     double t;
     if (SC == SC_TRAPEZE) {                       // f(t_i, X_i, U_i, v): trapeze.jl:60-69
@@ -523,7 +554,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
-        const double tip1 = time_of<P>(kp, cx.v, slot_tau(cx, k, 1));
+        const double tip1 = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1));
         if (L.euler == 0) {
             t = 0.5 * (ti + tip1);
 #pragma unroll
@@ -536,7 +567,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
-        const double h = time_of<P>(kp, cx.v, slot_tau(cx, k, 1)) - ti;
+        const double h = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1)) - ti;
         t = ti + butcher_c<S>(L, j) * h;
         const double* K = base + n + L.cu;
 #pragma unroll
@@ -553,6 +584,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
     if constexpr (SymDyn<P>::value) {
         // every partial of the point by the generated straight-line code, on the lane of the first direction chunk
         if (q != 0) return;
+        CTD_SUB(kp, 6);
         double prm[1 + n + m + nv];
         prm[0] = t;
 #pragma unroll
@@ -561,7 +593,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int c = 0; c < m; ++c) prm[1 + n + c] = uv[c];
 #pragma unroll
         for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = cx.v[c];
-        SymDyn<P>::eval(prm, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+        SymDyn<P>::eval(prm, ev);
         return;
     }
     // seed directions [x | u | t | v] of this chunk
@@ -591,7 +623,6 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int d = 0; d < DC; ++d) V[c].d[d] = (P::DYN_V && g0 + d == gV + c) ? 1.0 : 0.0;
     }
     P::template dynamics<D>(out, Tt, X, U, V);
-    double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
 #pragma unroll
     for (int d = 0; d < DC; ++d) {
         const int g = g0 + d;
@@ -685,23 +716,38 @@ CTD_HD void eval_path(const KParams& kp, double* rec, double t, const double* xv
     }
 }
 
-template <class P, int SC, int S>
+template <class P, int SC, int S, bool REG = false>
 CTD_HD void eval_step_path(const KParams& kp, const BlockCtx& cx, int k, int q) {
-    constexpr int n = P::NX, m = P::NU;
+    constexpr int n = P::NX, m = P::NU, np = P::NPATH;
     constexpr RecLayout R = RL<P, SC, S>::R;
+    constexpr int eqs = RL<P, SC, S>::cb - P::NPATH;      // = L.eqs
     const Layout& L = kp.L;
     const int64_t i = slot_index(kp, cx, k);
     if (i < 0 || i >= L.N) return;
-    const double* base = cx.in + k * cx.in_stride;
+    const double* base = slot_base(kp, cx, k);
     double uv[m > 0 ? m : 1];
     path_control<P, S>(kp, cx, k, i, uv);
     double xv[n > 0 ? n : 1];
 #pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[c];
     double* rec = cx.rec + k * R.stride;
-    const double tau = slot_tau(cx, k, 0);
-    eval_path<P, SC, S>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR + L.eqs);
-    if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, rec, tau);
+    const double tau = slot_tau(kp, cx, k, 0);
+    if constexpr (REG) {
+        // the path block and the path values are composed in registers (a private copy of the record's fields, every index a
+        // compile-time constant) and stored once: no read-modify-write through LDS
+        double lrec[R.oR + eqs + (np > 0 ? np : 1)];
+#pragma unroll
+        for (int e = R.oPx; e < R.oR; ++e) lrec[e] = 0.0;
+        eval_path<P, SC, S>(kp, lrec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR + eqs);
+        if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, lrec, tau);
+#pragma unroll
+        for (int e = R.oPx; e < R.oR; ++e) rec[e] = lrec[e];
+#pragma unroll
+        for (int r = 0; r < np; ++r) rec[R.oR + eqs + r] = lrec[R.oR + eqs + r];
+    } else {
+        eval_path<P, SC, S>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR + L.eqs);
+        if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, rec, tau);
+    }
 }
 
 // path constraints at the final time (DOCP_functions.jl:100) with the convention u(tf) = U_N unless U_{N+1} exists
@@ -710,7 +756,7 @@ CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
     constexpr int n = P::NX, m = P::NU;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const Layout& L = kp.L;
-    const double* base = cx.in + kp.edge_slot_last * cx.in_stride;
+    const double* base = slot_base(kp, cx, kp.edge_slot_last);
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
 #pragma unroll
     for (int c = 0; c < n; ++c) xv[c] = base[L.blk + c];
@@ -719,7 +765,7 @@ CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
         for (int c = 0; c < m; ++c) uv[c] = base[L.blk + n + c];
     } else node_control<P, S>(kp, base, uv);
     double* rec = cx.rec + kp.edge_fp * R.stride;
-    const double tau = final_tau(cx);
+    const double tau = final_tau(kp, cx);
     eval_path<P, SC, S>(kp, rec, time_of<P>(kp, cx.v, tau), xv, uv, cx.v, q, R.oR);
     if (Dirs<P>::FUSED) fin_path<P, SC, S>(kp, rec, tau);
 }
@@ -731,8 +777,8 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
     using D = Dual<DC>;
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
-    const double* b0 = cx.in + kp.edge_slot_first * cx.in_stride;
-    const double* bf = cx.in + kp.edge_slot_last * cx.in_stride + L.blk;
+    const double* b0 = slot_base(kp, cx, kp.edge_slot_first);
+    const double* bf = slot_base(kp, cx, kp.edge_slot_last) + L.blk;
     D X0[n > 0 ? n : 1], XF[n > 0 ? n : 1], V[nv > 0 ? nv : 1], out[nb > 0 ? nb : 1];
     const int g0 = q * DC;
 #pragma unroll
@@ -773,53 +819,117 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
     }
 }
 
-template <class P, int SC, int S>
+// REG (direct tiles of small FUSED problems): a lane composes its eval block in registers and stores it to the LDS record
+// once, instead of writing the partials to LDS and finishing the chain rule with reads and writes of the same words
+template <class P, int SC> struct RegEval {
+    static constexpr bool value = DirectTile<P, SC>::value && (P::NX * (P::NX + P::NU + P::NV + 2) <= 64);
+};
+
+template <class P, int SC, int S, bool REG = false>
 CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     constexpr bool FUSED = Dirs<P>::FUSED;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
-    // task = (role << lg) | slot with the slot count rounded up to a power of two: decoding is a shift and a mask, and
-    // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
-    // passes, one lead role (coefficients + state rows, fused mode); the edge block appends its few special tasks.
-    int lg = 0;
-    while ((1 << lg) < ns) ++lg;
-    const int mask = (1 << lg) - 1;
     constexpr int r_dyn = S * Dirs<P>::NCH_DYN;
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
     constexpr int r_lead = FUSED ? 1 : 0;
-    const int n_slot_tasks = (r_dyn + r_path + r_lead) << lg;
-    int n_fp = 0, n_b = 0, n_aux = 0;
     if (cx.is_edge) {
-        n_fp = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
-        n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
-        n_aux = 2;                                   // coefficients of the final-path and boundary records
-    }
-    const int total = n_slot_tasks + n_fp + n_b + n_aux;
-    for (int task = tid; task < total; task += nthr) {
-        if (task < n_slot_tasks) {
-            const int k = task & mask, role = task >> lg;
-            if (k >= ns) continue;
-            if (role < r_dyn) {
-                const int j = role / Dirs<P>::NCH_DYN, q = role % Dirs<P>::NCH_DYN;
-                eval_dynamics<P, SC, S>(kp, cx, k, j, q);
-                if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j);
-            } else if (role < r_dyn + r_path) {
-                eval_step_path<P, SC, S>(kp, cx, k, role - r_dyn);
+        // Edge block: a handful of slots, but every KIND of task (dynamics, path, lead, final-time path, boundary).  Lanes of
+        // one wave that run different kinds execute them one after the other, so each kind gets waves of its own:
+        //   dynamics passes | path passes + final-time path | lead + coefficient records | boundary passes
+        // (8 lanes per role; segment starts are rounded up to a wave).  Falls back to one task per lane in index order when the
+        // workgroup has too few waves.
+        constexpr int n_fp = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+        constexpr int n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
+        constexpr int seg0 = 0;
+        constexpr int seg1 = seg0 + ((r_dyn * 8 + 63) & ~63);
+        constexpr int seg2 = seg1 + ((r_path * 8 + n_fp + 63) & ~63);
+        constexpr int seg3 = seg2 + ((r_lead * 8 + 2 + 63) & ~63);
+        constexpr int segE = seg3 + ((n_b + 63) & ~63);
+        const bool wide = ns <= 8 && segE <= nthr;
+        const int total = wide ? segE : (r_dyn + r_path + r_lead) * ns + n_fp + n_b + 2;
+        for (int task = tid; task < total; task += nthr) {
+            int kind, k = 0, role = 0;          // kind: 0 dyn, 1 path, 2 lead, 3 final path, 4 boundary, 5 coefficient records
+            if (wide) {
+                if (task < seg1) { const int l = task - seg0; kind = 0; role = l >> 3; k = l & 7; if (role >= r_dyn) continue; }
+                else if (task < seg2) {
+                    const int l = task - seg1;
+                    if (l < r_path * 8) { kind = 1; role = l >> 3; k = l & 7; }
+                    else if (l < r_path * 8 + n_fp) { kind = 3; role = l - r_path * 8; }
+                    else continue;
+                } else if (task < seg3) {
+                    const int l = task - seg2;
+                    if (l < r_lead * 8) { kind = 2; k = l & 7; }
+                    else if (l < r_lead * 8 + 2) { kind = 5; role = l - r_lead * 8; }
+                    else continue;
+                } else { const int l = task - seg3; if (l >= n_b) continue; kind = 4; role = l; }
+                if (k >= ns) continue;
             } else {
-                fin_lead<P, SC, S>(kp, cx, k);
+                int t = task;
+                if (t < r_dyn * ns) { kind = 0; role = t / ns; k = t - role * ns; }
+                else if ((t -= r_dyn * ns) < r_path * ns) { kind = 1; role = t / ns; k = t - role * ns; }
+                else if ((t -= r_path * ns) < r_lead * ns) { kind = 2; k = t; }
+                else if ((t -= r_lead * ns) < n_fp) { kind = 3; role = t; }
+                else if ((t -= n_fp) < n_b) { kind = 4; role = t; }
+                else { kind = 5; role = t - n_b; }
             }
-            continue;
+            if (kind == 0) {
+                const int j = role / Dirs<P>::NCH_DYN, q = role % Dirs<P>::NCH_DYN;
+                double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+                eval_dynamics<P, SC, S>(kp, cx, k, j, q, ev);
+                if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j, ev);
+            } else if (kind == 1) eval_step_path<P, SC, S>(kp, cx, k, role);
+            else if (kind == 2) fin_lead<P, SC, S>(kp, cx, k);
+            else if (kind == 3) eval_final_path<P, SC, S>(kp, cx, role);
+            else if (kind == 4) eval_boundary<P, SC, S>(kp, cx, role);
+            else fill_const_coefs<P>(kp, cx.rec + (role == 0 ? kp.edge_fp : kp.edge_b) * R.stride + R.oC);
         }
-        int t = task - n_slot_tasks;
-        if (t < n_fp) { eval_final_path<P, SC, S>(kp, cx, t); continue; }
-        t -= n_fp;
-        if (t < n_b) { eval_boundary<P, SC, S>(kp, cx, t); continue; }
-        t -= n_b;
-        fill_const_coefs<P>(kp, cx.rec + (t == 0 ? kp.edge_fp : kp.edge_b) * R.stride + R.oC);
+        for (int k = tid; k < ns + 2; k += nthr) cx.rec[k * R.stride] = 1.0;
+        return;
+    }
+    // Tiles: task = (role << lg) | slot with the slot count rounded up to a power of two: decoding is a shift and a mask, and
+    // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
+    // passes, one lead role (coefficients + state rows, fused mode).
+    CTD_SUB(kp, 0);
+    const int lg = ns <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ns - 1));
+    const int mask = (1 << lg) - 1;
+    const int total = (r_dyn + r_path + r_lead) << lg;
+    for (int task = tid; task < total; task += nthr) {
+        const int k = task & mask, role = task >> lg;
+        if (k >= ns) continue;
+        if (role < r_dyn) {
+            const int j = role / Dirs<P>::NCH_DYN, q = role % Dirs<P>::NCH_DYN;
+            double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+            if constexpr (REG) {
+                double evr[R.eval_sz];
+#pragma unroll
+                for (int e = 0; e < R.eval_sz; ++e) evr[e] = 0.0;
+                CTD_SUB(kp, 1);
+                eval_dynamics<P, SC, S>(kp, cx, k, j, q, evr);
+                CTD_SUB(kp, 2);
+                fin_stage<P, SC, S>(kp, cx, k, j, evr);
+                CTD_SUB(kp, 3);
+                const int64_t i = slot_index(kp, cx, k);
+                if (i >= 0 && i < kp.L.N) {
+#pragma unroll
+                    for (int e = 0; e < R.eval_sz; ++e) ev[e] = evr[e];
+                }
+                CTD_SUB(kp, 4);
+            } else {
+                eval_dynamics<P, SC, S>(kp, cx, k, j, q, ev);
+                if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j, ev);
+            }
+        } else if (role < r_dyn + r_path) {
+            eval_step_path<P, SC, S, REG>(kp, cx, k, role - r_dyn);
+        } else {
+            CTD_SUB(kp, 1);
+            fin_lead<P, SC, S>(kp, cx, k);
+            CTD_SUB(kp, 4);
+        }
     }
     // record header: [0] = 1.0 (every record of the block, used by constant entries of the pattern)
-    const int nrec = cx.is_edge ? ns + 2 : ns;
-    for (int k = tid; k < nrec; k += nthr) cx.rec[k * R.stride] = 1.0;
+    for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
+    CTD_SUB(kp, 5);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -838,7 +948,7 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
         if (t < n_stage) {
             const int k = t % ns, jr = t / ns;
             if (rows > 1) fin_stage_row<P, S>(kp, cx, k, jr / rows, jr % rows);
-            else fin_stage<P, SC, S>(kp, cx, k, jr);
+            else fin_stage<P, SC, S>(kp, cx, k, jr, cx.rec + k * R.stride + R.oEval + jr * R.eval_sz);
             continue;
         }
         t -= n_stage;
@@ -846,10 +956,10 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
         t -= n_lead;
         if (t < n_path) {
             const int64_t i = slot_index(kp, cx, t);
-            if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + t * R.stride, slot_tau(cx, t, 0));
+            if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + t * R.stride, slot_tau(kp, cx, t, 0));
             continue;
         }
-        fin_path<P, SC, S>(kp, cx.rec + kp.edge_fp * R.stride, final_tau(cx));
+        fin_path<P, SC, S>(kp, cx.rec + kp.edge_fp * R.stride, final_tau(kp, cx));
     }
 }
 
@@ -953,16 +1063,52 @@ CTD_HD void emit_stream(const RecLayout R, const BlockCtx& cx, double* out, int 
     }
 }
 
+// The codes a lane needs in phase_emit when it owns ONE position of each period (period <= workgroup size): read from the
+// global tables before the evaluation starts, so their latency hides behind it and the emission starts from registers.
+struct EmitPre { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; };     // edge block: b = the code of edge entry `tid`, eidx its index
+template <class P>
+CTD_HD EmitPre emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+    EmitPre pre;
+    pre.b = 0u;
+    pre.eidx = 0;
+#pragma unroll
+    for (int kk = 0; kk < kMaxNV; ++kk) pre.v[kk] = 0u;
+    if (cx.is_edge) {
+        const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
+        if (tid < ntot) {
+            const int e = tid < n1 ? kp.edge_begin + tid : kp.edge2_begin + (tid - n1);
+            pre.b = kp.edge_code[e];
+            pre.eidx = kp.edge_idx[e];
+        }
+        return pre;
+    }
+    const int Ls = kp.Lseg;
+    if (Ls > 0 && Ls <= nthr) {
+        const int k = tid - (int)fast_div((uint32_t)tid, kp.div_Lseg) * Ls;
+        pre.b = kp.tmpl[k];
+    }
+    const int vr = kp.vr;
+#pragma unroll
+    for (int kk = 0; kk < kMaxNV; ++kk) {
+        if (kk < P::NV && vr > 0 && vr <= nthr) {
+            const int k = tid - (int)fast_div((uint32_t)tid, kp.div_vr) * vr;
+            pre.v[kk] = kp.vtmpl[kk * vr + k];
+        }
+    }
+    return pre;
+}
+
 template <class P, int SC, int S>
-CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPre* pre = nullptr) {
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
     if (cx.is_edge) {
         const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
         for (int w = tid; w < ntot; w += nthr) {
             const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
-            const uint32_t code = kp.edge_code[e];
-            const int64_t idx = kp.edge_idx[e];
+            const bool have = pre != nullptr && w == tid;          // first pass: prefetched before the evaluation
+            const uint32_t code = have ? pre->b : kp.edge_code[e];
+            const int64_t idx = have ? pre->eidx : kp.edge_idx[e];
             const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);
             if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
             else if (kp.vals) kp.vals[idx] = val;
@@ -1037,7 +1183,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
             if (par >= 1) {
                 if (tid < par * Ls) {
                     const int g = (int)fast_div((uint32_t)tid, kp.div_Lseg), k = tid - g * Ls;
-                    const uint32_t code = cx.codes[k];
+                    const uint32_t code = pre ? pre->b : cx.codes[k];
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
@@ -1051,11 +1197,6 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
                             a[u] = pc[s * stride];
                             b[u] = pd[s * stride];
                         }
-                        if (kp.debug_stop == 5) {          // ablation: LDS reads + arithmetic, no stores
-                            if (a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] == 1.2345e300) out[k] = beta;
-                            continue;
-                        }
-                        if (kp.debug_stop == 6) { a[0] = a[1] = a[2] = a[3] = 1.0; b[0] = b[1] = b[2] = b[3] = 2.0; }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int s = s0 + u * par;
@@ -1091,13 +1232,14 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     if (kp.vr > 0) {
         const int vr = kp.vr;
         const int par = (int)fast_div((uint32_t)nthr, kp.div_vr);
+#pragma unroll
         for (int kk = 0; kk < P::NV; ++kk) {
             double* out = kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)vr;
             const uint32_t* codes = cx.vcodes + kk * vr;
             if (par >= 1) {
                 if (tid < par * vr) {
                     const int g = (int)fast_div((uint32_t)tid, kp.div_vr), k = tid - g * vr;
-                    const uint32_t code = codes[k];
+                    const uint32_t code = pre ? pre->v[kk] : codes[k];
                     const double* pc = cx.rec + (slot0 + g) * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);
                     const int adv = par * stride;

@@ -16,29 +16,73 @@ namespace ctd {
 
 // Fused constraints + sparse Jacobian values.  One workgroup = one tile of time steps (block 0 = edge block when
 // kp.has_edge).  Dynamic LDS = lds_doubles(kp) * 8 bytes.
+// DBG = true is the diagnostics instantiation (ctd_debug_stamps, env CTD_DEBUG_STOP): phase stamps and early returns.  The
+// default instantiation holds neither, so no launch pays for their branches or their kernel-argument loads.
+template <bool DBG>
 __device__ __forceinline__ void ctd_stamp(const KParams& kp, int slot) {
-    if (kp.stamps && threadIdx.x == 0) {
-        unsigned long long* p = kp.stamps + ((size_t)blockIdx.x * 6 + slot) * 2;
-        p[0] = wall_clock64();   // constant 100 MHz counter, comparable across workgroups
-        p[1] = clock64();        // shader cycles
+    if constexpr (DBG) {
+        if (kp.stamps && threadIdx.x == 0) {
+            unsigned long long* p = kp.stamps + ((size_t)blockIdx.x * 6 + slot) * 2;
+            p[0] = wall_clock64();   // constant 100 MHz counter, comparable across workgroups
+            p[1] = clock64();        // shader cycles
+        }
     }
 }
 
-template <class P, int SC, int S>
+// The kernel arguments are read with scalar loads where they are first used; behind branches that is one dependent
+// scalar-cache miss after the other (nine rounds in the first version of this kernel, ~1 us before the first load of x was
+// issued).  Naming every field the tile path needs as an input of one empty asm statement makes the compiler issue all their
+// loads back to back at the top of the kernel: one miss latency, then everything sits in scalar registers.
+template <int S>
+__device__ __forceinline__ void ctd_pin_kernargs(const KParams& kp, const double* xu) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(kp.has_edge), "s"(kp.ntiles), "s"(kp.T), "s"(kp.HL), "s"(kp.HH), "s"(kp.step_begin),
+                 "s"(kp.step_end), "s"(kp.L.blk), "s"(kp.L.N), "s"(kp.L.v_off), "s"(kp.L.cu), "s"(kp.L.stagewise), "s"(kp.L.nv),
+                 "s"(kp.L.cb), "s"(kp.L.eqs), "s"(kp.L.euler), "s"(kp.tau), "s"(kp.L.t0), "s"(kp.L.tf), "s"(xu), "s"(blockDim.x));
+    asm volatile("" ::"s"(kp.tmpl), "s"(kp.vtmpl), "s"(kp.Lseg), "s"(kp.vr), "s"(kp.div_cb.M), "s"(kp.div_Lseg.M), "s"(kp.div_vr.M),
+                 "s"(kp.div_cb.d), "s"(kp.div_Lseg.d), "s"(kp.div_vr.d), "s"(kp.seg_base), "s"(kp.reg_first), "s"(kp.reg_last),
+                 "s"(kp.vcol_base[0]), "s"(kp.c), "s"(kp.vals));
+    if (S >= 1) asm volatile("" ::"s"(kp.L.a[0]), "s"(kp.L.b[0]), "s"(kp.L.c[0]));
+    if (S >= 2) asm volatile("" ::"s"(kp.L.a[1]), "s"(kp.L.a[3]), "s"(kp.L.a[4]), "s"(kp.L.b[1]), "s"(kp.L.c[1]));
+    if (S >= 3) asm volatile("" ::"s"(kp.L.a[2]), "s"(kp.L.a[5]), "s"(kp.L.a[6]), "s"(kp.L.a[7]), "s"(kp.L.a[8]), "s"(kp.L.b[2]), "s"(kp.L.c[2]));
+#endif
+}
+
+template <class P, int SC, int S, bool DBG>
 __global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
     extern __shared__ double ctd_lds[];
-    ctd_stamp(kp, 0);
-    if (kp.debug_stop == 1) return;
-    const BlockCtx cx = make_ctx(kp, (int)blockIdx.x, ctd_lds);
+    ctd_pin_kernargs<SC == SC_IRK ? S : 0>(kp, xu);
+    ctd_stamp<DBG>(kp, 0);
+    if (DBG && kp.debug_stop == 1) return;
     const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    if constexpr (DirectTile<P, SC>::value) {
+        // direct driver: no staging of xu, one barrier (see make_direct_ctx); the staged phases below are not instantiated
+        const BlockCtx cx = make_direct_ctx(kp, (int)blockIdx.x, ctd_lds, xu);
+        const EmitPre pre = emit_prefetch<P>(kp, cx, tid, nthr);
+        ctd_stamp<DBG>(kp, 1);
+        phase_eval<P, SC, S, RegEval<P, SC>::value>(kp, cx, tid, nthr);
+        __syncthreads();
+        ctd_stamp<DBG>(kp, 2);
+        ctd_stamp<DBG>(kp, 3);
+        if (DBG && kp.debug_stop >= 2 && kp.debug_stop <= 4) return;
+        phase_emit<P, SC, S>(kp, cx, tid, nthr, &pre);
+        ctd_stamp<DBG>(kp, 4);
+        if (DBG && kp.stamps) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            ctd_stamp<DBG>(kp, 5);
+        }
+        return;
+    }
+    const BlockCtx cx = make_ctx(kp, (int)blockIdx.x, ctd_lds);
     phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
     __syncthreads();
-    ctd_stamp(kp, 1);
-    if (kp.debug_stop == 2) return;
+    ctd_stamp<DBG>(kp, 1);
+    if (DBG && kp.debug_stop == 2) return;
     phase_eval<P, SC, S>(kp, cx, tid, nthr);
     __syncthreads();
-    ctd_stamp(kp, 2);
-    if (kp.debug_stop == 3) return;
+    ctd_stamp<DBG>(kp, 2);
+    if (DBG && kp.debug_stop == 3) return;
     if (!Dirs<P>::FUSED) {
         phase_fin<P, SC, S>(kp, cx, tid, nthr);
         __syncthreads();
@@ -47,100 +91,15 @@ __global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, con
         phase_fin2<P, SC, S>(kp, cx, tid, nthr);
         __syncthreads();
     }
-    ctd_stamp(kp, 3);
-    if (kp.debug_stop == 4) return;
+    ctd_stamp<DBG>(kp, 3);
+    if (DBG && kp.debug_stop == 4) return;
     phase_emit<P, SC, S>(kp, cx, tid, nthr);
-    ctd_stamp(kp, 4);
-    if (kp.stamps) {             // diagnostics: time until this workgroup's stores have left the CU
+    ctd_stamp<DBG>(kp, 4);
+    if (DBG && kp.stamps) {      // diagnostics: time until this workgroup's stores have left the CU
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        ctd_stamp(kp, 5);
+        ctd_stamp<DBG>(kp, 5);
     }
-}
-
-// ---- pipelined driver -------------------------------------------------------------------------------------------
-// Co-resident workgroups of the classic driver run in lock-step (all evaluate, then all store), so HBM idles during
-// every load/eval phase.  Here a workgroup owns a chunk of consecutive steps and software-pipelines it in sub-tiles:
-// in iteration q wave 0 (producer) evaluates sub-tile q+1 into the other record buffer while waves 1.. (consumers)
-// prefetch the inputs of sub-tile q+2 and stream sub-tile q out; one workgroup barrier per iteration.  The grid is sized
-// to what is resident at once, so the store stream only waits for the prologue.
-__device__ __forceinline__ void ctd_wave_sync() {
-    // LDS results of this wave's earlier instructions become visible to all its lanes (program order + drained counters)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <class P, int SC, int S>
-__device__ __forceinline__ void ctd_produce(const KParams& kp, const BlockCtx& cx, int lane) {
-    // the producer's dependent FP64 chain is the pole of every iteration: let it win issue arbitration against the
-    // co-resident consumer waves (whose stores are in flight anyway)
-    __builtin_amdgcn_s_setprio(3);
-    phase_eval<P, SC, S>(kp, cx, lane, 64);
-    if (!Dirs<P>::FUSED) {
-        ctd_wave_sync();
-        phase_fin<P, SC, S>(kp, cx, lane, 64);
-    }
-    if (SC == SC_TRAPEZE) {
-        ctd_wave_sync();
-        phase_fin2<P, SC, S>(kp, cx, lane, 64);
-    }
-    __builtin_amdgcn_s_setprio(0);
-}
-
-template <class P, int SC, int S>
-__global__ void __launch_bounds__(P::MAXB) cons_jac_pipe_kernel(const KParams kp, const double* __restrict__ xu) {
-    extern __shared__ double ctd_lds[];
-    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
-    if (kp.has_edge && blockIdx.x == 0) {          // edge block: same phases as the classic driver
-        const BlockCtx cx = make_ctx(kp, 0, ctd_lds);
-        phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
-        __syncthreads();
-        phase_eval<P, SC, S>(kp, cx, tid, nthr);
-        __syncthreads();
-        if (!Dirs<P>::FUSED) {
-            phase_fin<P, SC, S>(kp, cx, tid, nthr);
-            __syncthreads();
-        }
-        phase_emit<P, SC, S>(kp, cx, tid, nthr);
-        return;
-    }
-    const int chunk = (int)blockIdx.x - (kp.has_edge ? 1 : 0);
-    const int64_t A = kp.step_begin + (int64_t)chunk * kp.pipe_chunk;
-    const int64_t B = A + kp.pipe_chunk < kp.step_end ? A + kp.pipe_chunk : kp.step_end;
-    if (A >= B) return;
-    const int Q = (int)((B - A + kp.pipe_Ts - 1) / kp.pipe_Ts);
-    const int wave = tid >> 6, lane = tid & 63;
-    const int ctid = tid - 64, cthr = nthr - 64;       // consumer lane id / count
-    ctd_stamp(kp, 0);
-    // prologue: inputs of sub-tiles 0 and 1, records of sub-tile 0
-    {
-        const BlockCtx c0 = make_sub_ctx(kp, ctd_lds, A, B, 0);
-        phase_load<P, SC, S, true>(kp, c0, xu, tid, nthr);
-        if (Q > 1) {
-            const BlockCtx c1 = make_sub_ctx(kp, ctd_lds, A, B, 1);
-            phase_load<P, SC, S, false>(kp, c1, xu, tid, nthr);
-        }
-        __syncthreads();
-        ctd_stamp(kp, 1);
-        if (wave == 0) ctd_produce<P, SC, S>(kp, c0, lane);
-        __syncthreads();
-        ctd_stamp(kp, 2);
-    }
-    for (int q = 0; q < Q; ++q) {
-        if (q == 1) ctd_stamp(kp, 3);          // diagnostics: end of iteration 0
-        if (q == Q - 1) ctd_stamp(kp, 4);      // start of the last iteration
-        if (wave == 0) {
-            if (q + 1 < Q) ctd_produce<P, SC, S>(kp, make_sub_ctx(kp, ctd_lds, A, B, q + 1), lane);
-        } else {
-            // emit first (its stores are fire-and-forget), then fetch the inputs of sub-tile q+2: the load latency then
-            // overlaps the producer's evaluation instead of delaying this iteration's stores
-            phase_emit<P, SC, S>(kp, make_sub_ctx(kp, ctd_lds, A, B, q), ctid, cthr);
-            if (q + 2 < Q) phase_load<P, SC, S, false>(kp, make_sub_ctx(kp, ctd_lds, A, B, q + 2), xu, ctid, cthr);
-        }
-        __syncthreads();
-    }
-    ctd_stamp(kp, 5);
 }
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
@@ -547,47 +506,25 @@ hipError_t launch_grad(int sc, int s, const GradParams& gp, const double* xu, in
 // OCP so the registry compiles in parallel, and ctd_engine.hip only sees `extern template` declarations.
 // Five kernel variants per OCP: (trapeze), (midpoint), (Gauss-Legendre s = 1, 2, 3); the stage count is a template
 // parameter so every loop over stages unrolls.
-template <class P, int SC, int S>
-hipError_t launch_variant(const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
-                          hipEvent_t e0, hipEvent_t e1) {
-    if (kp.pipe_Ts > 0) {
-        if (lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)cons_jac_pipe_kernel<P, SC, S>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return e;
-        }
-        if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_pipe_kernel<P, SC, S>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
-        else cons_jac_pipe_kernel<P, SC, S><<<grid, block, lds_bytes, st>>>(kp, xu);
-        return hipGetLastError();
-    }
+template <class P, int SC, int S, bool DBG>
+hipError_t launch_variant_dbg(const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
+                              hipEvent_t e0, hipEvent_t e1) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC, S, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
     // e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel, so
     // hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
-    if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
-    else cons_jac_kernel<P, SC, S><<<grid, block, lds_bytes, st>>>(kp, xu);
+    if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S, DBG>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);
+    else cons_jac_kernel<P, SC, S, DBG><<<grid, block, lds_bytes, st>>>(kp, xu);
     return hipGetLastError();
 }
-
-// resident workgroups per CU of the pipelined kernel for this geometry (occupancy API; advisory)
 template <class P, int SC, int S>
-int pipe_blocks_per_cu(int block, size_t lds_bytes) {
-    int nb = 0;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)cons_jac_pipe_kernel<P, SC, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cons_jac_pipe_kernel<P, SC, S>, block, lds_bytes) != hipSuccess) return 0;
-    return nb;
-}
-template <class P>
-int pipe_occupancy(int sc, int s, int block, size_t lds_bytes) {
-    if (sc == SC_TRAPEZE) return pipe_blocks_per_cu<P, SC_TRAPEZE, 1>(block, lds_bytes);
-    if (sc == SC_MIDPOINT) return pipe_blocks_per_cu<P, SC_MIDPOINT, 1>(block, lds_bytes);
-    if (s == 1) return pipe_blocks_per_cu<P, SC_IRK, 1>(block, lds_bytes);
-    if (s == 2) return pipe_blocks_per_cu<P, SC_IRK, 2>(block, lds_bytes);
-    return pipe_blocks_per_cu<P, SC_IRK, 3>(block, lds_bytes);
+hipError_t launch_variant(const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
+                          hipEvent_t e0, hipEvent_t e1) {
+    if (kp.stamps || kp.debug_stop) return launch_variant_dbg<P, SC, S, true>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    return launch_variant_dbg<P, SC, S, false>(kp, xu, grid, block, lds_bytes, st, e0, e1);
 }
 
 template <class P>
@@ -614,13 +551,11 @@ hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, i
     template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, \
                                            hipEvent_t);                                                                    \
     template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);                       \
-    template int pipe_occupancy<P>(int, int, int, size_t);                                                                \
     template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 #define CTD_EXTERN_LAUNCHERS(P)                                                                                            \
     extern template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t,      \
                                                   hipEvent_t, hipEvent_t);                                                 \
     extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);               \
-    extern template int pipe_occupancy<P>(int, int, int, size_t);                                                         \
     extern template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 
 #endif  // !__HIPCC_RTC__

@@ -165,10 +165,6 @@ struct KParams {
     int32_t edge_fp, edge_b;            // record ids of the final-path and boundary records
     int32_t edge_slot_first, edge_slot_last;   // slots holding step 0 and step N-1
     int64_t edge_steps[kMaxEdgeSlots];
-    // pipelined driver (cons_jac_pipe_kernel): each workgroup owns pipe_chunk consecutive steps and walks them in
-    // sub-tiles of pipe_Ts steps; 0 = classic one-tile-per-workgroup driver
-    int32_t pipe_Ts;
-    int32_t pipe_chunk;
     // outputs (global indexing); either may be null
     double* c;
     double* vals;

@@ -5,16 +5,24 @@ The reference has no parallelism of any kind; what is part
 `for i in 1:docp.time.steps` (src/DOCP_functions.jl:92-98): step i reads X_i, U_i, K_i, X_{i+1} and v, and writes only
 its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows.
 
-  * x is replicated (it is the solver's iterate; 1e6 doubles = 8 MB), so no halo exchange is needed;
-  * rank r evaluates the contiguous block of steps [r N/G, (r+1) N/G); the last rank also owns the final-time path rows
-    and the boundary rows, the first rank the irregular first-step columns;
+  * rank r evaluates the contiguous block of steps [r N/G, (r+1) N/G); the first rank also owns the irregular first-step
+    columns, the last rank the final-state columns;
+  * the ITERATE is sharded like the steps: rank r holds the variables of its own steps inside a
+    full-length buffer (global indexing, so the engine's shard handles read it as it is).  What a rank needs from the
+    others is tiny: the state X of the NEXT rank's first node (+ its control for trapeze), the first and the final state for
+    the boundary rows, and the replicated optimisation variables v.  `exchange_halo` moves them with ONE all-gather of
+    n (+m) + n doubles per rank per iterate;
+  * a consumer that keeps the whole iterate on one rank calls `broadcast_iterate` instead: one broadcast of nvar doubles;
   * each rank writes its rows straight into a full-length c buffer at their global position, and every rank computes the
     p+bc tail rows (final-time path and boundary constraints) itself;
   * outputs stay ROW-SHARDED: rank r holds its rows of c and, for the Jacobian values, one contiguous range of the global
     CSC value array (its step columns) plus its slice of every V column -- what a distributed KKT consumer wants;
     `DOCP.shard` gives the ranges.  The evaluation itself needs no collective;
-  * a consumer that wants the residual vector whole on every rank asks for it (`stitch=True`): ONE in-place all-gather of
-    the row blocks per evaluation.
+  * a consumer that wants the residual vector whole on every rank asks for it (`stitch=True`): ONE all-gather of the row
+    blocks per evaluation (in place when the blocks are equal, through a padded buffer + one index kernel when ragged).
+
+Every collective is enqueued on torch's current stream, and so are the engine's kernels (`ShardedDOCP` rebinds the handle
+to that stream): nothing here synchronises with the host.
 """
 import torch
 import torch.distributed as dist
@@ -27,31 +35,60 @@ def shard_steps(N, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def stitch_constraints(c, N, cb, world, rank, group=None):
-    """All-gather the per-rank row blocks of `c` in place.  `c` is the full-length constraint vector in which this
-    rank has already written its step rows [begin*cb, end*cb) and the tail rows [N*cb, ncon) (every rank computes
-    those).  Returns c.
+class _Stitcher:
+    """All-gather of the per-rank row blocks of c.  Equal blocks: in place, the rank's own block is the send buffer.
+    Ragged blocks: every rank sends a block padded to the longest one, ONE all_gather_into_tensor, then one index kernel
+    drops the padding (index built once)."""
 
-    Equal blocks (world | N): ONE all_gather_into_tensor over c[:N*cb] with the rank's own block as the send buffer
-    (in place).  Ragged blocks fall back to one broadcast per rank."""
-    if world == 1:
-        return c
-    if N % world == 0:
-        S = (N // world) * cb
+    def __init__(self, N, cb, world, rank, device, group=None):
+        self.N, self.cb, self.world, self.rank, self.group = N, cb, world, rank, group
+        self.equal = (N % world == 0)
+        if not self.equal and world > 1:
+            blocks = [shard_steps(N, world, r) for r in range(world)]
+            self.smax = max(e - b for b, e in blocks) * cb
+            self.begin, self.end = blocks[rank][0] * cb, blocks[rank][1] * cb
+            idx = torch.empty(N * cb, dtype=torch.long)
+            for r, (b, e) in enumerate(blocks):
+                idx[b * cb:e * cb] = r * self.smax + torch.arange((e - b) * cb)
+            self.idx = idx.to(device)
+            self.send = torch.zeros(self.smax, dtype=torch.float64, device=device)
+            self.recv = torch.zeros(world * self.smax, dtype=torch.float64, device=device)
+
+    def __call__(self, c):
+        if self.world == 1:
+            return c
+        N, cb, world, rank = self.N, self.cb, self.world, self.rank
         body = c[:N * cb]
+        if self.equal:
+            S = (N // world) * cb
+            try:
+                dist.all_gather_into_tensor(body, body[rank * S:(rank + 1) * S], group=self.group)
+            except (RuntimeError, NotImplementedError):
+                dist.all_gather([body[r * S:(r + 1) * S] for r in range(world)], body[rank * S:(rank + 1) * S].clone(),
+                                group=self.group)
+            return c
+        self.send[:self.end - self.begin].copy_(body[self.begin:self.end])
         try:
-            dist.all_gather_into_tensor(body, body[rank * S:(rank + 1) * S], group=group)
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         except (RuntimeError, NotImplementedError):
-            dist.all_gather([body[r * S:(r + 1) * S] for r in range(world)], body[rank * S:(rank + 1) * S].clone(), group=group)
-    else:
-        for r in range(world):
-            b, e = shard_steps(N, world, r)
-            dist.broadcast(c[b * cb:e * cb], src=r, group=group)
-    return c
+            dist.all_gather([self.recv[r * self.smax:(r + 1) * self.smax] for r in range(world)], self.send, group=self.group)
+        torch.index_select(self.recv, 0, self.idx, out=body)
+        return c
+
+
+def stitch_constraints(c, N, cb, world, rank, group=None):
+    """All-gather the per-rank row blocks of `c`.  `c` is the full-length constraint vector in which this rank has already
+    written its step rows [begin*cb, end*cb) and the tail rows [N*cb, ncon) (every rank computes those).  Returns c.
+    (One-shot form; `ShardedDOCP` keeps a `_Stitcher` so the ragged case builds its index only once.)"""
+    return _Stitcher(N, cb, world, rank, c.device, group)(c)
 
 
 def reduce_objective(partial, group=None, device=None):
-    """Sum of the per-shard objective partials (Lagrange partial sums; the last shard adds the Mayer term)."""
+    """Sum of the per-shard objective partials (Lagrange partial sums; the last shard adds the Mayer term).  `partial`: a
+    float, or a 1-element tensor that is reduced in place and returned (no host round trip)."""
+    if torch.is_tensor(partial):
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+        return partial
     t = torch.tensor([partial], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t[0])
@@ -59,10 +96,11 @@ def reduce_objective(partial, group=None, device=None):
 
 def reduce_hessian_vv(vals, vv_idx, group=None):
     """Adds the shards' partial sums of the variable x variable Hessian entries (the only entries of hess_coord! that sum
-    over every time step): one all-reduce of nv (nv+1)/2 doubles, in place.  `vv_idx` from DOCP.hess_shard_info()."""
+    over every time step): one all-reduce of nv (nv+1)/2 doubles, in place.  `vv_idx` from DOCP.hess_shard_info(), or the
+    same positions as a long tensor on vals' device."""
     if len(vv_idx) == 0:
         return vals
-    idx = torch.as_tensor(vv_idx, dtype=torch.long, device=vals.device)
+    idx = vv_idx if torch.is_tensor(vv_idx) else torch.as_tensor(vv_idx, dtype=torch.long, device=vals.device)
     part = vals.index_select(0, idx)
     dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     vals.index_copy_(0, idx, part)
@@ -80,37 +118,117 @@ class ShardedDOCP:
         self.N = N
         self.steps = shard_steps(N, self.world, self.rank)
         self.docp = make_docp(steps=self.steps)
-        disc = self.docp.discretization
+        d = self.docp
+        disc = d.discretization
         self.cb = disc._state_stage_eqs_block + disc._step_pathcons_block
+        self.blk = disc._step_variables_block
+        self.n, self.m = d.dims.NLP_x, d.dims.NLP_u
+        self.halo_w = self.n + (self.m if getattr(disc, "_final_control", False) else 0)     # trapeze: the next node's control too
+        self._dev = None
+        if d.device is not None and d.device >= 0:
+            self._dev = torch.device("cuda", d.device)
+            d.set_stream(None)              # launch on torch's current stream: ordered with the collectives issued here
+        self._stitch = None
+        self._halo = None
+        self._vv = None
+        self._f = None
+
+    # ---- iterate distribution ------------------------------------------------------------------------------------------
+    def owned_variables(self):
+        """[begin, end) of the entries of x this rank owns: the blocks of its own steps; the last rank also the final state
+        (+ final control) -- the optimisation variables v at the tail are replicated on every rank."""
+        b, e = self.steps
+        end = e * self.blk
+        if self.rank == self.world - 1:
+            end = self.docp.dim_NLP_variables - self.docp.dims.NLP_v
+        return b * self.blk, end
+
+    def exchange_halo(self, x):
+        """Sharded iterate: fills, inside this rank's full-length x, the few entries other ranks own that its rows read --
+        the next rank's first node (X, + U for trapeze), X_1 and X_{N+1} (boundary rows, Mayer cost) -- with ONE all-gather of
+        (halo_w + n) doubles per rank.  v is replicated by the solver and not touched."""
+        if self.world == 1:
+            return x
+        w, n, blk, N = self.halo_w, self.n, self.blk, self.N
+        if self._halo is None:
+            self._halo = (torch.zeros(w + n, dtype=torch.float64, device=x.device),
+                          torch.zeros(self.world * (w + n), dtype=torch.float64, device=x.device))
+        send, recv = self._halo
+        b, e = self.steps
+        send[:w].copy_(x[b * blk:b * blk + w])                          # my first node
+        if self.rank == self.world - 1:
+            send[w:].copy_(x[N * blk:N * blk + n])                      # the final state
+        try:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([recv[r * (w + n):(r + 1) * (w + n)] for r in range(self.world)], send, group=self.group)
+        if self.rank + 1 < self.world:
+            x[e * blk:e * blk + w].copy_(recv[(self.rank + 1) * (w + n):(self.rank + 1) * (w + n) + w])
+            x[N * blk:N * blk + n].copy_(recv[(self.world - 1) * (w + n) + w:(self.world - 1) * (w + n) + w + n])
+        if self.rank > 0:
+            x[:n].copy_(recv[:n])
+        return x
+
+    def broadcast_iterate(self, x, src=0):
+        """Replicated iterate: the rank that holds the new x sends all of it (nvar doubles) to every other rank."""
+        if self.world > 1:
+            dist.broadcast(x, src=src, group=self.group)
+        return x
+
+    # ---- callbacks -------------------------------------------------------------------------------------------------------
+    def _stitcher(self, c):
+        if self._stitch is None:
+            self._stitch = _Stitcher(self.N, self.cb, self.world, self.rank, c.device, self.group)
+        return self._stitch
 
     def cons_jac(self, x, c, vals, stitch=True):
         """Evaluate this rank's rows into the full-length c / vals buffers; `stitch`: all-gather the row blocks of c so that
         every rank holds the whole residual (the Jacobian values always stay sharded)."""
         self.docp.cons_jac(x, c, vals, sync=False)
         if stitch:
-            stitch_constraints(c, self.N, self.cb, self.world, self.rank, self.group)
+            self._stitcher(c)(c)
         return c, vals
 
-    def bind_cons_jac(self, x, c, vals, stitch=True):
-        """Zero-argument callable: enqueue this rank's evaluation (+ the all-gather of c when `stitch`), pointers pre-bound."""
+    def bind_cons_jac(self, x, c, vals, stitch=True, x_mode=None):
+        """Zero-argument callable for a solver loop, pointers pre-bound: [distribute the iterate: x_mode "halo" (sharded x,
+        exchange_halo) / "broadcast" (replicated x from rank 0) / None] + enqueue this rank's evaluation [+ the all-gather of c
+        when `stitch`]."""
         launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
-        if self.world == 1 or not stitch:
+        if self.world == 1:
             return launch
-        N, cb, world, rank, group = self.N, self.cb, self.world, self.rank, self.group
+        pre = {None: None, "halo": self.exchange_halo, "broadcast": self.broadcast_iterate}[x_mode]
+        post = self._stitcher(c) if stitch else None
 
         def call():
+            if pre is not None:
+                pre(x)
             launch()
-            stitch_constraints(c, N, cb, world, rank, group)
+            if post is not None:
+                post(c)
         return call
 
     def hess_coord(self, x, y, obj_weight, vals):
         """This rank's entries of hess_coord!(nlp, x, y, vals; obj_weight) into the full-length `vals` (they stay sharded like
-        the Jacobian values), plus the all-reduced variable x variable entries on every rank."""
+        the Jacobian values), plus the all-reduced variable x variable entries on every rank.  No host synchronisation: the
+        kernel and the all-reduce are ordered on torch's current stream."""
         self.docp.hess_coord(x, y, obj_weight, vals, sync=False)
         if self.world > 1:
-            self.docp.sync()
-            reduce_hessian_vv(vals, self.docp.hess_shard_info()[2], self.group)
+            if self._vv is None:
+                self._vv = torch.as_tensor(self.docp.hess_shard_info()[2], dtype=torch.long, device=vals.device)
+            reduce_hessian_vv(vals, self._vv, self.group)
         return vals
 
-    def obj(self, x):
-        return reduce_objective(self.docp.obj(x), self.group, device=x.device if hasattr(x, "device") else None)
+    def obj(self, x, as_tensor=False):
+        """Objective of the whole transcription: the shards' partial sums added with one all-reduce of one double that never
+        leaves the device; `as_tensor=False` reads the result back at the end (the only host round trip)."""
+        if not torch.is_tensor(x):
+            return reduce_objective(self.docp.obj(x), self.group)
+        if self._f is None:
+            self._f = torch.zeros(1, dtype=torch.float64, device=x.device)
+        self.docp.obj_async(x, self._f)
+        if self.world > 1:
+            dist.all_reduce(self._f, op=dist.ReduceOp.SUM, group=self.group)
+        return self._f if as_tensor else float(self._f.item())
+
+    def close(self):
+        self.docp.close()

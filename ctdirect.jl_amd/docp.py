@@ -267,7 +267,7 @@ class DOCP:
         o = np.zeros(8, dtype=np.int64)
         self._ck(_lib.lib().ctd_launch_info(self._h, _ip(o)))
         return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]),
-                    csc_period=int(o[4]), edge_entries=int(o[5]), pipe_subtile=int(o[6]), pipe_chunk=int(o[7]))
+                    csc_period=int(o[4]), edge_entries=int(o[5]), direct_tiles=int(o[6]))
 
     def dropped_nonzeros(self):
         n = C.c_int64()
@@ -416,14 +416,16 @@ class DOCP:
                                                   self._dev_ptr(vals, self.nnzj, "vals"), int(iters), C.byref(ms)))
         return ms.value
 
-    def debug_stamps(self, x, c, vals):
+    def debug_stamps(self, x, c, vals, sub=False):
         """Diagnostics: per-workgroup phase stamps of one launch, array [grid, 6, 2] (realtime 100 MHz, shader cycles)."""
         grid = self.launch_info()["grid"]
-        out = np.zeros(grid * 12, dtype=np.uint64)
+        out = np.zeros(grid * (28 if sub else 12), dtype=np.uint64)
         self._ck(_lib.lib().ctd_debug_stamps(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
                                              self._dev_ptr(c, self.dim_NLP_constraints, "c"),
                                              self._dev_ptr(vals, self.nnzj, "vals"),
                                              out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        if sub:      # experiment builds (-DCTD_SUBSTAMPS): [grid, wave 0/1, 8] cycle stamps inside the evaluation phase
+            return out[:grid * 12].reshape(grid, 6, 2), out[grid * 12:].reshape(grid, 2, 8)
         return out.reshape(grid, 6, 2)
 
     # ---- Hessian of the Lagrangian ------------------------------------------------------------------------

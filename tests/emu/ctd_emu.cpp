@@ -31,60 +31,21 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
     const int64_t nlds = lds_doubles(kp);
     for (int b = 0; b < nblocks; ++b) {
         std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
+        if (DirectTile<P, SC>::value) {
+            // direct driver (cons_jac_kernel): no staging of xu, codes prefetched per lane, one barrier before the emission
+            BlockCtx cx = make_direct_ctx(kp, b, lds.data(), xu);
+            std::vector<EmitPre> pre(nthr);
+            for (int t = 0; t < nthr; ++t) pre[t] = emit_prefetch<P>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S, RegEval<P, SC>::value>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr, &pre[t]);
+            continue;
+        }
         BlockCtx cx = make_ctx(kp, b, lds.data());
         for (int t = 0; t < nthr; ++t) phase_load<P, SC, S>(kp, cx, xu, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_fin2<P, SC, S>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr);
-    }
-}
-
-// serial stepping of cons_jac_pipe_kernel (ctd_kernels.hpp): wave 0 = producer, the other lanes = consumers
-template <class P, int SC, int S>
-static void run_pipe_blocks(const KParams& kp, const double* xu, int nthr) {
-    const int64_t nsteps = kp.step_end - kp.step_begin;
-    const int nchunks = (int)((nsteps + kp.pipe_chunk - 1) / kp.pipe_chunk);
-    const int nblocks = nchunks + (kp.has_edge ? 1 : 0);
-    const int64_t nlds = pipe_lds_doubles(kp);
-    auto produce = [&](const BlockCtx& cx) {
-        for (int l = 0; l < 64; ++l) phase_eval<P, SC, S>(kp, cx, l, 64);
-        if (!Dirs<P>::FUSED) for (int l = 0; l < 64; ++l) phase_fin<P, SC, S>(kp, cx, l, 64);
-        if (SC == SC_TRAPEZE) for (int l = 0; l < 64; ++l) phase_fin2<P, SC, S>(kp, cx, l, 64);
-    };
-    for (int b = 0; b < nblocks; ++b) {
-        std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
-        if (kp.has_edge && b == 0) {
-            BlockCtx cx = make_ctx(kp, 0, lds.data());
-            for (int t = 0; t < nthr; ++t) phase_load<P, SC, S>(kp, cx, xu, t, nthr);
-            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
-            for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
-            for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr);
-            continue;
-        }
-        const int chunk = b - (kp.has_edge ? 1 : 0);
-        const int64_t A = kp.step_begin + (int64_t)chunk * kp.pipe_chunk;
-        const int64_t B = A + kp.pipe_chunk < kp.step_end ? A + kp.pipe_chunk : kp.step_end;
-        if (A >= B) continue;
-        const int Q = (int)((B - A + kp.pipe_Ts - 1) / kp.pipe_Ts);
-        const int cthr = nthr - 64;
-        BlockCtx c0 = make_sub_ctx(kp, lds.data(), A, B, 0);
-        for (int t = 0; t < nthr; ++t) phase_load<P, SC, S, true>(kp, c0, xu, t, nthr);
-        if (Q > 1) {
-            BlockCtx c1 = make_sub_ctx(kp, lds.data(), A, B, 1);
-            for (int t = 0; t < nthr; ++t) phase_load<P, SC, S, false>(kp, c1, xu, t, nthr);
-        }
-        produce(c0);
-        for (int q = 0; q < Q; ++q) {
-            // consumers first, then the producer: on the GPU they run concurrently on disjoint buffers
-            BlockCtx cq = make_sub_ctx(kp, lds.data(), A, B, q);
-            for (int t = 0; t < cthr; ++t) phase_emit<P, SC, S>(kp, cq, t, cthr);
-            if (q + 2 < Q) {
-                BlockCtx c2 = make_sub_ctx(kp, lds.data(), A, B, q + 2);
-                for (int t = 0; t < cthr; ++t) phase_load<P, SC, S, false>(kp, c2, xu, t, cthr);
-            }
-            if (q + 1 < Q) produce(make_sub_ctx(kp, lds.data(), A, B, q + 1));
-        }
     }
 }
 
@@ -145,7 +106,7 @@ int emu_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* 
 }
 
 int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
-                 int64_t step_begin, int64_t step_end, const double* x, double* c, double* vals, int pipe_Ts, int pipe_chunk) {
+                 int64_t step_begin, int64_t step_end, const double* x, double* c, double* vals) {
     Model mo;
     HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
     int st = build_model(d, mo, g_err);
@@ -162,24 +123,6 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     kp.edge_code = mo.edge_code.data();
     kp.c = c;
     kp.vals = vals;
-    if (pipe_Ts != 0) {
-        kp.pipe_Ts = pipe_Ts > 0 ? pipe_Ts : default_pipe_tile(mo);
-        kp.pipe_chunk = pipe_chunk > 0 ? pipe_chunk : 3 * kp.pipe_Ts;
-        if (nthr < 128) nthr = 128;
-        bool okp = for_problem(problem, [&](auto tag) {
-            using P = typename decltype(tag)::type;
-            switch (mo.L.sc) {
-                case SC_TRAPEZE: run_pipe_blocks<P, SC_TRAPEZE, 1>(kp, x, nthr); break;
-                case SC_MIDPOINT: run_pipe_blocks<P, SC_MIDPOINT, 1>(kp, x, nthr); break;
-                default:
-                    if (mo.L.s == 1) run_pipe_blocks<P, SC_IRK, 1>(kp, x, nthr);
-                    else if (mo.L.s == 2) run_pipe_blocks<P, SC_IRK, 2>(kp, x, nthr);
-                    else run_pipe_blocks<P, SC_IRK, 3>(kp, x, nthr);
-                    break;
-            }
-        });
-        return okp ? 0 : 5;
-    }
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {

@@ -51,8 +51,7 @@ def csc(problem, scheme, mode, N, time_grid=None):
     return colptr, rowval
 
 
-def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_begin=0, step_end=0, c=None, vals=None,
-             pipe_Ts=0, pipe_chunk=0):
+def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_begin=0, step_end=0, c=None, vals=None):
     nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
     tg, n = _tg(time_grid)
     x = np.ascontiguousarray(x, dtype=np.float64)
@@ -63,8 +62,7 @@ def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_
         vals = np.full(nnz, 666.666)
     st = lib().emu_cons_jac(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
                             C.c_int64(n), tile, nthr, C.c_int64(step_begin), C.c_int64(step_end),
-                            x.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
-                            int(pipe_Ts), int(pipe_chunk))
+                            x.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p))
     if st:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return c, vals

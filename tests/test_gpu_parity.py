@@ -171,27 +171,6 @@ def test_shards_compose_on_gpu(torch_cuda):
         full.close()
 
 
-def test_pipelined_driver_on_gpu(oracle_lib, torch_cuda, monkeypatch):
-    """The optional pipelined driver (CTD_PIPE=1: producer / consumer waves over sub-tiles) gives the same results."""
-    torch = torch_cuda
-    monkeypatch.setenv("CTD_PIPE", "1")
-    for prob, sch, N in (("goddard", "gauss_legendre_3", 2000), ("goddard_all", "gauss_legendre_2", 777),
-                         ("quadrotor", "gauss_legendre_2_constant_control", 300), ("double_integrator_path", "midpoint", 1500),
-                         ("goddard_all", "trapeze", 501)):
-        o = oracle_lib.OracleDOCP(prob, sch, N)
-        o.set_pattern_mode(1)
-        d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
-        assert d.launch_info()["pipe_subtile"] > 0
-        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
-        c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
-        v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
-        d.cons_jac(torch.from_numpy(x).cuda(), c, v)
-        c, v = c.cpu().numpy(), v.cpu().numpy()
-        assert not np.any(c == SENT) and not np.any(v == SENT)
-        assert relerr(c, o.constraints(x)) <= TOL and relerr(v, o.jac_coord(x)) <= TOL
-        d.close()
-
-
 def test_gradient_full_size_directional(oracle_lib, torch_cuda):
     """grad! at the bench size: g . d against central differences of the GPU objective and, cheaply, against the oracle's
     directional derivative (one dual pass is O(N), unlike its full gradient)."""
