@@ -2,13 +2,24 @@
 """bench.py -- NLP-callback throughput of the MI355X collocation engine (BASELINE.json metric).
 
 One "step" = one fused evaluation (constraints c(x) + sparse Jacobian values, `ctd_cons_jac_dev_async`) of the workload
-on inputs already resident in HBM.  Workload at N GPUs: Goddard rocket, Gauss-Legendre 2 (stagewise), 10 000 time steps
-PER GPU -- BASELINE.json configs[1] at N = 1; at N > 1 the global grid has 10 000 x N steps, sharded by time step (weak
-scaling); each rank's rows of c and its Jacobian values stay on the rank (row-sharded outputs, no collective on the path).
-`value` = (shard evaluations all ranks completed) / (max-over-ranks wall time of the K timed steps).  At N > 1 the line
-also carries `stitched_c`: the same step followed by the RCCL all-gather that hands every rank the whole constraint vector.
+on inputs already resident in HBM.  Workloads (`--config`):
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    cfg2_weak    Goddard, Gauss-Legendre 2 (stagewise), 10 000 time steps PER GPU (default): BASELINE.json configs[1]
+                 at N = 1; at N > 1 the global grid has 10 000 x N steps (weak scaling)
+    cfg2_strong  the same 10 000-step transcription sharded over the N GPUs (strong scaling, north_star's 1/2/4/8 line)
+    cfg4         Goddard, Gauss-Legendre 3, 80 000 steps sharded over the N GPUs            (BASELINE.json configs[3])
+    cfg5         12-state quadrotor, Gauss-Legendre 3, 20 000 steps sharded over the N GPUs (BASELINE.json configs[4])
+
+The grid is sharded by time step; each rank's rows of c and its Jacobian values stay on the rank (row-sharded outputs).
+At N > 1 the timed step starts by DISTRIBUTING THE ITERATE: the solver's x is sharded like the steps and every rank
+fetches the few entries of other ranks its rows read (next rank's first node, first / final state) with one RCCL
+all-gather of n + n doubles per rank (`ShardedDOCP.exchange_halo`); then it evaluates its shard.  The same line carries
+`stitched_c` (+ the all-gather that hands every rank the whole constraint vector) and `broadcast_x` (a replicated iterate
+sent whole from rank 0 instead of the halo exchange) as secondary figures, and the per-rank kernel times.
+`value`: weak scaling = shard evaluations all ranks completed per second; strong scaling = evaluations of the whole
+transcription per second; both over the max-over-ranks wall time of the K timed steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]      (N > 1: launched by torch.distributed.run)
 """
 import argparse
 import json
@@ -20,43 +31,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PROBLEM, SCHEME, STEPS_PER_GPU = "goddard", "gauss_legendre_2", 10000
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+CONFIGS = {
+    "cfg2_weak": dict(problem="goddard", scheme="gauss_legendre_2", steps=10000, per_gpu=True, scaling="weak",
+                      what="BASELINE.json configs[1] per GPU"),
+    "cfg2_strong": dict(problem="goddard", scheme="gauss_legendre_2", steps=10000, per_gpu=False, scaling="strong",
+                        what="BASELINE.json configs[1] sharded over the GPUs"),
+    "cfg4": dict(problem="goddard", scheme="gauss_legendre_3", steps=80000, per_gpu=False, scaling="strong",
+                 what="BASELINE.json configs[3]"),
+    "cfg5": dict(problem="quadrotor12", scheme="gauss_legendre_3", steps=20000, per_gpu=False, scaling="strong",
+                 what="BASELINE.json configs[4]"),
+}
 
 
-def cpu_baseline(x, budget_s=12.0):
-    """Reference-faithful CPU path on the host cores of this box: the oracle (a C++ restatement of the Julia reference,
-    kind = "port") evaluates cons! once and the Jacobian the way ADNLPModels does -- one pass of the constraints on
-    one-partial duals per colour of the pattern -- single-threaded, as the reference is."""
+def cpu_baseline(problem, scheme, N, x, budget_s=10.0):
+    """CPU figures on the host cores of this box, from the oracle (a C++ restatement of the Julia reference, kind = "port"):
+    `value` = reference-faithful mode: cons! once + the Jacobian the way ADNLPModels obtains it (one pass of the constraints
+    on one-partial duals per colour of the pattern), single-threaded as the reference is.  `best_effort` = what a CPU
+    implementation written for speed reaches: per-step block Jacobians, OpenMP over the time steps, all cores."""
     from oracle.oracle import OracleDOCP
-    o = OracleDOCP(PROBLEM, SCHEME, STEPS_PER_GPU)
+    o = OracleDOCP(problem, scheme, N)
     o.jac_pattern()                      # build pattern + colouring outside the timed region (build-time in the reference)
     o.constraints(x); o.jac_coord(x)     # warm
-    n, t0 = 0, time.perf_counter()
-    while True:
-        o.constraints(x)
-        o.jac_coord(x)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
+
+    def rate(fn, budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return n, el
+
+    n, el = rate(lambda: (o.constraints(x), o.jac_coord(x)), budget_s)
     out = {"value": n / el, "unit": "evals/s", "cores": 1, "kind": "port",
            "sample": f"{n} fused evaluations (cons! + {o.jac_ncolors()}-colour forward-dual jac_coord!) of the same "
-                     f"{PROBLEM}/{SCHEME} N={STEPS_PER_GPU} workload in {el:.1f} s, oracle/ctd_oracle.cpp, 1 thread"}
-    # the same passes with the colours spread over the host cores this process may use (the reference itself is
-    # single-threaded; this is the multi-core figure a CPU implementation could reach with the same algorithm)
-    cores = max(1, min(o.jac_ncolors(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+                     f"{problem}/{scheme} N={N} workload in {el:.1f} s, oracle/ctd_oracle.cpp, 1 thread"}
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(o.jac_ncolors(), avail))
     o.jac_coord_mt(x, cores)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        o.constraints(x)
-        o.jac_coord_mt(x, cores)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s / 2:
-            break
+    n, el = rate(lambda: (o.constraints(x), o.jac_coord_mt(x, cores)), budget_s / 3)
     out["multithreaded"] = {"value": n / el, "unit": "evals/s", "cores": cores,
                             "sample": f"{n} evaluations in {el:.1f} s, one colour pass per thread"}
+    if hasattr(o, "cons_jac_block"):
+        o.cons_jac_block(x, avail)
+        n, el = rate(lambda: o.cons_jac_block(x, avail), budget_s / 2)
+        out["best_effort"] = {"value": n / el, "unit": "evals/s", "cores": avail, "kind": "port",
+                              "sample": f"{n} fused evaluations in {el:.1f} s: per-step block Jacobians (dense local forward "
+                                        f"duals), OpenMP over the time steps, {avail} threads (oracle/ctd_oracle.cpp "
+                                        f"orc_cons_jac_block)"}
     return out
 
 
@@ -65,8 +88,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2_weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernel-only figures of the other configs")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    PROBLEM, SCHEME = cfg["problem"], cfg["scheme"]
 
     import numpy as np
     import torch
@@ -89,15 +116,16 @@ def main():
         local_rank = int(os.environ["CTD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("CTD_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("CTD_BENCH_BACKEND", "nccl")
         if backend == "nccl":     # bind the communicator to this rank's GPU up front (barriers need no device guess)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    N = STEPS_PER_GPU * world
+    N = cfg["steps"] * world if cfg["per_gpu"] else cfg["steps"]
+
     def make(steps=None):      # the handle launches on torch's current stream: ordered with the RCCL collectives
         return ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, steps=steps, stream="torch")
 
@@ -112,17 +140,22 @@ def main():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
 
     region = {}
+    # the timing machinery itself is warmed before the timed region (first creation / recording of HIP events costs tens of
+    # microseconds once per process)
+    _w0, _w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _w0.record(); _w1.record(); torch.cuda.synchronize(dev); _w0.elapsed_time(_w1)
 
     def timed(step, warmup, steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(warmup):
             step()
+        e0.record(); e1.record()
         sync_all()
         # HIP events on the launch stream (the handle launches on torch's current stream) bracket the timed region: GPU-side
         # duration of the K launches, the figure the roofline uses
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()
         for _ in range(steps):
@@ -137,45 +170,57 @@ def main():
             el = float(t[0])
         return el
 
-    # One fused evaluation of the rank's shard, pointers pre-bound.  The path has no exchange step: c rows and Jacobian
-    # values are left row-sharded for a distributed consumer, so the timed step holds no collective.
-    el = timed(sh.bind_cons_jac(x, c, vals, stitch=False), args.warmup, args.steps)
+    # The timed step.  N = 1: one fused evaluation, pointers pre-bound.  N > 1: iterate distribution (halo exchange of the
+    # sharded x) + the rank's evaluation; outputs stay row-sharded, so no collective follows the kernel.
+    x_mode = "halo" if world > 1 else None
+    el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), args.warmup, args.steps)
     region_ms = region["ms_per_launch"]
-    stitched = None
+    per_step_value = (world if cfg["scaling"] == "weak" else 1)
+    secondary = {}
     if world > 1:
-        # the optional service for a consumer that wants the whole residual on every rank: + one in-place RCCL all-gather
-        # of the row blocks of c per evaluation (reported beside `value`, never instead of it)
         ks = max(1, min(args.steps, 500))
-        try:
-            els = timed(sh.bind_cons_jac(x, c, vals, stitch=True), min(args.warmup, 50), ks)
-            stitched = {"value": ks * world / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3, "steps": ks,
-                        "what": "same step + in-place all-gather of the row blocks of c (every rank ends with the whole c)"}
-        except Exception as e:            # the secondary figure must never cost the line
-            stitched = {"error": repr(e)[:300]}
+        for key, kw, what in (
+                ("stitched_c", dict(stitch=True, x_mode="halo"), "same step + all-gather of the row blocks of c (every rank ends with the whole c)"),
+                ("broadcast_x", dict(stitch=False, x_mode="broadcast"), "replicated iterate: rank 0 broadcasts all of x instead of the halo exchange"),
+                ("no_exchange", dict(stitch=False, x_mode=None), "evaluation only (x already in place on every rank): what the collectives cost is the difference")):
+            try:      # a secondary figure must never cost the line
+                els = timed(sh.bind_cons_jac(x, c, vals, **kw), min(args.warmup, 50), ks)
+                secondary[key] = {"value": ks * per_step_value / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3,
+                                  "steps": ks, "what": what}
+            except Exception as e:
+                secondary[key] = {"error": repr(e)[:300]}
 
-    # roofline of the dominant (only) kernel: per-dispatch HIP events on the stream it is launched on
-    # average launch duration of the kernel: (a) HIP events around the K timed launches on the launch stream (above) -- the
-    # launches run back to back, so elapsed / K is the kernel's average duration including the dispatch gap; (b) per-dispatch
-    # start / stop events (hipExtLaunchKernelGGL), median of five batches of 200 -- noisier (clock state), reported beside it
+    # roofline of the dominant (only) kernel, per rank.  kernel_ms: N = 1: HIP events on the launch stream around the K
+    # timed launches / K (back-to-back launches: the kernel's average duration including the dispatch gap); N > 1 (the
+    # region also holds collectives): per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
     per_dispatch = sorted(docp.time_cons_jac(x, c, vals, iters=200) for _ in range(5))[2]
-    kernel_ms = region_ms
-    sh_nnz = docp.nnzj if world == 1 else None
-    # algorithmic bytes of one launch: read x, write c rows and Jacobian values of the shard
-    # B = 8 (nvar + ncon + nnzj) for the per-GPU 10 000-step problem
-    one = ct.DOCP(PROBLEM, STEPS_PER_GPU, SCHEME, device=-1)
+    kernel_ms = region_ms if world == 1 else per_dispatch
+    # algorithmic bytes of one launch: read the shard's x, write its c rows and Jacobian values:
+    # B = 8 (nvar + ncon + nnzj) of the per-rank sub-problem
+    b, e = sh.steps
+    one = ct.DOCP(PROBLEM, e - b, SCHEME, device=-1)
     alg_bytes = 8 * (one.dim_NLP_variables + one.dim_NLP_constraints + one.nnzj)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    per_rank = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = per_dispatch
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [{"rank": r, "kernel_ms": float(t[r]), "frac": alg_bytes / (float(t[r]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    for r in range(world)]
+    traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if world == 1 and args.config == "cfg2_weak" and os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("bench_kernel", {}).get("hbm_bytes_per_launch")
+            traffic_src = ("IMPORTED from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, "
+                           "profiles/collect.sh); not measured in this run")
         except Exception:
             traffic = None
 
     # the other single-GPU BASELINE configs (parity-test cases, not the bench line): kernel time and roofline fraction
-    others = []
-    if world == 1:
+    others, hessian = [], []
+    if world == 1 and not args.no_extras:
         for prob, sch, n in (("double_integrator_path", "midpoint", 100000), ("goddard", "gauss_legendre_3", 80000),
                              ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000)):
             d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch")
@@ -188,13 +233,9 @@ def main():
                            "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
             d2.close()
             del x2, c2, v2
-
-    # the Hessian-of-the-Lagrangian row (hess_coord!): kernel-only figures, not part of `value`.
-    # Algorithmic bytes: read x and y, write the lower-triangular values: 8 (nvar + ncon + nnzh).
-    hessian = []
-    if world == 1:
-        import numpy as np
-        for prob, sch, n in ((PROBLEM, SCHEME, STEPS_PER_GPU), ("goddard", "gauss_legendre_3", 80000),
+        # the Hessian-of-the-Lagrangian row (hess_coord!): kernel-only figures, not part of `value`.
+        # Algorithmic bytes: read x and y, write the lower-triangular values: 8 (nvar + ncon + nnzh).
+        for prob, sch, n in (("goddard", "gauss_legendre_2", 10000), ("goddard", "gauss_legendre_3", 80000),
                              ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000)):
             d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch")
             x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
@@ -208,41 +249,48 @@ def main():
             del x2, y2, h2
 
     if rank == 0:
+        shard_txt = (f"{cfg['steps']} time steps per GPU (global grid {N} steps, time-step sharded)" if cfg["per_gpu"]
+                     else f"{N} time steps" + (f" sharded over {world} GPUs ({e - b} per GPU)" if world > 1 else ""))
         out = {
             "metric": "NLP callback evals/s (constraints+sparse Jac), N-step Goddard, 1/2/4/8 GPU",
-            "value": args.steps * world / el,
+            "value": args.steps * per_step_value / el,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{PROBLEM} / {SCHEME} (stagewise), {STEPS_PER_GPU} time steps per GPU "
-                            f"(global grid {N} steps, time-step sharded); fused cons!+jac_coord! on HBM-resident x; "
-                            + ("single GPU = BASELINE.json configs[1]" if world == 1 else
-                               "outputs row-sharded (no collective on the path); value counts one 10000-step shard "
-                               "evaluation per GPU per step; `stitched_c` = the same with c all-gathered"),
+                "workload": f"{args.config}: {PROBLEM} / {SCHEME}, {shard_txt}; fused cons!+jac_coord! on HBM-resident x; "
+                            + cfg["what"] + ("" if world == 1 else
+                                             "; timed step = halo exchange of the sharded iterate (one all-gather) + shard "
+                                             "evaluation, outputs row-sharded; value counts "
+                                             + ("one shard evaluation per GPU per step" if cfg["scaling"] == "weak"
+                                                else "one evaluation of the whole transcription per step")),
                 "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,
                 "launch": docp.launch_info(),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ctd::cons_jac_kernel<GoddardOCP, SC_IRK>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": f"ctd::cons_jac_kernel<{PROBLEM}, {SCHEME}>", "kernel_ms": kernel_ms,
                          "kernel_ms_per_dispatch_events": per_dispatch,
-                         "timing": "HIP events on the launch stream around the K timed launches / K",
+                         "timing": ("HIP events on the launch stream around the K timed launches / K" if world == 1 else
+                                    "per-dispatch HIP events of rank 0's kernel (the timed region also holds collectives)"),
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "other_configs_kernel_only": others,
-            "hessian_kernel_only": hessian,
         }
+        if per_rank is not None:
+            out["roofline"]["per_rank"] = per_rank
+        if others:
+            out["other_configs_kernel_only"] = others
+        if hessian:
+            out["hessian_kernel_only"] = hessian
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(x_host)
-        if stitched is not None:
-            out["stitched_c"] = stitched
+            out["cpu_baseline"] = cpu_baseline(PROBLEM, SCHEME, N, x_host)
+        out.update(secondary)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctdirect_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (include/ctdirect_hip.h)
-CTD_OK, CTD_EINVAL, CTD_EGRID, CTD_ESCHEME, CTD_EPATTERN, CTD_EPROBLEM, CTD_ENODEVICE, CTD_EHIP, CTD_ENOMEM = range(9)
+CTD_OK, CTD_EINVAL, CTD_EGRID, CTD_ESCHEME, CTD_EPATTERN, CTD_EPROBLEM, CTD_ENODEVICE, CTD_EHIP, CTD_ENOMEM, CTD_ERCCL = range(10)
 
 
 class ctd_desc(C.Structure):
@@ -89,6 +89,17 @@ SYMBOLS = {
     "ctd_hess_launch_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_shard_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_debug_stamps": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, C.POINTER(C.c_uint64), C.c_int64]),
+    # one transcription on several GPUs of one process
+    "ctd_create_sharded": (C.c_int32, [C.POINTER(ctd_desc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)]),
+    "ctd_sharded_destroy": (C.c_int32, [_vp]),
+    "ctd_sharded_last_error": (C.c_char_p, [_vp]),
+    "ctd_sharded_handle": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp)]),
+    "ctd_sharded_shard_info": (C.c_int32, [_vp, C.c_int32, _ip]),
+    "ctd_cons_jac_sharded_dev_async": (C.c_int32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_int32, C.c_int32]),
+    "ctd_sharded_sync": (C.c_int32, [_vp]),
+    "ctd_dev_alloc": (C.c_int32, [C.c_int32, C.c_size_t, C.POINTER(_vp)]),
+    "ctd_dev_free": (C.c_int32, [C.c_int32, _vp]),
+    "ctd_dev_copy": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32]),
 }
 
 

@@ -1020,4 +1020,218 @@ int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_de
                            [&](hipEvent_t a, hipEvent_t b) { return enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev, a, b); });
 }
 
+// ---- one transcription on several GPUs of one process --------------------------------------------------------------------
+}  // extern "C"
+
+struct ctd_sharded {
+    std::vector<ctd_handle*> h;
+    std::vector<int> dev;
+    std::vector<hipEvent_t> x_ready;     // recorded on shard k's stream when this call's reads of x_dev[k] by OTHER shards may start
+    std::vector<hipEvent_t> done;        // recorded on shard k's stream after its kernel (its rows of c are final)
+    std::vector<hipEvent_t> pulled;      // recorded on shard k's stream after it has pulled the others' row blocks (stitching)
+    bool pulls_pending = false;          // the last call stitched: the next kernels must not overwrite rows still being pulled
+    int64_t N = 0;
+    std::string err;
+    ~ctd_sharded() {
+        for (size_t k = 0; k < h.size(); ++k) {
+            if (h[k]) { DeviceGuard dg(dev[k]); if (x_ready[k]) (void)hipEventDestroy(x_ready[k]); if (done[k]) (void)hipEventDestroy(done[k]); if (pulled[k]) (void)hipEventDestroy(pulled[k]); }
+            if (h[k]) (void)ctd_destroy(h[k]);
+        }
+    }
+};
+
+static int32_t sfail(ctd_sharded* s, int32_t code, const std::string& msg) {
+    if (s) s->err = msg; else g_create_err = msg;
+    return code;
+}
+// a copy between two shards' buffers on shard k's stream: peer-to-peer over xGMI (or a plain device copy when both shards
+// sit on one device)
+static hipError_t shard_copy(ctd_sharded* s, int k, double* dst, int from, const double* src, int64_t count) {
+    if (count <= 0) return hipSuccess;
+    if (s->dev[k] == s->dev[from]) return hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyDeviceToDevice, s->h[k]->stream);
+    return hipMemcpyPeerAsync(dst, s->dev[k], src, s->dev[from], sizeof(double) * count, s->h[k]->stream);
+}
+#define SH_TRY(s, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return sfail(s, CTD_ERCCL, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int32_t ctd_create_sharded(const ctd_desc* desc, const int32_t* devices, int32_t n_devices, ctd_sharded** out) {
+    if (!desc || !devices || !out || n_devices < 1) return sfail(nullptr, CTD_EINVAL, "ctd_create_sharded: bad argument");
+    *out = nullptr;
+    if (desc->step_begin != 0 || desc->step_end != 0) return sfail(nullptr, CTD_EINVAL, "ctd_create_sharded: the descriptor must name the whole grid");
+    const int64_t N = desc->time_grid ? desc->time_grid_len - 1 : desc->grid_size;
+    if (N < n_devices) return sfail(nullptr, CTD_EINVAL, "ctd_create_sharded: fewer time steps than devices");
+    std::unique_ptr<ctd_sharded> s(new (std::nothrow) ctd_sharded());
+    if (!s) return sfail(nullptr, CTD_ENOMEM, "ctd_create_sharded: out of memory");
+    s->N = N;
+    s->h.assign(n_devices, nullptr); s->dev.assign(devices, devices + n_devices);
+    s->x_ready.assign(n_devices, nullptr); s->done.assign(n_devices, nullptr); s->pulled.assign(n_devices, nullptr);
+    const int64_t base = N / n_devices, rem = N % n_devices;
+    for (int k = 0; k < n_devices; ++k) {
+        ctd_desc dk = *desc;
+        dk.device = devices[k];
+        dk.step_begin = k * base + (k < rem ? k : rem);
+        dk.step_end = dk.step_begin + base + (k < rem ? 1 : 0);
+        dk.stream = nullptr;
+        dk.stream_mode = CTD_STREAM_OWN;
+        const int32_t st = ctd_create(&dk, &s->h[k]);
+        if (st) return st;                                   // message in ctd_last_error(NULL)
+        DeviceGuard dg(devices[k]);
+        if (dg.err != hipSuccess || hipEventCreateWithFlags(&s->x_ready[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->done[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->pulled[k], hipEventDisableTiming) != hipSuccess)
+            return sfail(nullptr, CTD_EHIP, "ctd_create_sharded: event creation failed");
+    }
+    // peer access between every pair of distinct devices (xGMI); hipMemcpyPeerAsync works without it, through the host
+    for (int a = 0; a < n_devices; ++a)
+        for (int b = 0; b < n_devices; ++b) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                DeviceGuard dg(devices[a]);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return sfail(nullptr, CTD_ERCCL, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        }
+    *out = s.release();
+    return CTD_OK;
+}
+
+int32_t ctd_sharded_destroy(ctd_sharded* s) {
+    if (!s) return CTD_EINVAL;
+    delete s;
+    return CTD_OK;
+}
+
+const char* ctd_sharded_last_error(const ctd_sharded* s) { return s ? s->err.c_str() : g_create_err.c_str(); }
+
+int32_t ctd_sharded_handle(ctd_sharded* s, int32_t k, ctd_handle** h) {
+    if (!s || !h || k < 0 || k >= (int32_t)s->h.size()) return CTD_EINVAL;
+    *h = s->h[k];
+    return CTD_OK;
+}
+
+int32_t ctd_sharded_shard_info(const ctd_sharded* s, int32_t k, int64_t* o) {
+    if (!s || !o || k < 0 || k >= (int32_t)s->h.size()) return CTD_EINVAL;
+    o[0] = (int64_t)s->h.size();
+    o[1] = s->dev[k];
+    return ctd_shard_info(s->h[k], o + 2);
+}
+
+int32_t ctd_sharded_sync(ctd_sharded* s) {
+    if (!s) return CTD_EINVAL;
+    for (size_t k = 0; k < s->h.size(); ++k) {
+        const int32_t st = ctd_sync(s->h[k]);
+        if (st) return sfail(s, st, ctd_last_error(s->h[k]));
+    }
+    return CTD_OK;
+}
+
+int32_t ctd_dev_alloc(int32_t device, size_t bytes, void** ptr) {
+    if (!ptr) return CTD_EINVAL;
+    *ptr = nullptr;
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
+    if (e == hipSuccess) e = hipMalloc(ptr, bytes ? bytes : 8);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_dev_alloc: ") + hipGetErrorString(e); return CTD_EHIP; }
+    return CTD_OK;
+}
+int32_t ctd_dev_free(int32_t device, void* ptr) {
+    if (!ptr) return CTD_OK;
+    DeviceGuard dg(device);
+    return (dg.err == hipSuccess && hipFree(ptr) == hipSuccess) ? CTD_OK : CTD_EHIP;
+}
+int32_t ctd_dev_copy(int32_t device, void* dst, const void* src, size_t bytes, int32_t kind) {
+    if (!dst || !src || (kind != 0 && kind != 1)) return CTD_EINVAL;
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
+    if (e == hipSuccess) e = hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_dev_copy: ") + hipGetErrorString(e); return CTD_EHIP; }
+    return CTD_OK;
+}
+
+int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, double* const* c_dev, double* const* vals_dev,
+                                       int32_t x_mode, int32_t stitch) {
+    if (!s || !x_dev) return CTD_EINVAL;
+    const int G = (int)s->h.size();
+    for (int k = 0; k < G; ++k)
+        if (!x_dev[k] || (stitch && (!c_dev || !c_dev[k]))) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: null buffer");
+    if (x_mode != CTD_X_IN_PLACE && x_mode != CTD_X_SHARDED && x_mode != CTD_X_FROM_DEVICE0)
+        return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: unknown x_mode");
+    const Layout& L = s->h[0]->model.L;
+    const int64_t N = L.N;
+    // (1) iterate distribution.  Every shard first marks the point of its stream behind which its x buffer may be read by
+    // the others (its own previous kernel has finished with it; the caller's writes are complete by contract).
+    if (x_mode != CTD_X_IN_PLACE && G > 1) {
+        for (int k = 0; k < G; ++k) {
+            DeviceGuard dg(s->dev[k]);
+            SH_TRY(s, hipEventRecord(s->x_ready[k], s->h[k]->stream));
+        }
+        const int64_t w = L.n + (L.final_control ? L.m : 0);
+        const int64_t lo = s->h[0]->model.HL > 0 ? L.blk : 0;
+        for (int k = 0; k < G; ++k) {
+            DeviceGuard dg(s->dev[k]);
+            ctd_handle* hk = s->h[k];
+            if (x_mode == CTD_X_FROM_DEVICE0) {
+                if (k == 0) continue;
+                SH_TRY(s, hipStreamWaitEvent(hk->stream, s->x_ready[0], 0));
+                SH_TRY(s, shard_copy(s, k, x_dev[k], 0, x_dev[0], L.nvar));
+                continue;
+            }
+            const int64_t b = hk->step_begin, e = hk->step_end;
+            if (k + 1 < G) {      // next shard's first node; the final state (boundary rows, Mayer cost)
+                SH_TRY(s, hipStreamWaitEvent(hk->stream, s->x_ready[k + 1], 0));
+                SH_TRY(s, shard_copy(s, k, x_dev[k] + e * L.blk, k + 1, x_dev[k + 1] + e * L.blk, w));
+                if (k + 1 != G - 1) SH_TRY(s, hipStreamWaitEvent(hk->stream, s->x_ready[G - 1], 0));
+                SH_TRY(s, shard_copy(s, k, x_dev[k] + N * L.blk, G - 1, x_dev[G - 1] + N * L.blk, L.n));
+            }
+            if (k > 0) {          // previous shard's last block (one-point schemes); the first state (boundary rows)
+                SH_TRY(s, hipStreamWaitEvent(hk->stream, s->x_ready[k - 1], 0));
+                if (lo) SH_TRY(s, shard_copy(s, k, x_dev[k] + (b - 1) * L.blk, k - 1, x_dev[k - 1] + (b - 1) * L.blk, lo));
+                if (k - 1 != 0) SH_TRY(s, hipStreamWaitEvent(hk->stream, s->x_ready[0], 0));
+                SH_TRY(s, shard_copy(s, k, x_dev[k], 0, x_dev[0], L.n));
+            }
+        }
+    }
+    // (2) the shards' kernels (after every other device has finished pulling this shard's rows of the previous stitched call)
+    if (s->pulls_pending) {
+        for (int k = 0; k < G; ++k) {
+            DeviceGuard dg(s->dev[k]);
+            for (int j = 0; j < G; ++j)
+                if (j != k) SH_TRY(s, hipStreamWaitEvent(s->h[k]->stream, s->pulled[j], 0));
+        }
+        s->pulls_pending = false;
+    }
+    for (int k = 0; k < G; ++k) {
+        const int32_t st = enqueue_cons_jac(s->h[k], x_dev[k], c_dev ? c_dev[k] : nullptr, vals_dev ? vals_dev[k] : nullptr);
+        if (st) return sfail(s, st, ctd_last_error(s->h[k]));
+    }
+    // (3) stitching: every device pulls the other shards' row blocks of c once those shards' kernels are done
+    if (stitch && G > 1) {
+        for (int k = 0; k < G; ++k) {
+            DeviceGuard dg(s->dev[k]);
+            SH_TRY(s, hipEventRecord(s->done[k], s->h[k]->stream));
+        }
+        for (int k = 0; k < G; ++k) {
+            DeviceGuard dg(s->dev[k]);
+            for (int j = 0; j < G; ++j) {
+                if (j == k) continue;
+                SH_TRY(s, hipStreamWaitEvent(s->h[k]->stream, s->done[j], 0));
+                // (the p + bc tail rows come from the last shard: the only one that holds everything they read when x is sharded)
+                const int64_t r0 = s->h[j]->step_begin * L.cb, r1 = (j == G - 1) ? L.ncon : s->h[j]->step_end * L.cb;
+                SH_TRY(s, shard_copy(s, k, c_dev[k] + r0, j, c_dev[j] + r0, r1 - r0));
+            }
+            SH_TRY(s, hipEventRecord(s->pulled[k], s->h[k]->stream));
+        }
+        s->pulls_pending = true;
+    }
+    return CTD_OK;
+}
+
 }  // extern "C"

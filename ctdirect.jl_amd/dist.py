@@ -13,8 +13,9 @@ its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows
     the boundary rows, and the replicated optimisation variables v.  `exchange_halo` moves them with ONE all-gather of
     n (+m) + n doubles per rank per iterate;
   * a consumer that keeps the whole iterate on one rank calls `broadcast_iterate` instead: one broadcast of nvar doubles;
-  * each rank writes its rows straight into a full-length c buffer at their global position, and every rank computes the
-    p+bc tail rows (final-time path and boundary constraints) itself;
+  * each rank writes its rows straight into a full-length c buffer at their global position; the p+bc tail rows
+    (final-time path and boundary constraints) are authoritative on the LAST rank (it owns X_{N+1} and the last controls and
+    receives X_1); other ranks only hold them after stitching;
   * outputs stay ROW-SHARDED: rank r holds its rows of c and, for the Jacobian values, one contiguous range of the global
     CSC value array (its step columns) plus its slice of every V column -- what a distributed KKT consumer wants;
     `DOCP.shard` gives the ranges.  The evaluation itself needs no collective;
@@ -35,21 +36,45 @@ def shard_steps(N, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-class _Stitcher:
-    """All-gather of the per-rank row blocks of c.  Equal blocks: in place, the rank's own block is the send buffer.
-    Ragged blocks: every rank sends a block padded to the longest one, ONE all_gather_into_tensor, then one index kernel
-    drops the padding (index built once)."""
+def _all_gather_into(recv, send, group=None):
+    """recv[r * len(send) : (r+1) * len(send)] = rank r's `send`.  RCCL: one all_gather_into_tensor (send may be a view of
+    recv: in place).  Backends without it (gloo moves host memory only -- CPU tests and the one-GPU rehearsal) go through the
+    list form, staged on the host when the tensors live on a GPU."""
+    try:
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return
+    except (RuntimeError, NotImplementedError, ValueError):
+        pass
+    world = dist.get_world_size(group)
+    n = send.numel()
+    if send.is_cuda:
+        hs = send.cpu()
+        parts = [torch.empty_like(hs) for _ in range(world)]
+        dist.all_gather(parts, hs, group=group)
+        recv.copy_(torch.cat(parts))
+    else:
+        dist.all_gather([recv[r * n:(r + 1) * n] for r in range(world)], send.clone(), group=group)
 
-    def __init__(self, N, cb, world, rank, device, group=None):
+
+class _Stitcher:
+    """All-gather of the per-rank row blocks of c, with the p + bc tail rows (final-time path and boundary constraints) taken
+    from the LAST rank -- the only one that holds everything they read when the iterate is sharded.  Every rank sends its
+    block padded to the longest one (+ the tail slot), ONE all_gather_into_tensor, then one index kernel writes the whole c
+    (index built once).  Equal blocks without tail rows are gathered in place."""
+
+    def __init__(self, N, cb, ncon, world, rank, device, group=None):
         self.N, self.cb, self.world, self.rank, self.group = N, cb, world, rank, group
-        self.equal = (N % world == 0)
-        if not self.equal and world > 1:
+        self.tail = ncon - N * cb
+        self.in_place = (N % world == 0) and self.tail == 0
+        if not self.in_place and world > 1:
             blocks = [shard_steps(N, world, r) for r in range(world)]
-            self.smax = max(e - b for b, e in blocks) * cb
+            self.smax = max(e - b for b, e in blocks) * cb + self.tail
             self.begin, self.end = blocks[rank][0] * cb, blocks[rank][1] * cb
-            idx = torch.empty(N * cb, dtype=torch.long)
+            idx = torch.empty(ncon, dtype=torch.long)
             for r, (b, e) in enumerate(blocks):
                 idx[b * cb:e * cb] = r * self.smax + torch.arange((e - b) * cb)
+            last_rows = (blocks[-1][1] - blocks[-1][0]) * cb
+            idx[N * cb:] = (world - 1) * self.smax + last_rows + torch.arange(self.tail)
             self.idx = idx.to(device)
             self.send = torch.zeros(self.smax, dtype=torch.float64, device=device)
             self.recv = torch.zeros(world * self.smax, dtype=torch.float64, device=device)
@@ -58,29 +83,25 @@ class _Stitcher:
         if self.world == 1:
             return c
         N, cb, world, rank = self.N, self.cb, self.world, self.rank
-        body = c[:N * cb]
-        if self.equal:
+        if self.in_place:
             S = (N // world) * cb
-            try:
-                dist.all_gather_into_tensor(body, body[rank * S:(rank + 1) * S], group=self.group)
-            except (RuntimeError, NotImplementedError):
-                dist.all_gather([body[r * S:(r + 1) * S] for r in range(world)], body[rank * S:(rank + 1) * S].clone(),
-                                group=self.group)
+            body = c[:N * cb]
+            _all_gather_into(body, body[rank * S:(rank + 1) * S], self.group)
             return c
-        self.send[:self.end - self.begin].copy_(body[self.begin:self.end])
-        try:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather([self.recv[r * self.smax:(r + 1) * self.smax] for r in range(world)], self.send, group=self.group)
-        torch.index_select(self.recv, 0, self.idx, out=body)
+        own = self.end - self.begin
+        self.send[:own].copy_(c[self.begin:self.end])
+        if rank == world - 1 and self.tail:
+            self.send[own:own + self.tail].copy_(c[N * cb:])
+        _all_gather_into(self.recv, self.send, self.group)
+        torch.index_select(self.recv, 0, self.idx, out=c)
         return c
 
 
 def stitch_constraints(c, N, cb, world, rank, group=None):
     """All-gather the per-rank row blocks of `c`.  `c` is the full-length constraint vector in which this rank has already
-    written its step rows [begin*cb, end*cb) and the tail rows [N*cb, ncon) (every rank computes those).  Returns c.
-    (One-shot form; `ShardedDOCP` keeps a `_Stitcher` so the ragged case builds its index only once.)"""
-    return _Stitcher(N, cb, world, rank, c.device, group)(c)
+    written its step rows [begin*cb, end*cb); the tail rows [N*cb, ncon) are taken from the last rank.  Returns c.
+    (One-shot form; `ShardedDOCP` keeps a `_Stitcher` so the index is built only once.)"""
+    return _Stitcher(N, cb, c.numel(), world, rank, c.device, group)(c)
 
 
 def reduce_objective(partial, group=None, device=None):
@@ -124,6 +145,9 @@ class ShardedDOCP:
         self.blk = disc._step_variables_block
         self.n, self.m = d.dims.NLP_x, d.dims.NLP_u
         self.halo_w = self.n + (self.m if getattr(disc, "_final_control", False) else 0)     # trapeze: the next node's control too
+        # one-point schemes (midpoint, Euler): the residual of the step BEFORE this rank's first one depends on this rank's
+        # first state, and the rank owns those Jacobian entries: it needs that step's block too
+        self.halo_lo = self.blk if (disc.stage == 0 and not getattr(disc, "_final_control", False)) else 0
         self._dev = None
         if d.device is not None and d.device >= 0:
             self._dev = torch.device("cuda", d.device)
@@ -144,28 +168,33 @@ class ShardedDOCP:
         return b * self.blk, end
 
     def exchange_halo(self, x):
-        """Sharded iterate: fills, inside this rank's full-length x, the few entries other ranks own that its rows read --
-        the next rank's first node (X, + U for trapeze), X_1 and X_{N+1} (boundary rows, Mayer cost) -- with ONE all-gather of
-        (halo_w + n) doubles per rank.  v is replicated by the solver and not touched."""
+        """Sharded iterate: fills, inside this rank's full-length x, the few entries other ranks own that its rows and its
+        Jacobian columns read -- the next rank's first node (X, + U for trapeze); for the one-point schemes (midpoint, Euler)
+        the previous rank's last step block, whose residual depends on this rank's first state; X_1 and X_{N+1} (boundary rows,
+        Mayer cost) -- with ONE all-gather of (halo_w + low + n) doubles per rank.  v is replicated by the solver and not
+        touched."""
         if self.world == 1:
             return x
-        w, n, blk, N = self.halo_w, self.n, self.blk, self.N
+        w, n, blk, N, lo = self.halo_w, self.n, self.blk, self.N, self.halo_lo
+        L = w + lo + n
         if self._halo is None:
-            self._halo = (torch.zeros(w + n, dtype=torch.float64, device=x.device),
-                          torch.zeros(self.world * (w + n), dtype=torch.float64, device=x.device))
+            self._halo = (torch.zeros(L, dtype=torch.float64, device=x.device),
+                          torch.zeros(self.world * L, dtype=torch.float64, device=x.device))
         send, recv = self._halo
         b, e = self.steps
         send[:w].copy_(x[b * blk:b * blk + w])                          # my first node
+        if lo:
+            send[w:w + lo].copy_(x[(e - 1) * blk:e * blk])              # my last step block
         if self.rank == self.world - 1:
-            send[w:].copy_(x[N * blk:N * blk + n])                      # the final state
-        try:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather([recv[r * (w + n):(r + 1) * (w + n)] for r in range(self.world)], send, group=self.group)
-        if self.rank + 1 < self.world:
-            x[e * blk:e * blk + w].copy_(recv[(self.rank + 1) * (w + n):(self.rank + 1) * (w + n) + w])
-            x[N * blk:N * blk + n].copy_(recv[(self.world - 1) * (w + n) + w:(self.world - 1) * (w + n) + w + n])
-        if self.rank > 0:
+            send[w + lo:].copy_(x[N * blk:N * blk + n])                 # the final state
+        _all_gather_into(recv, send, self.group)
+        r = self.rank
+        if r + 1 < self.world:
+            x[e * blk:e * blk + w].copy_(recv[(r + 1) * L:(r + 1) * L + w])
+            x[N * blk:N * blk + n].copy_(recv[(self.world - 1) * L + w + lo:self.world * L])
+        if r > 0:
+            if lo:
+                x[(b - 1) * blk:b * blk].copy_(recv[(r - 1) * L + w:(r - 1) * L + w + lo])
             x[:n].copy_(recv[:n])
         return x
 
@@ -178,7 +207,7 @@ class ShardedDOCP:
     # ---- callbacks -------------------------------------------------------------------------------------------------------
     def _stitcher(self, c):
         if self._stitch is None:
-            self._stitch = _Stitcher(self.N, self.cb, self.world, self.rank, c.device, self.group)
+            self._stitch = _Stitcher(self.N, self.cb, c.numel(), self.world, self.rank, c.device, self.group)
         return self._stitch
 
     def cons_jac(self, x, c, vals, stitch=True):

@@ -662,3 +662,80 @@ def unpack_solution(docp, x, multipliers=None, multipliers_L=None, multipliers_U
         out["path_constraints_dual"] = raw / np.concatenate([h, h[-1:]])[:, None]
         out["boundary_constraints_dual"] = y[N * cb + p:N * cb + p + bc].copy()
     return out
+
+
+class MultiDeviceDOCP:
+    """One transcription sharded by time step over several GPUs of THIS process (`ctd_create_sharded`): the single-process
+    counterpart of `dist.ShardedDOCP`.  Buffers are full-length on every device (global indexing); shard k writes its rows
+    of c and its CSC ranges of the Jacobian values.  `devices` may repeat an ordinal (tests on a one-GPU box)."""
+
+    X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0 = 0, 1, 2
+
+    def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual"):
+        L = _lib.lib()
+        pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
+        scheme = SCHEME_ALIASES.get(scheme, scheme) if isinstance(scheme, str) else scheme
+        d = _lib.ctd_desc()
+        d.problem, d.scheme = pid, SCHEMES[scheme] if isinstance(scheme, str) else int(scheme)
+        d.pattern_mode = PATTERN_MODES[pattern] if isinstance(pattern, str) else int(pattern)
+        d.device = -1
+        self._tg = None
+        if time_grid is not None:
+            self._tg = np.ascontiguousarray(time_grid, dtype=np.float64)
+            d.time_grid, d.time_grid_len, d.grid_size = _dp(self._tg), len(self._tg), len(self._tg) - 1
+        else:
+            d.time_grid, d.time_grid_len, d.grid_size = None, 0, int(grid_size)
+        self.devices = [int(k) for k in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        st = L.ctd_create_sharded(C.byref(d), arr, len(self.devices), C.byref(h))
+        if st != _lib.CTD_OK:
+            _raise(st, L.ctd_sharded_last_error(None).decode())
+        self._s = h
+        self.shards = []
+        for k in range(len(self.devices)):
+            o = np.zeros(10, dtype=np.int64)
+            self._ck(L.ctd_sharded_shard_info(self._s, k, _ip(o)))
+            self.shards.append(SimpleNamespace(device=int(o[1]), step_begin=int(o[2]), step_end=int(o[3]), c_row_begin=int(o[4]),
+                                               c_row_end=int(o[5]), vals_main_begin=int(o[6]), vals_main_end=int(o[7])))
+        nvar, ncon, nnzj, nnzh = (C.c_int64() for _ in range(4))
+        h0 = C.c_void_p()
+        self._ck(L.ctd_sharded_handle(self._s, 0, C.byref(h0)))
+        L.ctd_sizes(h0, C.byref(nvar), C.byref(ncon), C.byref(nnzj), C.byref(nnzh))
+        self.dim_NLP_variables, self.dim_NLP_constraints, self.nnzj, self.nnzh = nvar.value, ncon.value, nnzj.value, nnzh.value
+
+    def _ck(self, st):
+        if st != _lib.CTD_OK:
+            _raise(st, _lib.lib().ctd_sharded_last_error(self._s).decode() or _lib.lib().ctd_strerror(st).decode())
+
+    def _ptrs(self, tensors, n, name):
+        import torch
+        if tensors is None:
+            return None
+        assert len(tensors) == len(self.devices)
+        for k, t in enumerate(tensors):
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n and t.device.index == self.devices[k]):
+                raise ValueError(f"{name}[{k}] must be a contiguous float64 tensor of {n} entries on cuda:{self.devices[k]}")
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def cons_jac(self, x, c, vals, x_mode=0, stitch=False, sync=True):
+        """x, c, vals: lists of one full-length tensor per shard (on that shard's device)."""
+        self._ck(_lib.lib().ctd_cons_jac_sharded_dev_async(self._s, self._ptrs(x, self.dim_NLP_variables, "x"),
+                                                           self._ptrs(c, self.dim_NLP_constraints, "c"),
+                                                           self._ptrs(vals, self.nnzj, "vals"), int(x_mode), int(bool(stitch))))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._ck(_lib.lib().ctd_sharded_sync(self._s))
+
+    def close(self):
+        if getattr(self, "_s", None):
+            _lib.lib().ctd_sharded_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

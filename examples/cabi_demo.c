@@ -2,7 +2,9 @@
  *
  *   gcc -std=c99 -Iinclude examples/cabi_demo.c -o cabi_demo -Lctdirect.jl_amd -lctdirect_hip -Wl,-rpath,$PWD/ctdirect.jl_amd
  *   ./cabi_demo            host-only part: sizes, bounds, default initial guess, Jacobian structure   (no GPU needed)
- *   ./cabi_demo gpu        + one fused evaluation of constraints and Jacobian values on device 0
+ *   ./cabi_demo gpu        + one fused evaluation of constraints and Jacobian values on device 0, and the same evaluation
+ *                          through the multi-device entry points (two shards; both on device 0 here, devices {0, 1, ..} on a
+ *                          multi-GPU node): iterate sent from shard 0, residual stitched on every shard
  *
  * Goddard problem, Gauss-Legendre 2 (stagewise controls), 100 steps: CTDirect.DOCP(goddard().ocp, 100, 1,
  * :gauss_legendre_2, nothing) in the reference (src/DOCP_data.jl:293). */
@@ -57,6 +59,33 @@ int main(int argc, char** argv) {
         CHECK(ctd_cons_jac(h, x, c, vals));               /* cons!(nlp, x, c) + jac_coord!(nlp, x, vals) in one launch */
         CHECK(ctd_obj(h, x, &f));
         printf("objective %.6f  c[0] %.6e  vals[0] %.6e\n", f, c[0], vals[0]);
+        {   /* one transcription on several devices of this process (ctd_create_sharded) */
+            ctd_sharded* s = NULL;
+            const int32_t devices[2] = {0, 0};
+            void *xd[2], *cd[2], *vd[2];
+            double* c2 = (double*)malloc(sizeof(double) * (size_t)ncon);
+            int64_t info[10];
+            int k, bad = 0;
+            d.device = -1;
+            if (ctd_create_sharded(&d, devices, 2, &s) != CTD_OK) { fprintf(stderr, "%s\n", ctd_sharded_last_error(NULL)); return 3; }
+            for (k = 0; k < 2; ++k) {
+                if (ctd_dev_alloc(devices[k], sizeof(double) * (size_t)nvar, &xd[k]) || ctd_dev_alloc(devices[k], sizeof(double) * (size_t)ncon, &cd[k]) ||
+                    ctd_dev_alloc(devices[k], sizeof(double) * (size_t)nnzj, &vd[k])) return 3;
+                ctd_sharded_shard_info(s, k, info);
+                printf("shard %d on device %lld: steps [%lld, %lld), c rows [%lld, %lld), CSC range [%lld, %lld)\n", k, (long long)info[1],
+                       (long long)info[2], (long long)info[3], (long long)info[4], (long long)info[5], (long long)info[6], (long long)info[7]);
+            }
+            if (ctd_dev_copy(devices[0], xd[0], x, sizeof(double) * (size_t)nvar, 0)) return 3;       /* the iterate lives on shard 0 */
+            if (ctd_cons_jac_sharded_dev_async(s, (double* const*)xd, (double* const*)cd, (double* const*)vd, CTD_X_FROM_DEVICE0, 1) ||
+                ctd_sharded_sync(s)) { fprintf(stderr, "%s\n", ctd_sharded_last_error(s)); return 3; }
+            if (ctd_dev_copy(devices[1], c2, cd[1], sizeof(double) * (size_t)ncon, 1)) return 3;      /* stitched: whole c on shard 1 too */
+            for (k = 0; k < (int)ncon; ++k) bad += (c2[k] != c[k]);
+            printf("multi-device: stitched c on shard 1 differs from the single-device c in %d of %lld rows\n", bad, (long long)ncon);
+            for (k = 0; k < 2; ++k) { ctd_dev_free(devices[k], xd[k]); ctd_dev_free(devices[k], cd[k]); ctd_dev_free(devices[k], vd[k]); }
+            ctd_sharded_destroy(s);
+            free(c2);
+            if (bad) return 4;
+        }
         free(c); free(vals);
     } else {
         double f;

@@ -49,7 +49,8 @@ enum {
     CTD_EPROBLEM = 5,   /* problem id not in the compiled registry */
     CTD_ENODEVICE = 6,  /* compute call on a host-only handle, or no usable HIP device */
     CTD_EHIP = 7,       /* a HIP runtime call failed (message in ctd_last_error) */
-    CTD_ENOMEM = 8
+    CTD_ENOMEM = 8,
+    CTD_ERCCL = 9       /* an exchange between the devices of a multi-device handle failed (peer access / peer copy) */
 };
 
 /* scheme symbols of the reference, src/DOCP_data.jl:307-349 */
@@ -293,6 +294,49 @@ int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* out13);
  * cap = capacity of out in uint64 words (needs grid * 10). */
 int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
                               uint64_t* out, int64_t cap);
+
+
+/* ---- one transcription on several GPUs of ONE process (SURVEY.md section 8b "device list", 8e) ------------------------------
+ * The reference has no counterpart (it is single-threaded): this serves a Julia host that owns all GPUs of a node from one
+ * process -- the same `ccall` shim, one multi-device handle instead of one handle.  The N time steps are split into
+ * n_devices contiguous blocks (block k = steps [k N / n, (k+1) N / n), the ceil / floor rule of a balanced split; the loop
+ * being partitioned is src/DOCP_functions.jl:92-98); shard k lives on devices[k] with a stream of its own.  Buffers are
+ * FULL-LENGTH on every device (global indexing): x_dev[k] (nvar), c_dev[k] (ncon), vals_dev[k] (nnzj) are device pointers on
+ * devices[k]; shard k writes its rows of c, its contiguous CSC range and its slices of the V columns
+ * (ctd_sharded_shard_info).  The same device may appear several times (tests on a one-GPU box).  Exchanges between the
+ * devices are peer-to-peer copies over xGMI (hipMemcpyPeerAsync on the shards' streams, ordered by events); a failure of one
+ * of them is reported as CTD_ERCCL. */
+typedef struct ctd_sharded ctd_sharded;
+
+enum {
+    CTD_X_IN_PLACE = 0,      /* every x_dev[k] already holds what shard k reads (e.g. the solver replicates x)               */
+    CTD_X_SHARDED = 1,       /* x_dev[k] holds shard k's own variables (+ the replicated v): the engine fetches the halos --   */
+                             /*   next shard's first node, previous shard's last block (midpoint / Euler), X_1, X_{N+1}      */
+    CTD_X_FROM_DEVICE0 = 2   /* x_dev[0] holds the whole iterate: the engine copies all of it to the other devices          */
+};
+
+/* desc->device, step_begin / step_end and stream are ignored (must be 0 / NULL); devices[k] are HIP ordinals */
+int32_t ctd_create_sharded(const ctd_desc* desc, const int32_t* devices, int32_t n_devices, ctd_sharded** out);
+int32_t ctd_sharded_destroy(ctd_sharded* s);
+const char* ctd_sharded_last_error(const ctd_sharded* s);
+/* the k-th shard's single-device handle (owned by s): sizes, patterns, bounds, ctd_shard_info, ctd_set_stream, and every
+ * single-device callback (objective, gradient, Hessian) on that shard */
+int32_t ctd_sharded_handle(ctd_sharded* s, int32_t k, ctd_handle** h);
+/* out[0..9] = n_devices, devices[k], then ctd_shard_info(shard k)[0..7] */
+int32_t ctd_sharded_shard_info(const ctd_sharded* s, int32_t k, int64_t* out10);
+/* Enqueue one fused evaluation on every device: [iterate distribution per x_mode] -> shard kernels -> [stitch != 0: every
+ * device receives the other shards' row blocks of c (the p + bc tail rows from the last shard), so each c_dev[k] ends up
+ * whole].  Nothing waits on the host.  The
+ * caller's writes to x_dev must be complete (or ordered before the shards' streams) when this is called. */
+int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, double* const* c_dev, double* const* vals_dev,
+                                       int32_t x_mode, int32_t stitch);
+/* waits for every shard's stream */
+int32_t ctd_sharded_sync(ctd_sharded* s);
+/* Device memory for hosts without a HIP binding of their own (examples/cabi_demo.c; a Julia host passes AMDGPU.jl arrays
+ * instead): hipMalloc / hipFree / hipMemcpy on the given device.  kind: 0 = host -> device, 1 = device -> host. */
+int32_t ctd_dev_alloc(int32_t device, size_t bytes, void** ptr);
+int32_t ctd_dev_free(int32_t device, void* ptr);
+int32_t ctd_dev_copy(int32_t device, void* dst, const void* src, size_t bytes, int32_t kind);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@
 
 #include "dual.hpp"
 #include "dual2.hpp"
+#include "dualn.hpp"
 #include "problems.hpp"
 
 namespace orc {
@@ -897,6 +898,96 @@ template <class P> static void jacobian_colored_mt(Docp& p, const double* xu, do
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BLOCK mode: fused constraints + Jacobian values, one time step at a time.
+// NOT how the reference obtains its Jacobian (that is jacobian_colored above).  Two uses: (1) the "best-effort CPU"
+// figure of bench.py (OpenMP over the time steps, direct per-step block Jacobian); (2) an
+// independent, fast checker of every Jacobian entry at the full BASELINE sizes, where ~100 coloured passes over 10^6
+// variables are too slow for a test.
+// Step i is differentiated as a ONE-STEP transcription of the same OCP on the grid {tau_i, tau_i+1}: its variables
+// [X_i, U_i.., K_i.., X_i+1, (U_i+1), V] are contiguous in xu apart from V, so the same `constraints` template evaluates
+// the step's rows on dense local duals (DN, one partial per local variable).  The final-time path rows come out of the
+// last step's sub-problem, the boundary rows are evaluated directly on duals of (X_1, X_N+1, V).
+// Not available for implicit Euler (its path rows read the previous step's control): returns false.
+// ---------------------------------------------------------------------------------------------
+template <class P> static void make_docp(Docp& p, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len);
+
+template <class P, int CAP> static void cons_jac_block_cap(const Docp& cp, const double* xu, double* c, double* vals, int nthreads) {
+    using DN = DNT<CAP>;
+    const Disc& d = cp.disc;
+    const int n = cp.dims.NLP_x, nv = cp.dims.NLP_v, np = cp.dims.path_cons, nb = cp.dims.boundary_cons;
+    const int64_t N = cp.steps, nvar = cp.dim_NLP_variables, ncon = cp.dim_NLP_constraints;
+    const int blk = d.step_variables_block, cb = d.state_stage_eqs_block + d.step_pathcons_block;
+#pragma omp parallel num_threads(nthreads)
+    {
+        Docp p1;
+        p1.problem = cp.problem;
+        make_docp<P>(p1, d.scheme, 1, nullptr, 0);
+        const int W = (int)p1.dim_NLP_variables;            // local variables of one step
+        const int nloc = W - nv;                             // contiguous in xu from (i-1) * blk
+        std::vector<DN> z(W), cz(p1.dim_NLP_constraints);
+        // scatter the partials of local rows [0, nr) (global rows row0 ...) into the pattern's CSC positions
+        auto scatter = [&](int64_t col, int l, int64_t row0, int nr, const DN* rows) {
+            const int64_t* b = cp.rowval.data() + cp.colptr[col];
+            const int64_t* e = cp.rowval.data() + cp.colptr[col + 1];
+            for (const int64_t* it = std::lower_bound(b, e, row0); it != e && *it < row0 + nr; ++it)
+                vals[it - cp.rowval.data()] = rows[*it - row0].d[l];
+        };
+#pragma omp for schedule(static)
+        for (int64_t i = 1; i <= N; ++i) {
+            p1.normalized_grid[0] = cp.normalized_grid[i - 1]; p1.normalized_grid[1] = cp.normalized_grid[i];
+            p1.fixed_grid[0] = cp.fixed_grid[i - 1]; p1.fixed_grid[1] = cp.fixed_grid[i];
+            const double* xs = xu + (i - 1) * (int64_t)blk;
+            for (int l = 0; l < nloc; ++l) z[l] = DN::variable(xs[l], l);
+            for (int k = 0; k < nv; ++k) z[nloc + k] = DN::variable(xu[nvar - nv + k], nloc + k);
+            constraints<P, DN>(p1, z.data(), cz.data());
+            const int64_t row0 = (i - 1) * (int64_t)cb;
+            if (c) for (int r = 0; r < cb; ++r) c[row0 + r] = cz[r].v;
+            const bool last = (i == N);
+            if (c && last) for (int r = 0; r < np; ++r) c[N * (int64_t)cb + r] = cz[cb + r].v;
+            if (vals) {
+                for (int l = 0; l < W; ++l) {
+                    const int64_t col = l < nloc ? (i - 1) * (int64_t)blk + l : nvar - nv + (l - nloc);
+                    scatter(col, l, row0, cb, cz.data());
+                    if (last && np > 0) scatter(col, l, N * (int64_t)cb, np, cz.data() + cb);
+                }
+            }
+        }
+#pragma omp single
+        if (nb > 0) {                                    // boundary rows: phi(X_1, X_N+1, V)   (DOCP_functions.jl:103-111)
+            const int Wb = 2 * n + nv;
+            std::vector<DN> x0(n), xf(n), v(nv > 0 ? nv : 1), out(nb);
+            for (int k = 0; k < n; ++k) { x0[k] = DN::variable(xu[k], k); xf[k] = DN::variable(xu[N * (int64_t)blk + k], n + k); }
+            for (int k = 0; k < nv; ++k) v[k] = DN::variable(xu[nvar - nv + k], 2 * n + k);
+            P::template boundary<DN>(out.data(), x0.data(), xf.data(), v.data());
+            const int64_t row0 = ncon - nb;
+            if (c) for (int r = 0; r < nb; ++r) c[row0 + r] = out[r].v;
+            if (vals)
+                for (int l = 0; l < Wb; ++l) {
+                    const int64_t col = l < n ? l : (l < 2 * n ? N * (int64_t)blk + (l - n) : nvar - nv + (l - 2 * n));
+                    scatter(col, l, row0, nb, out.data());
+                }
+        }
+    }
+}
+
+template <class P> static bool cons_jac_block(Docp& p, const double* xu, double* c, double* vals, int nthreads) {
+    ensure_pattern(p);
+    const Disc& d = p.disc;
+    if (d.euler && !d.euler_explicit) return false;
+    if (nthreads < 1) nthreads = 1;
+    if (vals) std::memset(vals, 0, sizeof(double) * p.rowval.size());
+    const int W = d.step_variables_block + p.dims.NLP_x + (d.final_control ? p.dims.NLP_u : 0) + p.dims.NLP_v;
+    const int Wb = 2 * p.dims.NLP_x + p.dims.NLP_v;
+    const int need = W > Wb ? W : Wb;
+    if (need <= 16) cons_jac_block_cap<P, 16>(p, xu, c, vals, nthreads);
+    else if (need <= 32) cons_jac_block_cap<P, 32>(p, xu, c, vals, nthreads);
+    else if (need <= 64) cons_jac_block_cap<P, 64>(p, xu, c, vals, nthreads);
+    else if (need <= 128) cons_jac_block_cap<P, 128>(p, xu, c, vals, nthreads);
+    else return false;
+    return true;
+}
+
 // one full column of the dense Jacobian (independent of any pattern)
 template <class P> static void jacobian_column(const Docp& p, const double* xu, int64_t col, double* out) {
     const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
@@ -1119,6 +1210,13 @@ void orc_jac_coord(void* h, const double* xu, double* vals) {
 void orc_jac_coord_mt(void* h, const double* xu, double* vals, int nthreads) {
     Docp& p = *(Docp*)h;
     orc::dispatch(p.problem, [&](auto tag) { orc::jacobian_colored_mt<typename decltype(tag)::type>(p, xu, vals, nthreads); });
+}
+// block mode: fused c + Jacobian values (either output may be NULL); returns 0 when the scheme has no block mode
+int orc_cons_jac_block(void* h, const double* xu, double* c, double* vals, int nthreads) {
+    Docp& p = *(Docp*)h;
+    bool ok = false;
+    orc::dispatch(p.problem, [&](auto tag) { ok = orc::cons_jac_block<typename decltype(tag)::type>(p, xu, c, vals, nthreads); });
+    return ok ? 1 : 0;
 }
 void orc_jac_column(void* h, const double* xu, int64_t col, double* out) {
     Docp& p = *(Docp*)h;

@@ -84,6 +84,8 @@ def lib():
         L.orc_jac_pattern.argtypes = [C.c_void_p, ip, ip]
         L.orc_jac_coord.argtypes = [C.c_void_p, dp, dp]
         L.orc_jac_coord_mt.argtypes = [C.c_void_p, dp, dp, C.c_int]
+        L.orc_cons_jac_block.argtypes = [C.c_void_p, dp, dp, dp, C.c_int]
+        L.orc_cons_jac_block.restype = C.c_int
         L.orc_jac_column.argtypes = [C.c_void_p, dp, C.c_int64, dp]
         L.orc_hess_nnz.argtypes = [C.c_void_p, ip, ip]
         L.orc_hess_lower_nnz.argtypes = [C.c_void_p]
@@ -221,6 +223,17 @@ class OracleDOCP:
         vals = np.zeros(self.jac_nnz())
         lib().orc_jac_coord_mt(self._h, _dp(xu), _dp(vals), int(nthreads))
         return vals
+
+    def cons_jac_block(self, xu, nthreads=1):
+        """Block mode (oracle/ctd_oracle.cpp cons_jac_block): fused (c, Jacobian values on the pattern), one time step at a
+        time on dense local duals, OpenMP over the steps.  Not the reference's algorithm: the best-effort CPU figure of
+        bench.py and a fast independent check of every Jacobian entry at full size.  Returns None for schemes without it."""
+        xu = np.ascontiguousarray(xu, dtype=np.float64)
+        if not hasattr(self, "_blk_c"):
+            self._blk_c = np.zeros(self.dim_NLP_constraints)
+            self._blk_v = np.zeros(self.jac_nnz())
+        ok = lib().orc_cons_jac_block(self._h, _dp(xu), _dp(self._blk_c), _dp(self._blk_v), int(nthreads))
+        return (self._blk_c, self._blk_v) if ok else None
 
     def jac_dense(self, xu):
         """Dense Jacobian, one dual pass per column (small problems only)."""

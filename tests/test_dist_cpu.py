@@ -54,7 +54,8 @@ def _worker(rank, world, port, N, prob, sch, q):
         c = torch.full((d.dim_NLP_constraints,), 666.666, dtype=torch.float64)
         a, b = d.shard.c_row_begin, d.shard.c_row_end
         c[a:b] = torch.from_numpy(full[a:b])
-        c[N * cb:] = torch.from_numpy(full[N * cb:])     # every rank computes the tail rows (final path + boundary)
+        if rank == world - 1:
+            c[N * cb:] = torch.from_numpy(full[N * cb:])     # the tail rows (final path + boundary) come from the last rank
         ctdist.stitch_constraints(c, N, cb, world, rank)
         ok = bool(np.array_equal(c.numpy(), full))
         tot = ctdist.reduce_objective(float(rank + 1))
@@ -70,13 +71,38 @@ def _worker(rank, world, port, N, prob, sch, q):
         lo, hi, _ = d.hess_shard_info()
         ok = ok and bool(np.allclose(hv.numpy()[vv], hfull[vv], rtol=1e-12, atol=1e-12))
         ok = ok and bool(np.allclose(hv.numpy()[lo:hi], hfull[lo:hi], rtol=1e-10, atol=1e-10))
+        # sharded iterate: the halo exchange fills exactly the foreign entries this rank's rows / columns read
+        sh = ctdist.ShardedDOCP(lambda steps=None: ct.DOCP(prob, N, sch, steps=steps, device=-1), N, world=world, rank=rank)
+        xs = np.full_like(x, np.nan)
+        oa, ob = sh.owned_variables()
+        xs[oa:ob] = x[oa:ob]
+        nv = d.dims.NLP_v
+        if nv:
+            xs[-nv:] = x[-nv:]
+        xt = torch.from_numpy(xs)
+        sh.exchange_halo(xt)
+        blk, n = sh.blk, sh.n
+        need = [(0, n), (N * blk, N * blk + n)]
+        if rank + 1 < world:
+            need.append((se * blk, se * blk + sh.halo_w))
+        if rank > 0 and sh.halo_lo:
+            need.append(((sb - 1) * blk, sb * blk))
+        for lo_, hi_ in need:
+            ok = ok and bool(np.array_equal(xt.numpy()[lo_:hi_], x[lo_:hi_]))
+        untouched = np.ones(x.size, dtype=bool)
+        untouched[oa:ob] = False
+        if nv:
+            untouched[-nv:] = False
+        for lo_, hi_ in need:
+            untouched[lo_:hi_] = False
+        ok = ok and bool(np.isnan(xt.numpy()[untouched]).all())
         q.put((rank, ok, tot))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("N,prob,sch", [(10, "goddard_all", "gauss_legendre_2"), (7, "goddard", "trapeze"),
-                                        (64, "double_integrator_path", "midpoint")])
+                                        (64, "double_integrator_path", "midpoint"), (9, "double_integrator_path", "midpoint")])
 def test_stitch_constraints_world2_gloo(N, prob, sch):
     world = 2
     ctx = mp.get_context("spawn")

@@ -1,0 +1,161 @@
+"""Two ranks on ONE GPU through the HIP engine (gloo carries the collectives: RCCL refuses two ranks on one device): the
+time-step sharded callbacks with a SHARDED iterate -- every entry of x a rank does not own is NaN until `exchange_halo`
+fetches the few it needs -- against the oracle.  The driver's 8-GPU run takes the same code path with one rank per GPU
+over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, prob, sch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        sys.path.insert(0, os.path.dirname(here))
+        import ctdirect_jl_amd as ct
+        from ctdirect_jl_amd import dist as ctdist
+        from helpers import TOL, bench_inputs, describe, relerr
+        from oracle.oracle import OracleDOCP
+        torch.cuda.set_device(0)
+        o = OracleDOCP(prob, sch, N)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        sh = ctdist.ShardedDOCP(lambda steps=None: ct.DOCP(prob, N, sch, device=0, steps=steps, pattern="structural"), N, world=world, rank=rank)
+        d = sh.docp
+        # sharded iterate: own entries + the replicated variables, NaN everywhere else
+        xs = np.full_like(x, np.nan)
+        a, b = sh.owned_variables()
+        xs[a:b] = x[a:b]
+        nv = d.dims.NLP_v
+        if nv:
+            xs[-nv:] = x[-nv:]
+        xd = torch.from_numpy(xs).cuda()
+        c = torch.full((d.dim_NLP_constraints,), 777.0, dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), 777.0, dtype=torch.float64, device="cuda")
+        step = sh.bind_cons_jac(xd, c, v, stitch=True, x_mode="halo")
+        step(); step()
+        torch.cuda.synchronize()
+        o.set_pattern_mode(1)
+        cref, vref = o.constraints(x), o.jac_coord(x)
+        chk = {}
+        chk['c'] = relerr(c.cpu().numpy(), cref) <= TOL                   # whole residual on every rank after stitching
+        lo, hi = d.shard.vals_main_begin, d.shard.vals_main_end          # the rank's contiguous CSC range
+        vh = v.cpu().numpy()
+        chk['J own range'] = bool(np.all(np.isfinite(vh[lo:hi]))) and relerr(vh[lo:hi], vref[lo:hi]) <= TOL
+        # the pieces composed over the ranks give the whole Jacobian: every entry written by exactly the ranks that own it
+        mine = torch.from_numpy((vh != 777.0).astype(np.float64))
+        tot = mine.clone()
+        dist.all_reduce(tot)
+        chk['J coverage'] = bool((tot >= 1).all())
+        vz = torch.from_numpy(np.where(vh != 777.0, vh, 0.0) / np.maximum(tot.numpy(), 1.0))
+        dist.all_reduce(vz)
+        chk['J composed'] = relerr(vz.numpy(), vref) <= TOL
+        # objective (one all-reduce of one double on the device) and the Hessian's all-reduced V x V entries
+        f = sh.obj(xd)
+        chk['obj'] = abs(f - o.objective(x)) <= TOL * max(1.0, abs(o.objective(x)))
+        y = np.cos(0.3 * np.arange(o.dim_NLP_constraints))
+        hv = torch.full((d.nnzh,), 777.0, dtype=torch.float64, device="cuda")
+        sh.hess_coord(xd, torch.from_numpy(y).cuda(), 0.5, hv)
+        torch.cuda.synchronize()
+        href = o.hess_coord(x, y, 0.5)
+        hlo, hhi, vv = d.hess_shard_info()
+        hh = hv.cpu().numpy()
+        chk['H own range'] = relerr(hh[hlo:hhi], href[hlo:hhi]) <= 1e-9
+        chk['H vv'] = relerr(hh[vv], href[vv]) <= 1e-9
+        # replicated iterate instead: rank 0 broadcasts all of x
+        xb = torch.from_numpy(x if rank == 0 else np.full_like(x, np.nan)).cuda()
+        c2 = torch.full_like(c, 777.0)
+        v2 = torch.full_like(v, 777.0)
+        sh.bind_cons_jac(xb, c2, v2, stitch=True, x_mode="broadcast")()
+        torch.cuda.synchronize()
+        chk['broadcast c'] = relerr(c2.cpu().numpy(), cref) <= TOL
+        sh.close()
+        bad = [k for k, v_ in chk.items() if not v_]
+        q.put((rank, True if not bad else bad))
+    except Exception as e:      # noqa: BLE001 -- the parent reports it
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,prob,sch", [(2000, "goddard", "gauss_legendre_2"), (1001, "goddard_all", "trapeze"),
+                                        (3000, "double_integrator_path", "midpoint"), (501, "quadrotor", "gauss_legendre_3"),
+                                        (777, "goddard_all", "euler_implicit")])
+def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
+    assert torch.cuda.is_available()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, prob, sch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok is True for _, ok in res), res
+
+
+@pytest.mark.parametrize("N,prob,sch", [(1000, "goddard", "gauss_legendre_2"), (1000, "goddard_all", "trapeze"),
+                                        (999, "double_integrator_path", "midpoint"), (400, "quadrotor12", "gauss_legendre_3"),
+                                        (500, "goddard_all", "euler_implicit")])
+def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
+    """ctd_create_sharded / ctd_cons_jac_sharded_dev_async (the single-process multi-GPU entry point of the C ABI) with the
+    one GPU of this box named three times: sharded iterate (NaN outside what a shard owns until the engine's peer copies
+    fetch the halos), stitched c on every shard, Jacobian pieces composed -- bit-identical to the unsharded handle."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import ctdirect_jl_amd as ct
+    from helpers import bench_inputs, describe
+    full = ct.DOCP(prob, N, sch, device=0, pattern="structural")
+    x = bench_inputs(describe(full, prob, sch), perturb=1e-3)
+    xd = torch.from_numpy(x).cuda()
+    cf, vf = full.cons_jac(xd)
+    md = ct.MultiDeviceDOCP(prob, N, sch, [0, 0, 0], pattern="structural")
+    assert (md.dim_NLP_variables, md.dim_NLP_constraints, md.nnzj) == (full.dim_NLP_variables, full.dim_NLP_constraints, full.nnzj)
+    assert [s.step_begin for s in md.shards] == [0, md.shards[0].step_end, md.shards[1].step_end] and md.shards[2].step_end == N
+    blk, nv = full.discretization._step_variables_block, full.dims.NLP_v
+    for mode in (md.X_SHARDED, md.X_FROM_DEVICE0, md.X_IN_PLACE):
+        xs = []
+        for k, s in enumerate(md.shards):
+            if mode == md.X_IN_PLACE or (mode == md.X_FROM_DEVICE0 and k == 0):
+                xs.append(xd.clone())
+                continue
+            t = np.full_like(x, np.nan)
+            if mode == md.X_SHARDED:
+                end = s.step_end * blk if k < 2 else x.size - nv
+                t[s.step_begin * blk:end] = x[s.step_begin * blk:end]
+                if nv:
+                    t[-nv:] = x[-nv:]
+            xs.append(torch.from_numpy(t).cuda())
+        cs = [torch.full_like(cf, 777.0) for _ in range(3)]
+        vs = [torch.full_like(vf, 777.0) for _ in range(3)]
+        for _ in range(2):            # twice: the second call must not overwrite rows another shard is still pulling
+            md.cons_jac(xs, cs, vs, x_mode=mode, stitch=True, sync=False)
+        md.sync()
+        v = torch.full_like(vf, 777.0)
+        for k in range(3):
+            assert torch.equal(cs[k], cf), (mode, k)                 # whole residual on every shard, bit for bit
+            v = torch.where(vs[k] != 777.0, vs[k], v)
+        assert torch.equal(v, vf), mode
+    md.close()
+    full.close()

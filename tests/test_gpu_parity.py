@@ -5,6 +5,8 @@ Tolerance (BASELINE.json north_star):  max |gpu - ref| / m
 values, Jacobian values and the objective; sparsity patterns bit-exact (checked on CPU in test_abi_cpu.py, re-checked
 here for the handles used).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -252,6 +254,12 @@ def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch
     assert _rel(d.obj(xd), o.objective(x)) <= TOL
     if d.nnzj <= 16_000_000:          # config 4: the oracle's coloured Jacobian is still affordable -> direct parity
         assert relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+    # EVERY Jacobian entry at full size (configs 5' and 5 included) against the oracle's block mode: the same `constraints`
+    # template differentiated one time step at a time on dense local duals (bit-identical to its coloured passes on the
+    # sizes where both run, tests/test_oracle_goldens.py), OpenMP over the steps
+    blk_ref = o.cons_jac_block(x, os.cpu_count() or 1)
+    assert blk_ref is not None
+    assert relerr(c.cpu().numpy(), blk_ref[0]) <= TOL and relerr(v.cpu().numpy(), blk_ref[1]) <= TOL
     # (3) directional derivative: J d (scipy, from the pattern + GPU values) vs central differences of the GPU's c(x)
     import scipy.sparse as sp
     rows, cols = d.jac_structure()
@@ -393,6 +401,8 @@ def test_c_program_evaluates_on_the_gpu(torch_cuda, tmp_path):
     x0 = ct.initial_guess(d)
     c, v = d.cons_jac(x0)
     assert f"objective {d.obj(x0):.6f}  c[0] {c[0]:.6e}  vals[0] {v[0]:.6e}" in out.stdout, out.stdout
+    # the multi-device entry points from plain C: two shards, iterate sent from shard 0, residual stitched on every shard
+    assert "differs from the single-device c in 0 of 904 rows" in out.stdout, out.stdout
     d.close()
 
 

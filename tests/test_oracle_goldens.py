@@ -216,3 +216,28 @@ def test_threaded_coloured_jacobian_equals_serial(oracle_lib, problem, scheme, N
     want = o.jac_coord(x)
     for nt in (1, 3, 64):
         assert np.array_equal(o.jac_coord_mt(x, nt), want)
+
+
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "double_integrator_path", "quadrotor", "quadrotor12",
+                                  "double_integrator_freet0tf", "least_squares_with_constraint"])
+def test_block_mode_equals_coloured_jacobian(oracle_lib, prob):
+    """The oracle's block mode (one time step at a time on dense local duals; the checker of the full-size Jacobians and
+    the best-effort CPU baseline) gives the constraints and, at every pattern position, the exact partial derivative: equal
+    to the coloured passes where the pattern is complete, to dense Jacobian columns where it is not (hazard H1)."""
+    from helpers import bench_inputs, describe
+    for sch in ("trapeze", "midpoint", "euler", "gauss_legendre_2", "gauss_legendre_3", "gauss_legendre_2_constant_control"):
+        for mode in (0, 1):
+            for N in (1, 2, 7):
+                o = oracle_lib.OracleDOCP(prob, sch, N)
+                o.set_pattern_mode(mode)
+                x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+                c, v = o.cons_jac_block(x, 3)
+                assert np.array_equal(c, o.constraints(x))
+                ref = o.jac_coord(x)
+                if not np.array_equal(v, ref):
+                    J = o.jac_dense(x)
+                    cp, rv = o.jac_pattern()
+                    ref = np.array([J[rv[k], j] for j in range(len(cp) - 1) for k in range(cp[j], cp[j + 1])])
+                assert np.array_equal(v, ref), (prob, sch, mode, N)
+    oi = oracle_lib.OracleDOCP(prob, "euler_implicit", 3)      # its path rows read the previous step's control: no block mode
+    assert oi.cons_jac_block(np.full(oi.dim_NLP_variables, 0.3), 1) is None
