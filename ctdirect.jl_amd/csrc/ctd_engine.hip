@@ -92,7 +92,6 @@ struct ctd_handle {
     int64_t* d_hedge_idx = nullptr;
     uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
-    unsigned int* d_hcounter = nullptr;
     std::string err;
 };
 
@@ -147,7 +146,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals, (void*)h->d_hcounter})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -227,7 +226,7 @@ std::vector<std::string> jit_first_exprs(int sc, int s) {
 }
 std::vector<std::string> jit_hess_exprs(int sc, int s) {
     const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
-    return {"ctd::hess_kernel<" + P + ", " + a + ", " + b + ">", "ctd::hess_finish_kernel<" + P + ">"};
+    return {"ctd::hess_kernel<" + P + ", " + a + ", " + b + ", false>", "ctd::hess_finish_kernel<" + P + ">"};
 }
 
 hipError_t jit_launch(hipFunction_t f, int grid, int block, size_t lds, hipStream_t st, void** args, hipEvent_t e0 = nullptr,
@@ -895,15 +894,8 @@ static int32_t ensure_hess(ctd_handle* h) {
     hp.edge_idx = h->d_hedge_idx; hp.eptr = h->d_heptr; hp.evptr = h->d_hevptr; hp.eterms = h->d_heterms;
     hp.tasks = h->d_htasks; hp.ptasks = h->d_hptasks; hp.btasks = h->d_hbtasks;
     hp.partials = h->d_hpartials;
-    // V x V partials: added by a second, one-workgroup kernel (default).  CTD_HESS_FINISH=last lets the last workgroup of
-    // the main kernel do it instead -- measured 2-7x SLOWER on MI355X (profiles/r01_hessian_kernel.md): the device-scope
-    // release every workgroup then needs writes the whole XCD L2 back.  Kept as a measured alternative only.
-    const char* fin = std::getenv("CTD_HESS_FINISH");
-    if (fin && std::string(fin) == "last") {
-        HIP_TRY(h, hipMalloc((void**)&h->d_hcounter, sizeof(unsigned int)));
-        HIP_TRY(h, hipMemset(h->d_hcounter, 0, sizeof(unsigned int)));
-        hp.done_counter = h->d_hcounter;
-    }
+    // V x V partials: added in a fixed order by a second, one-workgroup kernel (a last-workgroup finish inside the main
+    // kernel measured 2-7x slower on MI355X, profiles/r01_hessian_kernel.md: device-scope release per workgroup)
     hp.debug_stop = env_int("CTD_HESS_STOP", 0);
     hp.xcd_remap = env_int("CTD_XCD", 0);
     h->hess_ready = true;
@@ -925,7 +917,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     if (h->rt) {
         void* args[] = {&hp, &x_dev, &y_dev};
         e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, te0, te1);
-        if (e == hipSuccess && hp.nvv > 0 && !hp.done_counter) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
+        if (e == hipSuccess && hp.nvv > 0) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
@@ -1008,8 +1000,10 @@ int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* o) {
     const int64_t b = h->step_end < H.reg_last ? h->step_end : H.reg_last;
     o[0] = H.seg_base + (a - H.reg_first) * (int64_t)H.Lseg;
     o[1] = b > a ? H.seg_base + (b - H.reg_first) * (int64_t)H.Lseg : o[0];
-    o[2] = H.nvv;
-    for (int e = 0; e < H.nvv; ++e) o[3 + e] = H.vv_idx[e];
+    int nvv = 0;                                     // (optimized pattern: entries no evaluation point feeds are not in the pattern)
+    for (int e = 0; e < H.nvv; ++e)
+        if (H.vv_idx[e] >= 0) o[3 + nvv++] = H.vv_idx[e];
+    o[2] = nvv;
     return CTD_OK;
 }
 

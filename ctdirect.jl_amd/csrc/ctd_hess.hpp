@@ -143,9 +143,6 @@ struct HParams {
     double obj_weight;
     double* vals;
     double* partials;           // (ntiles + 1) * nvv: V x V partial sums per workgroup (workgroup 0 = edge)
-    // experiment (CTD_HESS_FINISH=last, slower on MI355X): when non-null the LAST workgroup to finish adds up the partials
-    // itself (device-scope fences + one atomic per workgroup) instead of a second kernel; it resets the counter to 0
-    unsigned int* done_counter;
     // diagnostics only (env CTD_HESS_STOP): 0 normal; 1 return after load, 2 after eval (ablation timing, outputs incomplete)
     int32_t debug_stop;
     // diagnostics only (ctd_hess_debug_stamps): lane 0 of every workgroup stores 5 x {100 MHz realtime, shader cycles}

@@ -209,6 +209,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         const uint32_t w0 = (st && tid <= hp.Lseg) ? hp.tptr[tid] : 0u, w1 = (st && tid < hp.nterms) ? hp.terms[tid] : 0u;
         const uint32_t w2 = (st && tid <= hp.nvv) ? hp.vptr[tid] : 0u, w3 = (st && tid < hp.nvterms) ? hp.vterms[tid] : 0u;
         const uint32_t w4 = (st && tid < hp.ntask) ? hp.tasks[tid] : 0u, w5 = (st && tid < hp.nptask) ? hp.ptasks[tid] : 0u;
+        const double tau_e = tid <= cx.nslots + 2 ? htau_global(hp, cx.lo - 1 + tid) : 0.0;     // (table load: issued with the rest)
         if (tid < cnt) dst[tid] = x0;
         if (tid + nthr < cnt) dst[tid + nthr] = x1;
         if (tid < ny) cx.ly[tid] = y0;
@@ -227,7 +228,8 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         }
         for (int e = tid + 2 * nthr; e < cnt; e += nthr) dst[e] = src[e];
         for (int e = tid + 2 * nthr; e < ny; e += nthr) cx.ly[e] = yval(e);
-        for (int e = tid; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
+        if (tid <= cx.nslots + 2) cx.tau[tid] = tau_e;
+        for (int e = tid + nthr; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
         return;
     }
     if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;

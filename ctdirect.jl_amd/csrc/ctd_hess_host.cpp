@@ -60,6 +60,13 @@ static void build_hess_tail(Model& mo) {
     }
     if (L.sc == SC_MIDPOINT) {                                          // midpoint.jl:284-290, euler.jl:337-343
         hpush(out, 0, n, xf0, xf1, true);
+        // explicit Euler's step blocks never reach the final state (euler.jl:297-326), so the reference's pattern has no
+        // (x_f, x_f) / (x_f, v) block although the boundary / Mayer / final-time path terms live there; the OPTIMIZED pattern
+        // (what a tracer finds) has them
+        if (mo.pattern_mode == 2 && L.euler == 1) {
+            hpush(out, xf0, xf1, xf0, xf1);
+            hpush(out, xf0, xf1, L.v_off, L.nvar, true);
+        }
         return;
     }
     // irk.jl:465-486 / irk_stagewise.jl:607-628 (u(tf) = U_N convention)
@@ -69,10 +76,15 @@ static void build_hess_tail(Model& mo) {
     hpush(out, xf0, xf1, uf0, uf1, true);
     // the reference's (xf_start:uf_end) x v block is an empty range (xf_start > uf_end): nothing pushed.  STRUCTURAL
     // mode adds the block the surrounding comment intends
-    if (mo.pattern_mode == 1) hpush(out, xf0, xf1, L.v_off, L.nvar, true);
+    if (mo.pattern_mode >= 1) hpush(out, xf0, xf1, L.v_off, L.nvar, true);
     hpush(out, uf0, uf1, L.v_off, L.nvar, true);
     hpush(out, 0, n, xf0, xf1, true);
 }
+
+// CTD_PATTERN_OPTIMIZED keeps the entries of the (structural) blocks that receive at least one structurally nonzero term --
+// the pairs the dependency-mask probe finds at the evaluation points, mapped through the scheme's chain rule: what a global
+// second-order tracer over the Lagrangian reports (nnzh 5259 for Goddard, midpoint, N = 250, test/ci/test_modeler_solver.jl:32)
+static bool hess_opt_keep(const Model& mo, int64_t row, int64_t col);
 
 void Model::hess_gen_column(int64_t j, std::vector<int64_t>& rows) const {
     rows.clear();
@@ -91,7 +103,8 @@ void Model::hess_gen_column(int64_t j, std::vector<int64_t>& rows) const {
     int64_t next = -1;
     for (auto& p : iv) {
         int64_t r = std::max(p.first, next);
-        for (; r < p.second; ++r) rows.push_back(r);
+        for (; r < p.second; ++r)
+            if (pattern_mode != 2 || hess_opt_keep(*this, r, j)) rows.push_back(r);
         next = std::max(next, p.second);
     }
 }
@@ -193,6 +206,48 @@ struct RuntimeFns {
         for (size_t q = 0; q < ro.p_boundary.size(); ++q) r[q] = run(ro.p_boundary[q], nullptr, nullptr, nullptr, v, x0, xf);
     }
 };
+
+// First-order masks of every output of the OCP functions, the way a global operator-overloading tracer sees them
+// (SparseConnectivityTracer behind ADNLPModels' default backend, src/collocation.jl:131-134): a dependence survives
+// `u * 0`, and time enters as the free-time variables.
+template <class F>
+static void probe_first_order(Model& mo, const F& fn) {
+    const Layout& L = mo.L;
+    const int n = L.n, m = L.m, nv = L.nv, np = L.p, nb = L.bc, vd = n + m;
+    uint32_t TV = 0;
+    if (L.it0 >= 0) TV |= 1u << (vd + L.it0);
+    if (L.itf >= 0) TV |= 1u << (vd + L.itf);
+    const SP t = SP::dir(TV);
+    std::vector<SP> x(n > 0 ? n : 1), u(m > 0 ? m : 1), v(nv > 0 ? nv : 1);
+    for (int r = 0; r < n; ++r) x[r] = SP::dir(1u << r);
+    for (int b = 0; b < m; ++b) u[b] = SP::dir(1u << (n + b));
+    for (int k = 0; k < nv; ++k) v[k] = SP::dir(1u << (vd + k));
+    std::vector<SP> f(n > 0 ? n : 1);
+    fn.dynamics(f.data(), t, x.data(), u.data(), v.data());
+    mo.dep_f.assign(n, 0);
+    for (int r = 0; r < n; ++r) mo.dep_f[r] = f[r].m1;
+    mo.dep_g.assign(np, 0);
+    if (np > 0) {
+        std::vector<SP> g(np);
+        fn.path(g.data(), t, x.data(), u.data(), v.data());
+        for (int q = 0; q < np; ++q) mo.dep_g[q] = g[q].m1;
+    }
+    mo.dep_b.assign(nb, 0);
+    if (nb > 0) {
+        std::vector<SP> x0(n > 0 ? n : 1), xf(n > 0 ? n : 1), vb(nv > 0 ? nv : 1), r_(nb);
+        for (int r = 0; r < n; ++r) { x0[r] = SP::dir(1u << r); xf[r] = SP::dir(1u << (n + r)); }
+        for (int k = 0; k < nv; ++k) vb[k] = SP::dir(1u << (2 * n + k));
+        fn.boundary(r_.data(), x0.data(), xf.data(), vb.data());
+        for (int b = 0; b < nb; ++b) mo.dep_b[b] = r_[b].m1;
+    }
+}
+
+void compute_dep_masks(Model& mo) {
+    if (!for_problem(mo.problem, [&](auto tag) { probe_first_order(mo, RegistryFns<typename decltype(tag)::type>{}); })) {
+        const RtOcp* ro = runtime_ocp(mo.problem);
+        if (ro) probe_first_order(mo, RuntimeFns{*ro});
+    }
+}
 
 template <class F>
 static void probe_structure(Model& mo, const F& fn) {
@@ -382,6 +437,21 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
     }
 }
 
+static bool hess_opt_keep(const Model& mo, int64_t row, int64_t col) {
+    const Layout& L = mo.L;
+    const HessRecLayout& R = mo.H.R;
+    if (row >= L.v_off && col >= L.v_off) {           // V x V: summed over every evaluation point
+        const int a = (int)(col - L.v_off), b = (int)(row - L.v_off), vd = L.n + L.m;
+        if (!mo.H.need_stage.empty() && mo.H.need_stage[sym_index(R.md, vd + a, vd + b)]) return true;
+        if (L.p > 0 && L.sc != SC_TRAPEZE && !mo.H.need_path.empty() && mo.H.need_path[sym_index(R.md, vd + a, vd + b)]) return true;
+        if ((L.bc > 0 || mo.info.mayer) && !mo.H.need_bnd.empty() && mo.H.need_bnd[sym_index(R.mdb, 2 * L.n + a, 2 * L.n + b)]) return true;
+        return false;
+    }
+    std::vector<Term> tt;
+    collect_terms(mo, row, col, tt);
+    return !tt.empty();
+}
+
 // id of the coefficient product C[c1] * C[c2] (registered on first use; -1 when the table is full)
 static int pair_id(HessModel& H, int c1, int c2) {
     if (c1 > c2) std::swap(c1, c2);
@@ -487,9 +557,12 @@ int build_hess_model(Model& mo, std::string& err) {
         const int md = H.R.md, vd = L.n + L.m;
         for (int kc = 0; kc < L.nv; ++kc) {
             mo.hess_gen_column(L.v_off + kc, rows);
-            if ((int)rows.size() != L.nv - kc) { err = "internal: V x V block is not dense lower-triangular"; return ST_EPATTERN; }
+            if (mo.pattern_mode != 2 && (int)rows.size() != L.nv - kc) { err = "internal: V x V block is not dense lower-triangular"; return ST_EPATTERN; }
             for (int kr = kc; kr < L.nv; ++kr, ++e) {
-                H.vv_idx[e] = mo.hess_column_start(L.v_off + kc) + (kr - kc);
+                // (optimized pattern: an entry no evaluation point feeds is not in the pattern: position -1, no terms)
+                const auto it = std::find(rows.begin(), rows.end(), L.v_off + kr);
+                H.vv_idx[e] = it == rows.end() ? -1 : mo.hess_column_start(L.v_off + kc) + (int64_t)(it - rows.begin());
+                if (it == rows.end()) { H.vptr.push_back((uint32_t)H.vterms.size()); continue; }
                 for (int j = 0; j < H.R.S; ++j)
                     if (H.need_stage[sym_index(md, vd + kc, vd + kr)])
                         H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + sym_index(md, vd + kc, vd + kr), 0, 0));

@@ -237,7 +237,7 @@ void Model::step_blocks(int64_t i, std::vector<Block>& out) const {
         push_block(out, path0, path1, vo, vo + n);                // :197
         push_block(out, path0, path1, vo + n, vo + n + m);        // :198
         push_block(out, path0, path1, v0, v1);                    // :203  (path rows only: hazard H1)
-        if (pattern_mode == 1) push_block(out, dyn0, dyn1, v0, v1);   // STRUCTURAL: the block the comment at :202 intends
+        if (pattern_mode >= 1) push_block(out, dyn0, dyn1, v0, v1);   // STRUCTURAL: the block the comment at :202 intends
     } else if (L.sc == SC_MIDPOINT) {                             // midpoint.jl:175-204; euler.jl:208-232 lists the same blocks
         push_block(out, co, co + n, vo, vo + blk + n);            // :192-194  x_i, u_i, x_i+1
         push_block(out, co + n, co + cb, vo, vo + n + m);         // :197-199
@@ -296,9 +296,92 @@ void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
     int64_t next = -1;
     for (auto& p : iv) {
         int64_t r = std::max(p.first, next);
-        for (; r < p.second; ++r) rows.push_back(r);
+        for (; r < p.second; ++r)
+            if (pattern_mode != 2 || opt_dep(r, j)) rows.push_back(r);      // OPTIMIZED: the traced subset of the structural blocks
         next = std::max(next, p.second);
     }
+}
+
+// CTD_PATTERN_OPTIMIZED: does constraint `row` depend on variable `col` at the operator level?  The rules restate what a
+// global tracer sees when it runs the reference's __constraints! (src/DOCP_functions.jl:80-115 with the scheme's step
+// function): own-state terms, the step length h (free times), and the arguments the OCP function is called with --
+// x_m = (X_i + X_{i+1}) / 2 (midpoint.jl:53-66), x_ij = X_i + h sum_l a_jl K^l (irk_stagewise.jl:424-446), the b-averaged
+// stage control of the path constraints (irk_stagewise.jl:197-205), ...  SURVEY.md Appendix A.6 derives Goddard / midpoint:
+// 6 + 8 + 4 entries per step + 4 boundary singletons = 4504 at N = 250 (test/ci/test_modeler_solver.jl:32).
+bool Model::opt_dep(int64_t row, int64_t col) const {
+    const int64_t N = L.N;
+    const int n = L.n, m = L.m, nv = L.nv, vd = n + m;
+    uint32_t TV = 0;
+    if (L.it0 >= 0) TV |= 1u << (vd + L.it0);
+    if (L.itf >= 0) TV |= 1u << (vd + L.itf);
+    auto xbit = [&](uint32_t mask, int c) { return (mask >> c & 1u) != 0; };
+    auto ubit = [&](uint32_t mask, int c) { return (mask >> (n + c) & 1u) != 0; };
+    auto vbit = [&](uint32_t mask, int k) { return (mask >> (vd + k) & 1u) != 0; };
+    const uint32_t xmask = (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
+    const bool isv = col >= L.v_off;
+    const int kv = isv ? (int)(col - L.v_off) : 0;
+    if (row >= N * L.cb + L.p) {                       // boundary row: phi_b(X_1, X_{N+1}, v)
+        const uint32_t mk = dep_b[row - N * L.cb - L.p];
+        if (isv) return (mk >> (2 * n + kv) & 1u) != 0;
+        if (col < n) return (mk >> col & 1u) != 0;
+        const int64_t q = col - N * L.blk;
+        return q >= 0 && q < n && (mk >> (n + q) & 1u) != 0;
+    }
+    if (row >= N * L.cb) {                             // final-time path row: g_q(t_f, X_{N+1}, u_f, v)
+        const uint32_t mk = dep_g[row - N * L.cb];
+        if (isv) return vbit(mk, kv);
+        const int64_t q = col - N * L.blk;
+        if (q >= 0 && q < n) return xbit(mk, (int)q);
+        if (L.sc == SC_TRAPEZE) return q >= n && q < n + m && ubit(mk, (int)(q - n));
+        const int64_t o = col - ((N - 1) * L.blk + n);                       // u(t_f) := controls of step N
+        return o >= 0 && o < L.cu && ubit(mk, (int)(L.stagewise ? o % m : o));
+    }
+    const int64_t i = row / L.cb;
+    const int lr = (int)(row % L.cb);
+    const int64_t q = isv ? -1 : col - i * L.blk;      // local column: own block [0, blk), X_{i+1} [blk, blk+n), U_{i+1} (trapeze)
+    if (!isv && (q < 0 || q >= L.blk + n + m)) return false;
+    if (lr >= L.eqs) {                                 // path row at node i: g_q(t_i, X_i, u_i, v)
+        const uint32_t mk = dep_g[lr - L.eqs];
+        if (isv) return vbit(mk, kv);
+        if (q < n) return xbit(mk, (int)q);
+        if (q < n + L.cu) return ubit(mk, (int)(L.stagewise ? (q - n) % m : q - n));     // stagewise: every stage control (average)
+        return false;
+    }
+    if (L.sc == SC_IRK) {
+        const int s = L.s;
+        if (lr < n) {                                  // state row: X_{i+1} - (X_i + h sum_j b_j K^j)
+            if (isv) return (TV >> (vd + kv) & 1u) != 0;
+            if (q < n) return q == lr;
+            if (q < n + L.cu) return false;
+            if (q < L.blk) return (q - n - L.cu) % n == lr;
+            return q - L.blk == lr && q < L.blk + n;
+        }
+        const int j = (lr - n) / n, r = (lr - n) % n;  // stage row: K^j - f(t_ij, x_ij, u_ij, v)
+        const uint32_t mk = dep_f[r];
+        const bool through_x = (mk & xmask) != 0;      // x_ij carries X_i, every K^l and (free times) h
+        if (isv) return vbit(mk, kv) || (through_x && (TV >> (vd + kv) & 1u));
+        if (q < n) return xbit(mk, (int)q);
+        if (q < n + L.cu) {
+            if (L.stagewise) return (q - n) / m == j && ubit(mk, (int)((q - n) % m));
+            return ubit(mk, (int)(q - n));
+        }
+        if (q < L.blk) {
+            const int l = (int)(q - n - L.cu) / n, c = (int)(q - n - L.cu) % n;
+            return (l == j && c == r) || xbit(mk, c);
+        }
+        (void)s;
+        return false;
+    }
+    // trapeze / midpoint / Euler: X_{i+1} - (X_i + h * (...f...))
+    const int r = lr;
+    const uint32_t mk = dep_f[r];
+    if (isv) return vbit(mk, kv) || (TV >> (vd + kv) & 1u);
+    const bool at_i = (L.sc == SC_TRAPEZE) || L.euler == 0 || L.euler == 1;       // f reads X_i (U_i always)
+    const bool at_ip1 = (L.sc == SC_TRAPEZE) || L.euler == 0 || L.euler == 2;     // f reads X_{i+1}
+    if (q < n) return q == r || (at_i && xbit(mk, (int)q));
+    if (q < L.blk) return ubit(mk, (int)(q - n));
+    if (q < L.blk + n) return q - L.blk == r || (at_ip1 && xbit(mk, (int)(q - L.blk)));
+    return L.sc == SC_TRAPEZE && ubit(mk, (int)(q - L.blk - n));                   // U_{i+1}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -688,7 +771,7 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
 int build_model(const HostDesc& d, Model& mo, std::string& err) {
     mo.problem = d.problem;
     mo.pattern_mode = d.pattern_mode;
-    if (d.pattern_mode != 0 && d.pattern_mode != 1) { err = "unknown pattern mode"; return ST_EPATTERN; }
+    if (d.pattern_mode < 0 || d.pattern_mode > 2) { err = "unknown pattern mode"; return ST_EPATTERN; }
     bool found = for_problem(d.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         mo.info = P::info();
@@ -724,6 +807,13 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         for (int64_t i = 0; i <= N; ++i) mo.fixed_grid[i] = mo.L.t0 + (mo.tau[i] * (mo.L.tf - mo.L.t0));
     build_bounds(mo);
     build_tail_blocks(mo);
+    if (mo.pattern_mode == 2) {
+        compute_dep_masks(mo);
+        if (mo.L.euler == 2 && mo.L.p > 0 && mo.L.m > 0) {
+            err = "optimized pattern: implicit Euler reads the path constraints' control from the previous step (not supported)";
+            return ST_EPATTERN;
+        }
+    }
     st = build_tables(mo, err);
     if (st) return st;
     return build_hess_model(mo, err);

@@ -92,6 +92,11 @@ struct Model {
     // tail columns [reg_last*blk, nvar); periodic in between (cp_tmpl is relative to the step's segment)
     std::vector<int64_t> cp_head, cp_tmpl, cp_tail;
 
+    // CTD_PATTERN_OPTIMIZED: operator-level dependence masks of the OCP functions (bits: x 0..n-1, u n..n+m-1, v n+m..;
+    // a dependence on t shows as the free-time variables).  Boundary masks: x0 0..n-1, xf n..2n-1, v 2n...
+    std::vector<uint32_t> dep_f, dep_g, dep_b;
+    bool opt_dep(int64_t row, int64_t col) const;     // (row, col) belongs to the optimized pattern
+
     struct Entry { int kind; int64_t cstep, dstep; int ci, di, beta; bool cconst; };   // kind 0 step row, 1 final path, 2 boundary
     Entry classify(int64_t row, int64_t col) const;
     void step_blocks(int64_t i, std::vector<Block>& out) const;
@@ -107,6 +112,8 @@ struct Model {
     void fill_hparams(HParams& hp, int tile, int64_t step_begin = 0, int64_t step_end = 0) const;
 };
 
+// operator-level dependence masks (Model::dep_f / dep_g / dep_b) of the OCP functions, for CTD_PATTERN_OPTIMIZED
+void compute_dep_masks(Model& m);
 // builds Model::H (pattern bookkeeping + term tables); called by build_model
 int build_hess_model(Model& m, std::string& err);
 int default_hess_tile(const Model& m);

@@ -260,6 +260,7 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const double vv = (LOAD_V && tid < P::NV) ? xu[L.v_off + tid] : 0.0;
         const uint32_t c0 = (codes && tid < kp.Lseg) ? kp.tmpl[tid] : 0u;
         const uint32_t c1 = (codes && tid < nvc) ? kp.vtmpl[tid] : 0u;
+        const double tau_e = tid <= cx.nslots + 1 ? tau_global(kp, cx.lo + tid) : 0.0;      // (table load: issued with the rest)
         if (tid < cnt) dst[tid] = x0;
         if (tid + nthr < cnt) dst[tid + nthr] = x1;
         if (LOAD_V && tid < kMaxNV) cx.v[tid] = vv;
@@ -271,7 +272,8 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
             for (int e = tid + nthr; e < nvc; e += nthr) cd[kp.Lseg + e] = kp.vtmpl[e];
         }
         for (int e = tid + 2 * nthr; e < cnt; e += nthr) dst[e] = src[e];
-        for (int e = tid; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
+        if (tid <= cx.nslots + 1) cx.tau[tid] = tau_e;
+        for (int e = tid + nthr; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
         return;
     }
     if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;

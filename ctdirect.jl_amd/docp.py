@@ -49,7 +49,7 @@ PROBLEMS = {
     "least_squares_with_constraint": 8,
     "double_integrator_freet0tf": 9,
 }
-PATTERN_MODES = {"manual": 0, "reference_manual": 0, "structural": 1}
+PATTERN_MODES = {"manual": 0, "reference_manual": 0, "structural": 1, "optimized": 2}
 
 
 class CTDirectError(RuntimeError):
@@ -204,6 +204,14 @@ class DOCP:
         self._h = h
         self.device = int(device)
         self._load_static()
+        if d.pattern_mode == 0 and self.dropped_nonzeros() > 0:
+            # the reference's :manual pattern leaves structural nonzeros out here (trapeze.jl:203: dynamics rows x variables;
+            # euler.jl:231: implicit Euler's path rows x previous control): values at the pattern's positions are exact, but
+            # a solver fed this Jacobian misses those entries
+            import warnings
+            warnings.warn(f"pattern='manual' reproduces the reference's DOCP_Jacobian_pattern, which omits {self.dropped_nonzeros()} "
+                          f"structural nonzeros for {self.problem_name} / {self.scheme}; pass pattern='structural' (or 'optimized') "
+                          "to solve with a complete Jacobian", stacklevel=2)
 
     # ---- static data ------------------------------------------------------------------------------------
     def _load_static(self):

@@ -83,7 +83,11 @@ enum {
 
 enum {
     CTD_PATTERN_REFERENCE_MANUAL = 0, /* DOCP_Jacobian_pattern exactly as written (bug-compatible, SURVEY hazards H1/H2) */
-    CTD_PATTERN_STRUCTURAL = 1        /* = manual + the dynamics-row x V block trapeze.jl:203 omits */
+    CTD_PATTERN_STRUCTURAL = 1,       /* = manual + the dynamics-row x V block trapeze.jl:203 omits */
+    CTD_PATTERN_OPTIMIZED = 2         /* the sparsity ADNLPModels' default backend detects itself (src/collocation.jl:131-134:
+                                         SparseConnectivityTracer over c! and the Lagrangian): operator-level dependence of every
+                                         row, e.g. nnzj 4504 / nnzh 5259 instead of 6028 / 6519 for Goddard, midpoint, N = 250
+                                         (test/ci/test_modeler_solver.jl:32,37).  Fewer entries = fewer bytes per evaluation */
 };
 
 /* replaces the arguments of CTDirect.DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293-365,

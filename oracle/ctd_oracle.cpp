@@ -833,9 +833,24 @@ static void color_columns(Docp& p, const std::vector<int64_t>& colptr, const std
     }
 }
 
+// pattern mode 2 (":optimized"): the sparsity ADNLPModels detects itself when no pattern is handed over
+// (src/collocation.jl:131-134: the `backend` preset -> SparseConnectivityTracer's global operator-overloading tracer over
+// c!(c, x) and the Lagrangian).  Restated with the sparse second-order number S2: its gradient / Hessian containers hold an
+// entry for every variable (pair) an operation chain touches, whatever the value -- the same conservative, operator-level
+// rule (`u * 0` still depends on u; test/ci/test_modeler_solver.jl:32 pins nnzj 4504 / nnzh 5259 for Goddard, midpoint, N = 250).
+static void traced_patterns(Docp& p, IJ& jac, std::vector<std::pair<int64_t, int64_t>>& hess_lower);
+
 static void ensure_pattern(Docp& p) {
     if (p.have_pattern) return;
     IJ ij;
+    if (p.pattern_mode == 2) {
+        std::vector<std::pair<int64_t, int64_t>> hl;
+        traced_patterns(p, ij, hl);
+        to_csc(ij, p.dim_NLP_variables, p.colptr, p.rowval);
+        color_columns(p, p.colptr, p.rowval);      // every structural nonzero is in the traced pattern: colour on it
+        p.have_pattern = true;
+        return;
+    }
     jacobian_pattern_ij(p, ij);
     to_csc(ij, p.dim_NLP_variables, p.colptr, p.rowval);
     // The colouring must see every TRUE structural nonzero or the compressed passes mix columns.  The reference's manual
@@ -1012,6 +1027,22 @@ template <class P> static void objective_gradient(const Docp& p, const double* x
 // hess_structure! (NLPModels convention row >= col) and the order hess_coord! fills.
 static void ensure_hess_pattern(Docp& p) {
     if (p.have_hess_pattern) return;
+    if (p.pattern_mode == 2) {                         // traced lower triangle (see traced_patterns)
+        IJ jac;
+        std::vector<std::pair<int64_t, int64_t>> hl;   // (col, row), row >= col
+        traced_patterns(p, jac, hl);
+        std::sort(hl.begin(), hl.end());
+        hl.erase(std::unique(hl.begin(), hl.end()), hl.end());
+        p.hcolptr.assign(p.dim_NLP_variables + 1, 0);
+        p.hrowval.clear();
+        size_t k = 0;
+        for (int64_t j = 0; j < p.dim_NLP_variables; ++j) {
+            for (; k < hl.size() && hl[k].first == j; ++k) p.hrowval.push_back(hl[k].second);
+            p.hcolptr[j + 1] = (int64_t)p.hrowval.size();
+        }
+        p.have_hess_pattern = true;
+        return;
+    }
     IJ ij;
     hessian_pattern_ij(p, ij);
     std::vector<int64_t> colptr, rowval;
@@ -1075,6 +1106,22 @@ template <class F> static void dispatch(int pid, F&& f) {
         case 9: f(Tag<DoubleIntegratorFreeT0Tf>{}); break;
         default: throw std::runtime_error("unknown problem id");
     }
+}
+
+template <class P> static void traced_patterns_for(const Docp& p, IJ& jac, std::vector<std::pair<int64_t, int64_t>>& hl) {
+    const int64_t nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    std::vector<S2> z(nvar), cz(ncon);
+    for (int64_t j = 0; j < nvar; ++j) z[j] = S2::variable(0.3 + 0.001 * (double)(j % 97), j);      // any point: only the structure is read
+    constraints<P, S2>(p, z.data(), cz.data());
+    for (int64_t i = 0; i < ncon; ++i) {
+        for (auto& e : cz[i].g) jac.single(i + 1, e.first + 1);
+        for (auto& e : cz[i].h) hl.emplace_back((int64_t)(e.first & 0xffffffffu), (int64_t)(e.first >> 32));
+    }
+    const S2 f = objective<P, S2>(p, z.data());
+    for (auto& e : f.h) hl.emplace_back((int64_t)(e.first & 0xffffffffu), (int64_t)(e.first >> 32));
+}
+static void traced_patterns(Docp& p, IJ& jac, std::vector<std::pair<int64_t, int64_t>>& hl) {
+    dispatch(p.problem, [&](auto tag) { traced_patterns_for<typename decltype(tag)::type>(p, jac, hl); });
 }
 
 template <class P> static void make_docp(Docp& p, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len) {

@@ -67,7 +67,7 @@ static void run_hess_blocks(const HParams& hp, const double* xu, const double* y
         for (int t = 0; t < fthr; ++t) red[t] = hess_finish_partial(hp, e, t, fthr);
         for (int off = fthr >> 1; off > 0; off >>= 1)
             for (int t = 0; t < off; ++t) red[t] = red[t] + red[t + off];
-        hp.vals[hp.vv_idx[e]] = red[0];
+        if (hp.vv_idx[e] >= 0) hp.vals[hp.vv_idx[e]] = red[0];
     }
 }
 
@@ -184,7 +184,6 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     hp.vals = vals;
     std::vector<double> partials((size_t)(hp.ntiles + 1) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
     hp.partials = partials.data();
-    hp.done_counter = nullptr;     // the emulator steps the separate finish
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {

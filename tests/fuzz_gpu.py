@@ -41,11 +41,10 @@ while time.time() < t_end:
     if rng.random() < 0.35 and N >= 2:
         a = int(rng.integers(0, N)); b = int(rng.integers(a + 1, N + 1)); steps = (a, b)
     os.environ["CTD_TILE"] = str(tile) if tile else ""; os.environ["CTD_HESS_TILE"] = str(htile) if htile else ""
-    fin_last = rng.random() < 0.15; os.environ["CTD_HESS_FINISH"] = "last" if fin_last else ""
     use_twin = JIT and prob in jit_defs.TWINS and rng.random() < 0.5
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
-            f"finlast={int(fin_last)} twin={int(use_twin)} api={api}")
+            f"twin={int(use_twin)} api={api}")
     try:
         d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps)
         o = OracleDOCP(prob, sch, N, time_grid=tg) if tg is not None else OracleDOCP(prob, sch, N)

@@ -245,3 +245,33 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     out = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "nvar 1104 ncon 904 nnzj 11128 nnzh 7722" in out.stdout and "no CPU fallback" in out.stdout
+
+
+def test_optimized_pattern_reference_golden_and_oracle_parity(oracle_lib):
+    """CTD_PATTERN_OPTIMIZED: the sparsity the reference's default backend detects (src/collocation.jl:131-134).  Golden of
+    the reference's CI: Goddard, midpoint, N = 250 -> nnzj 4504 / nnzh 5259 (test/ci/test_modeler_solver.jl:32); for every
+    registry problem x scheme both patterns equal the oracle's traced ones, bit for bit in CSC order."""
+    d = ct.DOCP("goddard", 250, "midpoint", pattern="optimized", device=-1)
+    assert (d.nnzj, d.nnzh) == (4504, 5259)
+    assert d.dropped_nonzeros() == 0
+    for prob in [p for p in ct.PROBLEMS if isinstance(p, str)]:
+        for sch in ct.SCHEMES:
+            for N in (1, 3, 5, 8):
+                try:
+                    d = ct.DOCP(prob, N, sch, pattern="optimized", device=-1)
+                except ct.CTDirectError as e:       # implicit Euler + path constraints + controls: refused, never silently wrong
+                    assert e.status == ct._lib.CTD_EPATTERN and sch in ("euler_implicit",)
+                    break
+                o = oracle_lib.OracleDOCP(prob, sch, N)
+                o.set_pattern_mode(2)
+                cp, rv = o.jac_pattern()
+                cp2, rv2 = ct.DOCP_Jacobian_pattern(d)
+                assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2), (prob, sch, N)
+                hp, hr = o.hess_pattern()
+                hp2, hr2 = ct.DOCP_Hessian_pattern(d)
+                assert np.array_equal(hp, hp2) and np.array_equal(hr, hr2), (prob, sch, N)
+    # fewer entries = fewer bytes per evaluation at the BASELINE sizes
+    for prob, sch, N in (("goddard", "gauss_legendre_3", 80000), ("quadrotor12", "gauss_legendre_3", 20000)):
+        a = ct.DOCP(prob, N, sch, device=-1)
+        b = ct.DOCP(prob, N, sch, pattern="optimized", device=-1)
+        assert b.nnzj < a.nnzj and b.nnzh <= a.nnzh

@@ -443,3 +443,32 @@ def test_distinct_handles_are_usable_from_concurrent_threads(torch_cuda):
         (c0, v0), g0, h0 = want[k][2], want[k][3], want[k][4]
         (c1, v1), g1, h1 = got[k]
         assert np.array_equal(c0, c1) and np.array_equal(v0, v1) and np.array_equal(g0, g1) and np.array_equal(h0, h1), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "double_integrator_path", "quadrotor", "quadrotor12",
+                                  "double_integrator_freet0tf", "least_squares_with_constraint"])
+def test_optimized_pattern_values_on_gpu(oracle_lib, torch_cuda, prob):
+    """CTD_PATTERN_OPTIMIZED (the sparsity the reference's default backend detects, src/collocation.jl:131-134): constraints,
+    Jacobian values and Hessian values on the smaller patterns equal the oracle's on its traced patterns; every entry written."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    for sch, N in (("trapeze", 257), ("midpoint", 1000), ("euler", 64), ("gauss_legendre_2", 257), ("gauss_legendre_3", 64),
+                   ("gauss_legendre_2_constant_control", 5), ("gauss_legendre_3", 3)):
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        o.set_pattern_mode(2)
+        d = ct.DOCP(prob, N, sch, pattern="optimized", device=0)
+        assert d.nnzj == o.jac_nnz() and d.nnzh == len(o.hess_pattern()[1])
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+        y = rng.standard_normal(o.dim_NLP_constraints)
+        xd = torch.from_numpy(x).cuda()
+        c = torch.full((d.dim_NLP_constraints,), SENT, dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), SENT, dtype=torch.float64, device="cuda")
+        h = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+        d.cons_jac(xd, c, v)
+        d.hess_coord(xd, torch.from_numpy(y).cuda(), 0.7, h)
+        assert not bool((c == SENT).any()) and not bool((v == SENT).any()) and not bool((h == SENT).any())
+        assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+        want, dropped = o.hess_coord(x, y, 0.7, return_dropped=True)
+        assert dropped == (0, 0) and relerr(h.cpu().numpy(), want) <= 1e-9
+        d.close()

@@ -94,6 +94,18 @@ def test_emulated_hessian_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
             vals = emu.hess(pid, sid, 0, N, x, y, sigma, tg, tile=tile, nthr=nthr)
             assert not np.any(vals == 666.666)
             assert relerr(vals, want) <= TOL
+        # the OPTIMIZED pattern (pattern mode 2): same values at its (fewer) positions, nothing of the exact Hessian left out
+        try:
+            ct.DOCP(prob, N, sch, time_grid=tg, pattern="optimized", device=-1)
+        except ct.CTDirectError:
+            assert sch == "euler_implicit"
+            continue
+        o.set_pattern_mode(2)
+        want, dropped = o.hess_coord(x, y, 0.7, return_dropped=True)
+        assert dropped == (0, 0)
+        vals = emu.hess(pid, sid, 2, N, x, y, 0.7, tg, tile=tile, nthr=nthr)
+        assert vals.size == want.size and not np.any(vals == 666.666)
+        assert relerr(vals, want) <= TOL
     # linearity in (obj_weight, y) and zero multipliers: H(0, 0) = 0
     o = oracle_lib.OracleDOCP(prob, sch, 7)
     x = bench_inputs(describe(o, prob, sch), perturb=1e-2)

@@ -38,15 +38,23 @@ def test_emulated_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
         x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
         cref = o.constraints(x)
         Jd = o.jac_dense(x) if N <= 13 else None
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
+            if mode == 2:      # OPTIMIZED: refused (never silently wrong) for implicit Euler with path constraints and controls
+                try:
+                    ct.DOCP(prob, N, sch, time_grid=tg, pattern="optimized", device=-1)
+                except ct.CTDirectError:
+                    assert sch == "euler_implicit"
+                    continue
             o.set_pattern_mode(mode)
             cp, rv = o.jac_pattern()
             if Jd is not None:
                 vref = dense_on_pattern(Jd, cp, rv)
-            elif mode == 1:
+            elif mode >= 1:
                 vref = o.jac_coord(x)
             else:
                 continue
+            cp2, rv2 = emu.csc(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, N, tg)
+            assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2)
             for tile, nthr in ((0, 64), (1, 5), (4, 33), (7, 256)):
                 c, vals = emu.cons_jac(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, N, x, tg, tile=tile, nthr=nthr)
                 assert not np.any(c == 666.666) and not np.any(vals == 666.666)      # every output written

@@ -241,3 +241,29 @@ def test_block_mode_equals_coloured_jacobian(oracle_lib, prob):
                 assert np.array_equal(v, ref), (prob, sch, mode, N)
     oi = oracle_lib.OracleDOCP(prob, "euler_implicit", 3)      # its path rows read the previous step's control: no block mode
     assert oi.cons_jac_block(np.full(oi.dim_NLP_variables, 0.3), 1) is None
+
+
+def test_G2_optimized_backend_counts(oracle_lib):
+    """The `:optimized` half of the reference's CI golden: Goddard, midpoint, N = 250 -> nnzj 4504, nnzh 5259
+    (test/ci/test_modeler_solver.jl:32: ADNLPModels detects the sparsity itself with its operator-overloading tracer).  The
+    oracle restates that detection with the sparse second-order number it pushes through `constraints` / `objective`
+    (pattern mode 2); goddard_all, trapeze, N = 1000 gives the archived Hessian count 11011 (test/archives/AD_backend.md:61)."""
+    o = oracle_lib.OracleDOCP("goddard", "midpoint", 250)
+    o.set_pattern_mode(2)
+    assert o.jac_nnz() == 4504
+    assert len(o.hess_pattern()[1]) == 5259
+    o2 = oracle_lib.OracleDOCP("goddard_all", "trapeze", 1000)
+    o2.set_pattern_mode(2)
+    assert len(o2.hess_pattern()[1]) == 11011
+    # the traced pattern holds every true nonzero: coloured values on it == dense Jacobian
+    o3 = oracle_lib.OracleDOCP("goddard_all", "trapeze", 6)
+    o3.set_pattern_mode(2)
+    from helpers import bench_inputs, describe
+    x = bench_inputs(describe(o3, "goddard_all", "trapeze"), perturb=1e-3)
+    J = o3.jac_dense(x)
+    cp, rv = o3.jac_pattern()
+    mask = np.zeros_like(J, dtype=bool)
+    for j in range(len(cp) - 1):
+        mask[rv[cp[j]:cp[j + 1]], j] = True
+    assert not np.any(J[~mask] != 0.0)
+    assert np.array_equal(o3.jac_coord(x), dense_on_pattern(J, cp, rv))
