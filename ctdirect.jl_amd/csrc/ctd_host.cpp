@@ -242,6 +242,9 @@ void Model::step_blocks(int64_t i, std::vector<Block>& out) const {
         push_block(out, co, co + n, vo, vo + blk + n);            // :192-194  x_i, u_i, x_i+1
         push_block(out, co + n, co + cb, vo, vo + n + m);         // :197-199
         push_block(out, co, co + cb, v0, v1);                     // :202
+        // STRUCTURAL / OPTIMIZED: implicit Euler evaluates the path constraints of node i >= 1 with u(t_i) = U_{i-1}
+        // (euler.jl:59-72), an entry euler.jl:231 does not list
+        if (L.euler == 2 && pattern_mode >= 1 && i >= 1) push_block(out, co + n, co + cb, vo - blk + n, vo - blk + n + m);
     } else {                                                      // irk.jl:330-380 / irk_stagewise.jl:483-524
         const int64_t s = L.s;
         const int64_t dyn0 = co, dyn1 = co + n, st0 = co + n, st1 = co + (s + 1) * n, path0 = st1, path1 = co + cb;
@@ -287,6 +290,7 @@ void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
         const int64_t sj = j / L.blk;
         if (sj - 1 >= 0 && sj - 1 < L.N) step_blocks(sj - 1, cand);
         if (sj < L.N) step_blocks(sj, cand);
+        if (L.euler == 2 && pattern_mode >= 1 && sj + 1 < L.N) step_blocks(sj + 1, cand);      // path rows of the next node read U_sj
     }
     for (const Block& b : tail) cand.push_back(b);
     std::vector<std::pair<int64_t, int64_t>> iv;
@@ -339,6 +343,12 @@ bool Model::opt_dep(int64_t row, int64_t col) const {
     const int64_t i = row / L.cb;
     const int lr = (int)(row % L.cb);
     const int64_t q = isv ? -1 : col - i * L.blk;      // local column: own block [0, blk), X_{i+1} [blk, blk+n), U_{i+1} (trapeze)
+    if (L.euler == 2 && lr >= L.eqs && i >= 1 && !isv) {      // implicit Euler: u(t_i) = U_{i-1} (euler.jl:59-72)
+        const uint32_t mk = dep_g[lr - L.eqs];
+        if (q >= 0 && q < n) return xbit(mk, (int)q);
+        const int64_t o = q + L.blk - n;
+        return o >= 0 && o < m && ubit(mk, (int)o);
+    }
     if (!isv && (q < 0 || q >= L.blk + n + m)) return false;
     if (lr >= L.eqs) {                                 // path row at node i: g_q(t_i, X_i, u_i, v)
         const uint32_t mk = dep_g[lr - L.eqs];
@@ -498,6 +508,11 @@ Model::Entry Model::classify(int64_t row, int64_t col) const {
         e.cstep = e.dstep = i;
         if (col >= L.v_off) { set(local_entry_v(*this, lr, (int)(col - L.v_off)), i); return e; }
         const int64_t q = col - i * L.blk;
+        if (L.euler == 2 && lr >= L.eqs && i >= 1 && q >= n - L.blk && q < n + m - L.blk) {
+            // implicit Euler: d path_i / d U_{i-1} (the control the path constraints of node i are evaluated with)
+            set(Loc{C_ONE, Rr.oPu + (lr - L.eqs) * Rr.ldu + (int)(q + L.blk - n), 0, false}, i);
+            return e;
+        }
         if (q < 0 || q >= L.blk + n + m || col >= L.v_off) return e;   // not a local variable of this step: zero
         set(local_entry(*this, lr, (int)q, i), i);
         return e;
@@ -556,9 +571,10 @@ static bool segment_codes(const Model& mo, int64_t i, std::vector<uint32_t>& cod
             int64_t crel = i - e.cstep, drel = i - e.dstep;
             if (e.cconst) crel = 0;
             if (e.di == 0) drel = 0;
-            if (crel < 0 || crel > 1 || drel < 0 || drel > 1) return false;
+            if (crel < 0 || crel > 1 || drel < -1 || drel > 1) return false;
             if (crel == 1 || drel == 1) need_prev = 1;
-            codes.push_back(pack_code(e.di, e.ci, e.beta, (int)drel, (int)crel));
+            if (drel == -1) need_prev |= 2;            // data of the NEXT step's record (record code kRecNext)
+            codes.push_back(pack_code(e.di, e.ci, e.beta, drel == -1 ? kRecNext : (int)drel, (int)crel));
             relrows.push_back(row - i * L.cb);
         }
         cp[lc + 1] = (int64_t)codes.size();
@@ -589,7 +605,8 @@ static int build_tables(Model& mo, std::string& err) {
             }
         }
         if (!ok) { err = "Jacobian pattern is not step-periodic"; return ST_EPATTERN; }
-        if (need_prev && mo.HL == 0) { err = "internal: template needs the previous step but the tile has no halo"; return ST_EPATTERN; }
+        if ((need_prev & 1) && mo.HL == 0) { err = "internal: template needs the previous step but the tile has no halo"; return ST_EPATTERN; }
+        if (need_prev & 2) mo.HH = 1;                  // implicit Euler: the path rows of node i+1 sit in the columns of U_i
         mo.reg_first = 1;
         mo.reg_last = N - 1;
         int np2 = 0;
@@ -720,7 +737,7 @@ static int build_tables(Model& mo, std::string& err) {
         mo.dropped = N * (int64_t)L.n * L.nv;
     // implicit Euler: the path rows of nodes 2..N depend on U_{i-1}, the pattern lists U_i (euler.jl:59-72 vs :231), in
     // either pattern mode (the periodic emit tables cannot reference the next step's record)
-    if (L.euler == 2 && L.p > 0 && L.m > 0) mo.dropped += (N - 1) * (int64_t)L.p * L.m;
+    if (L.euler == 2 && L.p > 0 && L.m > 0 && mo.pattern_mode == 0) mo.dropped += (N - 1) * (int64_t)L.p * L.m;
     return ST_OK;
 }
 
@@ -809,10 +826,6 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
     build_tail_blocks(mo);
     if (mo.pattern_mode == 2) {
         compute_dep_masks(mo);
-        if (mo.L.euler == 2 && mo.L.p > 0 && mo.L.m > 0) {
-            err = "optimized pattern: implicit Euler reads the path constraints' control from the previous step (not supported)";
-            return ST_EPATTERN;
-        }
     }
     st = build_tables(mo, err);
     if (st) return st;

@@ -1111,7 +1111,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             const bool have = pre != nullptr && w == tid;          // first pass: prefetched before the evaluation
             const uint32_t code = have ? pre->b : kp.edge_code[e];
             const int64_t idx = have ? pre->eidx : kp.edge_idx[e];
-            const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec(code) * R.stride, code);
+            const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec_raw(code) * R.stride, code);
             if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
             else if (kp.vals) kp.vals[idx] = val;
         }

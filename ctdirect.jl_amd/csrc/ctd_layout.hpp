@@ -124,7 +124,11 @@ CTD_HD uint32_t pack_code(int di, int ci, int beta, int drec, int crec) {
 CTD_HD int code_di(uint32_t c) { return (int)(c & 0xFFFFu); }
 CTD_HD int code_ci(uint32_t c) { return (int)((c >> 16) & 0x3Fu); }
 CTD_HD int code_beta(uint32_t c) { return (int)((c >> 22) & 0x3u); }
-CTD_HD int code_drec(uint32_t c) { return (int)((c >> 24) & 0x7u); }
+// inside tile templates a record code of kRecNext means the NEXT step's record (relative -1): implicit Euler's path rows of
+// node i+1 sit in the columns of U_i
+constexpr int kRecNext = 7;
+CTD_HD int code_drec(uint32_t c) { const int r = (int)((c >> 24) & 0x7u); return r == kRecNext ? -1 : r; }
+CTD_HD int code_drec_raw(uint32_t c) { return (int)((c >> 24) & 0x7u); }     // absolute record ids of the edge list
 CTD_HD int code_crec(uint32_t c) { return (int)((c >> 27) & 0x7u); }
 
 // exact x / d for the small operands of the emit loops (x * d < 2^32): q = umulhi(x, M), M = floor(2^32 / d) + 1 (d > 1)

@@ -685,6 +685,10 @@ static void jacobian_pattern_ij(const Docp& p, IJ& ij) {
             ij.block(path_start, path_end, xi_start, xi_end);                                  // :230-232
             ij.block(path_start, path_end, ui_start, ui_end);
             ij.block(path_start, path_end, v_start, v_end);
+            // STRUCTURAL: implicit Euler evaluates the path constraints of node i >= 2 with u(t_i) = U_{i-1} (euler.jl:59-72),
+            // which :231 does not list
+            if (p.pattern_mode == 1 && !d.euler_explicit && i >= 2)
+                ij.block(path_start, path_end, ui_start - blk, ui_end - blk);
         }
     } else if (d.scheme == MIDPOINT) {                                 // midpoint.jl:163-233
         for (int64_t i = 1; i <= N; ++i) {

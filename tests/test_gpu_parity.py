@@ -472,3 +472,36 @@ def test_optimized_pattern_values_on_gpu(oracle_lib, torch_cuda, prob):
         want, dropped = o.hess_coord(x, y, 0.7, return_dropped=True)
         assert dropped == (0, 0) and relerr(h.cpu().numpy(), want) <= 1e-9
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob", ["goddard_all", "double_integrator_path", "quadrotor"])
+def test_implicit_euler_structural_pattern_is_complete(oracle_lib, torch_cuda, prob):
+    """Implicit Euler evaluates the path constraints of node i with U_{i-1} (euler.jl:59-72) while the reference's pattern lists
+    U_i (euler.jl:231).  The manual pattern is bug-compatible (and says how many true nonzeros it drops); the structural and
+    optimized patterns hold the (path_i, U_{i-1}) entries: J d equals central differences of c along random directions, and
+    the values equal the oracle's."""
+    torch = torch_cuda
+    import scipy.sparse as sp
+    N = 300
+    man = ct.DOCP(prob, N, "euler_implicit", device=-1)
+    assert man.dropped_nonzeros() == (N - 1) * man.dims.path_cons * man.dims.NLP_u
+    for pattern, mode in (("structural", 1), ("optimized", 2)):
+        d = ct.DOCP(prob, N, "euler_implicit", pattern=pattern, device=0)
+        assert d.dropped_nonzeros() == 0
+        o = oracle_lib.OracleDOCP(prob, "euler_implicit", N)
+        o.set_pattern_mode(mode)
+        x = bench_inputs(describe(o, prob, "euler_implicit"), perturb=1e-2)
+        xd = torch.from_numpy(x).cuda()
+        c, v = d.cons_jac(xd)
+        assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+        rows, cols = d.jac_structure()
+        J = sp.coo_matrix((v.cpu().numpy(), (rows - 1, cols - 1)), shape=(d.dim_NLP_constraints, d.dim_NLP_variables)).tocsr()
+        rng = np.random.default_rng(3)
+        for _ in range(3):
+            dirv = rng.uniform(-0.5, 0.5, d.dim_NLP_variables)
+            eps = 1e-6
+            fd = ((d.cons(torch.from_numpy(x + eps * dirv).cuda()) - d.cons(torch.from_numpy(x - eps * dirv).cuda())) / (2 * eps)).cpu().numpy()
+            err = float(np.max(np.abs(J @ dirv - fd) / np.maximum(1.0, np.abs(fd))))
+            assert err <= 2e-5, (pattern, err)
+        d.close()
