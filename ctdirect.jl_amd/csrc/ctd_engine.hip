@@ -377,8 +377,11 @@ int32_t ctd_register_ocp(const ctd_ocp_def* def, int32_t* problem_id) {
 
 int32_t ctd_ocp_source(int32_t problem_id, char* buf, int64_t cap) {
     const RtOcp* ro = runtime_ocp(problem_id);
-    if (!ro || !buf || cap < 1) return CTD_EINVAL;
-    std::snprintf(buf, (size_t)cap, "%s", ro->functor_src.c_str());
+    if (!ro) return fail(nullptr, CTD_EINVAL, "ctd_ocp_source: not a run-time problem id");
+    const int64_t need = (int64_t)ro->functor_src.size() + 1;
+    if (!buf || cap < need)        // never a silently truncated text: the message names the capacity to come back with
+        return fail(nullptr, CTD_EINVAL, "ctd_ocp_source: buffer too small, needs " + std::to_string(need) + " bytes");
+    std::memcpy(buf, ro->functor_src.c_str(), (size_t)need);
     return CTD_OK;
 }
 

@@ -435,6 +435,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
     if ((d->npath > 0 && !d->path) || (d->nbc > 0 && !d->boundary)) { err = "path / boundary expressions missing"; return CTD_EINVAL; }
     auto o = std::make_unique<RtOcp>();
     o->name = d->name ? d->name : "user_ocp";
+    // the name goes into a comment of the generated source: only [A-Za-z0-9_.-] (anything else -- a newline above all --
+    // could smuggle text into the compiled module; the ABI accepts expressions, never C++)
+    if (o->name.empty() || o->name.size() > 64) { err = "problem name must have 1..64 characters"; return CTD_EINVAL; }
+    for (const char ch : o->name)
+        if (!((ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || (ch >= '0' && ch <= '9') || ch == '_' || ch == '.' || ch == '-')) {
+            err = "problem name may only hold the characters A-Z a-z 0-9 _ . -";
+            return CTD_EINVAL;
+        }
     ExprCtx c0{d->n, d->m, d->nv, 0, {}}, c1{d->n, d->m, d->nv, 1, {}};
     if (!parse_constants(d->constants, c0.constants, err)) return CTD_EINVAL;
     c1.constants = c0.constants;

@@ -73,6 +73,14 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
+def _host_out(a, n, name):
+    """A caller-supplied NumPy output of the host-pointer entry points: the library writes n doubles through the raw pointer,
+    so anything but a C-contiguous float64 array of exactly n entries would corrupt host memory."""
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"] and a.size == n):
+        raise ValueError(f"{name} must be a writeable C-contiguous float64 NumPy array of {n} entries")
+    return a
+
+
 def _is_tensor(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
@@ -129,11 +137,18 @@ def register_ocp(name, *, dynamics, n=None, m=0, nv=0, lagrange=None, mayer=None
 
 def ocp_source(name):
     """The functor text generated for a run-time OCP (diagnostics)."""
-    buf = C.create_string_buffer(1 << 16)
-    st = _lib.lib().ctd_ocp_source(PROBLEMS[name], buf, len(buf))
-    if st != _lib.CTD_OK:
-        _raise(st, "not a run-time problem")
-    return buf.value.decode()
+    L = _lib.lib()
+    cap = 1 << 16
+    for _ in range(2):
+        buf = C.create_string_buffer(cap)
+        st = L.ctd_ocp_source(PROBLEMS[name], buf, len(buf))
+        if st == _lib.CTD_OK:
+            return buf.value.decode()
+        msg = L.ctd_last_error(None).decode()
+        if "needs" not in msg:
+            _raise(st, msg)
+        cap = int(msg.split("needs")[1].split()[0])
+    _raise(st, msg)
 
 
 def jit_check(name, scheme):
@@ -311,10 +326,8 @@ class DOCP:
                         self._dev_ptr(c, self.dim_NLP_constraints, "c"), self._dev_ptr(vals, self.nnzj, "vals")))
             return c, vals
         x = np.ascontiguousarray(x, dtype=np.float64)
-        if c is None:
-            c = np.empty(self.dim_NLP_constraints)
-        if vals is None:
-            vals = np.empty(self.nnzj)
+        c = np.empty(self.dim_NLP_constraints) if c is None else _host_out(c, self.dim_NLP_constraints, "c")
+        vals = np.empty(self.nnzj) if vals is None else _host_out(vals, self.nnzj, "vals")
         self._ck(L.ctd_cons_jac(self._h, _dp(x), _dp(c), _dp(vals)))
         return c, vals
 
@@ -347,8 +360,7 @@ class DOCP:
                                         self._dev_ptr(c, self.dim_NLP_constraints, "c"), None))
             return c
         x = np.ascontiguousarray(x, dtype=np.float64)
-        if c is None:
-            c = np.empty(self.dim_NLP_constraints)
+        c = np.empty(self.dim_NLP_constraints) if c is None else _host_out(c, self.dim_NLP_constraints, "c")
         self._ck(L.ctd_cons(self._h, _dp(x), _dp(c)))
         return c
 
@@ -364,8 +376,7 @@ class DOCP:
                                         self._dev_ptr(vals, self.nnzj, "vals")))
             return vals
         x = np.ascontiguousarray(x, dtype=np.float64)
-        if vals is None:
-            vals = np.empty(self.nnzj)
+        vals = np.empty(self.nnzj) if vals is None else _host_out(vals, self.nnzj, "vals")
         self._ck(L.ctd_jac_coord(self._h, _dp(x), _dp(vals)))
         return vals
 
@@ -399,8 +410,7 @@ class DOCP:
             self._ck(fn(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"), self._dev_ptr(g, self.dim_NLP_variables, "g")))
             return g
         x = np.ascontiguousarray(x, dtype=np.float64)
-        if g is None:
-            g = np.empty(self.dim_NLP_variables)
+        g = np.empty(self.dim_NLP_variables) if g is None else _host_out(g, self.dim_NLP_variables, "g")
         self._ck(L.ctd_grad(self._h, _dp(x), _dp(g)))
         return g
 
@@ -460,8 +470,7 @@ class DOCP:
         y = np.ascontiguousarray(y, dtype=np.float64)
         if y.size != self.dim_NLP_constraints:
             raise ValueError(f"y has {y.size} entries, expected dim_NLP_constraints = {self.dim_NLP_constraints}")
-        if vals is None:
-            vals = np.empty(self.nnzh)
+        vals = np.empty(self.nnzh) if vals is None else _host_out(vals, self.nnzh, "vals")
         self._ck(L.ctd_hess_coord(self._h, _dp(x), _dp(y), float(obj_weight), _dp(vals)))
         return vals
 

@@ -157,7 +157,8 @@ typedef struct ctd_ocp_def {
     const double *path_lb, *path_ub, *boundary_lb, *boundary_ub;
 } ctd_ocp_def;
 int32_t ctd_register_ocp(const ctd_ocp_def* def, int32_t* problem_id);
-/* the functor text generated for a registered OCP (diagnostics / tests) */
+/* the functor text generated for a registered OCP (diagnostics / tests).  cap too small: CTD_EINVAL and ctd_last_error(NULL)
+ * = "... needs <n> bytes" (nothing is written, never a truncated text) */
 int32_t ctd_ocp_source(int32_t problem_id, char* buf, int64_t cap);
 /* compile-only check, no device needed: the kernels of `scheme` build for gfx950 (ctd_last_error(NULL) holds the log) */
 int32_t ctd_jit_check(int32_t problem_id, int32_t scheme);

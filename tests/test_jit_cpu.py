@@ -104,3 +104,27 @@ def test_committed_registry_stage_functions_are_what_the_generator_writes(tmp_pa
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-o", exe, os.path.join(csrc, "ctd_gen_sym.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
     assert out == open(os.path.join(csrc, "ctd_sym_registry.hpp")).read()
+
+
+def test_problem_name_cannot_inject_source_and_source_is_never_truncated():
+    """ADVICE (round 1): the name lands in a comment of the generated source -> only [A-Za-z0-9_.-]; ctd_ocp_source reports the
+    size it needs instead of truncating"""
+    import ctypes as C
+    for bad in ("evil\n} struct X {", "trailing\\", "sp ace", ""):
+        with pytest.raises(ct.CTDirectError):
+            ct.register_ocp(bad, dynamics=["u1"], n=1, m=1)
+    name = ct.register_ocp("ok_name-1.x", dynamics=["u1 - x1"], n=1, m=1)
+    src = ct.ocp_source(name)
+    assert "struct UserOCP" in src and src.rstrip().endswith("// namespace ctd")      # complete text, not cut
+    buf = C.create_string_buffer(16)
+    st = ct._lib.lib().ctd_ocp_source(ct.PROBLEMS[name], buf, len(buf))
+    assert st == ct._lib.CTD_EINVAL and b"needs" in ct._lib.lib().ctd_last_error(None) and buf.value == b""
+
+
+def test_host_outputs_are_validated():
+    d = ct.DOCP("goddard", 8, "midpoint", device=-1)
+    x = np.full(d.dim_NLP_variables, 0.1)
+    for bad in (np.zeros(d.dim_NLP_constraints, dtype=np.float32), np.zeros(d.dim_NLP_constraints - 1),
+                np.zeros(2 * d.dim_NLP_constraints)[::2]):
+        with pytest.raises(ValueError):
+            d.cons(x, bad)
