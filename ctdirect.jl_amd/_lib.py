@@ -89,6 +89,7 @@ SYMBOLS = {
     "ctd_hess_launch_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_shard_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_debug_stamps": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, C.POINTER(C.c_uint64), C.c_int64]),
+    "ctd_eval_all_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     # one transcription on several GPUs of one process
     "ctd_create_sharded": (C.c_int32, [C.POINTER(ctd_desc), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_vp)]),
     "ctd_sharded_destroy": (C.c_int32, [_vp]),

@@ -21,6 +21,7 @@
 #include "ctd_host.hpp"
 #include "ctd_kernels.hpp"
 #include "ctd_hess_kernels.hpp"
+#include "ctd_iter_kernels.hpp"
 #include "ctd_jit.hpp"
 
 using namespace ctd;
@@ -47,6 +48,16 @@ CTD_EXTERN_HESS(EstimateInitialConditionOCP)
 CTD_EXTERN_HESS(EstimateRotationRateOCP)
 CTD_EXTERN_HESS(LeastSquaresConstraintOCP)
 CTD_EXTERN_HESS(DoubleIntegratorFreeT0TfOCP)
+CTD_EXTERN_ITER(GoddardOCP)
+CTD_EXTERN_ITER(GoddardAllOCP)
+CTD_EXTERN_ITER(DoubleIntegratorPathOCP)
+CTD_EXTERN_ITER(QuadrotorOCP)
+CTD_EXTERN_ITER(Quadrotor12OCP)
+CTD_EXTERN_ITER(StagewiseScalarOCP)
+CTD_EXTERN_ITER(EstimateInitialConditionOCP)
+CTD_EXTERN_ITER(EstimateRotationRateOCP)
+CTD_EXTERN_ITER(LeastSquaresConstraintOCP)
+CTD_EXTERN_ITER(DoubleIntegratorFreeT0TfOCP)
 }  // namespace ctd
 
 struct ctd_handle {
@@ -641,6 +652,9 @@ int32_t ctd_cons_jac(ctd_handle* h, const double* x, double* c, double* vals) {
     return host_cons_jac(h, x, c, vals);
 }
 
+// kernel parameters of the objective pass; returns the quadrature workgroups (0 for a Mayer-only cost)
+static int fill_obj_params(ctd_handle* h, double* f_dev, ObjParams& op);
+
 static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
@@ -648,6 +662,24 @@ static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
     ObjParams op;
+    const int blocks = fill_obj_params(h, f_dev, op);
+    const bool lagrange = h->model.info.lagrange;
+    hipError_t e = hipErrorInvalidValue;
+    if (h->rt) {
+        void* args[] = {&op, &x_dev};
+        e = lagrange ? jit_launch(h->f_obj_partial, blocks, 256, 0, h->stream, args) : hipSuccess;
+        if (e == hipSuccess) e = jit_launch(h->f_obj_finish, 1, 64, 0, h->stream, args);
+    }
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_obj<P>(L.sc, op, x_dev, lagrange ? blocks : 0, 256, h->stream);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return CTD_OK;
+}
+
+static int fill_obj_params(ctd_handle* h, double* f_dev, ObjParams& op) {
+    const Layout& L = h->model.L;
     std::memset(&op, 0, sizeof(op));
     op.L = L;
     op.tau = h->d_tau;
@@ -664,18 +696,7 @@ static int32_t enqueue_obj(ctd_handle* h, const double* x_dev, double* f_dev) {
     if (blocks < 1) blocks = 1;
     const bool lagrange = h->model.info.lagrange;      // Mayer-only cost: no quadrature pass, the finish kernel alone
     op.nblocks = lagrange ? blocks : 0;
-    hipError_t e = hipErrorInvalidValue;
-    if (h->rt) {
-        void* args[] = {&op, &x_dev};
-        e = lagrange ? jit_launch(h->f_obj_partial, blocks, 256, 0, h->stream, args) : hipSuccess;
-        if (e == hipSuccess) e = jit_launch(h->f_obj_finish, 1, 64, 0, h->stream, args);
-    }
-    for_problem(h->model.problem, [&](auto tag) {
-        using P = typename decltype(tag)::type;
-        e = launch_obj<P>(L.sc, op, x_dev, lagrange ? blocks : 0, 256, h->stream);
-    });
-    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return CTD_OK;
+    return lagrange ? blocks : 0;
 }
 
 int32_t ctd_obj_dev_async(ctd_handle* h, const double* x_dev, double* f_dev) { return enqueue_obj(h, x_dev, f_dev); }
@@ -689,7 +710,7 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
     return CTD_OK;
 }
 
-static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev);
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params = nullptr);
 int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev) { return enqueue_grad(h, x_dev, g_dev); }
 int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
     int32_t st = enqueue_grad(h, x_dev, g_dev);
@@ -698,7 +719,7 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
     return CTD_OK;
 }
 
-static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev) {
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
@@ -719,6 +740,7 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev) {
     gp.g = g_dev;
     gp.partial = h->d_gpartial;
     gp.nblocks = blocks;
+    if (only_params) { gp.nblocks = h->model.info.lagrange ? blocks : 0; *only_params = gp; return CTD_OK; }
     // With a Lagrange cost the per-step kernel writes every entry of the step blocks (owner computes), only the tail
     // (final state, variables) needs zeroing before the finish kernel adds the Mayer part; a Mayer-only gradient is zero
     // except at x_0, x_f, v: one memset and the finish kernel
@@ -955,6 +977,61 @@ int32_t ctd_hess_coord(ctd_handle* h, const double* x, const double* y, double o
     if (st) return st;
     HIP_TRY(h, hipMemcpyAsync(vals, h->d_hvals, sizeof(double) * mo.H.nnzh, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTD_OK;
+}
+
+// ---- one solver iteration in one call --------------------------------------------------------------------------------
+// obj(x), grad(x), cons(x) + jac_coord(x) and hess_coord(x, y; obj_weight) only depend on (x, y).  Registry problems: the
+// horizontally fused kernel of ctd_iter_kernels.hpp (+ its finish kernel): two launches per iteration.  Run-time OCPs (their
+// kernels are compiled by hiprtc per callback): the same callbacks one after the other on the handle's stream.
+int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* f_dev, double* g_dev,
+                               double* c_dev, double* vals_dev, double* hvals_dev) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
+    if (!x_dev) return fail(h, CTD_EINVAL, "x is null");
+    if (hvals_dev && !y_dev) return fail(h, CTD_EINVAL, "y is null");
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
+    int32_t st = CTD_OK;
+    if (hvals_dev) { st = ensure_hess(h); if (st) return st; }      // first use uploads the tables (not capturable)
+    if (h->rt || env_int("CTD_ITER_SERIAL", 0)) {
+        if (f_dev) st = enqueue_obj(h, x_dev, f_dev);
+        if (!st && g_dev) st = enqueue_grad(h, x_dev, g_dev);
+        if (!st && (c_dev || vals_dev)) st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);
+        if (!st && hvals_dev) st = enqueue_hess(h, x_dev, y_dev, obj_weight, hvals_dev);
+        return st;
+    }
+    IterParams ip;
+    std::memset(&ip, 0, sizeof(ip));
+    size_t lds = 4 * kMaxNV * sizeof(double) + 64;
+    ip.kp = h->kp;       // (Layout is read from kp / hp / gp / op by the respective bodies)
+    ip.hp = h->hp;
+    if (hvals_dev) {
+        ip.hp.obj_weight = obj_weight;
+        ip.hp.vals = hvals_dev;
+        ip.nb_h = ip.hp.ntiles + 1;
+        lds = std::max(lds, h->hess_lds_bytes);
+    }
+    if (c_dev || vals_dev) {
+        ip.kp.c = c_dev;
+        ip.kp.vals = vals_dev;
+        ip.nb_cj = h->grid;
+        lds = std::max(lds, h->lds_bytes);
+    }
+    if (g_dev) {
+        st = enqueue_grad(h, x_dev, g_dev, &ip.gp);          // fills the parameters only (and sizes the partials buffer)
+        if (st) return st;
+        ip.zero_g = h->model.info.lagrange ? 0 : 1;
+        const Layout& L = h->model.L;
+        ip.nb_g = ip.zero_g ? (int)std::min<int64_t>(64, (L.nvar + 4095) / 4096) : ip.gp.nblocks;
+        if (ip.nb_g < 1) ip.nb_g = 1;
+    }
+    if (f_dev) ip.nb_o = fill_obj_params(h, f_dev, ip.op);
+    hipError_t e = hipErrorInvalidValue;
+    for_problem(h->model.problem, [&](auto tag) {
+        using P = typename decltype(tag)::type;
+        e = launch_iter<P>(ip, x_dev, y_dev, lds, h->stream);
+    });
+    if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;
 }
 

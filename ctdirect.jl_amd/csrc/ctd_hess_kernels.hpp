@@ -56,13 +56,12 @@ __device__ __forceinline__ void hess_pin_kernargs(const HParams& hp, const doubl
 #endif
 // DBG = true: diagnostics instantiation (ctd_hess_debug_stamps, env CTD_HESS_STOP); the default one holds no stamp / stop code
 template <class P, int SC, int S, bool DBG>
-__global__ __launch_bounds__(kHessBlock) CTD_HESS_CAP void hess_kernel(const HParams hp, const double* __restrict__ xu,
-                                                          const double* __restrict__ y) {
-    extern __shared__ double hess_lds[];
+__device__ __forceinline__ void hess_body(const HParams& hp, const double* __restrict__ xu, const double* __restrict__ y, int block,
+                                          double* hess_lds) {
     hess_pin_kernargs(hp, xu, y);
     const int tid = threadIdx.x, nthr = blockDim.x;
     hess_stamp<DBG>(hp, 0);
-    const HBlockCtx cx = make_hctx(hp, blockIdx.x, hess_lds);
+    const HBlockCtx cx = make_hctx(hp, block, hess_lds);
     hess_phase_load<P>(hp, cx, xu, y, tid, nthr);
     __syncthreads();
     hess_stamp<DBG>(hp, 1);
@@ -71,10 +70,10 @@ __global__ __launch_bounds__(kHessBlock) CTD_HESS_CAP void hess_kernel(const HPa
     __syncthreads();
     hess_stamp<DBG>(hp, 2);
     if (DBG && hp.debug_stop == 2) return;
-    hess_phase_emit<P, SC, S>(hp, cx, blockIdx.x, tid, nthr);
+    hess_phase_emit<P, SC, S>(hp, cx, block, tid, nthr);
     if (hp.nvv > 0) {
         __syncthreads();
-        hess_phase_vvsum(hp, cx, blockIdx.x, tid, nthr);
+        hess_phase_vvsum(hp, cx, block, tid, nthr);
     }
     hess_stamp<DBG>(hp, 3);
     if (DBG && hp.stamps) {      // diagnostics: time until this workgroup's stores have left the CU
@@ -84,10 +83,15 @@ __global__ __launch_bounds__(kHessBlock) CTD_HESS_CAP void hess_kernel(const HPa
     }
 }
 
+template <class P, int SC, int S, bool DBG>
+__global__ __launch_bounds__(kHessBlock) CTD_HESS_CAP void hess_kernel(const HParams hp, const double* __restrict__ xu,
+                                                          const double* __restrict__ y) {
+    extern __shared__ double hess_lds[];
+    hess_body<P, SC, S, DBG>(hp, xu, y, (int)blockIdx.x, hess_lds);
+}
+
 // V x V entries: fixed-order sum of the per-workgroup partials (one workgroup)
-template <class P>
-__global__ __launch_bounds__(kHessBlock) void hess_finish_kernel(const HParams hp) {
-    __shared__ double red[kHessBlock];
+__device__ __forceinline__ void hess_finish_body(const HParams& hp, double* red) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int e = 0; e < hp.nvv; ++e) {
         red[tid] = hess_finish_partial(hp, e, tid, nthr);
@@ -99,6 +103,11 @@ __global__ __launch_bounds__(kHessBlock) void hess_finish_kernel(const HParams h
         if (tid == 0 && hp.vv_idx[e] >= 0) hp.vals[hp.vv_idx[e]] = red[0];
         __syncthreads();
     }
+}
+template <class P>
+__global__ __launch_bounds__(kHessBlock) void hess_finish_kernel(const HParams hp) {
+    __shared__ double red[kHessBlock];
+    hess_finish_body(hp, red);
 }
 
 #if !defined(__HIPCC_RTC__)

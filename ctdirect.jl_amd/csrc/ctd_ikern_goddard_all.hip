@@ -1,0 +1,5 @@
+// Fused iteration kernels (ctd_iter_kernels.hpp) of one registry entry (GoddardAllOCP).
+#include "ctd_iter_kernels.hpp"
+namespace ctd {
+CTD_INSTANTIATE_ITER(GoddardAllOCP)
+}

@@ -48,16 +48,16 @@ __device__ __forceinline__ void ctd_pin_kernargs(const KParams& kp, const double
 #endif
 }
 
+// workgroup `block` of the evaluation (the kernel below; also a branch of the fused iteration kernel, ctd_iter_kernels.hpp)
 template <class P, int SC, int S, bool DBG>
-__global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
-    extern __shared__ double ctd_lds[];
+__device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* __restrict__ xu, int block, double* ctd_lds) {
     ctd_pin_kernargs<SC == SC_IRK ? S : 0>(kp, xu);
     ctd_stamp<DBG>(kp, 0);
     if (DBG && kp.debug_stop == 1) return;
     const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
     if constexpr (DirectTile<P, SC>::value) {
         // direct driver: no staging of xu, one barrier (see make_direct_ctx); the staged phases below are not instantiated
-        const BlockCtx cx = make_direct_ctx(kp, (int)blockIdx.x, ctd_lds, xu);
+        const BlockCtx cx = make_direct_ctx(kp, block, ctd_lds, xu);
         const EmitPre pre = emit_prefetch<P>(kp, cx, tid, nthr);
         ctd_stamp<DBG>(kp, 1);
         phase_eval<P, SC, S, RegEval<P, SC>::value>(kp, cx, tid, nthr);
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, con
         }
         return;
     }
-    const BlockCtx cx = make_ctx(kp, (int)blockIdx.x, ctd_lds);
+    const BlockCtx cx = make_ctx(kp, block, ctd_lds);
     phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
     __syncthreads();
     ctd_stamp<DBG>(kp, 1);
@@ -100,6 +100,12 @@ __global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, con
         __syncthreads();
         ctd_stamp<DBG>(kp, 5);
     }
+}
+
+template <class P, int SC, int S, bool DBG>
+__global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
+    extern __shared__ double ctd_lds[];
+    cons_jac_body<P, SC, S, DBG>(kp, xu, (int)blockIdx.x, ctd_lds);
 }
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
@@ -166,15 +172,16 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     return h * local;
 }
 
+// body of the quadrature pass for workgroup `block` of `nblocks` (wsum: 4+ doubles of LDS); also a branch of the fused
+// iteration kernel (iter_main_kernel)
 template <class P, int SC>
-__global__ void __launch_bounds__(256) obj_partial_kernel(const ObjParams op, const double* __restrict__ xu) {
-    __shared__ double wsum[4];
+__device__ __forceinline__ void obj_partial_body(const ObjParams& op, const double* __restrict__ xu, int block, int nblocks, double* wsum) {
     double v[P::NV > 0 ? P::NV : 1];
     for (int k = 0; k < P::NV; ++k) v[k] = xu[op.L.v_off + k];
     double acc = 0.0;
     if (P::HAS_LAGRANGE) {
-        for (int64_t i = op.unit_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < op.unit_end;
-             i += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t i = op.unit_begin + (int64_t)block * blockDim.x + threadIdx.x; i < op.unit_end;
+             i += (int64_t)nblocks * blockDim.x)
             acc += lagrange_unit<P, SC>(op, xu, v, i);
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -184,13 +191,18 @@ __global__ void __launch_bounds__(256) obj_partial_kernel(const ObjParams op, co
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += wsum[w];
-        op.partial[blockIdx.x] = s;
+        op.partial[block] = s;
     }
+}
+template <class P, int SC>
+__global__ void __launch_bounds__(256) obj_partial_kernel(const ObjParams op, const double* __restrict__ xu) {
+    __shared__ double wsum[4];
+    obj_partial_body<P, SC>(op, xu, (int)blockIdx.x, (int)gridDim.x, wsum);
 }
 
 template <class P>
-__global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__ xu) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+__device__ __forceinline__ void obj_finish_body(const ObjParams& op, const double* __restrict__ xu) {
+    if (threadIdx.x >= 64) return;
     // one wave: lane l adds the partials l, l + 64, ... in index order, then a fixed shuffle tree (deterministic; the
     // loads of the 64 lanes are in flight together instead of one dependent chain of nblocks loads)
     double s = 0.0;
@@ -206,6 +218,11 @@ __global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__
         mayer = P::template mayer<double>(x0, xf, v);
     }
     op.out[0] = mayer + s;
+}
+template <class P>
+__global__ void obj_finish_kernel(const ObjParams op, const double* __restrict__ xu) {
+    if (blockIdx.x != 0) return;
+    obj_finish_body<P>(op, xu);
 }
 
 // ---- objective gradient: grad!(nlp, x, g) -----------------------------------------------------------------------------
@@ -332,15 +349,15 @@ template <class P> __device__ __forceinline__ double grad_time(const GradParams&
     return t0 + tau * (tf - t0);
 }
 
+// body of the gradient pass for workgroup `block` (wsum: 4 * kMaxNV doubles of LDS); also a branch of iter_main_kernel
 template <class P, int SC, int S>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) grad_units_kernel(const GradParams gp, const double* __restrict__ xu) {
+__device__ __forceinline__ void grad_units_body(const GradParams& gp, const double* __restrict__ xu, int block, double (*wsum)[kMaxNV]) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV;
     constexpr bool FREE = (P::IT0 >= 0) || (P::ITF >= 0);
-    __shared__ double wsum[4][kMaxNV];
     const Layout& L = gp.L;
     double v[nv > 0 ? nv : 1], gv[nv > 0 ? nv : 1];
     for (int k = 0; k < nv; ++k) { v[k] = xu[L.v_off + k]; gv[k] = 0.0; }
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = (int64_t)block * blockDim.x + threadIdx.x;
     const int64_t units = (SC == SC_IRK) ? L.N : L.N + 1;      // steps, or nodes for trapeze / midpoint
     if (P::HAS_LAGRANGE && i < units) {
         double* g = gp.g;
@@ -457,13 +474,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) g
         for (int k = 0; k < nv; ++k) {
             double sacc = 0.0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sacc += wsum[w][k];
-            gp.partial[(size_t)blockIdx.x * kMaxNV + k] = sacc;
+            gp.partial[(size_t)block * kMaxNV + k] = sacc;
         }
+}
+template <class P, int SC, int S>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) grad_units_kernel(const GradParams gp, const double* __restrict__ xu) {
+    __shared__ double wsum[4][kMaxNV];
+    grad_units_body<P, SC, S>(gp, xu, (int)blockIdx.x, wsum);
 }
 
 template <class P>
-__global__ void grad_finish_kernel(const GradParams gp, const double* __restrict__ xu) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+__device__ __forceinline__ void grad_finish_body(const GradParams& gp, const double* __restrict__ xu) {
+    if (threadIdx.x >= 64) return;
     constexpr int n = P::NX, nv = P::NV;
     const Layout& L = gp.L;
     double gvs[nv > 0 ? nv : 1];
@@ -483,6 +505,11 @@ __global__ void grad_finish_kernel(const GradParams gp, const double* __restrict
         for (int k = 0; k < nv; ++k) gvs[k] += gmv[k];
     }
     for (int k = 0; k < nv; ++k) gp.g[L.v_off + k] = gvs[k];
+}
+template <class P>
+__global__ void grad_finish_kernel(const GradParams gp, const double* __restrict__ xu) {
+    if (blockIdx.x != 0) return;
+    grad_finish_body<P>(gp, xu);
 }
 
 #if !defined(__HIPCC_RTC__)

@@ -414,6 +414,19 @@ class DOCP:
         self._ck(L.ctd_grad(self._h, _dp(x), _dp(g)))
         return g
 
+    def eval_all(self, x, y=None, obj_weight=1.0, f=None, g=None, c=None, vals=None, hvals=None, sync=False):
+        """One solver iteration in one call (`ctd_eval_all_dev_async`): objective -> f[0], gradient -> g, constraints -> c,
+        Jacobian values -> vals, Hessian values of the Lagrangian -> hvals, for device tensors; outputs left None are skipped.
+        The callbacks run side by side on the GPU."""
+        self._check_x(x)
+        P = lambda t, n, name: None if t is None else self._dev_ptr(t, n, name)      # noqa: E731
+        self._ck(_lib.lib().ctd_eval_all_dev_async(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                                   P(y, self.dim_NLP_constraints, "y"), float(obj_weight), P(f, 1, "f"),
+                                                   P(g, self.dim_NLP_variables, "g"), P(c, self.dim_NLP_constraints, "c"),
+                                                   P(vals, self.nnzj, "vals"), P(hvals, self.nnzh, "hvals")))
+        if sync:
+            self.sync()
+
     def sync(self):
         self._ck(_lib.lib().ctd_sync(self._h))
 

@@ -274,6 +274,15 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* out8);
  * contiguous CSC range), the first / last shard also the irregular first-step / final-state entries, and leaves its PARTIAL
  * sums in the nv (nv+1)/2 variable x variable entries (they sum over every step): ctd_hess_shard_info names them for the
  * one all-reduce the caller has to do. */
+/* One solver iteration in one call: obj(nlp, x) -> f_dev[0], grad!(nlp, x, g), cons!(nlp, x, c) + jac_coord!(nlp, x, vals) and
+ * hess_coord!(nlp, x, y, hvals; obj_weight) -- the NLPModels calls an interior-point iteration makes on the ADNLPModel of
+ * src/collocation.jl:137-149 -- in TWO launches for registry problems: one grid whose workgroups take the bodies of the four
+ * evaluation kernels by index range (all resident together: the launch costs about what the longest of them, the Hessian,
+ * costs instead of their sum), then the fixed-order cross-workgroup sums.  Any output may be NULL to skip that callback.
+ * Enqueue-only, like the *_dev_async entry points. */
+int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* f_dev,
+                               double* g_dev, double* c_dev, double* vals_dev, double* hvals_dev);
+
 /* 1-based (rows[k], cols[k]), k < nnzh, CSC order */
 int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
 /* same pattern as 0-based CSC (colptr[nvar + 1], rowval[nnzh]) */

@@ -505,3 +505,45 @@ def test_implicit_euler_structural_pattern_is_complete(oracle_lib, torch_cuda, p
             err = float(np.max(np.abs(J @ dirv - fd) / np.maximum(1.0, np.abs(fd))))
             assert err <= 2e-5, (pattern, err)
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob,sch,N", [("goddard", "gauss_legendre_2", 10000), ("goddard_all", "trapeze", 1001),
+                                        ("double_integrator_path", "midpoint", 3000), ("quadrotor", "gauss_legendre_3", 300),
+                                        ("least_squares_with_constraint", "gauss_legendre_2_constant_control", 64),
+                                        ("double_integrator_freet0tf", "euler_implicit", 5), ("goddard", "midpoint", 3)])
+def test_whole_iteration_in_two_launches(oracle_lib, torch_cuda, prob, sch, N):
+    """ctd_eval_all_dev_async: objective, gradient, constraints + Jacobian values and Hessian values of one iterate from the
+    horizontally fused kernel (+ finish kernel).  f, g, c and the Jacobian values are bit-identical to the single-purpose
+    kernels (same bodies, same rounding mode), the Hessian values agree to rounding (its single-purpose build contracts
+    multiply-adds); everything matches the oracle; subsets of the outputs work too."""
+    torch = torch_cuda
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    o.set_pattern_mode(1)
+    d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+    y = np.cos(0.41 * np.arange(o.dim_NLP_constraints))
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    new = lambda n: torch.full((n,), SENT, dtype=torch.float64, device="cuda")      # noqa: E731
+    f, g, c, v, h = new(1), new(d.dim_NLP_variables), new(d.dim_NLP_constraints), new(d.nnzj), new(d.nnzh)
+    for _ in range(2):
+        d.eval_all(xd, yd, 0.9, f, g, c, v, h)
+    d.sync()
+    f2, g2, h2 = new(1), new(d.dim_NLP_variables), new(d.nnzh)
+    d.obj_async(xd, f2)
+    d.grad(xd, g2, sync=False)
+    c2, v2 = d.cons_jac(xd)
+    d.hess_coord(xd, yd, 0.9, h2)
+    assert torch.equal(f, f2) and torch.equal(g, g2) and torch.equal(c, c2) and torch.equal(v, v2)
+    assert relerr(h.cpu().numpy(), h2.cpu().numpy()) <= 1e-11
+    assert _rel(float(f[0]), o.objective(x)) <= TOL and relerr(g.cpu().numpy(), o.gradient(x)) <= TOL
+    assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
+    assert relerr(h.cpu().numpy(), o.hess_coord(x, y, 0.9)) <= 1e-9
+    # subsets: only first-order callbacks; only the Hessian
+    g3, c3, v3 = new(d.dim_NLP_variables), new(d.dim_NLP_constraints), new(d.nnzj)
+    d.eval_all(xd, None, 1.0, None, g3, c3, v3, None, sync=True)
+    assert torch.equal(g3, g2) and torch.equal(c3, c2) and torch.equal(v3, v2)
+    h3 = new(d.nnzh)
+    d.eval_all(xd, yd, 0.9, hvals=h3, sync=True)
+    assert torch.equal(h3, h)
+    d.close()
