@@ -8,7 +8,7 @@
 # committed).
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -44,7 +44,7 @@ for name, c in res["pmc_mean_per_launch"].items():
          "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
          "rocprof_avg_kernel_ns": float(res["kernels"].get(name, {}).get("AverageNs", "nan"))}
     if "hess_kernel" in name: traffic["hessian_kernels"][name] = e
-    elif "cons_jac_kernel<ctd::GoddardOCP, 2, 2>" in name: traffic["bench_kernel"] = e
+    elif "cons_jac_kernel<ctd::GoddardOCP, 2, 2" in name: traffic["bench_kernel"] = e
     else: traffic["other_kernels"][name] = e
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res["kernels"], indent=1)[:3000])

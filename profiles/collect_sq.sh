@@ -7,7 +7,7 @@
 # issue, issuing).
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
