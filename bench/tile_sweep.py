@@ -12,8 +12,9 @@ import ctdirect_jl_amd as ct  # noqa: E402
 from helpers import bench_inputs, describe  # noqa: E402
 from stamps import CFGS  # noqa: E402
 
-TILES = {"cfg2": (8, 10, 14, 16, 20, 21, 24, 32, 40), "cfg3": (32, 64, 96, 128, 196, 256, 391), "cfg4": (16, 24, 32, 48, 64)}
-BLOCKS = (256, 320, 384, 512)
+TILES = {"cfg2": (8, 10, 14, 16, 20, 21, 24, 32, 40), "cfg3": (32, 64, 96, 128, 196, 256, 391), "cfg4": (16, 24, 32, 48, 64),
+         "cfg5p": (6, 8, 10, 12, 14, 16, 20), "cfg5": (4, 5, 6, 7, 8, 9, 10)}
+BLOCKS = tuple(int(b) for b in os.environ.get("SWEEP_BLOCKS", "256,320,384,512").split(","))
 
 
 def main():
@@ -28,7 +29,7 @@ def main():
                 c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
                 v = torch.zeros(d.nnzj, dtype=torch.float64, device="cuda")
                 ms = sorted(d.time_cons_jac(x, c, v, iters=200) for _ in range(3))[1]
-                row.append(f"T={d.launch_info()['steps_per_tile']}:{ms * 1e3:.2f}")
+                row.append(f"T={d.launch_info()['steps_per_tile']}(lds {d.launch_info()['lds_bytes'] // 1024}K):{ms * 1e3:.2f}")
                 d.close()
             print(f"{name} block={blk}  " + "  ".join(row), flush=True)
     os.environ.pop("CTD_TILE", None)

@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctdirect_hip.so")
+LIB_PATH = os.environ.get("CTD_LIB_PATH") or os.path.join(_HERE, "libctdirect_hip.so")      # (override: A/B runs of experiment builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 # status codes (include/ctdirect_hip.h)

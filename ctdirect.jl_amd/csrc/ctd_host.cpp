@@ -737,7 +737,12 @@ static int build_tables(Model& mo, std::string& err) {
         mo.dropped = N * (int64_t)L.n * L.nv;
     // implicit Euler: the path rows of nodes 2..N depend on U_{i-1}, the pattern lists U_i (euler.jl:59-72 vs :231), in
     // either pattern mode (the periodic emit tables cannot reference the next step's record)
-    if (L.euler == 2 && L.p > 0 && L.m > 0 && mo.pattern_mode == 0) mo.dropped += (N - 1) * (int64_t)L.p * L.m;
+    if (L.euler == 2 && L.p > 0 && L.m > 0 && mo.pattern_mode == 0) {
+        int64_t pairs = 0;                                  // (path row, control) pairs the path functions really couple
+        for (int q = 0; q < L.p; ++q)
+            for (int c = 0; c < L.m; ++c) pairs += (mo.dep_g.size() > (size_t)q && (mo.dep_g[q] >> (L.n + c) & 1u)) ? 1 : 0;
+        mo.dropped += (N - 1) * pairs;
+    }
     return ST_OK;
 }
 
@@ -753,6 +758,10 @@ int default_tile(const Model& mo, int64_t nsteps) {
     const int64_t cap = (L.sc == SC_IRK) ? 32 : 64;
     int64_t T = 1;
     while (T * 2 <= fit && T * 2 <= cap) T *= 2;
+    // wide OCPs (several direction chunks per evaluation point: the quadrotors): the emit phase runs at the chip's write rate
+    // only while the other phases of co-resident workgroups overlap it, so three workgroups per CU (52 KiB each) beat two
+    // larger ones; at most 8 steps (profiles/r02_tile_sweeps.log: 12-state quadrotor 7 steps 117 us vs 8 steps 122 us)
+    if (!mo.fused) T = std::max<int64_t>(4, std::min<int64_t>(8, (52 * 1024) / per_step - mo.HL - mo.HH));
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
     if ((nsteps + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (nsteps + 479) / 480));
     return (int)T;
@@ -824,8 +833,8 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         for (int64_t i = 0; i <= N; ++i) mo.fixed_grid[i] = mo.L.t0 + (mo.tau[i] * (mo.L.tf - mo.L.t0));
     build_bounds(mo);
     build_tail_blocks(mo);
+    compute_dep_masks(mo);          // operator-level dependence masks: the OPTIMIZED pattern, and the count of dropped nonzeros
     if (mo.pattern_mode == 2) {
-        compute_dep_masks(mo);
     }
     st = build_tables(mo, err);
     if (st) return st;

@@ -331,7 +331,10 @@ static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag,
 // constraint / Jacobian kernel (ctd_layout.hpp: F[n x ldx] | G[n x ldu] | W[n x nv] | f[n] | ft[n]): body of
 // UserOCP::dyn_sym(t, x, u, v, ev).  Every entry of F and G is written (structural zeros as 0.0); ft / W only when the
 // dynamics depend on t / v explicitly, as eval_dynamics does.
-static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err) {
+// `nparts` > 1: body = the cases of a switch on `part`; part k holds the outputs of the rows r = k, k + nparts, ... (the rows
+// of an OCP come in classes of similar cost -- kinematics, rotation, inertia -- so striding balances the parts); the lanes of
+// one evaluation point that would each differentiate a chunk of directions with duals split the symbolic code this way
+static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err, int nparts = 1) {
     const int n = d->n, m = d->m, nv = d->nv;
     const RecLayout R = make_rec_layout(n, m, nv, d->npath, d->nbc, 0, n + d->npath);     // eval-block offsets depend on n, m, nv only
     sym::Graph g;
@@ -352,15 +355,19 @@ static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bo
         f[r] = v.node;
         dyn_t = dyn_t || ps.uses_t; dyn_v = dyn_v || ps.uses_v;
     }
-    std::vector<std::pair<std::string, int>> outs;
-    for (int r = 0; r < n; ++r) {
-        for (int c = 0; c < n; ++c) outs.emplace_back("ev[" + std::to_string(R.oF + r * R.ldx + c) + "]", g.at_zero(g.diff(f[r], 1 + c)));
-        for (int b = 0; b < m; ++b) outs.emplace_back("ev[" + std::to_string(R.oG + r * R.ldu + b) + "]", g.at_zero(g.diff(f[r], 1 + n + b)));
-        if (dyn_t) outs.emplace_back("ev[" + std::to_string(R.oft + r) + "]", g.at_zero(g.diff(f[r], 0)));
-        if (dyn_v) for (int k = 0; k < nv; ++k) outs.emplace_back("ev[" + std::to_string(R.oW + r * nv + k) + "]", g.at_zero(g.diff(f[r], 1 + n + m + k)));
-        outs.emplace_back("ev[" + std::to_string(R.of + r) + "]", g.at_zero(f[r]));
+    body.clear();
+    for (int part = 0; part < nparts; ++part) {
+        std::vector<std::pair<std::string, int>> outs;
+        for (int r = part; r < n; r += nparts) {
+            for (int c = 0; c < n; ++c) outs.emplace_back("ev[" + std::to_string(R.oF + r * R.ldx + c) + "]", g.at_zero(g.diff(f[r], 1 + c)));
+            for (int b = 0; b < m; ++b) outs.emplace_back("ev[" + std::to_string(R.oG + r * R.ldu + b) + "]", g.at_zero(g.diff(f[r], 1 + n + b)));
+            if (dyn_t) outs.emplace_back("ev[" + std::to_string(R.oft + r) + "]", g.at_zero(g.diff(f[r], 0)));
+            if (dyn_v) for (int k = 0; k < nv; ++k) outs.emplace_back("ev[" + std::to_string(R.oW + r * nv + k) + "]", g.at_zero(g.diff(f[r], 1 + n + m + k)));
+            outs.emplace_back("ev[" + std::to_string(R.of + r) + "]", g.at_zero(f[r]));
+        }
+        if (nparts == 1) body = g.codegen(outs, "p", "        ");
+        else body += "            case " + std::to_string(part) + ": {\n" + g.codegen(outs, "p", "                ") + "            } break;\n";
     }
-    body = g.codegen(outs, "p", "        ");
     return true;
 }
 

@@ -523,7 +523,9 @@ template <class P, int S> CTD_HD void path_control(const KParams& kp, const Bloc
 // specialisation generated at build time for a registry problem (ctd_sym_registry.hpp, included at the end of this header)
 template <class P> struct SymDyn {
     static constexpr bool value = P::HAS_SYM_DYN;
+    static constexpr int parts = 1;       // lanes the generated code of one evaluation point is split over (registry: by rows)
     CTD_HD static void eval(const double* p, double* ev) { if constexpr (P::HAS_SYM_DYN) P::dyn_sym(p, ev); }
+    CTD_HD static void eval_part(int, const double* p, double* ev) { eval(p, ev); }
 };
 template <class P> struct SymPath {
     static constexpr bool value = P::HAS_SYM_PATH;
@@ -536,7 +538,9 @@ template <class P> struct SymLag {       // Lagrange cost: out = [value | l_x | 
 template <class P> struct SymStage;
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
-template <class P, int SC, int S>
+// SPLIT: the caller runs the NCH_DYN lanes of this point in different waves (uniform q per wave), so the generated code may be
+// split over them by rows; otherwise the lane of chunk 0 evaluates all of it
+template <class P, int SC, int S, bool SPLIT = false>
 CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q, double* ev) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
     using D = Dual<DC>;
@@ -584,8 +588,10 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int c = 0; c < m; ++c) uv[c] = U[c];
     }
     if constexpr (SymDyn<P>::value) {
-        // every partial of the point by the generated straight-line code, on the lane of the first direction chunk
-        if (q != 0) return;
+        // every partial of the point by the generated straight-line code: on the lane of the first direction chunk, or split
+        // by rows over the lanes of all chunks when the generator provides the parts
+        constexpr bool split = SPLIT && SymDyn<P>::parts > 1 && SymDyn<P>::parts == Dirs<P>::NCH_DYN;
+        if (!split && q != 0) return;
         CTD_SUB(kp, 6);
         double prm[1 + n + m + nv];
         prm[0] = t;
@@ -595,7 +601,8 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int c = 0; c < m; ++c) prm[1 + n + c] = uv[c];
 #pragma unroll
         for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = cx.v[c];
-        SymDyn<P>::eval(prm, ev);
+        if constexpr (split) SymDyn<P>::eval_part(q, prm, ev);
+        else SymDyn<P>::eval(prm, ev);
         return;
     }
     // seed directions [x | u | t | v] of this chunk
@@ -893,6 +900,29 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
     // passes, one lead role (coefficients + state rows, fused mode).
     CTD_SUB(kp, 0);
+#ifndef CTD_NO_SPLIT
+    // (four parts and more: measured +2 % for the 12-state quadrotor, -4 % for the 8-state one with three, profiles/r02_tile_sweeps.log)
+    if constexpr (SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !FUSED) {
+        // Wide OCPs: the symbolic code of one evaluation point is long (12 states: ~1300 instructions) and only S * ns lanes
+        // would run it.  It comes split by rows into NCH_DYN parts: part q of every point runs in wave q (uniform code per
+        // wave, the parts side by side on different SIMDs); the path passes take lanes 32.. of the same waves.
+        constexpr int NP = Dirs<P>::NCH_DYN;
+        const int nd = S * ns;
+        if (nd <= 32 && ns <= 32 && r_path <= NP && NP * 64 <= nthr) {
+            const int wave = tid >> 6, l = tid & 63;
+            if (wave < NP) {
+                if (l < nd) {
+                    const int j = l / ns, k = l - j * ns;
+                    eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+                } else if (l >= 32 && l < 32 + ns && wave < r_path) {
+                    eval_step_path<P, SC, S>(kp, cx, l - 32, wave);
+                }
+            }
+            for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
+            return;
+        }
+    }
+#endif
     const int lg = ns <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ns - 1));
     const int mask = (1 << lg) - 1;
     const int total = (r_dyn + r_path + r_lead) << lg;
@@ -1088,6 +1118,8 @@ CTD_HD EmitPre emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int
     if (Ls > 0 && Ls <= nthr) {
         const int k = tid - (int)fast_div((uint32_t)tid, kp.div_Lseg) * Ls;
         pre.b = kp.tmpl[k];
+    } else if (Ls > nthr) {
+        pre.b = kp.tmpl[tid];              // first of the positions tid, tid + nthr, ... this lane owns
     }
     const int vr = kp.vr;
 #pragma unroll
@@ -1207,8 +1239,12 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                     }
                 }
             } else {
+                // long periods (more positions than lanes): a lane owns positions tid, tid + nthr, ...; the code of the NEXT
+                // position is fetched while the current one is streamed out (the table is read from global memory / L2 here:
+                // a dependent load at the top of every position would expose its latency a dozen times per tile)
+                uint32_t code = (pre && tid < Ls) ? pre->b : (tid < Ls ? cx.codes[tid] : 0u);
                 for (int k = tid; k < Ls; k += nthr) {
-                    const uint32_t code = cx.codes[k];
+                    const uint32_t nxt = k + nthr < Ls ? cx.codes[k + nthr] : 0u;
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
@@ -1226,6 +1262,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                         for (int u = 0; u < 4; ++u)
                             if (s0 + u < nreg) out[(s0 + u) * Ls + k] = a[u] * b[u] + beta;
                     }
+                    code = nxt;
                 }
             }
         }

@@ -485,7 +485,9 @@ def test_implicit_euler_structural_pattern_is_complete(oracle_lib, torch_cuda, p
     import scipy.sparse as sp
     N = 300
     man = ct.DOCP(prob, N, "euler_implicit", device=-1)
-    assert man.dropped_nonzeros() == (N - 1) * man.dims.path_cons * man.dims.NLP_u
+    # (path row, control) pairs the path functions really couple (goddard_all: rows u and x1+x2+x3+u+v; the double integrator's
+    # path constraint q + 0.1 w^2 has none; the quadrotor's cos(theta) cos(phi) has none)
+    assert man.dropped_nonzeros() == (N - 1) * {"goddard_all": 2, "double_integrator_path": 0, "quadrotor": 0}[prob]
     for pattern, mode in (("structural", 1), ("optimized", 2)):
         d = ct.DOCP(prob, N, "euler_implicit", pattern=pattern, device=0)
         assert d.dropped_nonzeros() == 0
