@@ -764,6 +764,13 @@ int default_tile(const Model& mo, int64_t nsteps) {
     if (!mo.fused) T = std::max<int64_t>(4, std::min<int64_t>(8, (52 * 1024) / per_step - mo.HL - mo.HH));
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
     if ((nsteps + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (nsteps + 479) / 480));
+    // light steps on long grids (double integrator, midpoint, 100 000 steps: 152 bytes of output per step): ONE round of ~512
+    // workgroups (two per CU) when such a tile still fits 80 KiB of LDS -- 196-step tiles 6.1 us vs 64-step tiles 7.6 us
+    // (profiles/r02_tile_sweeps.log); heavier steps keep the smaller tile
+    if (mo.fused) {
+        const int64_t T1 = (nsteps + 511) / 512;
+        if (T1 > T && (T1 + mo.HL + mo.HH + 1) * per_step <= 80 * 1024) T = T1;
+    }
     return (int)T;
 }
 

@@ -1093,6 +1093,94 @@ template <class P> static void lagrangian_hessian(Docp& p, const double* xu, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// BLOCK mode of the Hessian of the Lagrangian: the Lagrangian is a sum over time steps (+ the boundary / Mayer point), so
+// the sparse second-order sweep of `lagrangian_hessian` can run one step at a time on the one-step sub-problem of
+// cons_jac_block (variables seeded with their GLOBAL indices) and in parallel over the steps.  Same number type, same
+// `constraints` / `objective` templates; contributions of neighbouring steps to a shared entry are added atomically (their
+// order is not fixed: a checker with a tolerance, not bit-reproducible).  Not how the reference obtains it; it exists so that
+// EVERY Hessian entry can be checked at the full BASELINE sizes.  Not available for implicit Euler.
+// ---------------------------------------------------------------------------------------------
+template <class P> static void make_docp(Docp& p, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len);
+
+template <class P> static bool hessian_block(Docp& p, const double* xu, const double* y, double sigma, double* vals, int64_t* dropped, int nthreads) {
+    ensure_hess_pattern(p);
+    const Disc& d = p.disc;
+    if (d.euler && !d.euler_explicit) return false;
+    const int n = p.dims.NLP_x, nv = p.dims.NLP_v, np = p.dims.path_cons, nb = p.dims.boundary_cons;
+    const int64_t N = p.steps, nvar = p.dim_NLP_variables, ncon = p.dim_NLP_constraints;
+    const int blk = d.step_variables_block, cb = d.state_stage_eqs_block + d.step_pathcons_block;
+    if (nthreads < 1) nthreads = 1;
+    const int64_t nnz = (int64_t)p.hrowval.size();
+    for (int64_t k = 0; k < nnz; ++k) vals[k] = 0.0;
+    const Docp& cp = p;
+    int64_t drop0 = 0, drop1 = 0;
+    auto scatter = [&](const S2::HVec& acc, int64_t& d0, int64_t& d1) {
+        for (auto& e : acc) {
+            const int64_t row = (int64_t)(e.first >> 32), col = (int64_t)(e.first & 0xffffffffu);
+            const int64_t* b = cp.hrowval.data() + cp.hcolptr[col];
+            const int64_t* en = cp.hrowval.data() + cp.hcolptr[col + 1];
+            const int64_t* it = std::lower_bound(b, en, row);
+            if (it != en && *it == row) {
+                double& dst = vals[it - cp.hrowval.data()];
+#pragma omp atomic
+                dst += e.second;
+            } else { d0++; if (e.second != 0.0) d1++; }
+        }
+    };
+#pragma omp parallel num_threads(nthreads) reduction(+ : drop0, drop1)
+    {
+        Docp p1;
+        p1.problem = cp.problem;
+        make_docp<P>(p1, d.scheme, 1, nullptr, 0);
+        p1.flags.mayer = false;                              // the Mayer term belongs to the boundary point below
+        const int W = (int)p1.dim_NLP_variables, nloc = W - nv;
+        std::vector<S2> z(W), cz(p1.dim_NLP_constraints);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 1; i <= N; ++i) {
+            p1.normalized_grid[0] = cp.normalized_grid[i - 1]; p1.normalized_grid[1] = cp.normalized_grid[i];
+            p1.fixed_grid[0] = cp.fixed_grid[i - 1]; p1.fixed_grid[1] = cp.fixed_grid[i];
+            const double* xs = xu + (i - 1) * (int64_t)blk;
+            for (int l = 0; l < nloc; ++l) z[l] = S2::variable(xs[l], (i - 1) * (int64_t)blk + l);
+            for (int k = 0; k < nv; ++k) z[nloc + k] = S2::variable(xu[nvar - nv + k], nvar - nv + k);
+            S2::HVec acc;
+            if (cp.flags.lagrange) {
+                const S2 f = objective<P, S2>(p1, z.data());
+                for (auto& e : f.h) acc.emplace_back(e.first, sigma * e.second);
+            }
+            constraints<P, S2>(p1, z.data(), cz.data());
+            const int64_t row0 = (i - 1) * (int64_t)cb;
+            for (int r = 0; r < cb; ++r)
+                for (auto& e : cz[r].h) acc.emplace_back(e.first, y[row0 + r] * e.second);
+            if (i == N)
+                for (int r = 0; r < np; ++r)
+                    for (auto& e : cz[cb + r].h) acc.emplace_back(e.first, y[N * (int64_t)cb + r] * e.second);
+            s2detail::compress(acc);
+            scatter(acc, drop0, drop1);
+        }
+#pragma omp single
+        if (nb > 0 || cp.flags.mayer) {                      // boundary rows + Mayer cost: phi(X_1, X_N+1, V), g(X_1, X_N+1, V)
+            std::vector<S2> x0(n), xf(n), v(nv > 0 ? nv : 1), out(nb > 0 ? nb : 1);
+            for (int k = 0; k < n; ++k) { x0[k] = S2::variable(xu[k], k); xf[k] = S2::variable(xu[N * (int64_t)blk + k], N * (int64_t)blk + k); }
+            for (int k = 0; k < nv; ++k) v[k] = S2::variable(xu[nvar - nv + k], nvar - nv + k);
+            S2::HVec acc;
+            if (nb > 0) {
+                P::template boundary<S2>(out.data(), x0.data(), xf.data(), v.data());
+                for (int r = 0; r < nb; ++r)
+                    for (auto& e : out[r].h) acc.emplace_back(e.first, y[ncon - nb + r] * e.second);
+            }
+            if (cp.flags.mayer) {
+                const S2 g = P::template mayer<S2>(x0.data(), xf.data(), v.data());
+                for (auto& e : g.h) acc.emplace_back(e.first, sigma * e.second);
+            }
+            s2detail::compress(acc);
+            scatter(acc, drop0, drop1);
+        }
+    }
+    dropped[0] = drop0; dropped[1] = drop1;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // problem registry
 // ---------------------------------------------------------------------------------------------
 template <class P> struct Tag { using type = P; };
@@ -1267,6 +1355,13 @@ int orc_cons_jac_block(void* h, const double* xu, double* c, double* vals, int n
     Docp& p = *(Docp*)h;
     bool ok = false;
     orc::dispatch(p.problem, [&](auto tag) { ok = orc::cons_jac_block<typename decltype(tag)::type>(p, xu, c, vals, nthreads); });
+    return ok ? 1 : 0;
+}
+// block mode of hess_coord (returns 0 when the scheme has none)
+int orc_hess_coord_block(void* h, const double* xu, const double* y, double obj_weight, double* vals, int64_t* dropped2, int nthreads) {
+    Docp& p = *(Docp*)h;
+    bool ok = false;
+    orc::dispatch(p.problem, [&](auto tag) { ok = orc::hessian_block<typename decltype(tag)::type>(p, xu, y, obj_weight, vals, dropped2, nthreads); });
     return ok ? 1 : 0;
 }
 void orc_jac_column(void* h, const double* xu, int64_t col, double* out) {

@@ -86,6 +86,8 @@ def lib():
         L.orc_jac_coord_mt.argtypes = [C.c_void_p, dp, dp, C.c_int]
         L.orc_cons_jac_block.argtypes = [C.c_void_p, dp, dp, dp, C.c_int]
         L.orc_cons_jac_block.restype = C.c_int
+        L.orc_hess_coord_block.argtypes = [C.c_void_p, dp, dp, C.c_double, dp, ip, C.c_int]
+        L.orc_hess_coord_block.restype = C.c_int
         L.orc_jac_column.argtypes = [C.c_void_p, dp, C.c_int64, dp]
         L.orc_hess_nnz.argtypes = [C.c_void_p, ip, ip]
         L.orc_hess_lower_nnz.argtypes = [C.c_void_p]
@@ -257,6 +259,18 @@ class OracleDOCP:
         rowval = np.zeros(nnz, dtype=np.int64)
         lib().orc_hess_pattern(self._h, _ip(colptr), _ip(rowval))
         return colptr, rowval
+
+    def hess_coord_block(self, xu, y, obj_weight=1.0, nthreads=1, return_dropped=False):
+        """Block mode of hess_coord (oracle/ctd_oracle.cpp hessian_block): the same second-order sweep one time step at a time,
+        OpenMP over the steps -- affordable at the full BASELINE sizes.  None for schemes without it (implicit Euler)."""
+        xu = np.ascontiguousarray(xu, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert xu.size == self.dim_NLP_variables and y.size == self.dim_NLP_constraints
+        vals = np.zeros(int(lib().orc_hess_lower_nnz(self._h)))
+        dropped = np.zeros(2, dtype=np.int64)
+        if not lib().orc_hess_coord_block(self._h, _dp(xu), _dp(y), float(obj_weight), _dp(vals), _ip(dropped), int(nthreads)):
+            return None
+        return (vals, (int(dropped[0]), int(dropped[1]))) if return_dropped else vals
 
     def hess_coord(self, xu, y, obj_weight=1.0, return_dropped=False):
         """hess_coord!(nlp, x, y, vals; obj_weight): sparse second-order forward sweep over objective and constraints."""

@@ -4,6 +4,8 @@ ABI (ctd_hess_structure / ctd_hess_coord / ctd_hess_coord_dev); the checker is t
 
 Tolerance: max |gpu - ref| / max(1, |ref|) <= 1e-10 on the values; the pattern (lower triangle of DOCP_Hessian_pattern)
 is bit-exact (CPU: tests/test_hessian_cpu.py; re-checked here for the handles used)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -176,6 +178,17 @@ def test_hessian_full_size_properties(torch_cuda, prob, sch, N):
     d.hess_coord(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), sigma, vd)
     assert not bool((vd == SENT).any()) and bool(torch.isfinite(vd).all())
     v = vd.cpu().numpy()
+    # EVERY entry at full size against the oracle's block mode (the second-order sweep of `lagrangian_hessian` one time step
+    # at a time, OpenMP over the steps; equal to the full sweep to 3e-15 where both run, tests/test_oracle_goldens.py).  Random
+    # multipliers of both signs make single entries sums of cancelling terms: criterion relative to the magnitude of what is
+    # summed, as in test_hessian_baseline_configs_direct_parity (b)
+    from oracle.oracle import OracleDOCP
+    o = OracleDOCP(prob, sch, N)
+    ncpu = os.cpu_count() or 1
+    ref, dropped = o.hess_coord_block(x, y, sigma, ncpu, return_dropped=True)
+    assert dropped == (0, 0)
+    scale = np.maximum(1.0, np.maximum(np.abs(ref), np.abs(o.hess_coord_block(x, np.abs(y), sigma, ncpu))))
+    assert float(np.max(np.abs(v - ref) / scale)) <= TOL
     rows, cols = d.hess_structure()
     Hl = sp.coo_matrix((v, (rows - 1, cols - 1)), shape=(nvar, nvar)).tocsr()
     diag = sp.diags(Hl.diagonal())

@@ -267,3 +267,23 @@ def test_G2_optimized_backend_counts(oracle_lib):
         mask[rv[cp[j]:cp[j + 1]], j] = True
     assert not np.any(J[~mask] != 0.0)
     assert np.array_equal(o3.jac_coord(x), dense_on_pattern(J, cp, rv))
+
+
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "double_integrator_path", "quadrotor", "least_squares_with_constraint",
+                                  "double_integrator_freet0tf"])
+def test_block_mode_equals_full_hessian_sweep(oracle_lib, prob):
+    """The oracle's block mode of hess_coord (one time step at a time, the checker of the full-size Hessians) against its full
+    sparse second-order sweep, all three pattern modes; the same entries are dropped by the reference's incomplete patterns."""
+    from helpers import bench_inputs, describe, relerr
+    for sch in ("trapeze", "midpoint", "euler", "gauss_legendre_2", "gauss_legendre_3_constant_control"):
+        for mode in (0, 1, 2):
+            for N in (1, 2, 7):
+                o = oracle_lib.OracleDOCP(prob, sch, N)
+                o.set_pattern_mode(mode)
+                x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+                y = np.cos(0.3 * np.arange(o.dim_NLP_constraints))
+                a, da = o.hess_coord(x, y, 0.7, return_dropped=True)
+                b, db = o.hess_coord_block(x, y, 0.7, 3, return_dropped=True)
+                assert relerr(b, a) <= 1e-12 and da[1] == db[1], (prob, sch, mode, N)
+    oi = oracle_lib.OracleDOCP(prob, "euler_implicit", 3)
+    assert oi.hess_coord_block(np.full(oi.dim_NLP_variables, 0.3), np.ones(oi.dim_NLP_constraints), 1.0, 1) is None
