@@ -67,7 +67,9 @@ def cpu_baseline(problem, scheme, N, x, budget_s=10.0):
     out = {"value": n / el, "unit": "evals/s", "cores": 1, "kind": "port",
            "sample": f"{n} fused evaluations (cons! + {o.jac_ncolors()}-colour forward-dual jac_coord!) of the same "
                      f"{problem}/{scheme} N={N} workload in {el:.1f} s, oracle/ctd_oracle.cpp, 1 thread"}
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # host threads: what the process may use, at most 16 (a one-GPU box shares its host: more threads than its CPU share only
+    # oversubscribe -- 256 OpenMP threads on such a box ran 100x slower than 16)
+    avail = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     cores = max(1, min(o.jac_ncolors(), avail))
     o.jac_coord_mt(x, cores)
     n, el = rate(lambda: (o.constraints(x), o.jac_coord_mt(x, cores)), budget_s / 3)
@@ -117,8 +119,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("CTD_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # CTD_DIST_FORCE=1 (rehearsal on the one-GPU box): a ONE-rank RCCL group, every collective of the multi-GPU step issued
+    dist_on = world > 1 or os.environ.get("CTD_DIST_FORCE") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":     # bind the communicator to this rank's GPU up front (barriers need no device guess)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
@@ -138,7 +143,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -164,7 +169,7 @@ def main():
         sync_all()
         el = time.perf_counter() - t0
         region["ms_per_launch"] = e0.elapsed_time(e1) / steps
-        if world > 1:
+        if dist_on:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
@@ -172,12 +177,12 @@ def main():
 
     # The timed step.  N = 1: one fused evaluation, pointers pre-bound.  N > 1: iterate distribution (halo exchange of the
     # sharded x) + the rank's evaluation; outputs stay row-sharded, so no collective follows the kernel.
-    x_mode = "halo" if world > 1 else None
+    x_mode = "halo" if dist_on else None
     el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), args.warmup, args.steps)
     region_ms = region["ms_per_launch"]
     per_step_value = (world if cfg["scaling"] == "weak" else 1)
     secondary = {}
-    if world > 1:
+    if dist_on:
         ks = max(1, min(args.steps, 500))
         for key, kw, what in (
                 ("stitched_c", dict(stitch=True, x_mode="halo"), "same step + all-gather of the row blocks of c (every rank ends with the whole c)"),
@@ -194,7 +199,7 @@ def main():
     # timed launches / K (back-to-back launches: the kernel's average duration including the dispatch gap); N > 1 (the
     # region also holds collectives): per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
     per_dispatch = sorted(docp.time_cons_jac(x, c, vals, iters=200) for _ in range(5))[2]
-    kernel_ms = region_ms if world == 1 else per_dispatch
+    kernel_ms = region_ms if not dist_on else per_dispatch
     # algorithmic bytes of one launch: read the shard's x, write its c rows and Jacobian values:
     # B = 8 (nvar + ncon + nnzj) of the per-rank sub-problem
     b, e = sh.steps
@@ -202,7 +207,7 @@ def main():
     alg_bytes = 8 * (one.dim_NLP_variables + one.dim_NLP_constraints + one.nnzj)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     per_rank = None
-    if world > 1:
+    if dist_on:
         t = torch.zeros(world, dtype=torch.float64, device=dev)
         t[rank] = per_dispatch
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -309,7 +314,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(PROBLEM, SCHEME, N, x_host)
         out.update(secondary)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

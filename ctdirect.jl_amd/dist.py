@@ -25,8 +25,15 @@ its own rows c[(i-1)(eqs+p)+1 : i(eqs+p)] and the Jacobian entries of those rows
 Every collective is enqueued on torch's current stream, and so are the engine's kernels (`ShardedDOCP` rebinds the handle
 to that stream): nothing here synchronises with the host.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# Rehearsal knob: run the collectives on a ONE-rank group too (they are no-ops for the data, but every RCCL call of the
+# multi-GPU path -- in-place / padded all-gather, halo all-gather, all-reduce, broadcast -- is issued exactly as on 8 GPUs),
+# so the one-GPU box can exercise the real backend
+_FORCE = os.environ.get("CTD_DIST_FORCE") == "1"
 
 
 def shard_steps(N, world, rank):
@@ -66,7 +73,7 @@ class _Stitcher:
         self.N, self.cb, self.world, self.rank, self.group = N, cb, world, rank, group
         self.tail = ncon - N * cb
         self.in_place = (N % world == 0) and self.tail == 0
-        if not self.in_place and world > 1:
+        if not self.in_place and (world > 1 or _FORCE):
             blocks = [shard_steps(N, world, r) for r in range(world)]
             self.smax = max(e - b for b, e in blocks) * cb + self.tail
             self.begin, self.end = blocks[rank][0] * cb, blocks[rank][1] * cb
@@ -80,7 +87,7 @@ class _Stitcher:
             self.recv = torch.zeros(world * self.smax, dtype=torch.float64, device=device)
 
     def __call__(self, c):
-        if self.world == 1:
+        if self.world == 1 and not _FORCE:
             return c
         N, cb, world, rank = self.N, self.cb, self.world, self.rank
         if self.in_place:
@@ -172,35 +179,39 @@ class ShardedDOCP:
         Jacobian columns read -- the next rank's first node (X, + U for trapeze); for the one-point schemes (midpoint, Euler)
         the previous rank's last step block, whose residual depends on this rank's first state; X_1 and X_{N+1} (boundary rows,
         Mayer cost) -- with ONE all-gather of (halo_w + low + n) doubles per rank.  v is replicated by the solver and not
-        touched."""
-        if self.world == 1:
+        touched.  Three small kernels around the collective: pack (index_select), unpack (index_select + index_copy_)."""
+        if self.world == 1 and not _FORCE:
             return x
-        w, n, blk, N, lo = self.halo_w, self.n, self.blk, self.N, self.halo_lo
-        L = w + lo + n
         if self._halo is None:
-            self._halo = (torch.zeros(L, dtype=torch.float64, device=x.device),
-                          torch.zeros(self.world * L, dtype=torch.float64, device=x.device))
-        send, recv = self._halo
-        b, e = self.steps
-        send[:w].copy_(x[b * blk:b * blk + w])                          # my first node
-        if lo:
-            send[w:w + lo].copy_(x[(e - 1) * blk:e * blk])              # my last step block
-        if self.rank == self.world - 1:
-            send[w + lo:].copy_(x[N * blk:N * blk + n])                 # the final state
+            w, n, blk, N, lo = self.halo_w, self.n, self.blk, self.N, self.halo_lo
+            L = w + lo + n
+            b, e = self.steps
+            r, G = self.rank, self.world
+            ar = torch.arange
+            pack = torch.cat([b * blk + ar(w), (e - 1) * blk + ar(lo), N * blk + ar(n)])      # my first node | last block | final state
+            dst, src = [], []
+            if r + 1 < G:
+                dst += [e * blk + ar(w), N * blk + ar(n)]
+                src += [(r + 1) * L + ar(w), (G - 1) * L + w + lo + ar(n)]
+            if r > 0:
+                if lo:
+                    dst.append((b - 1) * blk + ar(lo))
+                    src.append((r - 1) * L + w + ar(lo))
+                dst.append(ar(n))
+                src.append(ar(n))
+            empty = torch.zeros(0, dtype=torch.long)
+            self._halo = (pack.to(x.device), (torch.cat(dst) if dst else empty).to(x.device), (torch.cat(src) if src else empty).to(x.device),
+                          torch.zeros(L, dtype=torch.float64, device=x.device), torch.zeros(G * L, dtype=torch.float64, device=x.device))
+        pack, dst, src, send, recv = self._halo
+        torch.index_select(x, 0, pack, out=send)
         _all_gather_into(recv, send, self.group)
-        r = self.rank
-        if r + 1 < self.world:
-            x[e * blk:e * blk + w].copy_(recv[(r + 1) * L:(r + 1) * L + w])
-            x[N * blk:N * blk + n].copy_(recv[(self.world - 1) * L + w + lo:self.world * L])
-        if r > 0:
-            if lo:
-                x[(b - 1) * blk:b * blk].copy_(recv[(r - 1) * L + w:(r - 1) * L + w + lo])
-            x[:n].copy_(recv[:n])
+        if dst.numel():
+            x.index_copy_(0, dst, recv.index_select(0, src))
         return x
 
     def broadcast_iterate(self, x, src=0):
         """Replicated iterate: the rank that holds the new x sends all of it (nvar doubles) to every other rank."""
-        if self.world > 1:
+        if self.world > 1 or _FORCE:
             dist.broadcast(x, src=src, group=self.group)
         return x
 
@@ -223,7 +234,7 @@ class ShardedDOCP:
         exchange_halo) / "broadcast" (replicated x from rank 0) / None] + enqueue this rank's evaluation [+ the all-gather of c
         when `stitch`]."""
         launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
-        if self.world == 1:
+        if self.world == 1 and not _FORCE:
             return launch
         pre = {None: None, "halo": self.exchange_halo, "broadcast": self.broadcast_iterate}[x_mode]
         post = self._stitcher(c) if stitch else None
@@ -241,7 +252,7 @@ class ShardedDOCP:
         the Jacobian values), plus the all-reduced variable x variable entries on every rank.  No host synchronisation: the
         kernel and the all-reduce are ordered on torch's current stream."""
         self.docp.hess_coord(x, y, obj_weight, vals, sync=False)
-        if self.world > 1:
+        if self.world > 1 or _FORCE:
             if self._vv is None:
                 self._vv = torch.as_tensor(self.docp.hess_shard_info()[2], dtype=torch.long, device=vals.device)
             reduce_hessian_vv(vals, self._vv, self.group)
@@ -255,7 +266,7 @@ class ShardedDOCP:
         if self._f is None:
             self._f = torch.zeros(1, dtype=torch.float64, device=x.device)
         self.docp.obj_async(x, self._f)
-        if self.world > 1:
+        if self.world > 1 or _FORCE:
             dist.all_reduce(self._f, op=dist.ReduceOp.SUM, group=self.group)
         return self._f if as_tensor else float(self._f.item())
 

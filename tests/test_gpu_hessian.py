@@ -184,7 +184,7 @@ def test_hessian_full_size_properties(torch_cuda, prob, sch, N):
     # summed, as in test_hessian_baseline_configs_direct_parity (b)
     from oracle.oracle import OracleDOCP
     o = OracleDOCP(prob, sch, N)
-    ncpu = os.cpu_count() or 1
+    ncpu = min(16, os.cpu_count() or 1)
     ref, dropped = o.hess_coord_block(x, y, sigma, ncpu, return_dropped=True)
     assert dropped == (0, 0)
     scale = np.maximum(1.0, np.maximum(np.abs(ref), np.abs(o.hess_coord_block(x, np.abs(y), sigma, ncpu))))

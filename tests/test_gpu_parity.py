@@ -113,7 +113,10 @@ def test_oracle_parity_midsize(oracle_lib, torch_cuda, prob, sch):
             # nonzeros the manual pattern drops (free times / v-dependent dynamics) and the handle reports them, or
             # the problem does not depend on v there and their values are exactly zero
             extra = Js - Js.multiply(mask)
-            assert dm.dropped_nonzeros() in (0, d.nnzj - dm.nnzj)
+            # (block count for the trapeze hazard; for implicit Euler only the (path row, control) pairs the path functions
+            # really couple are counted: at most the block)
+            assert 0 <= dm.dropped_nonzeros() <= d.nnzj - dm.nnzj
+            assert dm.dropped_nonzeros() in (0, d.nnzj - dm.nnzj) or sch == "euler_implicit"
             if dm.dropped_nonzeros() == 0:
                 assert abs(extra).max() == 0.0
             else:
@@ -257,7 +260,7 @@ def test_baseline_configs_full_size_properties(oracle_lib, torch_cuda, prob, sch
     # EVERY Jacobian entry at full size (configs 5' and 5 included) against the oracle's block mode: the same `constraints`
     # template differentiated one time step at a time on dense local duals (bit-identical to its coloured passes on the
     # sizes where both run, tests/test_oracle_goldens.py), OpenMP over the steps
-    blk_ref = o.cons_jac_block(x, os.cpu_count() or 1)
+    blk_ref = o.cons_jac_block(x, min(16, os.cpu_count() or 1))
     assert blk_ref is not None
     assert relerr(c.cpu().numpy(), blk_ref[0]) <= TOL and relerr(v.cpu().numpy(), blk_ref[1]) <= TOL
     # (3) directional derivative: J d (scipy, from the pattern + GPU values) vs central differences of the GPU's c(x)
