@@ -27,6 +27,9 @@ enum { HC_ONE = 0, HC_HALF = 1,
        HC_B = 20,     // b_l               at HC_B + l
        HC_NBH = 23 }; // -b_l dh/dv_k      at HC_NBH + 3 k + l   (k < kMaxNV)
 
+// a coefficient as constant * step-dependent factor: F(HF_ONE) = 1, F(HF_H) = h, F(HF_DH + k) = dh/dv_k
+enum { HF_ONE = 0, HF_H = 1, HF_DH = 2 };
+
 constexpr int kMaxPairs = 64;          // distinct coefficient products C[c1] * C[c2] the term tables may use
 constexpr int kMaxTerms = 6;           // terms per output entry (S stage points + path point + state-equation row)
 constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
@@ -91,6 +94,12 @@ CTD_HD uint32_t pack_term(int di, int pair, int slot) {
 CTD_HD int term_di(uint32_t c) { return (int)(c & 0xFFFFu); }
 CTD_HD int term_pair(uint32_t c) { return (int)((c >> 16) & 0xFFu); }
 CTD_HD int term_slot(uint32_t c) { return (int)((c >> 24) & 0x7u); }
+// The tile templates carry their terms as the two LDS offsets (doubles, signed 16 bit) from the entry's own slot: low half
+// into the coefficient products (pair - sd * npairs), high half into the records (di - sd * stride), sd = +1 / -1 for the
+// record of the previous / next step.
+CTD_HD uint32_t pack_tile_term(int a_off, int b_off) { return ((uint32_t)a_off & 0xFFFFu) | ((uint32_t)b_off << 16); }
+CTD_HD int tile_term_a(uint32_t c) { return (int)(int16_t)(c & 0xFFFFu); }
+CTD_HD int tile_term_b(uint32_t c) { return (int)(int16_t)(c >> 16); }
 
 // ---- kernel parameters -------------------------------------------------------------------------------------
 struct HParams {
@@ -109,7 +118,7 @@ struct HParams {
     // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])
     int32_t Lseg;
     const uint32_t* tptr;       // Lseg + 1 offsets
-    const uint32_t* terms;
+    const uint32_t* terms;      // pack_tile_term codes
     int32_t nterms;
     int64_t seg_base, reg_first, reg_last;
     // V x V block: entry e (nvv = nv (nv+1)/2 of them, at vals[vv_idx[e]]) is a sum over ALL evaluation points; tile
@@ -129,16 +138,17 @@ struct HParams {
     int32_t n_edge_slots;
     int32_t edge_fp, edge_b;    // record ids of the final-path and boundary records
     int64_t edge_steps[kMaxHessEdgeSlots];
-    // coefficient pairs: CP[i] = C[pairs[i] & 0xFF] * C[pairs[i] >> 8], i < npairs (pair 0 is ONE * ONE)
+    // coefficient pairs: CP[i] = pair_c[i] * F(pairs[i] & 0xFF) * F(pairs[i] >> 8), i < npairs (pair 0 is ONE * ONE)
     int32_t npairs;
     uint16_t pairs[kMaxPairs];
+    const double* pair_c;
     // eval tasks: outer direction p (bits 0-4) and up to 4 inner directions q_i (bits 5+5i, 31 = none) per lane
     const uint32_t* tasks;      // stage-type points
     const uint32_t* ptasks;     // path points
     const uint32_t* btasks;     // boundary + Mayer point
     int32_t ntask, nptask, nbtask;
     int32_t slot_tasks;         // S * ntask + nptask
-    FastDiv div_ntask, div_slot_tasks, div_Lseg;
+    FastDiv div_ntask, div_slot_tasks, div_Lseg, div_npairs;
     // inputs / outputs
     double obj_weight;
     double* vals;

@@ -49,14 +49,14 @@ struct HBlockCtx {
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
     const uint32_t *tptr, *terms, *vptr, *vterms;
     const uint32_t *tasks, *ptasks;
-    // LDS copies of the Butcher tables (a[9] | b[3] | c[3]) and of the coefficient-pair codes: both sit in the kernel
-    // arguments, where a lane-dependent index would cost a global load per use
-    const double* abc;
+    // LDS copies of the coefficient-pair tables (factor kinds from the kernel arguments, where a lane-dependent index
+    // would cost a global load per use; constants from hp.pair_c)
     const uint32_t* pairs;
+    const double* pc;
 };
 
-// doubles at the head of every workgroup's LDS: abc (15, padded to 16) | pair codes (kMaxPairs words)
-constexpr int kHessCoefDoubles = 16 + kMaxPairs / 2;
+// doubles at the head of every workgroup's LDS: pair factor kinds (kMaxPairs words) | pair constants (kMaxPairs)
+constexpr int kHessCoefDoubles = kMaxPairs / 2 + kMaxPairs;
 
 // words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks | ptasks
 constexpr int kMaxStagedHessWords = 3072;
@@ -76,8 +76,8 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     const Layout& L = hp.L;
     cx.tptr = hp.tptr; cx.terms = hp.terms; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
     cx.tasks = hp.tasks; cx.ptasks = hp.ptasks;
-    cx.abc = lds;
-    cx.pairs = reinterpret_cast<const uint32_t*>(lds + 16);
+    cx.pairs = reinterpret_cast<const uint32_t*>(lds);
+    cx.pc = lds + kMaxPairs / 2;
     lds += kHessCoefDoubles;
     if (block == 0) {
         cx.is_edge = 1;
@@ -153,24 +153,25 @@ CTD_HD double hess_y_of(const HParams& hp, const double* __restrict__ y, int64_t
 // ------------------------------------------------------------------------------------------------------
 // phase: load
 // ------------------------------------------------------------------------------------------------------
-CTD_HD double hess_butcher_entry(const Layout& L, int e) {
-    return e < 9 ? L.a[e < 9 ? e : 0] : (e < 12 ? L.b[e < 12 ? e - 9 : 0] : (e < 15 ? L.c[e - 12] : 0.0));
-}
-// cf / pc: entry `tid` of the two tables, loaded by the caller ahead of its other copies (workgroups narrower than the
+// cf / pk: entry `tid` of the two pair tables, loaded by the caller ahead of its other copies (workgroups narrower than the
 // tables, which only the emulator uses, fetch the rest here)
-CTD_HD void hess_stage_coefs(const HParams& hp, const HBlockCtx& cx, double cf, uint32_t pc, int tid, int nthr) {
-    if (tid < 16) const_cast<double*>(cx.abc)[tid] = cf;
-    if (tid < kMaxPairs) const_cast<uint32_t*>(cx.pairs)[tid] = pc;
-    for (int e = tid + nthr; e < 16; e += nthr) const_cast<double*>(cx.abc)[e] = hess_butcher_entry(hp.L, e);
-    for (int e = tid + nthr; e < hp.npairs; e += nthr) const_cast<uint32_t*>(cx.pairs)[e] = hp.pairs[e];
+CTD_HD void hess_stage_coefs(const HParams& hp, const HBlockCtx& cx, double cf, uint32_t pk, int tid, int nthr) {
+    if (tid < kMaxPairs) {
+        const_cast<double*>(cx.pc)[tid] = cf;
+        const_cast<uint32_t*>(cx.pairs)[tid] = pk;
+    }
+    for (int e = tid + nthr; e < hp.npairs; e += nthr) {
+        const_cast<double*>(cx.pc)[e] = hp.pair_c[e];
+        const_cast<uint32_t*>(cx.pairs)[e] = hp.pairs[e];
+    }
 }
 
 template <class P>
 CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double* __restrict__ xu,
                             const double* __restrict__ y, int tid, int nthr) {
     const Layout& L = hp.L;
-    // Butcher tables and pair codes (issued first: their latency overlaps the copies below)
-    const double cf = hess_butcher_entry(L, tid);
+    // pair tables (issued first: their latency overlaps the copies below)
+    const double cf = tid < hp.npairs ? hp.pair_c[tid] : 0.0;
     const uint32_t pc = tid < hp.npairs ? hp.pairs[tid] : 0u;
     if (cx.is_edge) {
         hess_stage_coefs(hp, cx, cf, pc, tid, nthr);
@@ -238,17 +239,18 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
 // ------------------------------------------------------------------------------------------------------
 // phase: eval
 // ------------------------------------------------------------------------------------------------------
-// value of chain-rule coefficient ci for a step of length h (dh[k] = dh/dv_k); see the HC_* enum
+// step-dependent factor of a chain-rule coefficient (HF_* in ctd_hess.hpp)
 template <class P>
-CTD_HD double hess_coef_value(const double* abc, int ci, double h, double tau0, double tau1) {
-    if (ci == HC_ONE) return 1.0;
-    if (ci == HC_HALF) return 0.5;
-    if (ci < HC_A) return h * abc[ci - HC_HA];
-    if (ci < HC_B) return abc[ci - HC_A];
-    if (ci < HC_NBH) return abc[9 + ci - HC_B];
-    const int k = (ci - HC_NBH) / 3, l = (ci - HC_NBH) - 3 * k;
-    const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, k) - dtime_of<P>(tau0, k) : 0.0;
-    return -(abc[9 + l] * dh);
+CTD_HD double hess_factor(int kind, double h, double tau0, double tau1) {
+    double f = kind == HF_H ? h : 1.0;
+    if constexpr (Dirs<P>::FREE) {
+#pragma unroll
+        for (int k = 0; k < P::NV; ++k)
+            if (kind == HF_DH + k) f = dtime_of<P>(tau1, k) - dtime_of<P>(tau0, k);
+    } else {
+        if (kind >= HF_DH) f = 0.0;
+    }
+    return f;
 }
 
 // coefficient products of one record (slot k, pair id) + the state-equation multipliers the K x V terms need
@@ -256,12 +258,11 @@ template <class P, int SC, int S>
 CTD_HD void hess_pair(const HParams& hp, const HBlockCtx& cx, int k, int pid) {
     constexpr int n = P::NX;
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
-    const Layout& L = hp.L;
     double* rec = cx.rec + k * R.stride;
     const double tau0 = hslot_tau(cx, k, 0), tau1 = hslot_tau(cx, k, 1);
     const double h = htime_of<P>(hp, cx.v, tau1) - htime_of<P>(hp, cx.v, tau0);
-    const int code = (int)cx.pairs[pid];
-    cx.cp[k * hp.npairs + pid] = hess_coef_value<P>(cx.abc, code & 0xFF, h, tau0, tau1) * hess_coef_value<P>(cx.abc, code >> 8, h, tau0, tau1);
+    const int kinds = (int)cx.pairs[pid];
+    cx.cp[k * hp.npairs + pid] = cx.pc[pid] * hess_factor<P>(kinds & 0xFF, h, tau0, tau1) * hess_factor<P>(kinds >> 8, h, tau0, tau1);
     if (pid == 0) rec[R.oZero] = 0.0;
     if (SC == SC_IRK && Dirs<P>::FREE && pid == 0) {
         const double* y = hslot_y(hp, cx, k);
@@ -629,8 +630,9 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
     constexpr bool PATH_PT = np > 0 && SC != SC_TRAPEZE;
     constexpr int PT = R.S + (PATH_PT ? 1 : 0);
     const Layout& L = hp.L;
-    for (int w = tid; w < cx.nslots * hp.npairs; w += nthr) {
-        const int k = w / hp.npairs;
+    // (the coefficient products start at the LAST lane: the waves the point evaluations below leave idle take them)
+    for (int w = nthr - 1 - tid; w < cx.nslots * hp.npairs; w += nthr) {
+        const int k = (int)fast_div((uint32_t)w, hp.div_npairs);
         hess_pair<P, SC, S>(hp, cx, k, w - k * hp.npairs);
     }
     const int total = cx.nslots * hp.slot_tasks;
@@ -676,9 +678,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         // coefficient products of the two extra records: no step length (only ONE, HALF and the b_l can occur)
         for (int e = tid; e < 2 * hp.npairs; e += nthr) {
             const int which = e / hp.npairs, pid = e - which * hp.npairs;
-            const int code = (int)cx.pairs[pid];
-            cx.cp[(hp.edge_fp + which) * hp.npairs + pid] =
-                hess_coef_value<P>(cx.abc, code & 0xFF, 0.0, 0.0, 0.0) * hess_coef_value<P>(cx.abc, code >> 8, 0.0, 0.0, 0.0);
+            cx.cp[(hp.edge_fp + which) * hp.npairs + pid] = cx.pairs[pid] == 0u ? cx.pc[pid] : 0.0;
         }
     }
 }
@@ -690,13 +690,13 @@ CTD_HD double hess_term(const double* rec, int stride, const double* cp, int npa
     return cp[slot * npairs + term_pair(code)] * rec[slot * stride + term_di(code)];
 }
 
-// largest term count among the (up to 64) segment positions w0 .. w0 + nwl - 1 handled by one wave: wave-uniform by
-// construction (every lane walks the same range), so the switch on it below does not diverge
+// Number of terms the lanes of one wave run in a pass over the segment: the largest count among them -- wave-uniform, so
+// the switch on it below does not diverge (w0 .. w0 + nwl - 1: the wave's segment positions, for the host build)
 CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDiv div_Lseg, int Lseg, int nwl) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int m = own;
+    int m = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    for (int t = 0; t < kMaxTerms; ++t) m += __any(own > t) ? 1 : 0;      // (a compare and a scalar test per term; no LDS)
     return m;
 #else
     int m = 0;
@@ -709,20 +709,30 @@ CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDi
 #endif
 }
 
-// the steps ibeg, ibeg + G, ... < iend of one segment entry with NT (possibly padded) terms
+// One lane, one segment entry with NT (possibly padded) terms: rounds u = 0 .. nu - 1 (uniform) are the steps of the lane,
+// G apart; the lane stores in rounds u < n_own.  pa / pb: the coefficient products and the record of the lane's first step;
+// da / db / dout: what one round adds to the two LDS offsets and to the output position (uniform).
 template <int NT>
-CTD_HD void hess_emit_steps(const double* rec, int stride, const double* cp, int npairs, const int* cpo, const int* dio, double* out,
-                            int64_t ibeg, int64_t iend, int G, int64_t lo, int64_t reg_first, int Lseg) {
-    for (int64_t i = ibeg; i < iend; i += G) {
-        const double* rk = rec + (int)(i - lo) * stride;
-        const double* ck = cp + (int)(i - lo) * npairs;
-        double a[NT > 0 ? NT : 1], b[NT > 0 ? NT : 1];
+CTD_HD void hess_emit_steps(const double* pa, const double* pb, const uint32_t* codes, int nt, int oZero, int da, int db, double* out,
+                            int64_t dout, int nu, int n_own) {
+    constexpr int M = NT > 0 ? NT : 1;
+    const double *qa[M], *qb[M];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { a[t] = ck[cpo[t]]; b[t] = rk[dio[t]]; }
-        double acc = 0.0;
+    for (int t = 0; t < NT; ++t) {        // absent terms read 1.0 * rec[oZero] = 0
+        const uint32_t code = t < nt ? codes[t] : pack_tile_term(0, oZero);
+        qa[t] = pa + tile_term_a(code);
+        qb[t] = pb + tile_term_b(code);
+    }
+    for (int u = 0; u < nu; ++u) {
+        if (u < n_own) {
+            double a[M], b[M];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc = acc + a[t] * b[t];
-        out[(i - reg_first) * (int64_t)Lseg] = acc;
+            for (int t = 0; t < NT; ++t) { a[t] = qa[t][u * da]; b[t] = qb[t][u * db]; }
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc = acc + a[t] * b[t];
+            out[u * dout] = acc;
+        }
     }
 }
 
@@ -755,37 +765,40 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
     const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
     // lane (e, g) owns entry e of the segment for the steps i0 + g, i0 + g + G, ...: its (few) term codes are read once,
     // then it walks its steps; short segments are replicated G times across the workgroup.  Inside a wave every lane
-    // runs the same number of terms (the wave's maximum, absent terms read 1.0 * rec[oZero]) so that all LDS reads of a
-    // step are in flight together instead of one exec-masked read-wait-fma chain per term.
-    const int G = (hp.Lseg > 0 && hp.Lseg < nthr) ? nthr / hp.Lseg : 1;
-    const int wave_lo = tid & ~63, nwl = nthr - wave_lo < 64 ? nthr - wave_lo : 64;
-    for (int w0 = wave_lo; w0 < hp.Lseg * G; w0 += nthr) {
-        const int w = w0 + (tid - wave_lo);
-        const bool live = w < hp.Lseg * G;
-        const int g = live ? (int)fast_div((uint32_t)w, hp.div_Lseg) : 0;
-        const int e = live ? w - g * hp.Lseg : 0;
-        const uint32_t t0 = cx.tptr[e];
-        const int nt = live ? (int)(cx.tptr[e + 1] - t0) : 0;
-        int cpo[kMaxTerms], dio[kMaxTerms];
-#pragma unroll
-        for (int t = 0; t < kMaxTerms; ++t) {
-            const uint32_t code = (t < nt) ? cx.terms[t0 + t] : 0u;
-            const int sl = (t < nt) ? term_slot(code) : 0;
-            const int sd = sl == 1 ? 1 : (sl == 2 ? -1 : 0);            // record of the previous / next step
-            cpo[t] = ((t < nt) ? term_pair(code) : 0) - sd * hp.npairs;
-            dio[t] = ((t < nt) ? term_di(code) : R.oZero) - sd * R.stride;
-        }
-        const int wmax = hess_wave_max(nt, w0, hp.Lseg * G, cx.tptr, hp.div_Lseg, hp.Lseg, nwl);
-        double* out = hp.vals + hp.seg_base + e;
-        const int64_t ibeg = live ? i0 + g : i1;
-        switch (wmax) {
-            case 0: hess_emit_steps<0>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 1: hess_emit_steps<1>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 2: hess_emit_steps<2>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 3: hess_emit_steps<3>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 4: hess_emit_steps<4>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            case 5: hess_emit_steps<5>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
-            default: hess_emit_steps<kMaxTerms>(cx.rec, R.stride, cx.cp, hp.npairs, cpo, dio, out, ibeg, i1, G, cx.lo, hp.reg_first, hp.Lseg); break;
+    // runs the same number of terms (the wave's maximum) so that all LDS reads of a step are in flight together instead
+    // of one exec-masked read-wait-fma chain per term.  The walk itself is address arithmetic on uniform strides: the
+    // output position of lane w in round u is  vals[seg_base + (i0 - reg_first) * Lseg + u * G * Lseg + w].
+    const int nreg = (int)(i1 - i0);
+    if (nreg > 0 && hp.Lseg > 0) {
+        const int G = hp.Lseg < nthr ? nthr / hp.Lseg : 1;
+        const int nu = (nreg + G - 1) / G;
+        const int k0 = (int)(i0 - cx.lo);
+        double* out0 = hp.vals + hp.seg_base + (i0 - hp.reg_first) * (int64_t)hp.Lseg;
+        const int64_t dout = (int64_t)G * hp.Lseg;
+        const int da = G * hp.npairs, db = G * R.stride;
+        const int wave_lo = tid & ~63, nwl = nthr - wave_lo < 64 ? nthr - wave_lo : 64;
+        for (int w0 = wave_lo; w0 < hp.Lseg * G; w0 += nthr) {
+            const int w = w0 + (tid - wave_lo);
+            const bool live = w < hp.Lseg * G;
+            const int g = live ? (int)fast_div((uint32_t)w, hp.div_Lseg) : 0;
+            const int e = live ? w - g * hp.Lseg : 0;
+            const uint32_t t0 = cx.tptr[e];
+            const int nt = live ? (int)(cx.tptr[e + 1] - t0) : 0;
+            const int n_own = live ? (nreg - g + G - 1) / G : 0;
+            const int wmax = hess_wave_max(nt, w0, hp.Lseg * G, cx.tptr, hp.div_Lseg, hp.Lseg, nwl);
+            const double* pa = cx.cp + (k0 + g) * hp.npairs;
+            const double* pb = cx.rec + (k0 + g) * R.stride;
+            const uint32_t* codes = cx.terms + t0;
+            double* out = out0 + w;
+            switch (wmax) {
+                case 0: hess_emit_steps<0>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 1: hess_emit_steps<1>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 2: hess_emit_steps<2>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 3: hess_emit_steps<3>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 4: hess_emit_steps<4>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 5: hess_emit_steps<5>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                default: hess_emit_steps<kMaxTerms>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+            }
         }
     }
     // V x V entries: one lane per (step of the tile, entry) adds up that step's terms; hess_phase_vvsum then sums the steps

@@ -685,6 +685,36 @@ int build_hess_model(Model& mo, std::string& err) {
     }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);
     make_tasks(H.R.mdb, H.need_bnd, false, H.btasks);
+    // ---- what the tiles read: terms as LDS offsets, coefficient pairs as constant * step-dependent factors ---------------
+    {
+        const int np = (int)H.pairs.size();
+        H.tcode.clear();
+        for (uint32_t c : H.terms) {
+            const int sl = term_slot(c), sd = sl == 1 ? 1 : (sl == 2 ? -1 : 0);
+            const int a = term_pair(c) - sd * np, b = term_di(c) - sd * H.R.stride;
+            if (a < -32768 || a > 32767 || b < -32768 || b > 32767) { err = "per-step Hessian record too large for 16-bit LDS offsets"; return ST_EPATTERN; }
+            H.tcode.push_back(pack_tile_term(a, b));
+        }
+        auto factor = [&](int ci, double& cst) -> int {       // C[ci] = cst * F(kind)   (HC_* in ctd_hess.hpp)
+            auto abc = [&](int e) { return e < 9 ? L.a[e] : L.b[e - 9]; };
+            if (ci == HC_ONE) { cst = 1.0; return HF_ONE; }
+            if (ci == HC_HALF) { cst = 0.5; return HF_ONE; }
+            if (ci < HC_A) { cst = abc(ci - HC_HA); return HF_H; }
+            if (ci < HC_B) { cst = abc(ci - HC_A); return HF_ONE; }
+            if (ci < HC_NBH) { cst = abc(9 + ci - HC_B); return HF_ONE; }
+            const int k = (ci - HC_NBH) / 3, l = (ci - HC_NBH) - 3 * k;
+            cst = -abc(9 + l);
+            return HF_DH + k;
+        };
+        H.pair_kind.assign(np, 0);
+        H.pair_c.assign(np, 0.0);
+        for (int i = 0; i < np; ++i) {
+            double c1 = 0.0, c2 = 0.0;
+            const int k1 = factor(H.pairs[i] & 0xFF, c1), k2 = factor(H.pairs[i] >> 8, c2);
+            H.pair_kind[i] = (uint16_t)(k1 | (k2 << 8));
+            H.pair_c[i] = c1 * c2;
+        }
+    }
     return ST_OK;
 }
 
@@ -753,7 +783,7 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.edge_fp = H.edge_fp; hp.edge_b = H.edge_b;
     for (int k = 0; k < kMaxHessEdgeSlots; ++k) hp.edge_steps[k] = H.edge_steps[k];
     hp.npairs = (int)H.pairs.size();
-    for (int i = 0; i < hp.npairs; ++i) hp.pairs[i] = H.pairs[i];
+    for (int i = 0; i < hp.npairs; ++i) hp.pairs[i] = H.pair_kind[i];
     hp.ntask = (int)H.tasks.size();
     hp.nptask = (int)H.ptasks.size();
     hp.nbtask = (int)H.btasks.size();
@@ -761,6 +791,7 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.div_ntask = make_fastdiv((uint32_t)(hp.ntask > 0 ? hp.ntask : 1));
     hp.div_slot_tasks = make_fastdiv((uint32_t)(hp.slot_tasks > 0 ? hp.slot_tasks : 1));
     hp.div_Lseg = make_fastdiv((uint32_t)(H.Lseg > 0 ? H.Lseg : 1));
+    hp.div_npairs = make_fastdiv((uint32_t)(hp.npairs > 0 ? hp.npairs : 1));
 }
 
 }  // namespace ctd

@@ -33,6 +33,7 @@ struct HessModel {
     int Lseg = 0, HL = 0, HH = 0;
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     std::vector<uint32_t> tptr, terms;            // Lseg + 1 offsets, term codes
+    std::vector<uint32_t> tcode;                  // the same terms as the tiles read them (pack_tile_term: LDS offsets)
     std::vector<uint32_t> vptr, vterms;           // V x V contributions of one step
     int nvv = 0;
     int64_t vv_idx[kMaxNV * (kMaxNV + 1) / 2] = {0};
@@ -50,6 +51,8 @@ struct HessModel {
     std::vector<uint32_t> tasks, ptasks, btasks;   // p | q_0 << 5 | q_1 << 10 | .. (31 = no direction)
     // coefficient pairs referenced by the term codes (pair 0 = ONE * ONE)
     std::vector<uint16_t> pairs;
+    std::vector<uint16_t> pair_kind;  // per pair: step-dependent factors k1 | k2 << 8 (HF_*) ...
+    std::vector<double> pair_c;       // ... and the constant factor: C[c1] C[c2] = pair_c * F(k1) * F(k2)
     // column starts (same scheme as the Jacobian's)
     std::vector<int64_t> cp_head, cp_tmpl, cp_tail;
 };
