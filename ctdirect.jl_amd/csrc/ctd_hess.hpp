@@ -116,8 +116,12 @@ struct HParams {
     int32_t edge_vv;                // 1: this shard adds the V x V terms of the final-path / boundary / last-node points
     // regular CSC segments of the lower triangle: step i in [reg_first, reg_last) owns
     // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])
-    int32_t Lseg;
-    const uint32_t* tptr;       // Lseg + 1 offsets
+    // The tiles walk nc entries: entry k sits at position cpos[k] of the segment and sums the terms [tptr[k], tptr[k+1]).
+    // compact = 0: all Lseg entries (position k).  compact = 1 (segments that are mostly structural zeros of the pattern):
+    // only the entries that have terms; the tile zero-fills its part of vals beforehand.
+    int32_t Lseg, nc, compact;
+    const uint32_t* tptr;       // nc + 1 offsets
+    const uint32_t* cpos;       // nc positions (compact only)
     const uint32_t* terms;      // pack_tile_term codes
     int32_t nterms;
     int64_t seg_base, reg_first, reg_last;
@@ -148,7 +152,7 @@ struct HParams {
     const uint32_t* btasks;     // boundary + Mayer point
     int32_t ntask, nptask, nbtask;
     int32_t slot_tasks;         // S * ntask + nptask
-    FastDiv div_ntask, div_slot_tasks, div_Lseg, div_npairs;
+    FastDiv div_ntask, div_slot_tasks, div_nc, div_npairs;
     // inputs / outputs
     double obj_weight;
     double* vals;

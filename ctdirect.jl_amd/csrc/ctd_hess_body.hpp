@@ -47,7 +47,7 @@ struct HBlockCtx {
     double* cp;     // coefficient products: npairs per slot (hess_pair), slot k at cp + k * npairs
     double* red;    // tile: nvv * T per-step V x V contributions (summed in step order by hess_phase_vvsum)
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
-    const uint32_t *tptr, *terms, *vptr, *vterms;
+    const uint32_t *tptr, *terms, *cpos, *vptr, *vterms;
     const uint32_t *tasks, *ptasks;
     // LDS copies of the coefficient-pair tables (factor kinds from the kernel arguments, where a lane-dependent index
     // would cost a global load per use; constants from hp.pair_c)
@@ -58,10 +58,10 @@ struct HBlockCtx {
 // doubles at the head of every workgroup's LDS: pair factor kinds (kMaxPairs words) | pair constants (kMaxPairs)
 constexpr int kHessCoefDoubles = kMaxPairs / 2 + kMaxPairs;
 
-// words (uint32) of table data a tile stages in LDS: tptr | terms | vptr | vterms | tasks | ptasks
+// words (uint32) of table data a tile stages in LDS: tptr | terms | cpos | vptr | vterms | tasks | ptasks
 constexpr int kMaxStagedHessWords = 3072;
 CTD_HD int hess_table_words(const HParams& hp) {
-    return (hp.Lseg + 1) + hp.nterms + (hp.nvv + 1) + hp.nvterms + hp.ntask + hp.nptask;
+    return (hp.nc + 1) + hp.nterms + (hp.compact ? hp.nc : 0) + (hp.nvv + 1) + hp.nvterms + hp.ntask + hp.nptask;
 }
 CTD_HD bool hess_tables_staged(const HParams& hp) { return hess_table_words(hp) <= kMaxStagedHessWords; }
 CTD_HD int hess_table_doubles(const HParams& hp) { return hess_tables_staged(hp) ? (hess_table_words(hp) + 1) / 2 : 0; }
@@ -74,7 +74,7 @@ CTD_HD double hslot_tau(const HBlockCtx& cx, int k, int d) { return cx.is_edge ?
 CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     HBlockCtx cx;
     const Layout& L = hp.L;
-    cx.tptr = hp.tptr; cx.terms = hp.terms; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
+    cx.tptr = hp.tptr; cx.terms = hp.terms; cx.cpos = hp.cpos; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
     cx.tasks = hp.tasks; cx.ptasks = hp.ptasks;
     cx.pairs = reinterpret_cast<const uint32_t*>(lds);
     cx.pc = lds + kMaxPairs / 2;
@@ -96,8 +96,9 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         const int cap = hp.T + hp.HL + hp.HH;
         if (hess_tables_staged(hp)) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
-            cx.tptr = w; w += hp.Lseg + 1;
+            cx.tptr = w; w += hp.nc + 1;
             cx.terms = w; w += hp.nterms;
+            if (hp.compact) { cx.cpos = w; w += hp.nc; }
             cx.vptr = w; w += hp.nvv + 1;
             cx.vterms = w; w += hp.nvterms;
             cx.tasks = w;
@@ -207,7 +208,8 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         const double x0 = tid < cnt ? src[tid] : 0.0, x1 = tid + nthr < cnt ? src[tid + nthr] : 0.0;
         const double y0 = tid < ny ? yval(tid) : 0.0, y1 = tid + nthr < ny ? yval(tid + nthr) : 0.0;
         const double vv = tid < P::NV ? xu[L.v_off + tid] : 0.0;
-        const uint32_t w0 = (st && tid <= hp.Lseg) ? hp.tptr[tid] : 0u, w1 = (st && tid < hp.nterms) ? hp.terms[tid] : 0u;
+        const uint32_t w0 = (st && tid <= hp.nc) ? hp.tptr[tid] : 0u, w1 = (st && tid < hp.nterms) ? hp.terms[tid] : 0u;
+        const uint32_t w6 = (st && hp.compact && tid < hp.nc) ? hp.cpos[tid] : 0u;
         const uint32_t w2 = (st && tid <= hp.nvv) ? hp.vptr[tid] : 0u, w3 = (st && tid < hp.nvterms) ? hp.vterms[tid] : 0u;
         const uint32_t w4 = (st && tid < hp.ntask) ? hp.tasks[tid] : 0u, w5 = (st && tid < hp.nptask) ? hp.ptasks[tid] : 0u;
         const double tau_e = tid <= cx.nslots + 2 ? htau_global(hp, cx.lo - 1 + tid) : 0.0;     // (table load: issued with the rest)
@@ -219,8 +221,9 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         hess_stage_coefs(hp, cx, cf, pc, tid, nthr);
         if (st) {
             uint32_t* d;
-            d = const_cast<uint32_t*>(cx.tptr);   if (tid <= hp.Lseg) d[tid] = w0;   for (int e = tid + nthr; e <= hp.Lseg; e += nthr) d[e] = hp.tptr[e];
+            d = const_cast<uint32_t*>(cx.tptr);   if (tid <= hp.nc) d[tid] = w0;     for (int e = tid + nthr; e <= hp.nc; e += nthr) d[e] = hp.tptr[e];
             d = const_cast<uint32_t*>(cx.terms);  if (tid < hp.nterms) d[tid] = w1;  for (int e = tid + nthr; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
+            if (hp.compact) { d = const_cast<uint32_t*>(cx.cpos); if (tid < hp.nc) d[tid] = w6; for (int e = tid + nthr; e < hp.nc; e += nthr) d[e] = hp.cpos[e]; }
             d = const_cast<uint32_t*>(cx.vptr);   if (tid <= hp.nvv) d[tid] = w2;    for (int e = tid + nthr; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
             d = const_cast<uint32_t*>(cx.vterms); if (tid < hp.nvterms) d[tid] = w3; for (int e = tid + nthr; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
             d = const_cast<uint32_t*>(cx.tasks);  if (tid < hp.ntask) d[tid] = w4;   for (int e = tid + nthr; e < hp.ntask; e += nthr) d[e] = hp.tasks[e];
@@ -623,6 +626,21 @@ CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const doubl
         if (q[i] < mdb) HB[p <= q[i] ? p * mdb + q[i] : q[i] * mdb + p] = phi.ab[i];
 }
 
+// Compact segments (HParams::compact): the tile's part of vals is zero-filled before the emit phase stores the entries that
+// have terms -- by the waves the point evaluations leave idle, at the start of the eval phase: the stores have long been
+// acknowledged when the barrier after that phase (which waits for them) is reached, so the entries written again in the
+// emit phase are ordered after them.
+CTD_HD void hess_zero_fill(const HParams& hp, const HBlockCtx& cx, int tid, int nthr) {
+    if (!hp.compact || cx.is_edge) return;
+    const int64_t i0 = cx.a > hp.reg_first ? cx.a : hp.reg_first;
+    const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
+    if (i1 <= i0) return;
+    double* out0 = hp.vals + hp.seg_base + (i0 - hp.reg_first) * (int64_t)hp.Lseg;
+    const int n = (int)(i1 - i0) * hp.Lseg, z0 = nthr > 64 ? 64 : 0;
+    if (tid >= z0)
+        for (int j = tid - z0; j < n; j += nthr - z0) out0[j] = 0.0;
+}
+
 template <class P, int SC, int S>
 CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int nthr) {
     constexpr int n = P::NX, np = P::NPATH;
@@ -630,6 +648,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
     constexpr bool PATH_PT = np > 0 && SC != SC_TRAPEZE;
     constexpr int PT = R.S + (PATH_PT ? 1 : 0);
     const Layout& L = hp.L;
+    hess_zero_fill(hp, cx, tid, nthr);
     // (the coefficient products start at the LAST lane: the waves the point evaluations below leave idle take them)
     for (int w = nthr - 1 - tid; w < cx.nslots * hp.npairs; w += nthr) {
         const int k = (int)fast_div((uint32_t)w, hp.div_npairs);
@@ -692,7 +711,7 @@ CTD_HD double hess_term(const double* rec, int stride, const double* cp, int npa
 
 // Number of terms the lanes of one wave run in a pass over the segment: the largest count among them -- wave-uniform, so
 // the switch on it below does not diverge (w0 .. w0 + nwl - 1: the wave's segment positions, for the host build)
-CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDiv div_Lseg, int Lseg, int nwl) {
+CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDiv div_nc, int nc, int nwl) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int m = 0;
 #pragma unroll
@@ -701,7 +720,7 @@ CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDi
 #else
     int m = 0;
     for (int w = w0; w < w0 + nwl && w < wend; ++w) {
-        const int g = (int)fast_div((uint32_t)w, div_Lseg), e = w - g * Lseg;
+        const int g = (int)fast_div((uint32_t)w, div_nc), e = w - g * nc;
         const int nt = (int)(tptr[e + 1] - tptr[e]);
         m = nt > m ? nt : m;
     }
@@ -763,33 +782,36 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
     }
     const int64_t i0 = cx.a > hp.reg_first ? cx.a : hp.reg_first;
     const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
-    // lane (e, g) owns entry e of the segment for the steps i0 + g, i0 + g + G, ...: its (few) term codes are read once,
+    // lane (k, g) owns entry k of the segment for the steps i0 + g, i0 + g + G, ...: its (few) term codes are read once,
     // then it walks its steps; short segments are replicated G times across the workgroup.  Inside a wave every lane
     // runs the same number of terms (the wave's maximum) so that all LDS reads of a step are in flight together instead
     // of one exec-masked read-wait-fma chain per term.  The walk itself is address arithmetic on uniform strides: the
-    // output position of lane w in round u is  vals[seg_base + (i0 - reg_first) * Lseg + u * G * Lseg + w].
+    // output position of lane (k, g) in round u is  vals[seg_base + (i0 - reg_first + g + u * G) * Lseg + cpos[k]].  Only the nc
+    // entries that have terms are walked; the positions of the others (structural zeros of the pattern) are zero-filled.
     const int nreg = (int)(i1 - i0);
     if (nreg > 0 && hp.Lseg > 0) {
-        const int G = hp.Lseg < nthr ? nthr / hp.Lseg : 1;
+        double* out0 = hp.vals + hp.seg_base + (i0 - hp.reg_first) * (int64_t)hp.Lseg;
+        const int nc = hp.nc;
+        const int G = (nc > 0 && nc < nthr) ? nthr / nc : 1;
         const int nu = (nreg + G - 1) / G;
         const int k0 = (int)(i0 - cx.lo);
-        double* out0 = hp.vals + hp.seg_base + (i0 - hp.reg_first) * (int64_t)hp.Lseg;
         const int64_t dout = (int64_t)G * hp.Lseg;
         const int da = G * hp.npairs, db = G * R.stride;
         const int wave_lo = tid & ~63, nwl = nthr - wave_lo < 64 ? nthr - wave_lo : 64;
-        for (int w0 = wave_lo; w0 < hp.Lseg * G; w0 += nthr) {
+        for (int w0 = wave_lo; w0 < nc * G; w0 += nthr) {
             const int w = w0 + (tid - wave_lo);
-            const bool live = w < hp.Lseg * G;
-            const int g = live ? (int)fast_div((uint32_t)w, hp.div_Lseg) : 0;
-            const int e = live ? w - g * hp.Lseg : 0;
-            const uint32_t t0 = cx.tptr[e];
-            const int nt = live ? (int)(cx.tptr[e + 1] - t0) : 0;
-            const int n_own = live ? (nreg - g + G - 1) / G : 0;
-            const int wmax = hess_wave_max(nt, w0, hp.Lseg * G, cx.tptr, hp.div_Lseg, hp.Lseg, nwl);
+            const bool live = w < nc * G;
+            const int g = live ? (int)fast_div((uint32_t)w, hp.div_nc) : 0;
+            const int k = live ? w - g * nc : 0;
+            const uint32_t t0 = cx.tptr[k];
+            const int nt = live ? (int)(cx.tptr[k + 1] - t0) : 0;
+            const int e = hp.compact ? (int)cx.cpos[k] : k;
+            const int n_own = live ? nu - (g + (nu - 1) * G >= nreg ? 1 : 0) : 0;
+            const int wmax = hess_wave_max(nt, w0, nc * G, cx.tptr, hp.div_nc, nc, nwl);
             const double* pa = cx.cp + (k0 + g) * hp.npairs;
             const double* pb = cx.rec + (k0 + g) * R.stride;
             const uint32_t* codes = cx.terms + t0;
-            double* out = out0 + w;
+            double* out = out0 + (int64_t)g * hp.Lseg + e;
             switch (wmax) {
                 case 0: hess_emit_steps<0>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
                 case 1: hess_emit_steps<1>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;

@@ -1,6 +1,7 @@
 // ctd_hess_host.cpp -- host side of the Hessian of the Lagrangian: the lower triangle of DOCP_Hessian_pattern in CSC
 // order (without materialising it for the step-periodic middle) and the term tables the Hessian kernel consumes.
 // See ctd_hess.hpp for the decomposition.
+#include <cstdlib>
 #include "ctd_host.hpp"
 #include "ctd_jit.hpp"
 #include "ctd_hess_body.hpp"
@@ -695,6 +696,19 @@ int build_hess_model(Model& mo, std::string& err) {
             if (a < -32768 || a > 32767 || b < -32768 || b > 32767) { err = "per-step Hessian record too large for 16-bit LDS offsets"; return ST_EPATTERN; }
             H.tcode.push_back(pack_tile_term(a, b));
         }
+        // Segments that are mostly structural zeros of the pattern (the manual patterns of the Gauss-Legendre schemes: 85 % of
+        // the 12-state quadrotor's 1890 entries per step): the tiles zero-fill their part of vals and walk only the entries
+        // that have terms -- 2 passes of a workgroup over the segment instead of 8.  CTD_HESS_COMPACT=0/1 overrides.
+        int nzero = 0;
+        for (int e = 0; e < H.Lseg; ++e) nzero += H.tptr[e + 1] == H.tptr[e];
+        H.compact = 2 * nzero >= H.Lseg && nzero > 0;
+        if (const char* ev = std::getenv("CTD_HESS_COMPACT"); ev && *ev) H.compact = (*ev == '1') && nzero > 0;
+        H.cpos.clear(); H.ctptr = H.tptr;
+        if (H.compact) {
+            H.ctptr.assign(1, 0u);
+            for (int e = 0; e < H.Lseg; ++e)
+                if (H.tptr[e + 1] > H.tptr[e]) { H.cpos.push_back((uint32_t)e); H.ctptr.push_back(H.tptr[e + 1]); }
+        }
         auto factor = [&](int ci, double& cst) -> int {       // C[ci] = cst * F(kind)   (HC_* in ctd_hess.hpp)
             auto abc = [&](int e) { return e < 9 ? L.a[e] : L.b[e - 9]; };
             if (ci == HC_ONE) { cst = 1.0; return HF_ONE; }
@@ -790,7 +804,9 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.slot_tasks = H.R.S * hp.ntask + hp.nptask;
     hp.div_ntask = make_fastdiv((uint32_t)(hp.ntask > 0 ? hp.ntask : 1));
     hp.div_slot_tasks = make_fastdiv((uint32_t)(hp.slot_tasks > 0 ? hp.slot_tasks : 1));
-    hp.div_Lseg = make_fastdiv((uint32_t)(H.Lseg > 0 ? H.Lseg : 1));
+    hp.nc = (int)H.ctptr.size() - 1;
+    hp.compact = H.compact ? 1 : 0;
+    hp.div_nc = make_fastdiv((uint32_t)(hp.nc > 0 ? hp.nc : 1));
     hp.div_npairs = make_fastdiv((uint32_t)(hp.npairs > 0 ? hp.npairs : 1));
 }
 

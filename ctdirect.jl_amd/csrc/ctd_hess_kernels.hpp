@@ -34,7 +34,7 @@ __device__ __forceinline__ void hess_pin_kernargs(const HParams& hp, const doubl
     asm volatile("" ::"s"(hp.T), "s"(hp.HL), "s"(hp.HH), "s"(hp.ntiles), "s"(hp.step_begin), "s"(hp.step_end), "s"(hp.L.blk),
                  "s"(hp.L.cb), "s"(hp.L.N), "s"(hp.L.v_off), "s"(hp.L.n), "s"(hp.L.m), "s"(hp.L.eqs), "s"(hp.L.cu), "s"(hp.tau),
                  "s"(xu), "s"(y), "s"(blockDim.x), "s"(hp.R.stride), "s"(hp.npairs));
-    asm volatile("" ::"s"(hp.Lseg), "s"(hp.tptr), "s"(hp.terms), "s"(hp.nterms), "s"(hp.nvv), "s"(hp.vptr), "s"(hp.vterms),
+    asm volatile("" ::"s"(hp.Lseg), "s"(hp.nc), "s"(hp.compact), "s"(hp.cpos), "s"(hp.tptr), "s"(hp.terms), "s"(hp.nterms), "s"(hp.nvv), "s"(hp.vptr), "s"(hp.vterms),
                  "s"(hp.nvterms), "s"(hp.tasks), "s"(hp.ptasks), "s"(hp.ntask), "s"(hp.nptask), "s"(hp.slot_tasks),
                  "s"(hp.seg_base), "s"(hp.reg_first), "s"(hp.reg_last), "s"(hp.vals));
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&hp);
@@ -51,6 +51,8 @@ __device__ __forceinline__ void hess_pin_kernargs(const HParams& hp, const doubl
 // at least two waves per SIMD: an instance a few registers over 256 per lane spills them instead of halving its occupancy
 #ifdef CTD_HESS_NO_CAP          // ablation
 #define CTD_HESS_CAP
+#elif defined(CTD_HESS_WAVES)   // experiment: more waves per SIMD (fewer registers per lane)
+#define CTD_HESS_CAP __attribute__((amdgpu_waves_per_eu(CTD_HESS_WAVES)))
 #else
 #define CTD_HESS_CAP __attribute__((amdgpu_waves_per_eu(2)))
 #endif
