@@ -915,7 +915,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     HIP_TRY(h, upload(&h->d_htasks, H.tasks));
     HIP_TRY(h, upload(&h->d_hptasks, H.ptasks));
     HIP_TRY(h, upload(&h->d_hbtasks, H.btasks));
-    HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(h->hp.ntiles + 1) * (H.nvv > 0 ? H.nvv : 1)));
+    HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(h->hp.ntiles + h->hp.n_edge_blocks) * (H.nvv > 0 ? H.nvv : 1)));
     HParams& hp = h->hp;
     hp.tau = h->d_tau;
     hp.tptr = h->d_htptr; hp.terms = h->d_hterms; hp.pair_c = h->d_hpair_c;
@@ -946,7 +946,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
         void* args[] = {&hp, &x_dev, &y_dev};
-        e = jit_launch(h->f_hess, hp.ntiles + 1, kHessBlock, h->hess_lds_bytes, h->stream, args, te0, te1);
+        e = jit_launch(h->f_hess, hp.ntiles + hp.n_edge_blocks, kHessBlock, h->hess_lds_bytes, h->stream, args, te0, te1);
         if (e == hipSuccess && hp.nvv > 0) e = jit_launch(h->f_hess_finish, 1, kHessBlock, 0, h->stream, args);
     }
     for_problem(h->model.problem, [&](auto tag) {
@@ -1013,7 +1013,7 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     if (hvals_dev) {
         ip.hp.obj_weight = obj_weight;
         ip.hp.vals = hvals_dev;
-        ip.nb_h = ip.hp.ntiles + 1;
+        ip.nb_h = ip.hp.ntiles + ip.hp.n_edge_blocks;
         lds = std::max(lds, h->hess_lds_bytes);
     }
     if (c_dev || vals_dev) {
@@ -1047,7 +1047,7 @@ int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* o) {
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
     int32_t st = ensure_hess(h);
     if (st) return st;
-    o[0] = h->hp.ntiles + 1; o[1] = kHessBlock; o[2] = (int64_t)h->hess_lds_bytes; o[3] = h->hess_tile; o[4] = h->hp.Lseg; o[5] = h->hp.n_edge;
+    o[0] = h->hp.ntiles + h->hp.n_edge_blocks; o[1] = kHessBlock; o[2] = (int64_t)h->hess_lds_bytes; o[3] = h->hess_tile; o[4] = h->hp.Lseg; o[5] = h->hp.n_edge;
     o[6] = h->hp.ntask; o[7] = h->hp.nptask; o[8] = h->hp.nbtask; o[9] = h->hp.nterms;
     return CTD_OK;
 }
@@ -1057,7 +1057,7 @@ int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* 
     if (!h || !out) return CTD_EINVAL;
     int32_t st = enqueue_hess(h, x_dev, y_dev, obj_weight, vals_dev);     // warm, no stamps
     if (st) return st;
-    const int64_t words = (int64_t)(h->hp.ntiles + 1) * 10;
+    const int64_t words = (int64_t)(h->hp.ntiles + h->hp.n_edge_blocks) * 10;
     if (cap < words) return fail(h, CTD_EINVAL, "stamp buffer too small");
     unsigned long long* d_st = nullptr;
     HIP_TRY(h, hipMalloc((void**)&d_st, sizeof(unsigned long long) * words));

@@ -109,6 +109,7 @@ struct HParams {
     int32_t T, HL, HH;          // steps per tile, records a tile needs below its first step (midpoint class: 1) and above its
                                 // last one (implicit Euler with path constraints: 1)
     int32_t ntiles;
+    int32_t n_edge_blocks;          // workgroups 0 .. n_edge_blocks - 1 share the edge entries, the tiles follow
     int64_t step_begin, step_end;   // shard of the time grid this launch evaluates (tiles cover [step_begin, step_end))
     int32_t xcd_remap;              // tiles follow xcd_tile(block - 1) (ctd_layout.hpp)
     int32_t edge_begin, edge_end;   // edge entries this shard emits: irregular leading columns of its own steps ...
@@ -156,7 +157,7 @@ struct HParams {
     // inputs / outputs
     double obj_weight;
     double* vals;
-    double* partials;           // (ntiles + 1) * nvv: V x V partial sums per workgroup (workgroup 0 = edge)
+    double* partials;           // (ntiles + n_edge_blocks) * nvv: V x V partial sums per workgroup (workgroup 0: the edge's)
     // diagnostics only (env CTD_HESS_STOP): 0 normal; 1 return after load, 2 after eval (ablation timing, outputs incomplete)
     int32_t debug_stop;
     // diagnostics only (ctd_hess_debug_stamps): lane 0 of every workgroup stores 5 x {100 MHz realtime, shader cycles}

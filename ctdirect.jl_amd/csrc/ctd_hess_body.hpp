@@ -37,6 +37,7 @@ template <class P, int SC, int S> struct HRL {
 
 struct HBlockCtx {
     int is_edge, nslots, in_stride;
+    int edge_part;  // edge blocks: which share of the edge entries
     int64_t a, b, lo;
     double* in;     // staged xu slice
     double* ly;     // multipliers: tile: (nslots + 1) * cb, block k + 1 = rows of step lo + k (block 0: step lo - 1);
@@ -79,7 +80,8 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     cx.pairs = reinterpret_cast<const uint32_t*>(lds);
     cx.pc = lds + kMaxPairs / 2;
     lds += kHessCoefDoubles;
-    if (block == 0) {
+    cx.edge_part = block;
+    if (block < hp.n_edge_blocks) {
         cx.is_edge = 1;
         cx.nslots = hp.n_edge_slots;
         cx.in_stride = edge_in_stride(L);
@@ -92,7 +94,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
         cx.cp = cx.rec + (cx.nslots + 2) * hp.R.stride;
         cx.red = cx.rec;
     } else {
-        const int tile = hp.xcd_remap ? xcd_tile(block - 1, hp.ntiles) : block - 1;
+        const int tile = hp.xcd_remap ? xcd_tile(block - hp.n_edge_blocks, hp.ntiles) : block - hp.n_edge_blocks;
         const int cap = hp.T + hp.HL + hp.HH;
         if (hess_tables_staged(hp)) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(lds);
@@ -759,8 +761,11 @@ template <class P, int SC, int S>
 CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, int tid, int nthr) {
     constexpr HessRecLayout R = HRL<P, SC, S>::R;
     if (cx.is_edge) {
+        // (the edge blocks share the entries: an entry is a chain of dependent global loads -- index, term range, codes)
         const int n1 = hp.edge_end - hp.edge_begin, ntot = n1 + (hp.edge2_end - hp.edge2_begin);
-        for (int w = tid; w < ntot; w += nthr) {
+        const int chunk = (ntot + hp.n_edge_blocks - 1) / hp.n_edge_blocks;
+        const int wend = (cx.edge_part + 1) * chunk < ntot ? (cx.edge_part + 1) * chunk : ntot;
+        for (int w = cx.edge_part * chunk + tid; w < wend; w += nthr) {
             const int e = w < n1 ? hp.edge_begin + w : hp.edge2_begin + (w - n1);
             double acc = 0.0;
             for (uint32_t t = hp.eptr[e]; t < hp.eptr[e + 1]; ++t) {
@@ -771,12 +776,12 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
         }
         for (int e = tid; e < hp.nvv; e += nthr) {
             double acc = 0.0;
-            if (hp.edge_vv)
+            if (hp.edge_vv && cx.edge_part == 0)
                 for (uint32_t t = hp.evptr[e]; t < hp.evptr[e + 1]; ++t) {
                     const uint32_t code = hp.eterms[t];
                     acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, code, term_slot(code));
                 }
-            hp.partials[e] = acc;
+            hp.partials[(int64_t)cx.edge_part * hp.nvv + e] = acc;
         }
         return;
     }
@@ -849,7 +854,7 @@ CTD_HD void hess_phase_vvsum(const HParams& hp, const HBlockCtx& cx, int block, 
 CTD_HD double hess_finish_partial(const HParams& hp, int e, int tid, int nthr) {
     double acc = 0.0;
     const volatile double* part = hp.partials;       // written by other workgroups of the same launch (last-workgroup finish)
-    for (int b = tid; b <= hp.ntiles; b += nthr) acc = acc + part[(int64_t)b * hp.nvv + e];
+    for (int b = tid; b < hp.ntiles + hp.n_edge_blocks; b += nthr) acc = acc + part[(int64_t)b * hp.nvv + e];
     return acc;
 }
 

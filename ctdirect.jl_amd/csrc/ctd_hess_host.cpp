@@ -786,6 +786,12 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.edge2_begin = H.edge_split;
     hp.edge2_end = step_end == L.N ? (int)H.edge_idx.size() : H.edge_split;
     hp.edge_vv = step_end == L.N ? 1 : 0;
+    // one edge workgroup per 256 edge entries (at most 16): every one of them evaluates the edge records, each emits its share
+    {
+        const int ntot = (hp.edge_end - hp.edge_begin) + (hp.edge2_end - hp.edge2_begin);
+        hp.n_edge_blocks = std::max(1, std::min(16, (ntot + 255) / 256));
+        if (const char* ev = std::getenv("CTD_HESS_EDGE_BLOCKS"); ev && *ev) hp.n_edge_blocks = std::max(1, std::min(64, std::atoi(ev)));
+    }
     hp.Lseg = H.Lseg;
     hp.nterms = (int)H.terms.size();
     hp.nvterms = (int)H.vterms.size();

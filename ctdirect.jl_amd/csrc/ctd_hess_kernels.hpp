@@ -31,7 +31,7 @@ __device__ __forceinline__ void hess_stamp(const HParams& hp, int slot) {
 // loads the compiler still places later (register pressure) hit the scalar cache.
 __device__ __forceinline__ void hess_pin_kernargs(const HParams& hp, const double* xu, const double* y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"s"(hp.T), "s"(hp.HL), "s"(hp.HH), "s"(hp.ntiles), "s"(hp.step_begin), "s"(hp.step_end), "s"(hp.L.blk),
+    asm volatile("" ::"s"(hp.T), "s"(hp.HL), "s"(hp.HH), "s"(hp.ntiles), "s"(hp.n_edge_blocks), "s"(hp.step_begin), "s"(hp.step_end), "s"(hp.L.blk),
                  "s"(hp.L.cb), "s"(hp.L.N), "s"(hp.L.v_off), "s"(hp.L.n), "s"(hp.L.m), "s"(hp.L.eqs), "s"(hp.L.cu), "s"(hp.tau),
                  "s"(xu), "s"(y), "s"(blockDim.x), "s"(hp.R.stride), "s"(hp.npairs));
     asm volatile("" ::"s"(hp.Lseg), "s"(hp.nc), "s"(hp.compact), "s"(hp.cpos), "s"(hp.tptr), "s"(hp.terms), "s"(hp.nterms), "s"(hp.nvv), "s"(hp.vptr), "s"(hp.vterms),
@@ -121,7 +121,7 @@ hipError_t launch_hess_variant_dbg(const HParams& hp, const double* xu, const do
                                            (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const int grid = hp.ntiles + 1;
+    const int grid = hp.ntiles + hp.n_edge_blocks;
     if (e0 || e1) hipExtLaunchKernelGGL((hess_kernel<P, SC, S, DBG>), dim3(grid), dim3(kHessBlock), lds_bytes, st, e0, e1, 0, hp, xu, y);
     else hess_kernel<P, SC, S, DBG><<<grid, kHessBlock, lds_bytes, st>>>(hp, xu, y);
     if (hp.nvv > 0) hess_finish_kernel<P><<<1, kHessBlock, 0, st>>>(hp);

@@ -53,7 +53,7 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
 template <class P, int SC, int S>
 static void run_hess_blocks(const HParams& hp, const double* xu, const double* y, int nthr) {
     const int64_t nlds = hess_lds_doubles(hp);
-    for (int b = 0; b <= hp.ntiles; ++b) {
+    for (int b = 0; b < hp.ntiles + hp.n_edge_blocks; ++b) {
         std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
         HBlockCtx cx = make_hctx(hp, b, lds.data());
         for (int t = 0; t < nthr; ++t) hess_phase_load<P>(hp, cx, xu, y, t, nthr);
@@ -183,7 +183,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     hp.tasks = H.tasks.data(); hp.ptasks = H.ptasks.data(); hp.btasks = H.btasks.data();
     hp.obj_weight = obj_weight;
     hp.vals = vals;
-    std::vector<double> partials((size_t)(hp.ntiles + 1) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
+    std::vector<double> partials((size_t)(hp.ntiles + hp.n_edge_blocks) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
     hp.partials = partials.data();
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
