@@ -153,7 +153,7 @@ struct HParams {
     const uint32_t* btasks;     // boundary + Mayer point
     int32_t ntask, nptask, nbtask;
     int32_t slot_tasks;         // S * ntask + nptask
-    FastDiv div_ntask, div_slot_tasks, div_nc, div_npairs;
+    FastDiv div_ntask, div_stage_tasks, div_nptask, div_nc, div_npairs;      // (stage_tasks = S * ntask)
     // inputs / outputs
     double obj_weight;
     double* vals;

@@ -656,16 +656,22 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int k = (int)fast_div((uint32_t)w, hp.div_npairs);
         hess_pair<P, SC, S>(hp, cx, k, w - k * hp.npairs);
     }
-    const int total = cx.nslots * hp.slot_tasks;
-    for (int w = tid; w < total; w += nthr) {
-        const int k = (int)fast_div((uint32_t)w, hp.div_slot_tasks);
-        const int r = w - k * hp.slot_tasks;
-        if (r < R.S * hp.ntask) {
-            const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-            if constexpr (SymStage<P>::value) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
-            else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
-        } else if (PATH_PT) {
-            const uint32_t code = cx.ptasks[r - R.S * hp.ntask];
+    // stage-type points: item (slot k, stage j, task) on lanes 0, 1, ...; path points: item (slot k, task) from the next wave
+    // boundary on (wrapping around): the two kinds run different code, lanes of one wave would take turns
+    const int nstage = cx.nslots * R.S * hp.ntask;
+    for (int w = tid; w < nstage; w += nthr) {
+        const int k = (int)fast_div((uint32_t)w, hp.div_stage_tasks);
+        const int r = w - k * R.S * hp.ntask;
+        const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
+        if constexpr (SymStage<P>::value) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
+        else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
+    }
+    if (PATH_PT) {
+        const int npath = cx.nslots * hp.nptask;
+        const int pofs = ((nstage + 63) & ~63) % nthr;
+        for (int w = tid >= pofs ? tid - pofs : tid - pofs + nthr; w < npath; w += nthr) {
+            const int k = (int)fast_div((uint32_t)w, hp.div_nptask);
+            const uint32_t code = cx.ptasks[w - k * hp.nptask];
             const int64_t s = hslot_step(hp, cx, k);
             if (s >= 0 && s < L.N) {
                 const double* base = cx.in + k * cx.in_stride;

@@ -809,7 +809,8 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.nbtask = (int)H.btasks.size();
     hp.slot_tasks = H.R.S * hp.ntask + hp.nptask;
     hp.div_ntask = make_fastdiv((uint32_t)(hp.ntask > 0 ? hp.ntask : 1));
-    hp.div_slot_tasks = make_fastdiv((uint32_t)(hp.slot_tasks > 0 ? hp.slot_tasks : 1));
+    hp.div_stage_tasks = make_fastdiv((uint32_t)(H.R.S * hp.ntask > 0 ? H.R.S * hp.ntask : 1));
+    hp.div_nptask = make_fastdiv((uint32_t)(hp.nptask > 0 ? hp.nptask : 1));
     hp.nc = (int)H.ctptr.size() - 1;
     hp.compact = H.compact ? 1 : 0;
     hp.div_nc = make_fastdiv((uint32_t)(hp.nc > 0 ? hp.nc : 1));
