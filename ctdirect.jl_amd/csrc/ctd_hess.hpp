@@ -35,12 +35,19 @@ constexpr int kMaxTerms = 6;           // terms per output entry (S stage points
 constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
 
 // ---- per-slot LDS record (doubles) ---------------------------------------------------------------------
-// S stage blocks (S = max(s, 1)), each:  HD[md*md]  (row p, column q >= p)   RK[nv*n]  (Gauss-Legendre with free times:
+// S stage blocks (S = max(s, 1)), each:  HD[md (md+1)/2]  (packed upper triangle, hess_tri)   RK[nv*n]  (Gauss-Legendre with free times:
 //     RK[k*n + a] = h HD[x_a][V_k] + dh/dv_k dPhi/dx_a, the d2/dK dV_k entry up to the factor a_jl)
-// HP[md*md]   path point of the step (Gauss-Legendre / midpoint with path constraints)
+// HP[md (md+1)/2]   path point of the step (Gauss-Legendre / midpoint with path constraints)
 // YX[n]       multipliers of the state-equation rows (Gauss-Legendre with free times: d2/dK^l dV_k of -h b_l y'K^l)
 // (the products C[c1] C[c2] of the chain-rule coefficients live in a separate LDS table of npairs doubles per slot, cx.cp)
-// The boundary record holds HB[mdb*mdb], mdb = 2n + nv (directions x0 | xf | V); the final-path record uses HP.
+// The boundary record holds HB[mdb (mdb+1)/2], mdb = 2n + nv (directions x0 | xf | V); the final-path record uses HP.
+// position of the pair {a, b} in the packed upper triangle (row-major, row <= column) of an md x md symmetric block: half the
+// LDS of the full square, so twice the steps per tile at the same LDS budget
+CTD_HD constexpr int hess_tri(int md, int a, int b) {
+    return a <= b ? a * (2 * md - a - 1) / 2 + b : b * (2 * md - b - 1) / 2 + a;
+}
+CTD_HD constexpr int hess_tri_size(int md) { return md * (md + 1) / 2; }
+
 struct HessRecLayout {
     int32_t md, mdb, S;
     int32_t stage_sz, oStage, oRK;   // stage block j at oStage + j * stage_sz: HD at +0, RK at +oRK
@@ -54,13 +61,13 @@ constexpr HessRecLayout make_hess_layout(int n, int m, int nv, int p, int sc, in
     r.mdb = 2 * n + nv;
     r.S = s > 0 ? s : 1;
     const bool rk = (sc == SC_IRK) && free_time;
-    r.oRK = r.md * r.md;
+    r.oRK = hess_tri_size(r.md);
     r.stage_sz = r.oRK + (rk ? nv * n : 0);
     r.oStage = 0;
     r.oHP = r.oStage + r.S * r.stage_sz;
-    r.oYX = r.oHP + ((p > 0 && sc != SC_TRAPEZE) ? r.md * r.md : 0);
+    r.oYX = r.oHP + ((p > 0 && sc != SC_TRAPEZE) ? hess_tri_size(r.md) : 0);
     int end_step = r.oYX + (rk ? n : 0);
-    int end_b = r.mdb * r.mdb;
+    int end_b = hess_tri_size(r.mdb);
     int body = end_step > end_b ? end_step : end_b;
     r.oZero = body;
     r.stride = body + 1;
@@ -98,8 +105,8 @@ CTD_HD int term_slot(uint32_t c) { return (int)((c >> 24) & 0x7u); }
 // into the coefficient products (pair - sd * npairs), high half into the records (di - sd * stride), sd = +1 / -1 for the
 // record of the previous / next step.
 CTD_HD uint32_t pack_tile_term(int a_off, int b_off) { return ((uint32_t)a_off & 0xFFFFu) | ((uint32_t)b_off << 16); }
-CTD_HD int tile_term_a(uint32_t c) { return (int)(int16_t)(c & 0xFFFFu); }
-CTD_HD int tile_term_b(uint32_t c) { return (int)(int16_t)(c >> 16); }
+CTD_HD int tile_term_a(uint32_t c) { return (int)(c << 16) >> 16; }      // (sign-extending shifts)
+CTD_HD int tile_term_b(uint32_t c) { return (int)c >> 16; }
 
 // ---- kernel parameters -------------------------------------------------------------------------------------
 struct HParams {

@@ -412,7 +412,7 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     double* HD = rec + R.oStage + j * R.stage_sz;
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < md) HD[p <= q[i] ? p * md + q[i] : q[i] * md + p] = phi.ab[i];
+        if (q[i] < md) HD[hess_tri(md, p, q[i])] = phi.ab[i];
     if (SC == SC_IRK && FREE) {
         // RK[k][a] = h d2Phi/dx_a dV_k + dh/dv_k dPhi/dx_a, from whichever of the two directions is the outer one
 #pragma unroll
@@ -582,7 +582,7 @@ CTD_HD void hess_eval_path(const HParams& hp, const double* xs, const double* ub
     for (int r = 0; r < np; ++r) phi = phi + g[r] * yrow[r];
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < md) HP[p <= q[i] ? p * md + q[i] : q[i] * md + p] = phi.ab[i];
+        if (q[i] < md) HP[hess_tri(md, p, q[i])] = phi.ab[i];
 }
 
 // boundary + Mayer point: directions x0 | xf | v
@@ -625,7 +625,7 @@ CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const doubl
     if (P::HAS_MAYER) phi = phi + P::template mayer<T>(x0, xf, v) * hp.obj_weight;
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if (q[i] < mdb) HB[p <= q[i] ? p * mdb + q[i] : q[i] * mdb + p] = phi.ab[i];
+        if (q[i] < mdb) HB[hess_tri(mdb, p, q[i])] = phi.ab[i];
 }
 
 // Compact segments (HParams::compact): the tile's part of vals is zero-filled before the emit phase stores the entries that

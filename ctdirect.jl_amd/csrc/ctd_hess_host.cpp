@@ -410,7 +410,7 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
                 if (mo.H.need_rk[vv->c * L.n + kv->c])
                     out.push_back(Term{PT_STAGE, s, base + R.oRK + vv->c * L.n + kv->c, HC_A + 3 * j + kv->l, HC_ONE});
             } else if (mo.H.need_stage[sym_index(R.md, a.d, b.d)]) {
-                out.push_back(Term{PT_STAGE, s, base + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+                out.push_back(Term{PT_STAGE, s, base + hess_tri(R.md, a.d, b.d), a.coef, b.coef});
             }
         }
         if (rk) {   // state-equation row -h sum_l b_l y'K^l: d2/dK^l_a dV_k = -b_l dh/dv_k y_a for the time variables
@@ -423,18 +423,18 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
             const int64_t us = (L.euler == 2 && s >= 1) ? s - 1 : s;
             const Dir a = map_path(L, s, us, vr), b = map_path(L, s, us, vc);
             if (a.ok && b.ok && mo.H.need_path[sym_index(R.md, a.d, b.d)])
-                out.push_back(Term{PT_PATH, s, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+                out.push_back(Term{PT_PATH, s, R.oHP + hess_tri(R.md, a.d, b.d), a.coef, b.coef});
         }
     }
     if (has_path_pt) {
         const Dir a = map_path(L, L.N, L.N - 1, vr), b = map_path(L, L.N, L.N - 1, vc);
         if (a.ok && b.ok && mo.H.need_path[sym_index(R.md, a.d, b.d)])
-            out.push_back(Term{PT_FPATH, 0, R.oHP + sym_index(R.md, a.d, b.d), a.coef, b.coef});
+            out.push_back(Term{PT_FPATH, 0, R.oHP + hess_tri(R.md, a.d, b.d), a.coef, b.coef});
     }
     if (L.bc > 0 || mo.info.mayer) {
         const Dir a = map_bnd(L, vr), b = map_bnd(L, vc);
         if (a.ok && b.ok && mo.H.need_bnd[sym_index(R.mdb, a.d, b.d)])
-            out.push_back(Term{PT_BND, 0, sym_index(R.mdb, a.d, b.d), HC_ONE, HC_ONE});
+            out.push_back(Term{PT_BND, 0, hess_tri(R.mdb, a.d, b.d), HC_ONE, HC_ONE});
     }
 }
 
@@ -566,9 +566,9 @@ int build_hess_model(Model& mo, std::string& err) {
                 if (it == rows.end()) { H.vptr.push_back((uint32_t)H.vterms.size()); continue; }
                 for (int j = 0; j < H.R.S; ++j)
                     if (H.need_stage[sym_index(md, vd + kc, vd + kr)])
-                        H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + sym_index(md, vd + kc, vd + kr), 0, 0));
+                        H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + hess_tri(md, vd + kc, vd + kr), 0, 0));
                 if (L.p > 0 && L.sc != SC_TRAPEZE && H.need_path[sym_index(md, vd + kc, vd + kr)])
-                    H.vterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), 0, 0));
+                    H.vterms.push_back(pack_term(H.R.oHP + hess_tri(md, vd + kc, vd + kr), 0, 0));
                 H.vptr.push_back((uint32_t)H.vterms.size());
             }
         }
@@ -625,11 +625,11 @@ int build_hess_model(Model& mo, std::string& err) {
         for (int kc = 0; kc < L.nv; ++kc)
             for (int kr = kc; kr < L.nv; ++kr) {
                 if (L.p > 0 && L.sc != SC_TRAPEZE && H.need_path[sym_index(md, vd + kc, vd + kr)])
-                    H.eterms.push_back(pack_term(H.R.oHP + sym_index(md, vd + kc, vd + kr), 0, H.edge_fp));
+                    H.eterms.push_back(pack_term(H.R.oHP + hess_tri(md, vd + kc, vd + kr), 0, H.edge_fp));
                 if ((L.bc > 0 || mo.info.mayer) && H.need_bnd[sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr)])
-                    H.eterms.push_back(pack_term(sym_index(mdb, 2 * L.n + kc, 2 * L.n + kr), 0, H.edge_b));
+                    H.eterms.push_back(pack_term(hess_tri(mdb, 2 * L.n + kc, 2 * L.n + kr), 0, H.edge_b));
                 if (L.sc == SC_TRAPEZE && H.need_stage[sym_index(md, vd + kc, vd + kr)])
-                    H.eterms.push_back(pack_term(H.R.oStage + sym_index(md, vd + kc, vd + kr), 0, slot_of[N]));
+                    H.eterms.push_back(pack_term(H.R.oStage + hess_tri(md, vd + kc, vd + kr), 0, slot_of[N]));
                 H.evptr.push_back((uint32_t)H.eterms.size());
             }
     }

@@ -313,9 +313,9 @@ static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag,
     for (int p = 0; p < md; ++p) d1[p] = g.diff(Phi, p);
     for (int p = 0; p < md; ++p)
         for (int q = p; q < md; ++q)
-            outs.emplace_back("HD[" + std::to_string(p * md + q) + "]", g.at_zero(g.diff(d1[p], q)));
+            outs.emplace_back("HD[" + std::to_string(hess_tri(md, p, q)) + "]", g.at_zero(g.diff(d1[p], q)));
     if (irk && free_time) {      // RK[k][a] = h d2Phi/dx_a dV_k + dh/dv_k dPhi/dx_a   (hess_eval_stage)
-        const int oRK = md * md;
+        const int oRK = hess_tri_size(md);
         for (int k = 0; k < nv; ++k)
             for (int a = 0; a < n; ++a)
                 outs.emplace_back("HD[" + std::to_string(oRK + k * n + a) + "]",
