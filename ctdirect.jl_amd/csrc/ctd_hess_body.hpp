@@ -840,7 +840,15 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
         const int si = w / hp.nvv, e = w - si * hp.nvv;
         const int k = si + (int)(cx.a - cx.lo);
         double acc = 0.0;
-        for (uint32_t t = cx.vptr[e]; t < cx.vptr[e + 1]; ++t) acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, cx.vterms[t], k);
+        uint32_t t = cx.vptr[e];
+        const uint32_t t1 = cx.vptr[e + 1];
+        for (; t + 4 <= t1; t += 4) {      // four terms in flight (a term is a code load -> two LDS reads -> multiply-add chain)
+            const uint32_t c0 = cx.vterms[t], c1 = cx.vterms[t + 1], c2 = cx.vterms[t + 2], c3 = cx.vterms[t + 3];
+            const double p0 = hess_term(cx.rec, R.stride, cx.cp, hp.npairs, c0, k), p1 = hess_term(cx.rec, R.stride, cx.cp, hp.npairs, c1, k);
+            const double p2 = hess_term(cx.rec, R.stride, cx.cp, hp.npairs, c2, k), p3 = hess_term(cx.rec, R.stride, cx.cp, hp.npairs, c3, k);
+            acc = (((acc + p0) + p1) + p2) + p3;
+        }
+        for (; t < t1; ++t) acc = acc + hess_term(cx.rec, R.stride, cx.cp, hp.npairs, cx.vterms[t], k);
         cx.red[e * hp.T + si] = acc;
     }
 }
@@ -851,7 +859,12 @@ CTD_HD void hess_phase_vvsum(const HParams& hp, const HBlockCtx& cx, int block, 
     const int ns = (int)(cx.b - cx.a);
     for (int e = tid; e < hp.nvv; e += nthr) {
         double acc = 0.0;
-        for (int si = 0; si < ns; ++si) acc = acc + cx.red[e * hp.T + si];
+        int si = 0;
+        for (; si + 4 <= ns; si += 4) {
+            const double r0 = cx.red[e * hp.T + si], r1 = cx.red[e * hp.T + si + 1], r2 = cx.red[e * hp.T + si + 2], r3 = cx.red[e * hp.T + si + 3];
+            acc = (((acc + r0) + r1) + r2) + r3;
+        }
+        for (; si < ns; ++si) acc = acc + cx.red[e * hp.T + si];
         hp.partials[(int64_t)block * hp.nvv + e] = acc;
     }
 }

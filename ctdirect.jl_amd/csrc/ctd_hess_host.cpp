@@ -746,10 +746,10 @@ int default_hess_tile(const Model& mo) {
         // symbolic stage functions (run-time OCPs): the eval phase is one short pass, so the tile is set by the other
         // phases -- MI355X sweeps (profiles/r01_hessian_symbolic.md): ~27 KiB of LDS per workgroup for light steps (five to six
         // workgroups per CU), ~48 KiB for steps of 2 KiB and more (the CSC period is then several wave passes per step)
-        const int64_t budget = per_step >= 2048 ? 48 * 1024 : 27 * 1024;
+        // (records hold packed triangles since round 2: sweeps in profiles/r02_hessian_tiles.log -- the 12-state quadrotor,
+        // 6.3 KiB per step: 8 steps = 57 KiB 90 us, 6 steps 101 us, 10 steps 95 us, 12 steps = one workgroup per CU 133 us)
+        const int64_t budget = per_step >= 5000 ? 58 * 1024 : (per_step >= 2048 ? 48 * 1024 : 27 * 1024);
         int64_t Ts = std::max<int64_t>(1, std::min<int64_t>(128, budget / per_step - H.HL - H.HH - 1));
-        // very heavy steps (the 12-state quadrotor, 11 KiB per step): up to 6 steps as long as two workgroups still share a
-        // CU's LDS (6 steps = 77 KiB: 151 us; 3 steps: 258 us; 7 steps = one workgroup per CU: 249 us)
         if (Ts < 6) Ts = std::max<int64_t>(Ts, std::min<int64_t>(6, (78 * 1024) / per_step - H.HL - H.HH - 1));
         while (Ts > 4 && (L.N + Ts - 1) / Ts < 512) Ts = (Ts + 1) / 2;      // small grids: about two workgroups per CU
         return (int)Ts;
