@@ -102,7 +102,7 @@ struct ctd_handle {
              *d_hevptr = nullptr, *d_heterms = nullptr;
     int64_t* d_hedge_idx = nullptr;
     double* d_hpair_c = nullptr;
-    uint32_t* d_hcpos = nullptr;
+    uint32_t *d_hcpos = nullptr, *d_hzpos = nullptr;
     uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
     std::string err;
@@ -159,7 +159,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -904,6 +904,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     }
     HIP_TRY(h, upload(&h->d_htptr, H.ctptr));
     HIP_TRY(h, upload(&h->d_hcpos, H.cpos));
+    HIP_TRY(h, upload(&h->d_hzpos, H.zpos));
     HIP_TRY(h, upload(&h->d_hterms, H.tcode));
     HIP_TRY(h, upload(&h->d_hpair_c, H.pair_c));
     HIP_TRY(h, upload(&h->d_hvptr, H.vptr));
@@ -919,7 +920,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     HParams& hp = h->hp;
     hp.tau = h->d_tau;
     hp.tptr = h->d_htptr; hp.terms = h->d_hterms; hp.pair_c = h->d_hpair_c;
-    hp.cpos = h->d_hcpos;
+    hp.cpos = h->d_hcpos; hp.zpos = h->d_hzpos;
     hp.vptr = h->d_hvptr; hp.vterms = h->d_hvterms;
     hp.edge_idx = h->d_hedge_idx; hp.eptr = h->d_heptr; hp.evptr = h->d_hevptr; hp.eterms = h->d_heterms;
     hp.tasks = h->d_htasks; hp.ptasks = h->d_hptasks; hp.btasks = h->d_hbtasks;

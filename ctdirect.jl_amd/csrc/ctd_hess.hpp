@@ -125,11 +125,13 @@ struct HParams {
     // regular CSC segments of the lower triangle: step i in [reg_first, reg_last) owns
     // vals[seg_base + (i - reg_first) * Lseg, +Lseg); entry e of the segment sums terms [tptr[e], tptr[e+1])
     // The tiles walk nc entries: entry k sits at position cpos[k] of the segment and sums the terms [tptr[k], tptr[k+1]).
-    // compact = 0: all Lseg entries (position k).  compact = 1 (segments that are mostly structural zeros of the pattern):
-    // only the entries that have terms; the tile zero-fills its part of vals beforehand.
-    int32_t Lseg, nc, compact;
+    // compact = 0: all Lseg entries (position k).  Else only the entries that have terms; the others (structural zeros of
+    // the pattern) are zero-filled: compact = 1 (segments that are mostly zeros): the tile zero-fills its whole part of vals
+    // beforehand; compact = 2: it stores zeros at the nz positions zpos[] of every step.
+    int32_t Lseg, nc, compact, nz;
     const uint32_t* tptr;       // nc + 1 offsets
     const uint32_t* cpos;       // nc positions (compact only)
+    const uint32_t* zpos;       // nz positions (compact = 2)
     const uint32_t* terms;      // pack_tile_term codes
     int32_t nterms;
     int64_t seg_base, reg_first, reg_last;
@@ -160,7 +162,7 @@ struct HParams {
     const uint32_t* btasks;     // boundary + Mayer point
     int32_t ntask, nptask, nbtask;
     int32_t slot_tasks;         // S * ntask + nptask
-    FastDiv div_ntask, div_stage_tasks, div_nptask, div_nc, div_npairs;      // (stage_tasks = S * ntask)
+    FastDiv div_ntask, div_stage_tasks, div_nptask, div_nc, div_nz, div_npairs;      // (stage_tasks = S * ntask)
     // inputs / outputs
     double obj_weight;
     double* vals;

@@ -48,7 +48,7 @@ struct HBlockCtx {
     double* cp;     // coefficient products: npairs per slot (hess_pair), slot k at cp + k * npairs
     double* red;    // tile: nvv * T per-step V x V contributions (summed in step order by hess_phase_vvsum)
     // term / task tables: LDS copies when small (staged by hess_phase_load), else the global tables
-    const uint32_t *tptr, *terms, *cpos, *vptr, *vterms;
+    const uint32_t *tptr, *terms, *cpos, *zpos, *vptr, *vterms;
     const uint32_t *tasks, *ptasks;
     // LDS copies of the coefficient-pair tables (factor kinds from the kernel arguments, where a lane-dependent index
     // would cost a global load per use; constants from hp.pair_c)
@@ -59,10 +59,10 @@ struct HBlockCtx {
 // doubles at the head of every workgroup's LDS: pair factor kinds (kMaxPairs words) | pair constants (kMaxPairs)
 constexpr int kHessCoefDoubles = kMaxPairs / 2 + kMaxPairs;
 
-// words (uint32) of table data a tile stages in LDS: tptr | terms | cpos | vptr | vterms | tasks | ptasks
+// words (uint32) of table data a tile stages in LDS: tptr | terms | cpos | zpos | vptr | vterms | tasks | ptasks
 constexpr int kMaxStagedHessWords = 3072;
 CTD_HD int hess_table_words(const HParams& hp) {
-    return (hp.nc + 1) + hp.nterms + (hp.compact ? hp.nc : 0) + (hp.nvv + 1) + hp.nvterms + hp.ntask + hp.nptask;
+    return (hp.nc + 1) + hp.nterms + (hp.compact ? hp.nc : 0) + hp.nz + (hp.nvv + 1) + hp.nvterms + hp.ntask + hp.nptask;
 }
 CTD_HD bool hess_tables_staged(const HParams& hp) { return hess_table_words(hp) <= kMaxStagedHessWords; }
 CTD_HD int hess_table_doubles(const HParams& hp) { return hess_tables_staged(hp) ? (hess_table_words(hp) + 1) / 2 : 0; }
@@ -75,7 +75,7 @@ CTD_HD double hslot_tau(const HBlockCtx& cx, int k, int d) { return cx.is_edge ?
 CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     HBlockCtx cx;
     const Layout& L = hp.L;
-    cx.tptr = hp.tptr; cx.terms = hp.terms; cx.cpos = hp.cpos; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
+    cx.tptr = hp.tptr; cx.terms = hp.terms; cx.cpos = hp.cpos; cx.zpos = hp.zpos; cx.vptr = hp.vptr; cx.vterms = hp.vterms;
     cx.tasks = hp.tasks; cx.ptasks = hp.ptasks;
     cx.pairs = reinterpret_cast<const uint32_t*>(lds);
     cx.pc = lds + kMaxPairs / 2;
@@ -101,6 +101,7 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
             cx.tptr = w; w += hp.nc + 1;
             cx.terms = w; w += hp.nterms;
             if (hp.compact) { cx.cpos = w; w += hp.nc; }
+            cx.zpos = w; w += hp.nz;
             cx.vptr = w; w += hp.nvv + 1;
             cx.vterms = w; w += hp.nvterms;
             cx.tasks = w;
@@ -211,7 +212,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         const double y0 = tid < ny ? yval(tid) : 0.0, y1 = tid + nthr < ny ? yval(tid + nthr) : 0.0;
         const double vv = tid < P::NV ? xu[L.v_off + tid] : 0.0;
         const uint32_t w0 = (st && tid <= hp.nc) ? hp.tptr[tid] : 0u, w1 = (st && tid < hp.nterms) ? hp.terms[tid] : 0u;
-        const uint32_t w6 = (st && hp.compact && tid < hp.nc) ? hp.cpos[tid] : 0u;
+        const uint32_t w6 = (st && hp.compact && tid < hp.nc) ? hp.cpos[tid] : 0u, w7 = (st && tid < hp.nz) ? hp.zpos[tid] : 0u;
         const uint32_t w2 = (st && tid <= hp.nvv) ? hp.vptr[tid] : 0u, w3 = (st && tid < hp.nvterms) ? hp.vterms[tid] : 0u;
         const uint32_t w4 = (st && tid < hp.ntask) ? hp.tasks[tid] : 0u, w5 = (st && tid < hp.nptask) ? hp.ptasks[tid] : 0u;
         const double tau_e = tid <= cx.nslots + 2 ? htau_global(hp, cx.lo - 1 + tid) : 0.0;     // (table load: issued with the rest)
@@ -226,6 +227,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
             d = const_cast<uint32_t*>(cx.tptr);   if (tid <= hp.nc) d[tid] = w0;     for (int e = tid + nthr; e <= hp.nc; e += nthr) d[e] = hp.tptr[e];
             d = const_cast<uint32_t*>(cx.terms);  if (tid < hp.nterms) d[tid] = w1;  for (int e = tid + nthr; e < hp.nterms; e += nthr) d[e] = hp.terms[e];
             if (hp.compact) { d = const_cast<uint32_t*>(cx.cpos); if (tid < hp.nc) d[tid] = w6; for (int e = tid + nthr; e < hp.nc; e += nthr) d[e] = hp.cpos[e]; }
+            d = const_cast<uint32_t*>(cx.zpos);   if (tid < hp.nz) d[tid] = w7;     for (int e = tid + nthr; e < hp.nz; e += nthr) d[e] = hp.zpos[e];
             d = const_cast<uint32_t*>(cx.vptr);   if (tid <= hp.nvv) d[tid] = w2;    for (int e = tid + nthr; e <= hp.nvv; e += nthr) d[e] = hp.vptr[e];
             d = const_cast<uint32_t*>(cx.vterms); if (tid < hp.nvterms) d[tid] = w3; for (int e = tid + nthr; e < hp.nvterms; e += nthr) d[e] = hp.vterms[e];
             d = const_cast<uint32_t*>(cx.tasks);  if (tid < hp.ntask) d[tid] = w4;   for (int e = tid + nthr; e < hp.ntask; e += nthr) d[e] = hp.tasks[e];
@@ -633,7 +635,7 @@ CTD_HD void hess_eval_boundary(const HParams& hp, const double* x0p, const doubl
 // acknowledged when the barrier after that phase (which waits for them) is reached, so the entries written again in the
 // emit phase are ordered after them.
 CTD_HD void hess_zero_fill(const HParams& hp, const HBlockCtx& cx, int tid, int nthr) {
-    if (!hp.compact || cx.is_edge) return;
+    if (hp.compact != 1 || cx.is_edge) return;
     const int64_t i0 = cx.a > hp.reg_first ? cx.a : hp.reg_first;
     const int64_t i1 = cx.b < hp.reg_last ? cx.b : hp.reg_last;
     if (i1 <= i0) return;
@@ -832,6 +834,11 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
                 case 5: hess_emit_steps<5>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
                 default: hess_emit_steps<kMaxTerms>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
             }
+        }
+        // compact = 2: zeros at the listed positions of every step (item j = step * nz + position index)
+        for (int j = tid; j < hp.nz * nreg; j += nthr) {
+            const int u = (int)fast_div((uint32_t)j, hp.div_nz);
+            out0[u * (int64_t)hp.Lseg + cx.zpos[j - u * hp.nz]] = 0.0;
         }
     }
     // V x V entries: one lane per (step of the tile, entry) adds up that step's terms; hess_phase_vvsum then sums the steps

@@ -701,13 +701,21 @@ int build_hess_model(Model& mo, std::string& err) {
         // that have terms -- 2 passes of a workgroup over the segment instead of 8.  CTD_HESS_COMPACT=0/1 overrides.
         int nzero = 0;
         for (int e = 0; e < H.Lseg; ++e) nzero += H.tptr[e + 1] == H.tptr[e];
-        H.compact = 2 * nzero >= H.Lseg && nzero > 0;
-        if (const char* ev = std::getenv("CTD_HESS_COMPACT"); ev && *ev) H.compact = (*ev == '1') && nzero > 0;
-        H.cpos.clear(); H.ctptr = H.tptr;
+        // Fewer zeros (goddard, 3 Gauss-Legendre stages: 30 of 135): the same walk -- 105 entries let every lane take every
+        // second step instead of every step -- and explicit zero stores at the listed positions.
+        // (37.7 vs 38.5 us at N = 80000; taken only where the shorter walk lets a lane skip steps)
+        {
+            const int ncz = H.Lseg - nzero, g0 = H.Lseg < 256 ? 256 / std::max(1, H.Lseg) : 1, g1 = ncz < 256 ? 256 / std::max(1, ncz) : 1;
+            H.compact = nzero == 0 ? 0 : (2 * nzero >= H.Lseg ? 1 : ((g1 > g0 && 8 * nzero >= H.Lseg) ? 2 : 0));
+        }
+        if (const char* ev = std::getenv("CTD_HESS_COMPACT"); ev && *ev) H.compact = nzero > 0 ? std::atoi(ev) : 0;
+        H.cpos.clear(); H.zpos.clear(); H.ctptr = H.tptr;
         if (H.compact) {
             H.ctptr.assign(1, 0u);
-            for (int e = 0; e < H.Lseg; ++e)
+            for (int e = 0; e < H.Lseg; ++e) {
                 if (H.tptr[e + 1] > H.tptr[e]) { H.cpos.push_back((uint32_t)e); H.ctptr.push_back(H.tptr[e + 1]); }
+                else if (H.compact == 2) H.zpos.push_back((uint32_t)e);
+            }
         }
         auto factor = [&](int ci, double& cst) -> int {       // C[ci] = cst * F(kind)   (HC_* in ctd_hess.hpp)
             auto abc = [&](int e) { return e < 9 ? L.a[e] : L.b[e - 9]; };
@@ -812,7 +820,9 @@ void Model::fill_hparams(HParams& hp, int tile, int64_t step_begin, int64_t step
     hp.div_stage_tasks = make_fastdiv((uint32_t)(H.R.S * hp.ntask > 0 ? H.R.S * hp.ntask : 1));
     hp.div_nptask = make_fastdiv((uint32_t)(hp.nptask > 0 ? hp.nptask : 1));
     hp.nc = (int)H.ctptr.size() - 1;
-    hp.compact = H.compact ? 1 : 0;
+    hp.compact = H.compact;
+    hp.nz = (int)H.zpos.size();
+    hp.div_nz = make_fastdiv((uint32_t)(hp.nz > 0 ? hp.nz : 1));
     hp.div_nc = make_fastdiv((uint32_t)(hp.nc > 0 ? hp.nc : 1));
     hp.div_npairs = make_fastdiv((uint32_t)(hp.npairs > 0 ? hp.npairs : 1));
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ void hess_pin_kernargs(const HParams& hp, const doubl
     asm volatile("" ::"s"(hp.T), "s"(hp.HL), "s"(hp.HH), "s"(hp.ntiles), "s"(hp.n_edge_blocks), "s"(hp.step_begin), "s"(hp.step_end), "s"(hp.L.blk),
                  "s"(hp.L.cb), "s"(hp.L.N), "s"(hp.L.v_off), "s"(hp.L.n), "s"(hp.L.m), "s"(hp.L.eqs), "s"(hp.L.cu), "s"(hp.tau),
                  "s"(xu), "s"(y), "s"(blockDim.x), "s"(hp.R.stride), "s"(hp.npairs));
-    asm volatile("" ::"s"(hp.Lseg), "s"(hp.nc), "s"(hp.compact), "s"(hp.cpos), "s"(hp.tptr), "s"(hp.terms), "s"(hp.nterms), "s"(hp.nvv), "s"(hp.vptr), "s"(hp.vterms),
+    asm volatile("" ::"s"(hp.Lseg), "s"(hp.nc), "s"(hp.compact), "s"(hp.nz), "s"(hp.cpos), "s"(hp.zpos), "s"(hp.tptr), "s"(hp.terms), "s"(hp.nterms), "s"(hp.nvv), "s"(hp.vptr), "s"(hp.vterms),
                  "s"(hp.nvterms), "s"(hp.tasks), "s"(hp.ptasks), "s"(hp.ntask), "s"(hp.nptask), "s"(hp.slot_tasks),
                  "s"(hp.seg_base), "s"(hp.reg_first), "s"(hp.reg_last), "s"(hp.vals));
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&hp);

@@ -36,8 +36,8 @@ struct HessModel {
     std::vector<uint32_t> tcode;                  // the same terms as the tiles read them (pack_tile_term: LDS offsets)
     // what the tiles walk (HParams::compact): all entries, or -- segments that are mostly structural zeros of the pattern --
     // only those that have terms (cpos: their positions, ctptr: offsets into tcode)
-    bool compact = false;
-    std::vector<uint32_t> cpos, ctptr;
+    int compact = 0;
+    std::vector<uint32_t> cpos, ctptr, zpos;
     std::vector<uint32_t> vptr, vterms;           // V x V contributions of one step
     int nvv = 0;
     int64_t vv_idx[kMaxNV * (kMaxNV + 1) / 2] = {0};

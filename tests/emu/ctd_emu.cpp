@@ -177,7 +177,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     const HessModel& H = mo.H;
     hp.tau = mo.uniform ? nullptr : mo.tau.data();
     hp.tptr = H.ctptr.data(); hp.terms = H.tcode.data(); hp.pair_c = H.pair_c.data();
-    hp.cpos = H.cpos.data();
+    hp.cpos = H.cpos.data(); hp.zpos = H.zpos.data();
     hp.vptr = H.vptr.data(); hp.vterms = H.vterms.data();
     hp.edge_idx = H.edge_idx.data(); hp.eptr = H.eptr.data(); hp.evptr = H.evptr.data(); hp.eterms = H.eterms.data();
     hp.tasks = H.tasks.data(); hp.ptasks = H.ptasks.data(); hp.btasks = H.btasks.data();
