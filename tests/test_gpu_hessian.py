@@ -95,6 +95,36 @@ def test_hessian_tile_shapes_and_idempotence(oracle_lib, torch_cuda, monkeypatch
         d.close()
 
 
+@pytest.mark.parametrize("prob,sch,N", [("goddard", "gauss_legendre_3", 1000), ("quadrotor", "gauss_legendre_3", 700),
+                                        ("quadrotor12", "gauss_legendre_2", 300)])
+def test_hessian_walk_modes_on_gpu(oracle_lib, torch_cuda, monkeypatch, prob, sch, N):
+    """the walk over the step-periodic segment (all entries / entries with terms after a zero fill / entries with terms +
+    explicit zero stores) and the number of edge workgroups do not change a bit of the result; every entry is written"""
+    torch = torch_cuda
+    o = oracle_lib.OracleDOCP(prob, sch, N)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+    y = np.cos(np.arange(o.dim_NLP_constraints) * 0.37)
+    want = o.hess_coord_block(x, y, 0.9) if hasattr(o, "hess_coord_block") and N > 500 else o.hess_coord(x, y, 0.9)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ref = None
+    for compact, eb in (("0", "1"), ("1", "1"), ("2", "1"), ("", ""), ("1", "5")):
+        if compact:
+            monkeypatch.setenv("CTD_HESS_COMPACT", compact)
+            monkeypatch.setenv("CTD_HESS_EDGE_BLOCKS", eb)
+        else:
+            monkeypatch.delenv("CTD_HESS_COMPACT", raising=False)
+            monkeypatch.delenv("CTD_HESS_EDGE_BLOCKS", raising=False)
+        d = ct.DOCP(prob, N, sch, device=0)
+        v = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+        d.hess_coord(xd, yd, 0.9, v)
+        assert not bool((v == SENT).any())
+        if ref is None:
+            ref = v.clone()
+            assert relerr(v.cpu().numpy(), want) <= TOL
+        assert torch.equal(v, ref)
+        d.close()
+
+
 @pytest.mark.parametrize("prob,sch", [("goddard_all", "midpoint"), ("goddard", "gauss_legendre_2"), ("quadrotor", "trapeze"),
                                       ("double_integrator_freet0tf", "euler_implicit"), ("goddard_all", "gauss_legendre_3_constant_control")])
 def test_hessian_shards_compose_on_gpu(oracle_lib, torch_cuda, prob, sch):

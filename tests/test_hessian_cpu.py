@@ -112,6 +112,27 @@ def test_emulated_hessian_kernel_matches_oracle_tiled(oracle_lib, prob, sch):
     assert not np.any(emu.hess(pid, sid, 0, 7, x, np.zeros(o.dim_NLP_constraints), 0.0))
 
 
+@pytest.mark.parametrize("compact", ["0", "1", "2"])
+@pytest.mark.parametrize("edge_blocks", ["1", "3"])
+def test_emulated_hessian_walk_modes(oracle_lib, monkeypatch, compact, edge_blocks):
+    """The tiles' walk over the step-periodic segment: all entries (0), entries with terms after a zero fill of the tile's
+    part of vals (1), entries with terms + explicit zero stores (2) -- and the edge entries shared by several edge
+    workgroups: same values, every entry written."""
+    monkeypatch.setenv("CTD_HESS_COMPACT", compact)
+    monkeypatch.setenv("CTD_HESS_EDGE_BLOCKS", edge_blocks)
+    rng = np.random.default_rng(21)
+    for prob, sch in (("goddard", "gauss_legendre_3"), ("quadrotor", "gauss_legendre_2"), ("goddard_all", "midpoint"),
+                      ("double_integrator_freet0tf", "gauss_legendre_3")):
+        pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+        for N, tile, nthr in ((19, 4, 256), (9, 3, 64)):
+            o = oracle_lib.OracleDOCP(prob, sch, N)
+            x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+            y = rng.standard_normal(o.dim_NLP_constraints)
+            vals = emu.hess(pid, sid, 0, N, x, y, 0.9, None, tile=tile, nthr=nthr)
+            assert not np.any(vals == 666.666)
+            assert relerr(vals, o.hess_coord(x, y, 0.9)) <= TOL
+
+
 @pytest.mark.parametrize("prob", ["goddard", "goddard_all", "quadrotor", "double_integrator_freet0tf", "least_squares_with_constraint"])
 def test_emulated_hessian_shards_compose(prob):
     """time-step shards (multi-GPU): every entry outside the V x V block is written by exactly one shard with the value of
