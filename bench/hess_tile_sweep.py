@@ -13,8 +13,8 @@ import ctdirect_jl_amd as ct  # noqa: E402
 from helpers import bench_inputs, describe  # noqa: E402
 from stamps import CFGS  # noqa: E402
 
-TILES = {"cfg2": (6, 8, 10, 12, 14, 17, 20, 24, 32, 40), "cfg3": (32, 64, 128, 196, 256), "cfg4": (8, 10, 12, 16, 20, 24, 32, 40, 48),
-         "cfg5p": (2, 3, 4, 5, 6, 8, 10), "cfg5": (2, 3, 4, 5, 6, 7)}
+TILES = {"cfg2": (6, 8, 10, 12, 14, 17, 20, 24, 32, 40), "cfg3": (32, 64, 128, 196, 256), "cfg4": (8, 10, 12, 16, 20, 24, 26, 28, 32, 40, 48),
+         "cfg5p": (3, 4, 5, 6, 8, 10, 12, 14), "cfg5": (4, 5, 6, 7, 8, 9, 10, 12)}
 
 
 def main():
