@@ -21,6 +21,7 @@
 #include "ctd_host.hpp"
 #include "ctd_kernels.hpp"
 #include "ctd_hess_kernels.hpp"
+#include "ctd_hess_step.hpp"
 #include "ctd_iter_kernels.hpp"
 #include "ctd_jit.hpp"
 
@@ -48,6 +49,16 @@ CTD_EXTERN_HESS(EstimateInitialConditionOCP)
 CTD_EXTERN_HESS(EstimateRotationRateOCP)
 CTD_EXTERN_HESS(LeastSquaresConstraintOCP)
 CTD_EXTERN_HESS(DoubleIntegratorFreeT0TfOCP)
+CTD_EXTERN_HESS_STEP(GoddardOCP)
+CTD_EXTERN_HESS_STEP(GoddardAllOCP)
+CTD_EXTERN_HESS_STEP(DoubleIntegratorPathOCP)
+CTD_EXTERN_HESS_STEP(QuadrotorOCP)
+CTD_EXTERN_HESS_STEP(Quadrotor12OCP)
+CTD_EXTERN_HESS_STEP(StagewiseScalarOCP)
+CTD_EXTERN_HESS_STEP(EstimateInitialConditionOCP)
+CTD_EXTERN_HESS_STEP(EstimateRotationRateOCP)
+CTD_EXTERN_HESS_STEP(LeastSquaresConstraintOCP)
+CTD_EXTERN_HESS_STEP(DoubleIntegratorFreeT0TfOCP)
 CTD_EXTERN_ITER(GoddardOCP)
 CTD_EXTERN_ITER(GoddardAllOCP)
 CTD_EXTERN_ITER(DoubleIntegratorPathOCP)
@@ -103,6 +114,13 @@ struct ctd_handle {
     int64_t* d_hedge_idx = nullptr;
     double* d_hpair_c = nullptr;
     uint32_t *d_hcpos = nullptr, *d_hzpos = nullptr;
+    // lane-per-step Hessian kernel (ctd_hess_step.hpp): position tables, parameters, the tile kernel's parameters for its edge blocks
+    int32_t *d_hssrc = nullptr, *d_hschunk = nullptr;
+    double* d_hsck = nullptr;
+    bool hess_step = false;
+    SParams sp{};
+    HParams hp_step{};
+    size_t hess_step_lds = 0;
     uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
     std::string err;
@@ -159,7 +177,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hssrc, (void*)h->d_hschunk, (void*)h->d_hsck, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -916,7 +934,25 @@ static int32_t ensure_hess(ctd_handle* h) {
     HIP_TRY(h, upload(&h->d_htasks, H.tasks));
     HIP_TRY(h, upload(&h->d_hptasks, H.ptasks));
     HIP_TRY(h, upload(&h->d_hbtasks, H.btasks));
-    HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(h->hp.ntiles + h->hp.n_edge_blocks) * (H.nvv > 0 ? H.nvv : 1)));
+    // Gauss-Legendre schemes with 2 / 3 stages of registry OCPs: the lane-per-step kernel takes the regular steps (CTD_HESS_STEP=0:
+    // the tile kernel everywhere)
+    std::vector<int32_t> ssrc, schunk;
+    int snout = -1;
+    const int64_t sb = std::max<int64_t>(h->hp.step_begin, H.reg_first), se = std::min<int64_t>(h->hp.step_end, H.reg_last);
+    // CTD_HESS_STEP: 0 never, 2 whenever the OCP has assembly functions, 1 (default) from the grid size on where it wins: a wave
+    // of the step kernel needs ~17 us for its 64 steps whatever the grid, the tile kernel's time grows with it (MI355X, Goddard:
+    // 3 stages 18.5 vs 19.9 us at 32 000 steps, 28.7 vs 37.7 at 80 000; 2 stages 10.4 vs 10.9 us at 10 000, 14.0 vs 17.8 at 50 000)
+    const int step_mode = env_int("CTD_HESS_STEP", 1);
+    const int64_t step_min = mo.L.s == 3 ? 28000 : 10000;
+    if (!h->rt && mo.L.sc == SC_IRK && (mo.L.s == 2 || mo.L.s == 3) && se > sb && step_mode != 0 && (step_mode == 2 || se - sb >= step_min)) {
+        const short* prs = nullptr;
+        for_problem(mo.problem, [&](auto tag) { prs = hess_step_pairs<typename decltype(tag)::type>(mo.L.s, mo.L.stagewise != 0, &snout); });
+        h->hess_step = prs && snout >= 0 && build_hess_step_tables(mo, prs, snout, kSymStepChunk, ssrc, schunk);
+    }
+    const int step_wgs = h->hess_step ? (int)((h->hp.step_end - h->hp.step_begin + kStepBlock - 1) / kStepBlock) : 0;
+    const int edge_step = 32;      // (upper bound of the edge workgroups of the step launch)
+    HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(std::max(h->hp.ntiles, step_wgs) + std::max(h->hp.n_edge_blocks, edge_step)) *
+                                                       (H.nvv > 0 ? H.nvv : 1)));
     HParams& hp = h->hp;
     hp.tau = h->d_tau;
     hp.tptr = h->d_htptr; hp.terms = h->d_hterms; hp.pair_c = h->d_hpair_c;
@@ -929,6 +965,44 @@ static int32_t ensure_hess(ctd_handle* h) {
     // kernel measured 2-7x slower on MI355X, profiles/r01_hessian_kernel.md: device-scope release per workgroup)
     hp.debug_stop = env_int("CTD_HESS_STOP", 0);
     hp.xcd_remap = env_int("CTD_XCD", 0);
+    if (h->hess_step) {
+        HIP_TRY(h, upload(&h->d_hssrc, ssrc));
+        HIP_TRY(h, upload(&h->d_hschunk, schunk));
+        SParams& sp = h->sp;
+        sp = SParams{};
+        sp.L = mo.L;
+        sp.tau = h->d_tau;
+        sp.step_begin = h->hp.step_begin; sp.step_end = h->hp.step_end;
+        sp.reg_lo = sb; sp.reg_hi = se;
+        sp.seg_base = H.seg_base; sp.reg_first = H.reg_first;
+        sp.Lseg = H.Lseg; sp.nout = snout; sp.nchunk = (int)schunk.size() - 1; sp.nvv = H.nvv;
+        sp.src = h->d_hssrc; sp.chunk_pos = h->d_hschunk;
+        {   // constant parts of the chain-rule coefficients (HC_*, ctd_hess.hpp) and of their pairs
+            const Layout& L = mo.L;
+            double kc[kHC];
+            for (int ci = 0; ci < kHC; ++ci) {
+                if (ci == HC_ONE) kc[ci] = 1.0;
+                else if (ci == HC_HALF) kc[ci] = 0.5;
+                else if (ci < HC_A) kc[ci] = L.a[ci - HC_HA];
+                else if (ci < HC_B) kc[ci] = L.a[ci - HC_A];
+                else if (ci < HC_NBH) kc[ci] = L.b[ci - HC_B];
+                else kc[ci] = -L.b[(ci - HC_NBH) % 3];
+            }
+            std::vector<double> ck((size_t)kHC * kHC);
+            for (int c1 = 0; c1 < kHC; ++c1)
+                for (int c2 = 0; c2 < kHC; ++c2) ck[(size_t)c1 * kHC + c2] = kc[c1] * kc[c2];
+            HIP_TRY(h, upload(&h->d_hsck, ck));
+            sp.ck = h->d_hsck;
+        }
+        sp.partials = h->d_hpartials;
+        // the tile kernel's edge path rides in the same launch on kStepBlock lanes: one edge workgroup per 64 edge entries
+        h->hp_step = hp;
+        const int ntot = (hp.edge_end - hp.edge_begin) + (hp.edge2_end - hp.edge2_begin);
+        h->hp_step.n_edge_blocks = std::max(1, std::min(edge_step, (ntot + kStepBlock - 1) / kStepBlock));
+        h->hp_step.ntiles = step_wgs;                 // (partials the finish kernel adds)
+        sp.part_base = h->hp_step.n_edge_blocks;
+        h->hess_step_lds = std::max(hess_step_lds_bytes(snout, mo.L.nv, H.Lseg), (size_t)hess_lds_doubles(h->hp_step) * sizeof(double));
+    }
     h->hess_ready = true;
     return CTD_OK;
 }
@@ -952,7 +1026,17 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     }
     for_problem(h->model.problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
-        e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, te0, te1);
+        if (h->hess_step && !hp.stamps && !hp.debug_stop) {
+            HParams he = h->hp_step;
+            he.obj_weight = obj_weight;
+            he.vals = vals_dev;
+            SParams sp = h->sp;
+            sp.obj_weight = obj_weight;
+            sp.vals = vals_dev;
+            e = launch_hess_step<P>(he, sp, x_dev, y_dev, h->hess_step_lds, h->stream, te0, te1);
+        } else {
+            e = launch_hess<P>(hp, x_dev, y_dev, h->hess_lds_bytes, h->stream, te0, te1);
+        }
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return CTD_OK;

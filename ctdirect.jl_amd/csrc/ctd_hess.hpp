@@ -92,6 +92,8 @@ constexpr SymPrm sym_prm(int n, int m, int nv, int np = 0) {
     return p;
 }
 
+constexpr int kSymStepChunk = 32;      // outputs of a step's assembly between two flushes (ctd_hess_step.hpp)
+
 // ---- 32-bit term code:  value += CP[pair] * rec[di]  of record `slot` ------------------------------------------
 // bits 0-15 di, 16-23 pair id, 24-26 slot.  Inside tile templates slot is relative (0 = the entry's own step,
 // 1 = the previous step, 2 = the next step); inside the edge lists it is the absolute record id of the edge block.

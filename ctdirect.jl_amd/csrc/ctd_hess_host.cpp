@@ -532,7 +532,7 @@ int build_hess_model(Model& mo, std::string& err) {
         H.reg_last = N - 1;
         if (segment_template(mo, N - 1, t2) && t2 == t1) H.reg_last = N;
         H.Lseg = (int)t1.relrow.size();
-        H.tptr = t1.tptr; H.terms = t1.terms; H.cp_tmpl = t1.cp;
+        H.tptr = t1.tptr; H.terms = t1.terms; H.cp_tmpl = t1.cp; H.relrow = t1.relrow;
     }
 
     // ---- column starts ----------------------------------------------------------------------------------------------
@@ -738,6 +738,31 @@ int build_hess_model(Model& mo, std::string& err) {
         }
     }
     return ST_OK;
+}
+
+bool build_hess_step_tables(const Model& mo, const short* pairs, int nout, int chunk, std::vector<int32_t>& src, std::vector<int32_t>& chunk_pos) {
+    const Layout& L = mo.L;
+    const HessModel& H = mo.H;
+    if (!pairs || nout < 0 || H.Lseg <= 0 || (int)H.relrow.size() != H.Lseg || (int)H.cp_tmpl.size() != L.blk + 1) return false;
+    if (H.HL != 0 || H.HH != 0) return false;
+    src.assign(H.Lseg, -1);
+    std::vector<int32_t> pos(nout);
+    for (int c = 0; c < nout; ++c) {
+        const int a = pairs[2 * c], b = pairs[2 * c + 1];
+        if (b < 0 || b >= L.blk) return false;
+        const int64_t want = a < L.blk ? (int64_t)a : ((int64_t)1 << 40) + (a - L.blk);
+        int e = -1;
+        for (int64_t q = H.cp_tmpl[b]; q < H.cp_tmpl[b + 1]; ++q)
+            if (H.relrow[q] == want) { e = (int)q; break; }
+        if (e < 0) return false;                                 // the pattern lacks an entry the step function produces
+        if (c > 0 && e <= pos[c - 1]) return false;              // (outputs come in CSC order)
+        pos[c] = e;
+        src[e] = c;
+    }
+    chunk_pos.assign(1, 0);
+    for (int c = chunk; c < nout; c += chunk) chunk_pos.push_back(pos[c]);
+    if (nout > 0) chunk_pos.push_back(H.Lseg);
+    return true;
 }
 
 int default_hess_tile(const Model& mo) {

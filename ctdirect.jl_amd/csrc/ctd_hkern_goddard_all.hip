@@ -1,5 +1,6 @@
 // Hessian-kernel instantiations of the collocation engine for one registry entry (GoddardAllOCP); see ctd_hess_kernels.hpp.
-#include "ctd_hess_kernels.hpp"
+#include "ctd_hess_step.hpp"
 namespace ctd {
 CTD_INSTANTIATE_HESS(GoddardAllOCP)
+CTD_INSTANTIATE_HESS_STEP(GoddardAllOCP)
 }

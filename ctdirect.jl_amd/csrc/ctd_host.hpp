@@ -33,6 +33,7 @@ struct HessModel {
     int Lseg = 0, HL = 0, HH = 0;
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     std::vector<uint32_t> tptr, terms;            // Lseg + 1 offsets, term codes
+    std::vector<int64_t> relrow;                  // row of every segment entry relative to its step block (V rows: 2^40 + k)
     std::vector<uint32_t> tcode;                  // the same terms as the tiles read them (pack_tile_term: LDS offsets)
     // what the tiles walk (HParams::compact): all entries, or -- segments that are mostly structural zeros of the pattern --
     // only those that have terms (cpos: their positions, ctptr: offsets into tcode)
@@ -123,6 +124,10 @@ struct Model {
 void compute_dep_masks(Model& m);
 // builds Model::H (pattern bookkeeping + term tables); called by build_model
 int build_hess_model(Model& m, std::string& err);
+// position tables of the lane-per-step Hessian kernel (ctd_hess_step.hpp): pairs = (row, column) of the nout outputs of the
+// step function; src[e] = output feeding position e of the segment (-1: structural zero), chunk_pos = positions per flush.
+// false: the pattern does not hold every output in the order the step function produces them (caller keeps the tile kernel)
+bool build_hess_step_tables(const Model& m, const short* pairs, int nout, int chunk, std::vector<int32_t>& src, std::vector<int32_t>& chunk_pos);
 int default_hess_tile(const Model& m);
 
 // status codes are those of include/ctdirect_hip.h; err receives a message on failure

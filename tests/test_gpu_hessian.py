@@ -187,6 +187,62 @@ def test_hessian_baseline_configs_direct_parity(oracle_lib, torch_cuda, prob, sc
     d.close()
 
 
+STEP_CASES = [(p, s) for p in ("goddard", "double_integrator_freet0tf", "estimate_rotation_rate", "estimate_initial_condition", "stagewise_scalar")
+              for s in ("gauss_legendre_2", "gauss_legendre_3", "gauss_legendre_2_constant_control", "gauss_legendre_3_constant_control")]
+
+
+@pytest.mark.parametrize("prob,sch", STEP_CASES, ids=[f"{p}-{s}" for p, s in STEP_CASES])
+def test_hessian_step_kernel(oracle_lib, torch_cuda, monkeypatch, prob, sch):
+    """The lane-per-step kernel (Gauss-Legendre schemes of OCPs without path constraints, ctd_hess_step.hpp), forced at small
+    sizes (CTD_HESS_STEP=2; by default it takes over from 10 000 / 28 000 steps): every entry written, values against the
+    oracle and against the tile kernel, full grids and shards (partial waves, irregular first / last steps), ragged time grid."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    for N, tg in ((6, None), (64, None), (200, None), (333, np.cumsum(rng.uniform(0.5, 1.5, 334)))):
+        o = oracle_lib.OracleDOCP(prob, sch, N, time_grid=tg)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-2)
+        y = rng.standard_normal(o.dim_NLP_constraints)
+        want = o.hess_coord(x, y, 0.7)
+        # random multipliers of both signs make single entries sums of cancelling terms: criterion relative to the magnitude of
+        # what is summed (as in test_hessian_full_size_properties)
+        scale = np.maximum(1.0, np.maximum(np.abs(want), np.abs(o.hess_coord(x, np.abs(y), 0.7))))
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        res = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("CTD_HESS_STEP", mode)
+            d = ct.DOCP(prob, N, sch, time_grid=tg, device=0)
+            v = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+            d.hess_coord(xd, yd, 0.7, v)
+            assert not bool((v == SENT).any())
+            res[mode] = v.cpu().numpy()
+            assert float(np.max(np.abs(res[mode] - want) / scale)) <= TOL
+            d.close()
+        assert float(np.max(np.abs(res["2"] - res["0"]) / scale)) <= 1e-12
+        # shards: disjoint outside the V x V block, V x V partials add up
+        if N >= 64:
+            monkeypatch.setenv("CTD_HESS_STEP", "2")
+            full = ct.DOCP(prob, N, sch, time_grid=tg, device=0)
+            _, _, vv = full.hess_shard_info()
+            notvv = np.ones(full.nnzh, dtype=bool)
+            notvv[vv] = False
+            acc = np.full(full.nnzh, SENT)
+            vvsum = np.zeros(len(vv))
+            for a, b in ((0, 70), (70, 71), (71, N)) if N > 71 else ((0, 31), (31, N)):
+                sh = ct.DOCP(prob, N, sch, time_grid=tg, device=0, steps=(a, b))
+                part = torch.full((full.nnzh,), SENT, dtype=torch.float64, device="cuda")
+                sh.hess_coord(xd, yd, 0.7, part)
+                pn = part.cpu().numpy()
+                wrote = (pn != SENT) & notvv
+                assert not np.any(wrote & (acc != SENT))
+                acc[wrote] = pn[wrote]
+                vvsum += pn[vv]
+                sh.close()
+            assert not np.any(acc[notvv] == SENT)
+            assert relerr(acc[notvv], res["2"][notvv]) <= 1e-14
+            assert relerr(vvsum, res["2"][vv]) <= 1e-12
+            full.close()
+
+
 BIG = [("double_integrator_path", "midpoint", 100000), ("quadrotor", "gauss_legendre_3", 20000),
        ("quadrotor12", "gauss_legendre_3", 20000)]
 
