@@ -943,7 +943,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     // of the step kernel needs ~17 us for its 64 steps whatever the grid, the tile kernel's time grows with it (MI355X, Goddard:
     // 3 stages 18.5 vs 19.9 us at 32 000 steps, 28.7 vs 37.7 at 80 000; 2 stages 10.4 vs 10.9 us at 10 000, 14.0 vs 17.8 at 50 000)
     const int step_mode = env_int("CTD_HESS_STEP", 1);
-    const int64_t step_min = mo.L.s == 3 ? 28000 : 10000;
+    const int64_t step_min = mo.L.s == 3 ? 28000 : 9000;
     if (!h->rt && mo.L.sc == SC_IRK && (mo.L.s == 2 || mo.L.s == 3) && se > sb && step_mode != 0 && (step_mode == 2 || se - sb >= step_min)) {
         const short* prs = nullptr;
         for_problem(mo.problem, [&](auto tag) { prs = hess_step_pairs<typename decltype(tag)::type>(mo.L.s, mo.L.stagewise != 0, &snout); });
@@ -1001,7 +1001,7 @@ static int32_t ensure_hess(ctd_handle* h) {
         h->hp_step.n_edge_blocks = std::max(1, std::min(edge_step, (ntot + kStepBlock - 1) / kStepBlock));
         h->hp_step.ntiles = step_wgs;                 // (partials the finish kernel adds)
         sp.part_base = h->hp_step.n_edge_blocks;
-        h->hess_step_lds = std::max(hess_step_lds_bytes(snout, mo.L.nv, H.Lseg), (size_t)hess_lds_doubles(h->hp_step) * sizeof(double));
+        h->hess_step_lds = std::max(hess_step_lds_bytes(snout, mo.L.nv, H.Lseg), (size_t)hess_edge_lds_doubles(h->hp_step) * sizeof(double));
     }
     h->hess_ready = true;
     return CTD_OK;

@@ -94,6 +94,15 @@ constexpr SymPrm sym_prm(int n, int m, int nv, int np = 0) {
 
 constexpr int kSymStepChunk = 32;      // outputs of a step's assembly between two flushes (ctd_hess_step.hpp)
 
+// parameters of the symbolically differentiated path point  Phi = sum_r WG_r g_r(t, x, u, v)  (SymPathH, lane-per-step kernel):
+// t = T0 + sum_k TD_k dv_k, x = X0 + dx, u = U0 + du, v = V0 + dv; outputs the packed md x md triangle (hess_tri)
+struct SymPathPrm { int T0, TD, X0, U0, V0, WG, count; };
+constexpr SymPathPrm sym_path_prm(int n, int m, int nv, int np) {
+    SymPathPrm p{};
+    p.T0 = 0; p.TD = 1; p.X0 = 1 + nv; p.U0 = p.X0 + n; p.V0 = p.U0 + m; p.WG = p.V0 + nv; p.count = p.WG + np;
+    return p;
+}
+
 // ---- 32-bit term code:  value += CP[pair] * rec[di]  of record `slot` ------------------------------------------
 // bits 0-15 di, 16-23 pair id, 24-26 slot.  Inside tile templates slot is relative (0 = the entry's own step,
 // 1 = the previous step, 2 = the next step); inside the edge lists it is the absolute record id of the edge block.

@@ -125,13 +125,18 @@ CTD_HD HBlockCtx make_hctx(const HParams& hp, int block, double* lds) {
     return cx;
 }
 
+// LDS (doubles) of an edge workgroup / of any workgroup of the tile kernel
+inline int64_t hess_edge_lds_doubles(const HParams& hp) {
+    const Layout& L = hp.L;
+    return kHessCoefDoubles + (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
+           3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * (hp.R.stride + hp.npairs);
+}
 inline int64_t hess_lds_doubles(const HParams& hp) {
     const Layout& L = hp.L;
     const int64_t cap = hp.T + hp.HL + hp.HH;
     const int64_t tile = kHessCoefDoubles + hess_table_doubles(hp) + (cap + 1) * L.blk + L.n + L.m + (cap + 1) * L.cb + kMaxNV + cap + 3 +
                          cap * (hp.R.stride + hp.npairs) + (int64_t)hp.nvv * hp.T;
-    const int64_t edge = kHessCoefDoubles + (int64_t)hp.n_edge_slots * edge_in_stride(L) + 2 * hp.n_edge_slots * L.cb + L.p + L.bc + kMaxNV +
-                         3 * kMaxHessEdgeSlots + 1 + (int64_t)(hp.n_edge_slots + 2) * (hp.R.stride + hp.npairs);
+    const int64_t edge = hess_edge_lds_doubles(hp);
     return tile > edge ? tile : edge;
 }
 

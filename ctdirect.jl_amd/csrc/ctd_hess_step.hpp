@@ -1,11 +1,12 @@
-// ctd_hess_step.hpp -- Hessian of the Lagrangian, one LANE per time step (Gauss-Legendre schemes with 2 and 3 stages of
-// registry OCPs without path constraints: SymAsm<P>, ctd_asm_registry.hpp).
+// ctd_hess_step.hpp -- Hessian of the Lagrangian, one LANE per time step (Gauss-Legendre schemes with 2 and 3 stages of the
+// registry OCPs: SymAsm<P>, ctd_asm_registry.hpp).
 //
 // The tile kernel of ctd_hess_body.hpp is bound by instruction issue on partly filled waves: a tile's stage points keep 20-80
 // lanes busy, its walk over the step-periodic segment 100-200, and every wave instruction costs four cycles of its SIMD
 // whatever the number of active lanes.  Here every lane owns a whole step, in registers: it reads the step's
 // variables and multipliers, runs the symbolically differentiated stage function (SymStage<P>::irk, the same code the tile
-// kernel runs) for each of the S stage points into a register copy R[] of the step record, and then the step's ASSEMBLY
+// kernel runs) for each of the S stage points and the symbolic path-point Hessian (SymPathH<P>) into a register copy R[] of
+// the step record, and then the step's ASSEMBLY
 // function: straight-line code, generated at build time from the term tables of the host model (ctd_gen_asm.cpp), that forms
 // every structurally nonzero entry of the step's segment in CSC order as  sum of (constant) x (1 | h | dh/dv_k) x R[..].
 // After every 32 entries the wave (= the workgroup: 64 steps) flushes them: the entries sit transposed in LDS, lane l takes
@@ -36,6 +37,11 @@ template <class P> struct SymAsm {
 }  // namespace ctd
 #include "ctd_asm_registry.hpp"
 namespace ctd {
+
+// The step kernel is taken for light OCPs only: a lane holds the used part of the step record in registers -- up to 8 directions
+// per evaluation point (Goddard: 255 registers, no scratch).  The quadrotors (13 / 17 directions) spill (276 B .. 2 KB of scratch
+// per lane) and run 1.3-4x slower than the tile kernel (50 vs 40 us and 168 vs 89 us at N = 20 000): they keep the tile kernel.
+template <class P> struct StepOK { static constexpr bool value = SymAsm<P>::value && (P::NX + P::NU + P::NV <= 8); };
 
 // (stages, stagewise controls) -> the generated variant
 template <class P, int S, bool SW> struct StepFn {
@@ -163,6 +169,30 @@ __global__ __launch_bounds__(kStepBlock) __attribute__((amdgpu_waves_per_eu(CTD_
 #pragma unroll
         for (int r = 0; r < n; ++r) R[R_.oYX + r] = yr[r];
     }
+    if constexpr (P::NPATH > 0) {      // path point of node i: (t_i, X_i, u_i, v), u_i = sum_l b_l U_i^l for stagewise controls
+        constexpr SymPathPrm QP = sym_path_prm(n, m, nv, P::NPATH);
+        double pp[QP.count];
+        pp[QP.T0] = tA;
+#pragma unroll
+        for (int k = 0; k < nv; ++k) { pp[QP.TD + k] = d0[k]; pp[QP.V0 + k] = v[k]; }
+#pragma unroll
+        for (int r = 0; r < n; ++r) pp[QP.X0 + r] = X[r];
+#pragma unroll
+        for (int b = 0; b < m; ++b) {
+            double uv;
+            if (SW) {
+                uv = L.b[0] * base[n + b];
+#pragma unroll
+                for (int l = 1; l < S; ++l) uv = uv + L.b[l] * base[n + l * m + b];
+            } else {
+                uv = base[n + b];
+            }
+            pp[QP.U0 + b] = uv;
+        }
+#pragma unroll
+        for (int r = 0; r < P::NPATH; ++r) pp[QP.WG + r] = yr[L.eqs + r];
+        SymPathH<P>::eval(pp, R + R_.oHP);
+    }
 
     double* buf = lds + lane * kStepBufStride;
     // the position table of the segment in LDS (the flushes read it per 64-position window: a global load there would expose
@@ -250,7 +280,7 @@ hipError_t launch_hess_step_variant(const HParams& hp, const SParams& sp, const 
 template <class P>
 hipError_t launch_hess_step(const HParams& hp, const SParams& sp, const double* xu, const double* y, size_t lds_bytes, hipStream_t st,
                             hipEvent_t e0, hipEvent_t e1) {
-    if constexpr (SymAsm<P>::value) {
+    if constexpr (StepOK<P>::value) {
         const bool sw = sp.L.stagewise != 0;
         if (sp.L.s == 2) return sw ? launch_hess_step_variant<P, 2, true>(hp, sp, xu, y, lds_bytes, st, e0, e1) : launch_hess_step_variant<P, 2, false>(hp, sp, xu, y, lds_bytes, st, e0, e1);
         if (sp.L.s == 3) return sw ? launch_hess_step_variant<P, 3, true>(hp, sp, xu, y, lds_bytes, st, e0, e1) : launch_hess_step_variant<P, 3, false>(hp, sp, xu, y, lds_bytes, st, e0, e1);
@@ -260,7 +290,7 @@ hipError_t launch_hess_step(const HParams& hp, const SParams& sp, const double* 
 // (row, column) pairs of the outputs of the variant (host side of the position tables); nullptr / -1: no such variant
 template <class P> const short* hess_step_pairs(int s, bool stagewise, int* nout) {
     *nout = -1;
-    if constexpr (SymAsm<P>::value) {
+    if constexpr (StepOK<P>::value) {
         if (s == 2) { if (stagewise) { *nout = StepFn<P, 2, true>::nout; return StepFn<P, 2, true>::pairs(); } *nout = StepFn<P, 2, false>::nout; return StepFn<P, 2, false>::pairs(); }
         if (s == 3) { if (stagewise) { *nout = StepFn<P, 3, true>::nout; return StepFn<P, 3, true>::pairs(); } *nout = StepFn<P, 3, false>::nout; return StepFn<P, 3, false>::pairs(); }
     }

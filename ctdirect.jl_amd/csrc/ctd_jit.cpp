@@ -327,6 +327,39 @@ static bool gen_sym_stage(const ctd_ocp_def* d, const ExprCtx& c0, bool has_lag,
     return true;
 }
 
+// Symbolic second derivatives of the path point  sum_r WG_r g_r(t, x, u, v)  (SymPathPrm in ctd_hess.hpp) along the record's
+// directions (x | u | v, the v directions including the motion of t): body of SymPathH<P>::eval(p, HP), HP = packed triangle.
+// Every entry is written (structural zeros as 0.0: the host's dependency probe may keep terms on entries that vanish identically).
+static bool gen_sym_pathh(const ctd_ocp_def* d, const ExprCtx& c0, std::string& body, std::string& err) {
+    const int n = d->n, m = d->m, nv = d->nv, np = d->npath, md = n + m + nv;
+    const SymPathPrm P = sym_path_prm(n, m, nv, np);
+    sym::Graph g;
+    std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
+    int t = g.param(P.T0);
+    for (int k = 0; k < nv; ++k) t = g.add(t, g.mul(g.param(P.TD + k), g.var(n + m + k)));
+    for (int r = 0; r < n; ++r) X[r] = g.add(g.param(P.X0 + r), g.var(r));
+    for (int b = 0; b < m; ++b) U[b] = g.add(g.param(P.U0 + b), g.var(n + b));
+    for (int k = 0; k < nv; ++k) V[k] = g.add(g.param(P.V0 + k), g.var(n + m + k));
+    int Phi = g.constant(0.0);
+    for (int r = 0; r < np; ++r) {
+        const std::string str(d->path[r]);
+        Parser ps(str, c0);
+        ps.g = &g; ps.g_t = t; ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();
+        Parser::Val v;
+        if (!ps.expr(v)) { err = ps.err; return false; }
+        Phi = g.add(Phi, g.mul(g.param(P.WG + r), v.node));
+    }
+    std::vector<std::pair<std::string, int>> outs;
+    for (int p = 0; p < md; ++p) {
+        const int d1 = g.diff(Phi, p);
+        for (int q = p; q < md; ++q) {
+            outs.emplace_back("HP[" + std::to_string(hess_tri(md, p, q)) + "]", g.at_zero(g.diff(d1, q)));
+        }
+    }
+    body = outs.empty() ? std::string() : g.codegen(outs, "p", "        ");
+    return true;
+}
+
 // First derivatives of the dynamics at an evaluation point, written straight into an eval block of the step record of the
 // constraint / Jacobian kernel (ctd_layout.hpp: F[n x ldx] | G[n x ldu] | W[n x nv] | f[n] | ft[n]): body of
 // UserOCP::dyn_sym(t, x, u, v, ev).  Every entry of F and G is written (structural zeros as 0.0); ft / W only when the

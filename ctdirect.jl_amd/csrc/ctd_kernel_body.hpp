@@ -536,6 +536,8 @@ template <class P> struct SymLag {       // Lagrange cost: out = [value | l_x | 
     CTD_HD static void eval(const double* p, double* out) { if constexpr (P::HAS_SYM_LAG) P::lag_sym(p, out); }
 };
 template <class P> struct SymStage;
+// symbolic second derivatives of the path point (lane-per-step Hessian kernel, ctd_hess_step.hpp)
+template <class P> struct SymPathH { static constexpr bool value = false; CTD_HD static void eval(const double*, double*) {} };
 
 // one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
 // SPLIT: the caller runs the NCH_DYN lanes of this point in different waves (uniform q per wave), so the generated code may be

@@ -187,14 +187,15 @@ def test_hessian_baseline_configs_direct_parity(oracle_lib, torch_cuda, prob, sc
     d.close()
 
 
-STEP_CASES = [(p, s) for p in ("goddard", "double_integrator_freet0tf", "estimate_rotation_rate", "estimate_initial_condition", "stagewise_scalar")
+STEP_CASES = [(p, s) for p in ("goddard", "goddard_all", "quadrotor", "quadrotor12", "double_integrator_path", "least_squares_with_constraint",
+                                "double_integrator_freet0tf", "estimate_rotation_rate", "estimate_initial_condition", "stagewise_scalar")
               for s in ("gauss_legendre_2", "gauss_legendre_3", "gauss_legendre_2_constant_control", "gauss_legendre_3_constant_control")]
 
 
 @pytest.mark.parametrize("prob,sch", STEP_CASES, ids=[f"{p}-{s}" for p, s in STEP_CASES])
 def test_hessian_step_kernel(oracle_lib, torch_cuda, monkeypatch, prob, sch):
-    """The lane-per-step kernel (Gauss-Legendre schemes of OCPs without path constraints, ctd_hess_step.hpp), forced at small
-    sizes (CTD_HESS_STEP=2; by default it takes over from 10 000 / 28 000 steps): every entry written, values against the
+    """The lane-per-step kernel (Gauss-Legendre schemes with 2 / 3 stages, ctd_hess_step.hpp), forced at small
+    sizes (CTD_HESS_STEP=2; by default it takes over from 9 000 / 28 000 steps): every entry written, values against the
     oracle and against the tile kernel, full grids and shards (partial waves, irregular first / last steps), ragged time grid."""
     torch = torch_cuda
     rng = np.random.default_rng(31)
