@@ -29,7 +29,7 @@ pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(out + f"/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "ctd::cons_jac_kernel" in r["Kernel_Name"] or "ctd::hess_kernel" in r["Kernel_Name"]:
+            if "ctd::cons_jac_kernel" in r["Kernel_Name"] or "ctd::hess_kernel" in r["Kernel_Name"] or "ctd::hess_step_kernel" in r["Kernel_Name"]:
                 pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res["pmc_mean_per_launch"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in pmc.items()}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
@@ -43,7 +43,7 @@ for name, c in res["pmc_mean_per_launch"].items():
     e = {"kernel": name, "FETCH_SIZE_KiB_raw": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB_raw": c.get("WRITE_SIZE"),
          "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
          "rocprof_avg_kernel_ns": float(res["kernels"].get(name, {}).get("AverageNs", "nan"))}
-    if "hess_kernel" in name: traffic["hessian_kernels"][name] = e
+    if "hess_kernel" in name or "hess_step_kernel" in name: traffic["hessian_kernels"][name] = e
     elif "cons_jac_kernel<ctd::GoddardOCP, 2, 2" in name: traffic["bench_kernel"] = e
     else: traffic["other_kernels"][name] = e
 json.dump(traffic, open(out + "/pmc_traffic.json", "w"), indent=1)

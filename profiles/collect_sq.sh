@@ -23,7 +23,7 @@ pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_sq1", "pmc_sq2"):
     for f in glob.glob(out + f"/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "ctd::cons_jac_kernel" in r["Kernel_Name"] or "ctd::hess_kernel" in r["Kernel_Name"]:
+            if "ctd::cons_jac_kernel" in r["Kernel_Name"] or "ctd::hess_kernel" in r["Kernel_Name"] or "ctd::hess_step_kernel" in r["Kernel_Name"]:
                 pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {"command": "python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline",
        "note": "mean per launch over all launches of the kernel; SQ_*_CYCLES / WAIT / ACTIVE counters are in quad-cycles summed "
