@@ -87,6 +87,7 @@ SYMBOLS = {
     "ctd_hess_coord_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp]),
     "ctd_time_hess_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, C.c_int32, _dp]),
     "ctd_hess_launch_info": (C.c_int32, [_vp, _ip]),
+    "ctd_hess_kernel_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_shard_info": (C.c_int32, [_vp, _ip]),
     "ctd_hess_debug_stamps": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, C.POINTER(C.c_uint64), C.c_int64]),
     "ctd_eval_all_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),

@@ -1137,6 +1137,16 @@ int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* o) {
     return CTD_OK;
 }
 
+int32_t ctd_hess_kernel_info(ctd_handle* h, int64_t* o) {
+    if (!h || !o) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    int32_t st = ensure_hess(h);
+    if (st) return st;
+    o[0] = h->hess_step ? 1 : 0;
+    o[1] = h->hess_step ? h->hp_step.n_edge_blocks + h->hp_step.ntiles : h->hp.ntiles + h->hp.n_edge_blocks;
+    return CTD_OK;
+}
+
 int32_t ctd_hess_debug_stamps(ctd_handle* h, const double* x_dev, const double* y_dev, double obj_weight, double* vals_dev,
                               uint64_t* out, int64_t cap) {
     if (!h || !out) return CTD_EINVAL;

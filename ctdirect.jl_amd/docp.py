@@ -519,6 +519,12 @@ class DOCP:
                     edge_entries=int(o[5]), stage_lanes=int(o[6]), path_lanes=int(o[7]), boundary_lanes=int(o[8]),
                     segment_terms=int(o[9]))
 
+    def hess_kernel_info(self):
+        """which Hessian kernel takes the regular steps: dict(kernel='tile' | 'step', grid=workgroups)"""
+        o = np.zeros(2, dtype=np.int64)
+        self._ck(_lib.lib().ctd_hess_kernel_info(self._h, _ip(o)))
+        return dict(kernel="step" if o[0] == 1 else "tile", grid=int(o[1]))
+
     def jac_structure(self):
         """jac_structure!(nlp, rows, cols): 1-based COO in CSC order."""
         rows = np.zeros(self.nnzj, dtype=np.int64)

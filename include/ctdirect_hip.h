@@ -300,6 +300,9 @@ int32_t ctd_time_hess_dev(ctd_handle* h, const double* x_dev, const double* y_de
  * CSC period of the lower triangle (entries per regular step), number of edge entries, second-order eval lanes per
  * stage point / path point / boundary point (after the structural-sparsity probe), terms of the periodic segment */
 int32_t ctd_hess_launch_info(ctd_handle* h, int64_t* out10);
+/* Which kernel ctd_hess_coord* launches for the regular steps of this handle: out[0] = 0 tile kernel (every scheme), 1 lane-per-step
+ * kernel (Gauss-Legendre schemes with 2 / 3 stages of the light registry OCPs on large grids); out[1] = its grid. */
+int32_t ctd_hess_kernel_info(ctd_handle* h, int64_t* out2);
 /* out[0..3 + nvv): vals_main_begin, vals_main_end (0-based contiguous range of the shard's step columns in the CSC value
  * array), nvv = nv (nv+1)/2, then the 0-based positions of the variable x variable entries (partial sums on a shard) */
 int32_t ctd_hess_shard_info(const ctd_handle* h, int64_t* out13);

@@ -219,6 +219,23 @@ def test_hessian_step_kernel(oracle_lib, torch_cuda, monkeypatch, prob, sch):
             assert float(np.max(np.abs(res[mode] - want) / scale)) <= TOL
             d.close()
         assert float(np.max(np.abs(res["2"] - res["0"]) / scale)) <= 1e-12
+        # the other sparsity patterns: the same assembly function, positions mapped by (row, column)
+        if N == 200:
+            for pat in ("structural", "optimized"):
+                vals = {}
+                for mode in ("0", "2"):
+                    monkeypatch.setenv("CTD_HESS_STEP", mode)
+                    d = ct.DOCP(prob, N, sch, time_grid=tg, device=0, pattern=pat)
+                    light = prob not in ("quadrotor", "quadrotor12")         # (the quadrotors keep the tile kernel: registers)
+                    if prob != "estimate_initial_condition":                 # (linear dynamics: no regular segment in the optimized pattern)
+                        assert d.hess_kernel_info()["kernel"] == ("step" if mode == "2" and light else "tile")
+                    v = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+                    d.hess_coord(xd, yd, 0.7, v)
+                    assert not bool((v == SENT).any())
+                    vals[mode] = v.cpu().numpy()
+                    d.close()
+                sc = np.maximum(1.0, np.abs(vals["0"]))
+                assert float(np.max(np.abs(vals["2"] - vals["0"]) / sc)) <= 1e-10
         # shards: disjoint outside the V x V block, V x V partials add up
         if N >= 64:
             monkeypatch.setenv("CTD_HESS_STEP", "2")
