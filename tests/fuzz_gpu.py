@@ -34,7 +34,12 @@ while time.time() < t_end:
     tg = None
     if rng.random() < 0.4:
         tg = np.concatenate([[0.0], np.cumsum(0.05 + rng.random(N))]); tg = tg / tg[-1] * (0.5 + rng.random()) + rng.random() * 0.3
-    mode = "structural" if rng.random() < 0.3 else "manual"
+    r_ = rng.random()
+    mode = "structural" if r_ < 0.25 else ("optimized" if r_ < 0.45 and sch != "euler_implicit" else "manual")
+    # round 2: the Hessian kernels' variants -- lane-per-step kernel forced / off, walk modes, edge workgroups
+    os.environ["CTD_HESS_STEP"] = str(rng.choice(["0", "1", "2", "2"]))
+    os.environ["CTD_HESS_COMPACT"] = str(rng.choice(["", "", "0", "1", "2"]))
+    os.environ["CTD_HESS_EDGE_BLOCKS"] = str(rng.choice(["", "", "1", "3", "7"]))
     tile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     htile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     steps = None
@@ -44,11 +49,13 @@ while time.time() < t_end:
     use_twin = JIT and prob in jit_defs.TWINS and rng.random() < 0.5
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
-            f"twin={int(use_twin)} api={api}")
+            f"twin={int(use_twin)} api={api} step={os.environ['CTD_HESS_STEP']} compact={os.environ['CTD_HESS_COMPACT']} "
+            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']}")
     try:
         d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps)
         o = OracleDOCP(prob, sch, N, time_grid=tg) if tg is not None else OracleDOCP(prob, sch, N)
         if mode == "structural": o.set_pattern_mode(1)
+        if mode == "optimized": o.set_pattern_mode(2)
         nvar, ncon = d.dim_NLP_variables, d.dim_NLP_constraints
         assert (nvar, ncon) == (o.dim_NLP_variables, o.dim_NLP_constraints)
         if rng.random() < 0.5:
