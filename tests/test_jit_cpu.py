@@ -128,3 +128,16 @@ def test_host_outputs_are_validated():
                 np.zeros(2 * d.dim_NLP_constraints)[::2]):
         with pytest.raises(ValueError):
             d.cons(x, bad)
+
+
+def test_committed_assembly_registry_is_what_the_generator_writes(tmp_path):
+    """ctd_asm_registry.hpp is generated (csrc/ctd_gen_asm.cpp: the host model's Hessian term tables of the registry problems ->
+    straight-line assembly functions of the lane-per-step kernel); the committed header must be what the tool writes from the
+    current host model (`make regen_asm` after a change of the term tables)."""
+    import os
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ctdirect.jl_amd", "csrc")
+    exe = str(tmp_path / "ctd_gen_asm")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-I", csrc, "-o", exe, os.path.join(csrc, "ctd_gen_asm.cpp")])
+    out = subprocess.check_output([exe]).decode()
+    assert out == open(os.path.join(csrc, "ctd_asm_registry.hpp")).read()
