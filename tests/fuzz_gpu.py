@@ -47,6 +47,9 @@ while time.time() < t_end:
         a = int(rng.integers(0, N)); b = int(rng.integers(a + 1, N + 1)); steps = (a, b)
     os.environ["CTD_TILE"] = str(tile) if tile else ""; os.environ["CTD_HESS_TILE"] = str(htile) if htile else ""
     use_twin = JIT and prob in jit_defs.TWINS and rng.random() < 0.5
+    # (operator-level dependence is a property of the expressions: Goddard's twin writes r' = x2 where the reference -- and the
+    # registry functor and the oracle -- write F0 + u F1 with a zero component, so their optimized patterns differ by design)
+    if use_twin and mode == "optimized": mode = "structural"
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
             f"twin={int(use_twin)} api={api} step={os.environ['CTD_HESS_STEP']} compact={os.environ['CTD_HESS_COMPACT']} "
