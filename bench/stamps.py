@@ -20,7 +20,10 @@ from helpers import bench_inputs, describe  # noqa: E402
 
 CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integrator_path", "midpoint", 100000),
         "cfg4": ("goddard", "gauss_legendre_3", 80000), "cfg5p": ("quadrotor", "gauss_legendre_3", 20000),
-        "cfg5": ("quadrotor12", "gauss_legendre_3", 20000)}
+        "cfg5": ("quadrotor12", "gauss_legendre_3", 20000),
+        # extra: OCPs whose kernels run the staged driver (path constraints in every scheme)
+        "gall_trap": ("goddard_all", "trapeze", 20000), "gall_gl2": ("goddard_all", "gauss_legendre_2", 20000),
+        "quad_trap": ("quadrotor", "trapeze", 20000)}
 
 
 def main():

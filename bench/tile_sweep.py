@@ -13,7 +13,8 @@ from helpers import bench_inputs, describe  # noqa: E402
 from stamps import CFGS  # noqa: E402
 
 TILES = {"cfg2": (8, 10, 14, 16, 20, 21, 24, 32, 40), "cfg3": (32, 64, 96, 128, 196, 256, 391), "cfg4": (16, 24, 32, 48, 64),
-         "cfg5p": (6, 8, 10, 12, 14, 16, 20), "cfg5": (4, 5, 6, 7, 8, 9, 10)}
+         "cfg5p": (6, 8, 10, 12, 14, 16, 20), "cfg5": (4, 5, 6, 7, 8, 9, 10),
+         "gall_trap": (8, 10, 12, 16, 20, 24, 32, 40, 64), "gall_gl2": (8, 10, 12, 16, 20, 24, 32, 40), "quad_trap": (8, 10, 12, 16, 20, 24, 32)}
 BLOCKS = tuple(int(b) for b in os.environ.get("SWEEP_BLOCKS", "256,320,384,512").split(","))
 
 

@@ -761,15 +761,19 @@ int default_tile(const Model& mo, int64_t nsteps) {
     // wide OCPs (several direction chunks per evaluation point: the quadrotors): the emit phase runs at the chip's write rate
     // only while the other phases of co-resident workgroups overlap it, so three workgroups per CU (52 KiB each) beat two
     // larger ones; at most 8 steps (profiles/r02_tile_sweeps.log: 12-state quadrotor 7 steps 117 us vs 8 steps 122 us)
-    if (!mo.fused) T = std::max<int64_t>(4, std::min<int64_t>(8, (52 * 1024) / per_step - mo.HL - mo.HH));
+    // (one-point schemes of those OCPs have light emit phases: 16 steps -- 8-state quadrotor, trapeze, N = 20 000: 16.5 vs 20.7 us)
+    const bool wide = mo.nch_dyn > 1;
+    if (wide) T = std::max<int64_t>(4, std::min<int64_t>(L.sc == SC_IRK ? 8 : 16, (52 * 1024) / per_step - mo.HL - mo.HH));
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
     if ((nsteps + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (nsteps + 479) / 480));
     // light steps on long grids (double integrator, midpoint, 100 000 steps: 152 bytes of output per step): ONE round of ~512
     // workgroups (two per CU) when such a tile still fits 80 KiB of LDS -- 196-step tiles 6.1 us vs 64-step tiles 7.6 us
     // (profiles/r02_tile_sweeps.log); heavier steps keep the smaller tile
-    if (mo.fused) {
+    // (OCPs with path constraints of their own direction chunks run the staged driver: the same holds up to ~40 KiB --
+    // goddard_all, trapeze, N = 20 000: 40 steps 6.1 us, the 8 steps of round 1's rule 12.0 us)
+    if (!wide) {
         const int64_t T1 = (nsteps + 511) / 512;
-        if (T1 > T && (T1 + mo.HL + mo.HH + 1) * per_step <= 80 * 1024) T = T1;
+        if (T1 > T && (T1 + mo.HL + mo.HH + 1) * per_step <= (mo.fused ? 80 : 40) * 1024) T = T1;
     }
     return (int)T;
 }
