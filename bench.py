@@ -86,6 +86,20 @@ def cpu_baseline(problem, scheme, N, x, budget_s=10.0):
 
 
 def main():
+    # exactly ONE line on stdout: libraries that print banners there (RCCL prints its version block on communicator creation)
+    # write to stderr for the duration of the run; the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _main(real_stdout)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _main(real_stdout):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -313,7 +327,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(PROBLEM, SCHEME, N, x_host)
         out.update(secondary)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
         dist.destroy_process_group()
 
