@@ -11,15 +11,22 @@ on inputs already resident in HBM.  Workloads (`--config`):
     cfg5         12-state quadrotor, Gauss-Legendre 3, 20 000 steps sharded over the N GPUs (BASELINE.json configs[4])
 
 The grid is sharded by time step; each rank's rows of c and its Jacobian values stay on the rank (row-sharded outputs).
-At N > 1 the timed step starts by DISTRIBUTING THE ITERATE: the solver's x is sharded like the steps and every rank
-fetches the few entries of other ranks its rows read (next rank's first node, first / final state) with one RCCL
-all-gather of n + n doubles per rank (`ShardedDOCP.exchange_halo`); then it evaluates its shard.  The same line carries
-`stitched_c` (+ the all-gather that hands every rank the whole constraint vector) and `broadcast_x` (a replicated iterate
-sent whole from rank 0 instead of the halo exchange) as secondary figures, and the per-rank kernel times.
+At N > 1 the ITERATE IS SHARDED like the steps: a rank's x buffer holds its own steps' variables and the replicated v, and
+NaN everywhere else.  The few entries of other ranks its rows read (next rank's first node, previous rank's last block for
+one-point schemes, first / final state) are loaded by the evaluation kernel IN PLACE from the owner's HBM over xGMI (IPC-
+mapped buffers, `ShardedDOCP.enable_peer_x` / `ctd_set_x_shards`): the timed step contains no collective, no copy and no
+extra kernel.  The same line carries secondary figures: `halo_allgather` (the entries fetched with one RCCL all-gather
+instead), `stitched_c` (+ the all-gather that hands every rank the whole constraint vector), `broadcast_x` (a replicated
+iterate sent whole from rank 0) and `no_exchange` (x in place), and the per-rank kernel times.
 `value`: weak scaling = shard evaluations all ranks completed per second; strong scaling = evaluations of the whole
 transcription per second; both over the max-over-ranks wall time of the K timed steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]      (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank;
+started plainly (`python bench.py --gpus N`) it spawns the N rank processes itself -- before anything touches the GPU --
+and relays rank 0's line.  On a box with fewer than N GPUs the ranks share the devices (gloo carries the barrier: RCCL
+refuses two ranks on one device) and the line says `"rehearsal": true`.
 """
 import argparse
 import json
@@ -85,7 +92,43 @@ def cpu_baseline(problem, scheme, N, x, budget_s=10.0):
     return out
 
 
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters; nothing in this
+    process has touched the GPU), relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if ndev < gpus:                       # rehearsal: the ranks share the box's device(s)
+            env["CTD_BENCH_DEVICE"] = str(r % max(ndev, 1))
+            env.setdefault("CTD_BENCH_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        ap = argparse.ArgumentParser(add_help=False)
+        ap.add_argument("--gpus", type=int, default=1)
+        gpus = ap.parse_known_args()[0].gpus
+        if gpus > 1:
+            sys.exit(self_launch(sys.argv[1:], gpus))
     # exactly ONE line on stdout: libraries that print banners there (RCCL prints its version block on communicator creation)
     # write to stderr for the duration of the run; the JSON line goes to the saved descriptor at the end
     sys.stdout.flush()
@@ -123,12 +166,12 @@ def _main(real_stdout):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the engine has no CPU path"
     # rehearsal knobs (one-GPU box): CTD_BENCH_DEVICE pins every rank to one device, CTD_BENCH_BACKEND=gloo replaces RCCL
     # (which refuses two ranks on one device).  The driver's multi-GPU run uses neither: one rank per GPU over RCCL/xGMI.
-    if os.environ.get("CTD_BENCH_DEVICE"):
+    rehearsal = bool(os.environ.get("CTD_BENCH_DEVICE"))
+    if rehearsal:
         local_rank = int(os.environ["CTD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -151,7 +194,17 @@ def _main(real_stdout):
     sh = ctdist.ShardedDOCP(make, N, world=world, rank=rank)
     docp = sh.docp
     x_host = bench_inputs(describe(docp, PROBLEM, SCHEME), perturb=1e-3)
-    x = torch.from_numpy(x_host).to(dev)
+    x_full = torch.from_numpy(x_host).to(dev)
+    if dist_on:           # sharded iterate: own variables + the replicated v, NaN everywhere else
+        xs = np.full_like(x_host, np.nan)
+        a_, b_ = sh.owned_variables()
+        xs[a_:b_] = x_host[a_:b_]
+        nv_ = docp.dims.NLP_v
+        if nv_:
+            xs[-nv_:] = x_host[-nv_:]
+        x = torch.from_numpy(xs).to(dev)
+    else:
+        x = x_full
     c = torch.zeros(docp.dim_NLP_constraints, dtype=torch.float64, device=dev)
     vals = torch.zeros(docp.nnzj, dtype=torch.float64, device=dev)
 
@@ -189,21 +242,36 @@ def _main(real_stdout):
             el = float(t[0])
         return el
 
-    # The timed step.  N = 1: one fused evaluation, pointers pre-bound.  N > 1: iterate distribution (halo exchange of the
-    # sharded x) + the rank's evaluation; outputs stay row-sharded, so no collective follows the kernel.
-    x_mode = "halo" if dist_on else None
+    # The timed step.  N = 1: one fused evaluation, pointers pre-bound.  N > 1: the rank's evaluation on the SHARDED iterate,
+    # the neighbours' entries read in place by the kernel (x_mode "peer"); outputs stay row-sharded: no
+    # collective before or after the kernel.
+    x_mode = "peer" if dist_on else None
     el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), args.warmup, args.steps)
     region_ms = region["ms_per_launch"]
     per_step_value = (world if cfg["scaling"] == "weak" else 1)
     secondary = {}
     if dist_on:
+        # the rank's outputs from the sharded iterate (NaN outside what it owns) equal those from the whole iterate, bit for bit
+        c_chk, v_chk = torch.zeros_like(c), torch.zeros_like(vals)
+        sh.bind_cons_jac(x_full, c_chk, v_chk, stitch=False, x_mode=None)()
+        sh.bind_cons_jac(x, c, vals, stitch=False, x_mode="peer")()
+        torch.cuda.synchronize(dev)
+        r0, r1 = docp.shard.c_row_begin, docp.shard.c_row_end
+        lo_, hi_ = docp.shard.vals_main_begin, docp.shard.vals_main_end
+        same = torch.tensor([float(torch.equal(c[r0:r1], c_chk[r0:r1]) and torch.equal(vals[lo_:hi_], v_chk[lo_:hi_])
+                                   and bool(torch.isnan(x).any()))], dtype=torch.float64, device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        secondary["sharded_iterate_check"] = {"bit_identical_to_whole_iterate_on_every_rank": bool(same.item() == 1.0),
+                                              "what": "each rank's c rows and CSC range from its NaN-padded shard of x vs from the whole x"}
         ks = max(1, min(args.steps, 500))
         for key, kw, what in (
-                ("stitched_c", dict(stitch=True, x_mode="halo"), "same step + all-gather of the row blocks of c (every rank ends with the whole c)"),
-                ("broadcast_x", dict(stitch=False, x_mode="broadcast"), "replicated iterate: rank 0 broadcasts all of x instead of the halo exchange"),
-                ("no_exchange", dict(stitch=False, x_mode=None), "evaluation only (x already in place on every rank): what the collectives cost is the difference")):
+                ("halo_allgather", dict(stitch=False, x_mode="halo"), "the neighbours' entries fetched with one all-gather (pack / all-gather / unpack) before the evaluation instead of read in place"),
+                ("stitched_c", dict(stitch=True, x_mode="peer"), "the timed step + all-gather of the row blocks of c (every rank ends with the whole c)"),
+                ("broadcast_x", dict(stitch=False, x_mode="broadcast"), "replicated iterate: rank 0 broadcasts all of x before the evaluation"),
+                ("no_exchange", dict(stitch=False, x_mode=None), "evaluation only, the whole x in place on every rank: what reading the neighbours' entries in place costs is the difference to the timed step")):
             try:      # a secondary figure must never cost the line
-                els = timed(sh.bind_cons_jac(x, c, vals, **kw), min(args.warmup, 50), ks)
+                xin = x if kw["x_mode"] in ("peer", "halo") else x_full
+                els = timed(sh.bind_cons_jac(xin, c, vals, **kw), min(args.warmup, 50), ks)
                 secondary[key] = {"value": ks * per_step_value / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3,
                                   "steps": ks, "what": what}
             except Exception as e:
@@ -212,7 +280,7 @@ def _main(real_stdout):
     # roofline of the dominant (only) kernel, per rank.  kernel_ms: N = 1: HIP events on the launch stream around the K
     # timed launches / K (back-to-back launches: the kernel's average duration including the dispatch gap); N > 1 (the
     # region also holds collectives): per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
-    per_dispatch = sorted(docp.time_cons_jac(x, c, vals, iters=200) for _ in range(5))[2]
+    per_dispatch = sorted(docp.time_cons_jac(x_full, c, vals, iters=200) for _ in range(5))[2]
     kernel_ms = region_ms if not dist_on else per_dispatch
     # algorithmic bytes of one launch: read the shard's x, write its c rows and Jacobian values:
     # B = 8 (nvar + ncon + nnzj) of the per-rank sub-problem
@@ -301,8 +369,8 @@ def _main(real_stdout):
             "config": {
                 "workload": f"{args.config}: {PROBLEM} / {SCHEME}, {shard_txt}; fused cons!+jac_coord! on HBM-resident x; "
                             + cfg["what"] + ("" if world == 1 else
-                                             "; timed step = halo exchange of the sharded iterate (one all-gather) + shard "
-                                             "evaluation, outputs row-sharded; value counts "
+                                             "; timed step = shard evaluation on the sharded iterate, neighbours' entries read "
+                                             "in place by the kernel (no collective in the step), outputs row-sharded; value counts "
                                              + ("one shard evaluation per GPU per step" if cfg["scaling"] == "weak"
                                                 else "one evaluation of the whole transcription per step")),
                 "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,
@@ -318,6 +386,9 @@ def _main(real_stdout):
         }
         if per_rank is not None:
             out["roofline"]["per_rank"] = per_rank
+        if rehearsal:
+            out["rehearsal"] = True
+            out["config"]["rehearsal"] = f"{world} ranks share device {local_rank} of a box with fewer GPUs; backend {backend}"
         if others:
             out["other_configs_kernel_only"] = others
         if optimized:

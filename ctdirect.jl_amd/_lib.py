@@ -102,6 +102,11 @@ SYMBOLS = {
     "ctd_dev_alloc": (C.c_int32, [C.c_int32, C.c_size_t, C.POINTER(_vp)]),
     "ctd_dev_free": (C.c_int32, [C.c_int32, _vp]),
     "ctd_dev_copy": (C.c_int32, [C.c_int32, _vp, _vp, C.c_size_t, C.c_int32]),
+    # sharded iterate read in place + buffers shared between the processes of a node
+    "ctd_set_x_shards": (C.c_int32, [_vp, C.c_int32, _ip, C.POINTER(_vp), C.c_int32]),
+    "ctd_ipc_export": (C.c_int32, [C.c_int32, _vp, _vp, _ip]),
+    "ctd_ipc_open": (C.c_int32, [C.c_int32, _vp, C.POINTER(_vp)]),
+    "ctd_ipc_close": (C.c_int32, [C.c_int32, _vp]),
 }
 
 

@@ -123,6 +123,9 @@ struct ctd_handle {
     size_t hess_step_lds = 0;
     uint32_t *d_htasks = nullptr, *d_hptasks = nullptr, *d_hbtasks = nullptr;
     double *d_hpartials = nullptr, *d_y = nullptr, *d_hvals = nullptr;
+    // sharded iterate read in place (ctd_set_x_shards): device table of the other shards' buffers, host copy of what it holds
+    XHalo* d_halo = nullptr;
+    XHalo halo_host{};
     std::string err;
 };
 
@@ -177,7 +180,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hssrc, (void*)h->d_hschunk, (void*)h->d_hsck, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hssrc, (void*)h->d_hschunk, (void*)h->d_hsck, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals, (void*)h->d_halo})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -558,6 +561,77 @@ int32_t ctd_shard_info(const ctd_handle* h, int64_t* o) {
     o[5] = mo.column_start(h->step_end * L.blk);
     o[6] = first; o[7] = last;
     return CTD_OK;
+}
+
+// Sharded iterate read in place: from now on the constraint / Jacobian kernels of this handle load the variables of OTHER
+// shards -- the next shard's first node, the previous shard's last step block, X_1, X_{N+1} -- from x_bufs[k] (peer-mapped or
+// IPC-mapped full-length buffers) instead of the x passed to the call.  The table is a few hundred bytes of device memory,
+// rewritten only when the arguments change.
+int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    if (n_shards <= 0 || !step_begin || !x_bufs) {         // back to "x holds everything this handle reads"
+        h->kp.halo = nullptr;
+        h->halo_host.G = 0;
+        return CTD_OK;
+    }
+    const Layout& L = h->model.L;
+    if (n_shards > kMaxShards) return fail(h, CTD_EINVAL, "ctd_set_x_shards: more than 16 shards");
+    if (self < 0 || self >= n_shards || step_begin[self] != h->step_begin || step_begin[self + 1] != h->step_end)
+        return fail(h, CTD_EINVAL, "ctd_set_x_shards: step_begin[self], step_begin[self + 1] do not name this handle's shard");
+    if (step_begin[0] != 0 || step_begin[n_shards] != L.N) return fail(h, CTD_EINVAL, "ctd_set_x_shards: the shards must cover [0, N)");
+    XHalo t{};
+    t.G = n_shards; t.self = self;
+    for (int k = 0; k < n_shards; ++k) {
+        if (step_begin[k + 1] <= step_begin[k]) return fail(h, CTD_EINVAL, "ctd_set_x_shards: empty shard");
+        if (k != self && !x_bufs[k]) return fail(h, CTD_EINVAL, "ctd_set_x_shards: null buffer");
+        t.vbegin[k] = step_begin[k] * (int64_t)L.blk;
+        t.x[k] = k == self ? nullptr : x_bufs[k];
+    }
+    t.vbegin[n_shards] = L.v_off;       // the last shard also owns the final node; v is replicated
+    if (h->kp.halo && std::memcmp(&t, &h->halo_host, sizeof(XHalo)) == 0) return CTD_OK;
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
+    if (!h->d_halo) HIP_TRY(h, hipMalloc((void**)&h->d_halo, sizeof(XHalo)));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));           // launches in flight still read the old table
+    HIP_TRY(h, hipMemcpy(h->d_halo, &t, sizeof(XHalo), hipMemcpyHostToDevice));
+    h->halo_host = t;
+    h->kp.halo = h->d_halo;
+    return CTD_OK;
+}
+
+// ---- device buffers shared between the processes of one node (one process per GPU) ------------------------------------
+// hipIpcGetMemHandle names a whole allocation: the handle of the allocation that holds dev_ptr plus dev_ptr's offset in it
+// (a torch tensor is a slice of the caching allocator's block).
+int32_t ctd_ipc_export(int32_t device, const void* dev_ptr, void* handle64, int64_t* offset) {
+    if (!dev_ptr || !handle64 || !offset) return CTD_EINVAL;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "CTD_IPC_HANDLE_BYTES");
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (e == hipSuccess) e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr);
+    hipIpcMemHandle_t hd;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, (void*)base);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_ipc_export: ") + hipGetErrorString(e); (void)hipGetLastError(); return CTD_EHIP; }
+    std::memcpy(handle64, &hd, sizeof(hd));
+    *offset = (int64_t)((const char*)dev_ptr - (const char*)base);
+    return CTD_OK;
+}
+int32_t ctd_ipc_open(int32_t device, const void* handle64, void** base) {
+    if (!handle64 || !base) return CTD_EINVAL;
+    *base = nullptr;
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
+    hipIpcMemHandle_t hd;
+    std::memcpy(&hd, handle64, sizeof(hd));
+    if (e == hipSuccess) e = hipIpcOpenMemHandle(base, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_ipc_open: ") + hipGetErrorString(e); (void)hipGetLastError(); return CTD_ERCCL; }
+    return CTD_OK;
+}
+int32_t ctd_ipc_close(int32_t device, void* base) {
+    if (!base) return CTD_OK;
+    DeviceGuard dg(device);
+    return (dg.err == hipSuccess && hipIpcCloseMemHandle(base) == hipSuccess) ? CTD_OK : CTD_EHIP;
 }
 
 int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
@@ -1336,13 +1410,28 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
     const int G = (int)s->h.size();
     for (int k = 0; k < G; ++k)
         if (!x_dev[k] || (stitch && (!c_dev || !c_dev[k]))) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: null buffer");
-    if (x_mode != CTD_X_IN_PLACE && x_mode != CTD_X_SHARDED && x_mode != CTD_X_FROM_DEVICE0)
+    if (x_mode != CTD_X_IN_PLACE && x_mode != CTD_X_SHARDED && x_mode != CTD_X_FROM_DEVICE0 && x_mode != CTD_X_SHARDED_COPY)
         return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: unknown x_mode");
     const Layout& L = s->h[0]->model.L;
     const int64_t N = L.N;
+    // (0) CTD_X_SHARDED: the kernels read the neighbours' entries in place through the peer mappings -- nothing is copied and
+    // nothing is ordered here; the table of buffers is rewritten only when the caller passes other pointers than last time
+    {
+        int64_t sb[kMaxShards + 1];
+        const bool peer = x_mode == CTD_X_SHARDED && G > 1;
+        if (peer) {
+            if (G > kMaxShards) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: CTD_X_SHARDED supports at most 16 shards");
+            for (int k = 0; k < G; ++k) sb[k] = s->h[k]->step_begin;
+            sb[G] = N;
+        }
+        for (int k = 0; k < G; ++k) {
+            const int32_t st = peer ? ctd_set_x_shards(s->h[k], G, sb, x_dev, k) : (s->h[k]->kp.halo ? ctd_set_x_shards(s->h[k], 0, nullptr, nullptr, 0) : CTD_OK);
+            if (st) return sfail(s, st, ctd_last_error(s->h[k]));
+        }
+    }
     // (1) iterate distribution.  Every shard first marks the point of its stream behind which its x buffer may be read by
     // the others (its own previous kernel has finished with it; the caller's writes are complete by contract).
-    if (x_mode != CTD_X_IN_PLACE && G > 1) {
+    if ((x_mode == CTD_X_SHARDED_COPY || x_mode == CTD_X_FROM_DEVICE0) && G > 1) {
         for (int k = 0; k < G; ++k) {
             DeviceGuard dg(s->dev[k]);
             SH_TRY(s, hipEventRecord(s->x_ready[k], s->h[k]->stream));

@@ -66,7 +66,17 @@ struct BlockCtx {
     double* rec;       // records
     const uint32_t* codes;   // emit template of the step segment (Lseg codes): LDS copy when small, else the global table
     const uint32_t* vcodes;  // V-column templates (nv * vr codes)
+    const XHalo* halo;       // sharded iterate read in place: non-null in the blocks that read other shards' variables (first /
+                             // last tile of the shard, edge block); null everywhere else and whenever xu holds all the block reads
+    const double* xu;        // the kernel's own iterate buffer (direct blocks with a halo table)
 };
+
+// blocks of a shard whose reads leave the shard's own variables (kp.halo set): the tiles at either end, the edge block
+CTD_HD const XHalo* block_halo(const KParams& kp, const BlockCtx& cx) {
+    if (!kp.halo) return nullptr;
+    if (cx.is_edge) return kp.halo;
+    return (cx.lo < kp.step_begin || cx.b + kp.HH >= kp.step_end) ? kp.halo : nullptr;
+}
 
 // doubles reserved at the start of the LDS for the emit templates (staged once per workgroup by load_codes)
 // (only small templates are staged: copying thousands of codes per workgroup costs more than the latency it hides)
@@ -109,6 +119,8 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + cap + 2;
     }
+    cx.xu = nullptr;
+    cx.halo = block_halo(kp, cx);
     return cx;
 }
 
@@ -128,6 +140,8 @@ CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const
     cx.v = const_cast<double*>(xu) + L.v_off;
     cx.tau = nullptr;
     cx.rec = lds + code_doubles(kp);
+    cx.xu = xu;
+    cx.halo = nullptr;
     if (kp.has_edge && block == 0) {
         // edge block: slot k holds step kp.edge_steps[k] (slot_base); X_{i+1} (and U_{i-1} for implicit Euler) are where
         // the global layout has them
@@ -135,6 +149,7 @@ CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const
         cx.nslots = kp.n_edge_slots;
         cx.a = cx.b = cx.lo = 0;
         cx.in = const_cast<double*>(xu);
+        cx.halo = kp.halo;
         return cx;
     }
     const int tile = block - (kp.has_edge ? 1 : 0);      // (the XCD-aware tile order of the staged driver measured neutral: not offered here)
@@ -144,13 +159,36 @@ CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const
     cx.lo = cx.a - kp.HL;
     cx.nslots = (int)(cx.b - cx.a) + kp.HL + kp.HH;
     cx.in = const_cast<double*>(xu) + cx.lo * (int64_t)L.blk;
+    cx.halo = block_halo(kp, cx);
     return cx;
 }
 
-// inputs of slot k: staged copy in LDS, or (direct) the step's own block of xu
+// inputs of slot k: staged copy in LDS, or (direct) the step's own block of xu -- of the owner's buffer when the iterate is
+// sharded and the step belongs to a neighbour
 CTD_HD const double* slot_base(const KParams& kp, const BlockCtx& cx, int k) {
+    if (cx.direct && cx.halo) {
+        const int64_t g = slot_index(kp, cx, k) * (int64_t)cx.in_stride;
+        return xsrc(cx.halo, cx.xu, g) + g;
+    }
     if (cx.direct && cx.is_edge) return cx.in + kp.edge_steps[k] * (int64_t)cx.in_stride;
     return cx.in + k * cx.in_stride;
+}
+// X_{i+1} (and U_{i+1}) of slot k: behind the step's block, in the staged copy and in every buffer that holds both -- the
+// next shard's buffer for the last step of a shard
+CTD_HD const double* slot_next(const KParams& kp, const BlockCtx& cx, int k) {
+    if (cx.direct && cx.halo) {
+        const int64_t g = (slot_index(kp, cx, k) + 1) * (int64_t)cx.in_stride;
+        return xsrc(cx.halo, cx.xu, g) + g;
+    }
+    return slot_base(kp, cx, k) + kp.L.blk;
+}
+// block of step i - 1 (implicit Euler's path control U_{i-1}); direct blocks only
+CTD_HD const double* slot_prev(const KParams& kp, const BlockCtx& cx, int k) {
+    if (cx.direct && cx.halo) {
+        const int64_t g = (slot_index(kp, cx, k) - 1) * (int64_t)cx.in_stride;
+        return xsrc(cx.halo, cx.xu, g) + g;
+    }
+    return slot_base(kp, cx, k) - kp.L.blk;
 }
 
 // LDS doubles a block needs (host uses this to size the launch)
@@ -239,7 +277,7 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
             int64_t g = kp.edge_steps[k] * L.blk + o;
             if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
                 g = (kp.edge_steps[k] >= 1 ? kp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
-            cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
+            cx.in[e] = (g < L.v_off) ? (cx.halo ? xsrc(cx.halo, xu, g) : xu)[g] : 0.0;
         }
         for (int e = tid; e <= 2 * cx.nslots; e += nthr)
             cx.tau[e] = (e == 2 * cx.nslots) ? tau_global(kp, L.N) : tau_global(kp, kp.edge_steps[e >> 1] + (e & 1));
@@ -255,6 +293,18 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         // share of the emit templates), then stores them to LDS: one exposed memory latency instead of one per copy loop
         const bool codes = LOAD_V && codes_staged(kp);
         const int nvc = kp.L.nv * kp.vr;
+        if (cx.halo) {
+            // first / last tile of a shard with the iterate sharded: every element from the buffer of the shard that owns it
+            for (int e = tid; e < cnt; e += nthr) dst[e] = xsrc(cx.halo, xu, g0 + e)[g0 + e];
+            if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
+            if (codes) {
+                uint32_t* cd = const_cast<uint32_t*>(cx.codes);
+                for (int e = tid; e < kp.Lseg; e += nthr) cd[e] = kp.tmpl[e];
+                for (int e = tid; e < nvc; e += nthr) cd[kp.Lseg + e] = kp.vtmpl[e];
+            }
+            for (int e = tid; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
+            return;
+        }
         const double x0 = tid < cnt ? src[tid] : 0.0;
         const double x1 = tid + nthr < cnt ? src[tid + nthr] : 0.0;
         const double vv = (LOAD_V && tid < P::NV) ? xu[L.v_off + tid] : 0.0;
@@ -305,6 +355,7 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
     const double h = time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0);
     if (SC == SC_IRK) {
         const double* base = slot_base(kp, cx, k);
+        const double* nxt = slot_next(kp, cx, k);
         const double* K = base + n + L.cu;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
@@ -318,7 +369,7 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
             double sumbk = L.b[0] * K[r];
 #pragma unroll
             for (int j = 1; j < S; ++j) sumbk = sumbk + L.b[j] * K[j * n + r];
-            rec[R.oR + r] = base[L.blk + r] - (base[r] + h * sumbk);
+            rec[R.oR + r] = nxt[r] - (base[r] + h * sumbk);
 #pragma unroll
             for (int kk = 0; kk < nv; ++kk) {
                 const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk) : 0.0;
@@ -383,10 +434,11 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
         }
     } else if (SC == SC_MIDPOINT) {
         const double h = (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0)) / 1.0;
+        const double* nxt = slot_next(kp, cx, k);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             const double f = ev[R.of + r];
-            rec[R.oR + r] = base[L.blk + r] - (base[r] + h * f);    // midpoint.jl:139
+            rec[R.oR + r] = nxt[r] - (base[r] + h * f);    // midpoint.jl:139
 #pragma unroll
             for (int kk = 0; kk < nv; ++kk) {
                 double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
@@ -511,7 +563,7 @@ template <class P, int S> CTD_HD void path_control(const KParams& kp, const Bloc
     const Layout& L = kp.L;
     const double* base = slot_base(kp, cx, k);
     if (L.euler == 2 && i >= 1 && (cx.is_edge || k >= 1)) {
-        const double* up = (cx.is_edge && !cx.direct) ? base + L.blk + P::NX + P::NU : base - L.blk + P::NX;
+        const double* up = (cx.is_edge && !cx.direct) ? base + L.blk + P::NX + P::NU : slot_prev(kp, cx, k) + P::NX;
 #pragma unroll
         for (int c = 0; c < P::NU; ++c) u[c] = up[c];
     } else {
@@ -563,14 +615,15 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
     } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
         const double tip1 = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1));
+        const double* nxt = slot_next(kp, cx, k);
         if (L.euler == 0) {
             t = 0.5 * (ti + tip1);
 #pragma unroll
-            for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + base[L.blk + c]);
+            for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + nxt[c]);
         } else {                                  // Euler: f(t_i, X_i, U_i, v) or f(t_{i+1}, X_{i+1}, U_i, v): euler.jl:86-102
             t = (L.euler == 1) ? ti : tip1;
 #pragma unroll
-            for (int c = 0; c < n; ++c) xv[c] = (L.euler == 1) ? base[c] : base[L.blk + c];
+            for (int c = 0; c < n; ++c) xv[c] = (L.euler == 1) ? base[c] : nxt[c];
         }
 #pragma unroll
         for (int c = 0; c < m; ++c) uv[c] = base[n + c];
@@ -768,12 +821,13 @@ CTD_HD void eval_final_path(const KParams& kp, const BlockCtx& cx, int q) {
     constexpr RecLayout R = RL<P, SC, S>::R;
     const Layout& L = kp.L;
     const double* base = slot_base(kp, cx, kp.edge_slot_last);
+    const double* nxt = slot_next(kp, cx, kp.edge_slot_last);
     double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
 #pragma unroll
-    for (int c = 0; c < n; ++c) xv[c] = base[L.blk + c];
+    for (int c = 0; c < n; ++c) xv[c] = nxt[c];
     if (SC == SC_TRAPEZE) {
 #pragma unroll
-        for (int c = 0; c < m; ++c) uv[c] = base[L.blk + n + c];
+        for (int c = 0; c < m; ++c) uv[c] = nxt[n + c];
     } else node_control<P, S>(kp, base, uv);
     double* rec = cx.rec + kp.edge_fp * R.stride;
     const double tau = final_tau(kp, cx);
@@ -789,7 +843,7 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const double* b0 = slot_base(kp, cx, kp.edge_slot_first);
-    const double* bf = slot_base(kp, cx, kp.edge_slot_last) + L.blk;
+    const double* bf = slot_next(kp, cx, kp.edge_slot_last);
     D X0[n > 0 ? n : 1], XF[n > 0 ? n : 1], V[nv > 0 ? nv : 1], out[nb > 0 ? nb : 1];
     const int g0 = q * DC;
 #pragma unroll

@@ -138,6 +138,28 @@ CTD_HD uint32_t fast_div(uint32_t x, FastDiv f) { return f.d > 1 ? (uint32_t)(((
 
 constexpr int64_t kEdgeCBit = (int64_t)1 << 62;   // edge_idx flag: the entry goes to c[], not vals[]
 
+// ---- sharded iterate read in place (multi-GPU) ------------------------------------
+// The time steps of one transcription are split over G shards (the loop being partitioned: src/DOCP_functions.jl:92-98);
+// each shard keeps the variables of its own steps in a full-length buffer of its own device.  The few entries a shard
+// reads from its neighbours -- the next shard's first node, the previous shard's last step block (one-point schemes),
+// X_1 and X_{N+1} for the boundary rows -- are loaded by the kernels straight from the owner's buffer (peer-mapped over
+// xGMI, or an IPC mapping of another process): no copy, no collective, no event in the evaluation.  The table lives in
+// device memory; only the first / last tile of a shard and its edge block ever look at it.
+constexpr int kMaxShards = 16;
+struct XHalo {
+    int32_t G, self;
+    int64_t vbegin[kMaxShards + 1];    // shard k owns the variables [vbegin[k], vbegin[k+1]); vbegin[G] = v_off (v is replicated)
+    const double* x[kMaxShards];       // full-length iterate buffer of shard k (entry `self` is not used: the kernel's own xu)
+};
+// buffer that holds variable g
+CTD_HD const double* xsrc(const XHalo* hl, const double* xu, int64_t g) {
+    const int G = hl->G;
+    if (g >= hl->vbegin[G]) return xu;
+    int k = 0;
+    while (k + 1 < G && g >= hl->vbegin[k + 1]) ++k;
+    return k == hl->self ? xu : hl->x[k];
+}
+
 // ---- kernel parameters (passed by value) ---------------------------------------------------------------
 struct KParams {
     Layout L;
@@ -178,6 +200,9 @@ struct KParams {
     // diagnostics only (env CTD_DEBUG_STOP): 0 = normal; k > 0: every workgroup returns after phase k (1 nothing, 2 load,
     // 3 eval, 4 fin) -- ablation timing, outputs are then incomplete
     int32_t debug_stop;
+    // sharded iterate read in place: where the other shards' variables live (device table), or null: xu holds everything
+    // this shard reads
+    const XHalo* halo;
 };
 
 }  // namespace ctd

@@ -43,15 +43,20 @@ def shard_steps(N, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+_FLAT_GATHER = {}
+
+
 def _all_gather_into(recv, send, group=None):
-    """recv[r * len(send) : (r+1) * len(send)] = rank r's `send`.  RCCL: one all_gather_into_tensor (send may be a view of
-    recv: in place).  Backends without it (gloo moves host memory only -- CPU tests and the one-GPU rehearsal) go through the
-    list form, staged on the host when the tensors live on a GPU."""
-    try:
+    """recv[r * len(send) : (r+1) * len(send)] = rank r's `send`.  RCCL ("nccl"): one all_gather_into_tensor (send may be a
+    view of recv: in place), unguarded -- a failing collective raises on the rank it fails on.  gloo (CPU tests and the
+    one-GPU rehearsal; it moves host memory only) goes through the list form, staged on the host when the tensors live on a
+    GPU.  The choice is made once per group from the backend's name, never by catching an error of the collective."""
+    flat = _FLAT_GATHER.get(group)
+    if flat is None:
+        flat = _FLAT_GATHER[group] = str(dist.get_backend(group)).lower() in ("nccl", "rccl")
+    if flat:
         dist.all_gather_into_tensor(recv, send, group=group)
         return
-    except (RuntimeError, NotImplementedError, ValueError):
-        pass
     world = dist.get_world_size(group)
     n = send.numel()
     if send.is_cuda:
@@ -156,13 +161,27 @@ class ShardedDOCP:
         # first state, and the rank owns those Jacobian entries: it needs that step's block too
         self.halo_lo = self.blk if (disc.stage == 0 and not getattr(disc, "_final_control", False)) else 0
         self._dev = None
+        self._stream = None
         if d.device is not None and d.device >= 0:
             self._dev = torch.device("cuda", d.device)
-            d.set_stream(None)              # launch on torch's current stream: ordered with the collectives issued here
+            self._rebind()                  # launch on torch's current stream: ordered with the collectives issued here
         self._stitch = None
         self._halo = None
         self._vv = None
         self._f = None
+        self._peer = None                   # data_ptr of the x buffer the peer table was built for (enable_peer_x)
+        self._peer_tables = {}              # x data_ptr -> mapped pointers of the other ranks' buffers
+        self._ipc_bases = []                # (device, base) of every IPC mapping this object opened
+
+    def _rebind(self):
+        """The engine's kernels and the collectives issued here must share a stream: follow torch's current stream (a cheap
+        integer compare per call; a caller inside `with torch.cuda.stream(s)` or a graph capture gets both on s)."""
+        if self._dev is None:
+            return
+        cur = torch.cuda.current_stream(self._dev).cuda_stream
+        if cur != self._stream:
+            self.docp.set_stream(cur)
+            self._stream = cur
 
     # ---- iterate distribution ------------------------------------------------------------------------------------------
     def owned_variables(self):
@@ -209,6 +228,55 @@ class ShardedDOCP:
             x.index_copy_(0, dst, recv.index_select(0, src))
         return x
 
+    def enable_peer_x(self, x):
+        """Sharded iterate read IN PLACE (`ctd_set_x_shards`): every rank exports its full-length x buffer once (IPC handle,
+        all-gathered as Python objects -- set-up, not the step), maps the other ranks' buffers, and from then on this rank's
+        constraint / Jacobian kernels load the few entries its neighbours own (next rank's first node, previous rank's last
+        block, X_1, X_{N+1}) straight from their HBM over xGMI.  The evaluation of a step then contains NO collective, no
+        pack / unpack kernel and no copy.  `x` must stay the iterate buffer (same storage) for the life of this object; the
+        solver's update of x on every rank has to be complete before the evaluations that follow it are enqueued (its step
+        acceptance is a collective anyway).  Objective / gradient / Hessian callbacks read the x they are given: run
+        `exchange_halo` before those."""
+        from . import _lib
+        import ctypes as C
+        if self.world == 1:
+            return x
+        begins = [shard_steps(self.N, self.world, r)[0] for r in range(self.world)] + [self.N]
+        if self._peer == x.data_ptr():
+            return x
+        if x.data_ptr() in self._peer_tables:            # mapped before (the caller alternates between modes)
+            self.docp.set_x_shards(begins, self._peer_tables[x.data_ptr()], self.rank)
+            self._peer = x.data_ptr()
+            return x
+        L = _lib.lib()
+        dev = x.device.index
+        hbuf = (C.c_ubyte * 64)()
+        off = C.c_int64()
+        st = L.ctd_ipc_export(dev, C.c_void_p(x.data_ptr()), hbuf, C.byref(off))
+        if st:
+            raise RuntimeError("ctd_ipc_export: " + L.ctd_last_error(None).decode())
+        mine = (bytes(hbuf), int(off.value), os.getpid(), int(x.data_ptr()))
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        ptrs = []
+        for r, (hb, o, pid, raw) in enumerate(everyone):
+            if r == self.rank:
+                ptrs.append(0)
+            elif pid == os.getpid():          # same process (several ranks of a test harness): the pointer is valid as it is
+                ptrs.append(raw)
+            else:
+                base = C.c_void_p()
+                st = L.ctd_ipc_open(dev, (C.c_ubyte * 64).from_buffer_copy(hb), C.byref(base))
+                if st:
+                    raise RuntimeError("ctd_ipc_open: " + L.ctd_last_error(None).decode())
+                self._ipc_bases.append((dev, base.value))
+                ptrs.append(base.value + o)
+        self.docp.set_x_shards(begins, ptrs, self.rank)
+        self._peer_tables[x.data_ptr()] = ptrs
+        self._peer = x.data_ptr()
+        dist.barrier(group=self.group)        # every rank has mapped the others before anyone evaluates (or frees)
+        return x
+
     def broadcast_iterate(self, x, src=0):
         """Replicated iterate: the rank that holds the new x sends all of it (nvar doubles) to every other rank."""
         if self.world > 1 or _FORCE:
@@ -224,19 +292,27 @@ class ShardedDOCP:
     def cons_jac(self, x, c, vals, stitch=True):
         """Evaluate this rank's rows into the full-length c / vals buffers; `stitch`: all-gather the row blocks of c so that
         every rank holds the whole residual (the Jacobian values always stay sharded)."""
+        self._rebind()
         self.docp.cons_jac(x, c, vals, sync=False)
         if stitch:
             self._stitcher(c)(c)
         return c, vals
 
     def bind_cons_jac(self, x, c, vals, stitch=True, x_mode=None):
-        """Zero-argument callable for a solver loop, pointers pre-bound: [distribute the iterate: x_mode "halo" (sharded x,
-        exchange_halo) / "broadcast" (replicated x from rank 0) / None] + enqueue this rank's evaluation [+ the all-gather of c
+        """Zero-argument callable for a solver loop, pointers pre-bound: [distribute the iterate: x_mode "peer" (sharded x,
+        neighbours' entries read in place by the kernel: nothing per step) / "halo" (sharded x, exchange_halo: one all-gather) /
+        "broadcast" (replicated x from rank 0) / None] + enqueue this rank's evaluation [+ the all-gather of c
         when `stitch`]."""
+        self._rebind()
         launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
         if self.world == 1 and not _FORCE:
             return launch
-        pre = {None: None, "halo": self.exchange_halo, "broadcast": self.broadcast_iterate}[x_mode]
+        if x_mode == "peer":                 # neighbours' entries are read in place by the kernel: nothing precedes the launch
+            self.enable_peer_x(x)
+        elif self._peer is not None:
+            self.docp.set_x_shards(None, None, 0)
+            self._peer = None
+        pre = {None: None, "peer": None, "halo": self.exchange_halo, "broadcast": self.broadcast_iterate}[x_mode]
         post = self._stitcher(c) if stitch else None
 
         def call():
@@ -251,6 +327,7 @@ class ShardedDOCP:
         """This rank's entries of hess_coord!(nlp, x, y, vals; obj_weight) into the full-length `vals` (they stay sharded like
         the Jacobian values), plus the all-reduced variable x variable entries on every rank.  No host synchronisation: the
         kernel and the all-reduce are ordered on torch's current stream."""
+        self._rebind()
         self.docp.hess_coord(x, y, obj_weight, vals, sync=False)
         if self.world > 1 or _FORCE:
             if self._vv is None:
@@ -265,10 +342,18 @@ class ShardedDOCP:
             return reduce_objective(self.docp.obj(x), self.group)
         if self._f is None:
             self._f = torch.zeros(1, dtype=torch.float64, device=x.device)
+        self._rebind()
         self.docp.obj_async(x, self._f)
         if self.world > 1 or _FORCE:
             dist.all_reduce(self._f, op=dist.ReduceOp.SUM, group=self.group)
         return self._f if as_tensor else float(self._f.item())
 
     def close(self):
+        if self._ipc_bases:
+            from . import _lib
+            torch.cuda.synchronize(self._dev)
+            for dev, b in self._ipc_bases:
+                _lib.lib().ctd_ipc_close(dev, b)
+            self._ipc_bases = []
+        self._peer = None
         self.docp.close()

@@ -348,6 +348,21 @@ class DOCP:
                 ck(st)
         return call
 
+    def set_x_shards(self, step_begins, x_ptrs, self_index):
+        """Sharded iterate read in place (`ctd_set_x_shards`): from now on the constraint / Jacobian kernels of this shard
+        handle load the entries other shards own (next shard's first node, previous shard's last block, X_1, X_{N+1}) straight
+        from `x_ptrs[k]` -- raw device pointers of the shards' full-length buffers (peer- or IPC-mapped).  `step_begins` has
+        one entry per shard plus N.  `step_begins=None` switches back."""
+        L = _lib.lib()
+        if step_begins is None:
+            self._ck(L.ctd_set_x_shards(self._h, 0, None, None, 0))
+            return
+        G = len(x_ptrs)
+        sb = np.ascontiguousarray(step_begins, dtype=np.int64)
+        assert sb.size == G + 1
+        arr = (C.c_void_p * G)(*[int(p) if p else None for p in x_ptrs])
+        self._ck(L.ctd_set_x_shards(self._h, G, _ip(sb), arr, int(self_index)))
+
     def cons(self, x, c=None):
         """cons!(nlp, x, c) = __constraints!(c, x, docp); returns c (the reference's closure must return c too)."""
         L = _lib.lib()
@@ -705,9 +720,9 @@ class MultiDeviceDOCP:
     counterpart of `dist.ShardedDOCP`.  Buffers are full-length on every device (global indexing); shard k writes its rows
     of c and its CSC ranges of the Jacobian values.  `devices` may repeat an ordinal (tests on a one-GPU box)."""
 
-    X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0 = 0, 1, 2
+    X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0, X_SHARDED_COPY = 0, 1, 2, 3
 
-    def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual"):
+    def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual", stream="torch"):
         L = _lib.lib()
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
         scheme = SCHEME_ALIASES.get(scheme, scheme) if isinstance(scheme, str) else scheme
@@ -739,6 +754,23 @@ class MultiDeviceDOCP:
         self._ck(L.ctd_sharded_handle(self._s, 0, C.byref(h0)))
         L.ctd_sizes(h0, C.byref(nvar), C.byref(ncon), C.byref(nnzj), C.byref(nnzh))
         self.dim_NLP_variables, self.dim_NLP_constraints, self.nnzj, self.nnzh = nvar.value, ncon.value, nnzj.value, nnzh.value
+        # stream="torch" (default, like DOCP): every shard launches on torch's current stream of its device, so the engine's
+        # copies and kernels are ordered with the caller's tensor work on x / c / vals (the private non-blocking streams of
+        # stream="own" are not: the caller then synchronises itself)
+        self._streams = None
+        if stream == "torch":
+            self.bind_torch_streams()
+
+    def bind_torch_streams(self):
+        import torch
+        L = _lib.lib()
+        cur = [torch.cuda.current_stream(dev).cuda_stream for dev in self.devices]
+        if cur != self._streams:
+            for k, st in enumerate(cur):
+                hk = C.c_void_p()
+                self._ck(L.ctd_sharded_handle(self._s, k, C.byref(hk)))
+                self._ck(L.ctd_set_stream(hk, C.c_void_p(st)))
+            self._streams = cur
 
     def _ck(self, st):
         if st != _lib.CTD_OK:
@@ -756,6 +788,8 @@ class MultiDeviceDOCP:
 
     def cons_jac(self, x, c, vals, x_mode=0, stitch=False, sync=True):
         """x, c, vals: lists of one full-length tensor per shard (on that shard's device)."""
+        if self._streams is not None:
+            self.bind_torch_streams()          # (a cheap compare; rebinds when the caller switched torch streams)
         self._ck(_lib.lib().ctd_cons_jac_sharded_dev_async(self._s, self._ptrs(x, self.dim_NLP_variables, "x"),
                                                            self._ptrs(c, self.dim_NLP_constraints, "c"),
                                                            self._ptrs(vals, self.nnzj, "vals"), int(x_mode), int(bool(stitch))))

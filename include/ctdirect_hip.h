@@ -327,9 +327,15 @@ typedef struct ctd_sharded ctd_sharded;
 
 enum {
     CTD_X_IN_PLACE = 0,      /* every x_dev[k] already holds what shard k reads (e.g. the solver replicates x)               */
-    CTD_X_SHARDED = 1,       /* x_dev[k] holds shard k's own variables (+ the replicated v): the engine fetches the halos --   */
-                             /*   next shard's first node, previous shard's last block (midpoint / Euler), X_1, X_{N+1}      */
-    CTD_X_FROM_DEVICE0 = 2   /* x_dev[0] holds the whole iterate: the engine copies all of it to the other devices          */
+    CTD_X_SHARDED = 1,       /* x_dev[k] holds shard k's own variables (+ the replicated v).  The kernels load the few entries */
+                             /*   a shard needs from its neighbours -- next shard's first node, previous shard's last block     */
+                             /*   (midpoint / Euler), X_1, X_{N+1} -- IN PLACE from the owner's buffer through the peer         */
+                             /*   mappings (xGMI): no copy, no event, no collective in the step (ctd_set_x_shards).  The       */
+                             /*   caller's writes to EVERY x_dev[k] must be complete, or ordered before every shard's stream    */
+    CTD_X_FROM_DEVICE0 = 2,  /* x_dev[0] holds the whole iterate: the engine copies all of it to the other devices          */
+    CTD_X_SHARDED_COPY = 3   /* as CTD_X_SHARDED, but the halo entries are COPIED into x_dev[k] (hipMemcpyPeerAsync on the   */
+                             /*   shards' streams, ordered by events: a shard's buffer is read behind the work already queued  */
+                             /*   on ITS stream); afterwards every callback of shard k's handle can run on x_dev[k]          */
 };
 
 /* desc->device, step_begin / step_end and stream are ignored (must be 0 / NULL); devices[k] are HIP ordinals */
@@ -347,6 +353,27 @@ int32_t ctd_sharded_shard_info(const ctd_sharded* s, int32_t k, int64_t* out10);
  * caller's writes to x_dev must be complete (or ordered before the shards' streams) when this is called. */
 int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, double* const* c_dev, double* const* vals_dev,
                                        int32_t x_mode, int32_t stitch);
+/* ---- sharded iterate read in place ------------------------------------------------------------------------------------------
+ * One shard handle (ctd_desc.step_begin / step_end) usually finds everything it reads in the x passed to the call.  With the
+ * iterate sharded like the steps (a shard holds its own steps' variables and the replicated v in a
+ * full-length buffer) a few entries belong to other shards: the next shard's first node, the previous shard's last step block
+ * (one-point schemes), X_1 and X_{N+1} (boundary rows).  After ctd_set_x_shards the constraint / Jacobian kernels of `h` load
+ * those entries straight from x_bufs[k], the full-length buffer of shard k = steps [step_begin[k], step_begin[k+1]) -- a
+ * peer-mapped pointer of another device of this process, or the mapping of another process' buffer (ctd_ipc_open below) --
+ * so the evaluation of a shard contains no exchange step at all: the loop being split is src/DOCP_functions.jl:92-98, and
+ * step i reads only X_i, U_i, K_i, X_{i+1}, v.  `self` = this handle's shard (x_bufs[self] is ignored: its x is the call's
+ * argument); n_shards <= 16; n_shards = 0 switches back.  The writers' updates of x must be complete (or ordered before this
+ * handle's stream) when an evaluation is enqueued -- the acceptance test of a solver iteration is a collective already.
+ * (Objective, gradient and Hessian callbacks read the x they are given: use CTD_X_SHARDED_COPY / an exchange for those.) */
+int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self);
+/* One process per GPU: export a device buffer (any pointer inside a hipMalloc'ed allocation, e.g. a tensor of a caching
+ * allocator: `handle64` names the allocation, `offset` the pointer's byte offset in it) and map it in another process of the
+ * node (ctd_ipc_open returns the allocation's base in this process; add the offset).  hipIpcGetMemHandle / hipIpcOpenMemHandle. */
+#define CTD_IPC_HANDLE_BYTES 64
+int32_t ctd_ipc_export(int32_t device, const void* dev_ptr, void* handle64, int64_t* offset);
+int32_t ctd_ipc_open(int32_t device, const void* handle64, void** base);
+int32_t ctd_ipc_close(int32_t device, void* base);
+
 /* waits for every shard's stream */
 int32_t ctd_sharded_sync(ctd_sharded* s);
 /* Device memory for hosts without a HIP binding of their own (examples/cabi_demo.c; a Julia host passes AMDGPU.jl arrays

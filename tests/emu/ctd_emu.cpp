@@ -138,6 +138,60 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     return ok ? 0 : 5;
 }
 
+// Sharded iterate read in place (ctd_set_x_shards): G shards with the engine's balanced split; shard k evaluates from a buffer
+// of its own that holds ONLY its own variables (+ the replicated v) and NaN everywhere else, the entries of other shards come
+// through the XHalo table from the owners' buffers.  All shards write into the shared c / vals.
+int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
+                         int G, const double* x, double* c, double* vals) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    const Layout& L = mo.L;
+    if (G < 1 || G > kMaxShards || G > L.N) { g_err = "bad shard count"; return 97; }
+    if (tile <= 0) tile = default_tile(mo);
+    std::vector<int64_t> sb(G + 1);
+    const int64_t base = L.N / G, rem = L.N % G;
+    for (int k = 0; k <= G; ++k) sb[k] = k * base + (k < rem ? k : rem);
+    std::vector<std::vector<double>> xs(G, std::vector<double>(L.nvar, std::numeric_limits<double>::quiet_NaN()));
+    for (int k = 0; k < G; ++k) {
+        const int64_t lo = sb[k] * L.blk, hi = (k == G - 1) ? L.v_off : sb[k + 1] * L.blk;
+        for (int64_t g = lo; g < hi; ++g) xs[k][g] = x[g];
+        for (int64_t g = L.v_off; g < L.nvar; ++g) xs[k][g] = x[g];
+    }
+    for (int k = 0; k < G; ++k) {
+        XHalo hl{};
+        hl.G = G; hl.self = k;
+        for (int j = 0; j < G; ++j) { hl.vbegin[j] = sb[j] * L.blk; hl.x[j] = j == k ? nullptr : xs[j].data(); }
+        hl.vbegin[G] = L.v_off;
+        KParams kp;
+        mo.fill_kparams(kp, sb[k], sb[k + 1], tile);
+        kp.tau = mo.uniform ? nullptr : mo.tau.data();
+        kp.tmpl = mo.tmpl.data();
+        kp.vtmpl = mo.vtmpl.data();
+        kp.edge_idx = mo.edge_idx.data();
+        kp.edge_code = mo.edge_code.data();
+        kp.c = c;
+        kp.vals = vals;
+        kp.halo = &hl;
+        const double* xk = xs[k].data();
+        bool ok = for_problem(problem, [&](auto tag) {
+            using P = typename decltype(tag)::type;
+            switch (mo.L.sc) {
+                case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE, 1>(kp, xk, nthr); break;
+                case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT, 1>(kp, xk, nthr); break;
+                default:
+                    if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, xk, nthr);
+                    else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, xk, nthr);
+                    else run_blocks<P, SC_IRK, 3>(kp, xk, nthr);
+                    break;
+            }
+        });
+        if (!ok) return 5;
+    }
+    return 0;
+}
+
 int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen) {
     Model mo;
     HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};

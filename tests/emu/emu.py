@@ -68,6 +68,23 @@ def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_
     return c, vals
 
 
+def cons_jac_sharded(problem, scheme, mode, N, x, G, time_grid=None, tile=0, nthr=64):
+    """All G shards of the engine's balanced split, each evaluating from a buffer that holds only its own variables (NaN
+    elsewhere) with the other shards' entries read in place through the XHalo table (ctd_set_x_shards)."""
+    nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
+    tg, n = _tg(time_grid)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert x.size == nvar
+    c = np.full(ncon, 666.666)
+    vals = np.full(nnz, 666.666)
+    st = lib().emu_cons_jac_sharded(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                                    C.c_int64(n), tile, nthr, G, x.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+                                    vals.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return c, vals
+
+
 def hess_csc(problem, scheme, mode, N, time_grid=None):
     nvar = sizes(problem, scheme, mode, N, time_grid)[0]
     tg, n = _tg(time_grid)

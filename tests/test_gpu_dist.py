@@ -87,6 +87,22 @@ def _worker(rank, world, port, N, prob, sch, q):
         sh.bind_cons_jac(xb, c2, v2, stitch=True, x_mode="broadcast")()
         torch.cuda.synchronize()
         chk['broadcast c'] = relerr(c2.cpu().numpy(), cref) <= TOL
+        # sharded iterate read IN PLACE: no exchange at all -- the kernels load the neighbour's entries from the other process'
+        # buffer (IPC mapping; over xGMI on a multi-GPU node).  The local copy of everything a rank does not own stays NaN
+        xp = torch.from_numpy(xs).cuda()
+        c3 = torch.full_like(c, 777.0)
+        v3 = torch.full_like(v, 777.0)
+        step = sh.bind_cons_jac(xp, c3, v3, stitch=False, x_mode="peer")
+        dist.barrier()
+        step(); step()
+        torch.cuda.synchronize()
+        dist.barrier()                      # nobody frees its buffer while the other rank's kernel may still read it
+        c3h, v3h = c3.cpu().numpy(), v3.cpu().numpy()
+        r0, r1 = d.shard.c_row_begin, d.shard.c_row_end
+        chk['peer c rows'] = bool(np.array_equal(c3h[r0:r1], c.cpu().numpy()[r0:r1]))          # bit-identical to the exchanged run
+        chk['peer c tail'] = bool(np.array_equal(c3h[N * sh.cb:], c.cpu().numpy()[N * sh.cb:]))
+        chk['peer J'] = bool(np.array_equal(v3h, vh))
+        chk['peer x untouched'] = bool(np.array_equal(np.isnan(xp.cpu().numpy()), np.isnan(xs)))
         sh.close()
         bad = [k for k, v_ in chk.items() if not v_]
         q.put((rank, True if not bad else bad))
@@ -121,7 +137,7 @@ def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
 def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
     """ctd_create_sharded / ctd_cons_jac_sharded_dev_async (the single-process multi-GPU entry point of the C ABI) with the
     one GPU of this box named three times: sharded iterate (NaN outside what a shard owns until the engine's peer copies
-    fetch the halos), stitched c on every shard, Jacobian pieces composed -- bit-identical to the unsharded handle."""
+    fetch the halos, or the kernels read them in place through ctd_set_x_shards), stitched c on every shard, Jacobian pieces composed -- bit-identical to the unsharded handle."""
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
     import ctdirect_jl_amd as ct
@@ -134,14 +150,14 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
     assert (md.dim_NLP_variables, md.dim_NLP_constraints, md.nnzj) == (full.dim_NLP_variables, full.dim_NLP_constraints, full.nnzj)
     assert [s.step_begin for s in md.shards] == [0, md.shards[0].step_end, md.shards[1].step_end] and md.shards[2].step_end == N
     blk, nv = full.discretization._step_variables_block, full.dims.NLP_v
-    for mode in (md.X_SHARDED, md.X_FROM_DEVICE0, md.X_IN_PLACE):
+    for mode in (md.X_SHARDED, md.X_SHARDED_COPY, md.X_FROM_DEVICE0, md.X_IN_PLACE):
         xs = []
         for k, s in enumerate(md.shards):
             if mode == md.X_IN_PLACE or (mode == md.X_FROM_DEVICE0 and k == 0):
                 xs.append(xd.clone())
                 continue
             t = np.full_like(x, np.nan)
-            if mode == md.X_SHARDED:
+            if mode in (md.X_SHARDED, md.X_SHARDED_COPY):
                 end = s.step_end * blk if k < 2 else x.size - nv
                 t[s.step_begin * blk:end] = x[s.step_begin * blk:end]
                 if nv:
@@ -152,6 +168,10 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
         for _ in range(2):            # twice: the second call must not overwrite rows another shard is still pulling
             md.cons_jac(xs, cs, vs, x_mode=mode, stitch=True, sync=False)
         md.sync()
+        if mode == md.X_SHARDED:          # read in place: nothing was copied into the shards' buffers
+            for k in range(3):
+                assert torch.isnan(xs[k]).any()
+                assert torch.isnan(xs[k][:md.shards[k].step_begin * blk]).all()
         v = torch.full_like(vf, 777.0)
         for k in range(3):
             assert torch.equal(cs[k], cf), (mode, k)                 # whole residual on every shard, bit for bit

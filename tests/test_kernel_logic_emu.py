@@ -87,6 +87,23 @@ def test_emulated_shards_compose_exactly(prob):
             assert np.array_equal(c, cf) and np.array_equal(v, vf)
 
 
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "quadrotor", "double_integrator_freet0tf", "double_integrator_path"])
+def test_emulated_sharded_iterate_read_in_place(prob):
+    """ctd_set_x_shards: every shard evaluates from a buffer that holds ONLY its own variables (NaN elsewhere); the next
+    shard's first node, the previous shard's last block, X_1 and X_{N+1} are read in place from the owners' buffers through
+    the XHalo table.  Bit-identical to the unsharded evaluation for every scheme, 2 / 3 / 5 shards (also one-step shards and
+    grids without a periodic part), both drivers."""
+    for sch in ct.SCHEMES:
+        for N, Gs in ((23, (2, 3, 5)), (4, (2, 4)), (7, (7,))):
+            d = ct.DOCP(prob, N, sch, device=-1, pattern="structural")
+            x = bench_inputs(describe(d, prob, sch), perturb=1e-3)
+            pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+            cf, vf = emu.cons_jac(pid, sid, 1, N, x, tile=4, nthr=64)
+            for G in Gs:
+                c, v = emu.cons_jac_sharded(pid, sid, 1, N, x, G, tile=3, nthr=64)
+                assert np.array_equal(c, cf) and np.array_equal(v, vf), (sch, N, G)
+
+
 @pytest.mark.parametrize("prob, sch", [("goddard", "gauss_legendre_3"), ("goddard_all", "trapeze"),
                                        ("double_integrator_freet0tf", "euler_implicit"),
                                        ("least_squares_with_constraint", "gauss_legendre_2_constant_control")])
