@@ -246,6 +246,13 @@ def _main(real_stdout):
     # the neighbours' entries read in place by the kernel (x_mode "peer"); outputs stay row-sharded: no
     # collective before or after the kernel.
     x_mode = "peer" if dist_on else None
+    peer_error = None
+    if dist_on and world > 1:
+        try:        # (raises on every rank together or on none: the ranks agree inside)
+            sh.enable_peer_x(x)
+        except RuntimeError as e:      # IPC mapping refused on this node: fall back to fetching the entries with one all-gather
+            peer_error = repr(e)[:300]
+            x_mode = "halo"
     el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), args.warmup, args.steps)
     region_ms = region["ms_per_launch"]
     per_step_value = (world if cfg["scaling"] == "weak" else 1)
@@ -254,7 +261,7 @@ def _main(real_stdout):
         # the rank's outputs from the sharded iterate (NaN outside what it owns) equal those from the whole iterate, bit for bit
         c_chk, v_chk = torch.zeros_like(c), torch.zeros_like(vals)
         sh.bind_cons_jac(x_full, c_chk, v_chk, stitch=False, x_mode=None)()
-        sh.bind_cons_jac(x, c, vals, stitch=False, x_mode="peer")()
+        sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode)()
         torch.cuda.synchronize(dev)
         r0, r1 = docp.shard.c_row_begin, docp.shard.c_row_end
         lo_, hi_ = docp.shard.vals_main_begin, docp.shard.vals_main_end
@@ -264,9 +271,11 @@ def _main(real_stdout):
         secondary["sharded_iterate_check"] = {"bit_identical_to_whole_iterate_on_every_rank": bool(same.item() == 1.0),
                                               "what": "each rank's c rows and CSC range from its NaN-padded shard of x vs from the whole x"}
         ks = max(1, min(args.steps, 500))
+        if peer_error:
+            secondary["peer_error"] = peer_error
         for key, kw, what in (
                 ("halo_allgather", dict(stitch=False, x_mode="halo"), "the neighbours' entries fetched with one all-gather (pack / all-gather / unpack) before the evaluation instead of read in place"),
-                ("stitched_c", dict(stitch=True, x_mode="peer"), "the timed step + all-gather of the row blocks of c (every rank ends with the whole c)"),
+                ("stitched_c", dict(stitch=True, x_mode=x_mode), "the timed step + all-gather of the row blocks of c (every rank ends with the whole c)"),
                 ("broadcast_x", dict(stitch=False, x_mode="broadcast"), "replicated iterate: rank 0 broadcasts all of x before the evaluation"),
                 ("no_exchange", dict(stitch=False, x_mode=None), "evaluation only, the whole x in place on every rank: what reading the neighbours' entries in place costs is the difference to the timed step")):
             try:      # a secondary figure must never cost the line
@@ -369,8 +378,11 @@ def _main(real_stdout):
             "config": {
                 "workload": f"{args.config}: {PROBLEM} / {SCHEME}, {shard_txt}; fused cons!+jac_coord! on HBM-resident x; "
                             + cfg["what"] + ("" if world == 1 else
-                                             "; timed step = shard evaluation on the sharded iterate, neighbours' entries read "
-                                             "in place by the kernel (no collective in the step), outputs row-sharded; value counts "
+                                             ("; timed step = shard evaluation on the sharded iterate, neighbours' entries read "
+                                              "in place by the kernel (no collective in the step), outputs row-sharded; value counts "
+                                              if x_mode == "peer" else
+                                              "; timed step = halo exchange of the sharded iterate (one all-gather; mapping the "
+                                              "neighbours' buffers failed on this node) + shard evaluation; value counts ")
                                              + ("one shard evaluation per GPU per step" if cfg["scaling"] == "weak"
                                                 else "one evaluation of the whole transcription per step")),
                 "nvar_per_gpu": one.dim_NLP_variables, "ncon_per_gpu": one.dim_NLP_constraints, "nnzj_per_gpu": one.nnzj,

@@ -586,7 +586,7 @@ static int build_tables(Model& mo, std::string& err) {
     const Layout& L = mo.L;
     const int64_t N = L.N;
     if (L.nv > kMaxNV) { err = "more than 4 optimisation variables are not supported by the emit tables"; return ST_EPATTERN; }
-    if (mo.R.stride >= 65536) { err = "per-step record too large for 16-bit data indices"; return ST_EPATTERN; }
+    if (mo.R.stride >= 65536 || mo.R.bsize >= 65536) { err = "per-step record too large for 16-bit data indices"; return ST_EPATTERN; }
     // halo of a tile: trapeze reads the next node and the previous step's coefficients; midpoint the previous step
     mo.HL = (L.sc == SC_IRK) ? 0 : 1;
     mo.HH = (L.sc == SC_TRAPEZE) ? 1 : 0;
@@ -763,7 +763,15 @@ int default_tile(const Model& mo, int64_t nsteps) {
     // larger ones; at most 8 steps (profiles/r02_tile_sweeps.log: 12-state quadrotor 7 steps 117 us vs 8 steps 122 us)
     // (one-point schemes of those OCPs have light emit phases: 16 steps -- 8-state quadrotor, trapeze, N = 20 000: 16.5 vs 20.7 us)
     const bool wide = mo.nch_dyn > 1;
-    if (wide) T = std::max<int64_t>(4, std::min<int64_t>(L.sc == SC_IRK ? 8 : 16, (52 * 1024) / per_step - mo.HL - mo.HH));
+    if (wide) {
+        // the largest tile that leaves three workgroups per CU (exact LDS accounting: 1280-byte granules)
+        T = L.sc == SC_IRK ? 8 : 16;
+        for (; T > 4; --T) {
+            KParams kp;
+            mo.fill_kparams(kp, 0, std::min<int64_t>(L.N, T * 4), (int)T);
+            if (wgs_per_cu(lds_doubles(kp) * 8) >= 3) break;
+        }
+    }
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
     if ((nsteps + T - 1) / T < 480) T = std::max<int64_t>(4, std::min<int64_t>(T, (nsteps + 479) / 480));
     // light steps on long grids (double integrator, midpoint, 100 000 steps: 152 bytes of output per step): ONE round of ~512
@@ -803,6 +811,15 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.edge_fp = edge_fp; kp.edge_b = edge_b;
     kp.edge_slot_first = edge_slot_first; kp.edge_slot_last = edge_slot_last;
     for (int k = 0; k < kMaxEdgeSlots; ++k) kp.edge_steps[k] = edge_steps[k];
+    // emit templates in LDS: short periods only, and never at the price of a resident workgroup (12-state quadrotor, optimized
+    // pattern: 2 KiB of codes pushed the 7-step tile from three workgroups per CU to two -- the LDS granule is 1280 bytes)
+    kp.stage_codes = (Lseg + L.nv * vr <= kMaxStagedCodes) ? 1 : 0;
+    if (kp.stage_codes) {
+        const int with = wgs_per_cu(lds_doubles(kp) * 8);
+        kp.stage_codes = 0;
+        const int without = wgs_per_cu(lds_doubles(kp) * 8);
+        kp.stage_codes = (without > with && with < 4) ? 0 : 1;
+    }
 }
 
 int build_model(const HostDesc& d, Model& mo, std::string& err) {

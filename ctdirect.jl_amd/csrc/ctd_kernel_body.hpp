@@ -41,12 +41,15 @@ namespace ctd {
 // and 1 after draining the wave's memory counters (so each segment is timed serialised: an upper bound of its share).
 // Words [grid * 12, grid * 28) of the ctd_debug_stamps buffer; never compiled into the shipped library.
 #if defined(CTD_SUBSTAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#ifndef CTD_SUB_WAVE0
+#define CTD_SUB_WAVE0 0          /* first of the two waves whose stamps are kept */
+#endif
 #define CTD_SUB(kp, id)                                                                                              \
     do {                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         __builtin_amdgcn_s_waitcnt(0);                                                                               \
-        if ((kp).stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 128)                                             \
-            (kp).stamps[(size_t)gridDim.x * 12 + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (id)] = clock64(); \
+        if ((kp).stamps && (threadIdx.x & 63) == 0 && threadIdx.x >= 64 * CTD_SUB_WAVE0 && threadIdx.x < 64 * CTD_SUB_WAVE0 + 128) \
+            (kp).stamps[(size_t)gridDim.x * 12 + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6) - CTD_SUB_WAVE0) * 8 + (id)] = clock64(); \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
 #else
@@ -81,7 +84,12 @@ CTD_HD const XHalo* block_halo(const KParams& kp, const BlockCtx& cx) {
 // doubles reserved at the start of the LDS for the emit templates (staged once per workgroup by load_codes)
 // (only small templates are staged: copying thousands of codes per workgroup costs more than the latency it hides)
 constexpr int kMaxStagedCodes = 1024;
-CTD_HD bool codes_staged(const KParams& kp) { return kp.Lseg + kp.L.nv * kp.vr <= kMaxStagedCodes; }
+CTD_HD bool codes_staged(const KParams& kp) { return kp.stage_codes != 0; }
+// LDS is handed out in granules of 320 dwords on gfx950 (160 KiB per CU): workgroups of `lds_bytes` that fit one CU
+inline int wgs_per_cu(int64_t lds_bytes) {
+    const int64_t g = (lds_bytes + 1279) / 1280 * 1280;
+    return g > 0 ? (int)((160 * 1024) / g) : 32;
+}
 CTD_HD int code_doubles(const KParams& kp) { return codes_staged(kp) ? (kp.Lseg + kp.L.nv * kp.vr + 1) / 2 : 0; }
 
 CTD_HD int64_t slot_index(const KParams& kp, const BlockCtx& cx, int k) {
@@ -197,7 +205,7 @@ inline int64_t lds_doubles(const KParams& kp) {
     const int64_t cap = kp.T + kp.HL + kp.HH;
     int64_t tile = code_doubles(kp) + (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
     int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * edge_in_stride(L) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
-                   (int64_t)(kp.n_edge_slots + 2) * kp.R.stride;
+                   (int64_t)(kp.n_edge_slots + 1) * kp.R.stride + kp.R.bsize;      // step slots, final-path record, boundary record
     return tile > edge ? tile : edge;
 }
 
@@ -341,15 +349,17 @@ template <class P> CTD_HD void fill_const_coefs(const KParams& kp, double* C) {
 }
 
 // per-record coefficients + (IRK) the state-equation rows, which depend on the inputs only
+// `row` < 0: the whole lead role of slot k; `row` = r >= 0 (Gauss-Legendre schemes, wide states): state row r only, the
+// coefficients with row 0 -- one lane per (step, row) instead of a serial walk over the n rows
 template <class P, int SC, int S>
-CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
+CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k, int row = -1) {
     constexpr int n = P::NX, nv = P::NV;
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int64_t i = slot_index(kp, cx, k);
     double* rec = cx.rec + k * R.stride;
     double* C = rec + R.oC;
-    fill_const_coefs<P>(kp, C);
+    if (row <= 0) fill_const_coefs<P>(kp, C);
     if (i < 0 || i >= L.N) return;
     const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     const double h = time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0);
@@ -357,11 +367,26 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k) {
         const double* base = slot_base(kp, cx, k);
         const double* nxt = slot_next(kp, cx, k);
         const double* K = base + n + L.cu;
+        if (row <= 0) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
+            for (int j = 0; j < S; ++j) {
 #pragma unroll
-            for (int l = 0; l < S; ++l) C[C_HA + 3 * j + l] = -(h * L.a[3 * j + l]);
-            C[C_HB + j] = -(h * L.b[j]);
+                for (int l = 0; l < S; ++l) C[C_HA + 3 * j + l] = -(h * L.a[3 * j + l]);
+                C[C_HB + j] = -(h * L.b[j]);
+            }
+        }
+        if (row >= 0) {          // one state row, r a runtime value (addresses only)
+            const int r = row;
+            double sumbk = L.b[0] * K[r];
+#pragma unroll
+            for (int j = 1; j < S; ++j) sumbk = sumbk + L.b[j] * K[j * n + r];
+            rec[R.oR + r] = nxt[r] - (base[r] + h * sumbk);
+#pragma unroll
+            for (int kk = 0; kk < nv; ++kk) {
+                const double dh = Dirs<P>::FREE ? dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk) : 0.0;
+                rec[R.oSv + r * nv + kk] = -(dh * sumbk);
+            }
+            return;
         }
         // state rows: X_{i+1} - (X_i + h sum_j b_j K^j)   (irk_stagewise.jl:456-457, irk.jl:304-306)
 #pragma unroll
@@ -890,6 +915,26 @@ template <class P, int SC> struct RegEval {
     static constexpr bool value = DirectTile<P, SC>::value && (P::NX * (P::NX + P::NU + P::NV + 2) <= 64);
 };
 
+// Wide OCPs: the symbolic code of one evaluation point is long (12 states: ~1300 instructions) and only S * ns lanes would run
+// it.  It comes split by rows into NCH_DYN parts: part q of every point runs in wave q (uniform code per wave, the parts side by
+// side on different SIMDs); the path passes and the lead role (per-step coefficients, state rows: inputs only) take the next
+// lanes of the same waves, so the fin phase that follows is ONE pass of one task per lane.
+template <class P, int SC, int S>
+CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
+#ifdef CTD_NO_SPLIT
+    return false;
+#else
+    // (four parts and more: measured +2 % for the 12-state quadrotor, -4 % for the 8-state one with three, profiles/r02_tile_sweeps.log)
+    constexpr bool ok = SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !Dirs<P>::FUSED;
+    constexpr int NP = Dirs<P>::NCH_DYN;
+    constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+    // lanes of a wave: S ns dynamics points | ns path points | lead tasks (Gauss-Legendre: (step, state row) tasks dealt round
+    // robin over the NP waves; one-point schemes: one cheap task per step on the last wave)
+    const int lead = SC == SC_IRK ? (cx.nslots * P::NX + NP - 1) / NP : cx.nslots;
+    return ok && !cx.is_edge && S * cx.nslots + cx.nslots + lead <= 64 && r_path <= NP && NP * 64 <= nthr;
+#endif
+}
+
 template <class P, int SC, int S, bool REG = false>
 CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     constexpr bool FUSED = Dirs<P>::FUSED;
@@ -956,29 +1001,37 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
     // passes, one lead role (coefficients + state rows, fused mode).
     CTD_SUB(kp, 0);
-#ifndef CTD_NO_SPLIT
-    // (four parts and more: measured +2 % for the 12-state quadrotor, -4 % for the 8-state one with three, profiles/r02_tile_sweeps.log)
     if constexpr (SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !FUSED) {
-        // Wide OCPs: the symbolic code of one evaluation point is long (12 states: ~1300 instructions) and only S * ns lanes
-        // would run it.  It comes split by rows into NCH_DYN parts: part q of every point runs in wave q (uniform code per
-        // wave, the parts side by side on different SIMDs); the path passes take lanes 32.. of the same waves.
-        constexpr int NP = Dirs<P>::NCH_DYN;
-        const int nd = S * ns;
-        if (nd <= 32 && ns <= 32 && r_path <= NP && NP * 64 <= nthr) {
+        if (split_eval<P, SC, S>(cx, nthr)) {
+            constexpr int NP = Dirs<P>::NCH_DYN;
+            const int nd = S * ns;
             const int wave = tid >> 6, l = tid & 63;
             if (wave < NP) {
                 if (l < nd) {
                     const int j = l / ns, k = l - j * ns;
                     eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
-                } else if (l >= 32 && l < 32 + ns && wave < r_path) {
-                    eval_step_path<P, SC, S>(kp, cx, l - 32, wave);
                 }
+                CTD_SUB(kp, 2);
+                if (l >= nd && l < nd + ns) {
+                    // symbolic path rows: ONE pass per point (chunk 0), on the wave whose part of the dynamics is the lightest
+                    // (part 1 of the 12-state quadrotor: 4100 cycles against 5100; the pass costs 3000); forward duals: chunk q on wave q
+                    constexpr int PW = NP > 1 ? 1 : 0;
+                    if (SymPath<P>::value ? wave == PW : wave < r_path) eval_step_path<P, SC, S>(kp, cx, l - nd, SymPath<P>::value ? 0 : wave);
+                }
+                CTD_SUB(kp, 3);
+                if (SC == SC_IRK) {       // lead role by (step, state row): task t = wave, wave + NP, ... on lane nd + ns + t / NP
+                    const int t = (l - nd - ns) * NP + wave;
+                    if (l >= nd + ns && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
+                } else if (l >= nd + ns && l < nd + 2 * ns && wave == NP - 1) {
+                    fin_lead<P, SC, S>(kp, cx, l - nd - ns);
+                }
+                CTD_SUB(kp, 4);
             }
             for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
+            CTD_SUB(kp, 5);
             return;
         }
     }
-#endif
     const int lg = ns <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ns - 1));
     const int mask = (1 << lg) - 1;
     const int total = (r_dyn + r_path + r_lead) << lg;
@@ -1029,7 +1082,10 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
     constexpr int rows = (SC == SC_IRK && P::NX > 4) ? P::NX : 1;    // rows of a stage per lane: 1 row each for wide states
-    const int n_stage = S * ns * rows, n_lead = ns, n_path = (P::NPATH > 0) ? ns : 0;
+    // after a split evaluation the lead role is done, and the path rows' total d/dv rides with the first stage task of its step:
+    // 12-state quadrotor, 7 steps x 3 stages x 12 rows = 252 tasks: one pass of 256 lanes (266 tasks before: two)
+    const bool split = split_eval<P, SC, S>(cx, nthr);
+    const int n_stage = S * ns * rows, n_lead = split ? 0 : ns, n_path = (P::NPATH > 0 && !split) ? ns : 0;
     const int n_fp = (cx.is_edge && P::NPATH > 0) ? 1 : 0;
     for (int task = tid; task < n_stage + n_lead + n_path + n_fp; task += nthr) {
         int t = task;
@@ -1037,6 +1093,10 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
             const int k = t % ns, jr = t / ns;
             if (rows > 1) fin_stage_row<P, S>(kp, cx, k, jr / rows, jr % rows);
             else fin_stage<P, SC, S>(kp, cx, k, jr, cx.rec + k * R.stride + R.oEval + jr * R.eval_sz);
+            if (split && P::NPATH > 0 && jr == 0) {
+                const int64_t i = slot_index(kp, cx, k);
+                if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + k * R.stride, slot_tau(kp, cx, k, 0));
+            }
             continue;
         }
         t -= n_stage;
@@ -1153,12 +1213,30 @@ CTD_HD void emit_stream(const RecLayout R, const BlockCtx& cx, double* out, int 
 
 // The codes a lane needs in phase_emit when it owns ONE position of each period (period <= workgroup size): read from the
 // global tables before the evaluation starts, so their latency hides behind it and the emission starts from registers.
-struct EmitPre { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; };     // edge block: b = the code of edge entry `tid`, eidx its index
-template <class P>
-CTD_HD EmitPre emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
-    EmitPre pre;
+// NB > 1 (long periods, e.g. 2904 codes per step for the 12-state quadrotor on Gauss-Legendre 3): more[q] = the code of position
+// tid + (q + 1) nthr -- ALL the positions a lane walks, fetched before the evaluation.  Read one position ahead inside the emit
+// loop instead, every code load queued behind the workgroups' own stores (microseconds under a full store queue): the emit phase
+// of that kernel was bound by those dependent loads, not by bandwidth.
+template <int NB> struct EmitPreT { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; uint32_t more[NB > 1 ? NB - 1 : 1]; };
+using EmitPre = EmitPreT<1>;     // edge block: b = the code of edge entry `tid`, eidx its index
+// upper bound of the CSC period of (OCP, scheme class, stages) -- the reference's dense-block patterns (Appendix A.4 of SURVEY.md)
+// -- in units of 256 positions: the codes a lane of a 256-lane workgroup may have to hold
+template <class P, int SC, int S> struct EmitN {
+    static constexpr int n = P::NX, m = P::NU, nv = P::NV, p = P::NPATH, s = SC == SC_IRK ? S : 0;
+    static constexpr int seg = SC == SC_IRK ? n * (2 * n + s * n + nv) + s * n * (n + s * m + s * n + nv) + p * (n + s * m + nv)
+                                            : n * (2 * n + 2 * m + nv) + p * (n + 2 * m + nv);
+#ifndef CTD_PRE_MAX
+#define CTD_PRE_MAX 1      /* measured on MI355X: holding all codes of a long period in registers is SLOWER (12-state quadrotor, Gauss-Legendre 3: +7 %) */
+#endif
+    static constexpr int value = (seg + 255) / 256 < 1 ? 1 : ((seg + 255) / 256 > CTD_PRE_MAX ? CTD_PRE_MAX : (seg + 255) / 256);
+};
+template <class P, int NB = 1>
+CTD_HD EmitPreT<NB> emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+    EmitPreT<NB> pre;
     pre.b = 0u;
     pre.eidx = 0;
+#pragma unroll
+    for (int q = 0; q < (NB > 1 ? NB - 1 : 1); ++q) pre.more[q] = 0u;
 #pragma unroll
     for (int kk = 0; kk < kMaxNV; ++kk) pre.v[kk] = 0u;
     if (cx.is_edge) {
@@ -1176,6 +1254,11 @@ CTD_HD EmitPre emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int
         pre.b = kp.tmpl[k];
     } else if (Ls > nthr) {
         pre.b = kp.tmpl[tid];              // first of the positions tid, tid + nthr, ... this lane owns
+        if constexpr (NB > 1) {
+#pragma unroll
+            for (int q = 0; q < NB - 1; ++q)
+                if (tid + (q + 1) * nthr < Ls) pre.more[q] = kp.tmpl[tid + (q + 1) * nthr];
+        }
     }
     const int vr = kp.vr;
 #pragma unroll
@@ -1188,8 +1271,8 @@ CTD_HD EmitPre emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid, int
     return pre;
 }
 
-template <class P, int SC, int S>
-CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPre* pre = nullptr) {
+template <class P, int SC, int S, int NB = 1>
+CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPreT<NB>* pre = nullptr) {
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
     if (cx.is_edge) {
@@ -1299,8 +1382,19 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                 // position is fetched while the current one is streamed out (the table is read from global memory / L2 here:
                 // a dependent load at the top of every position would expose its latency a dozen times per tile)
                 uint32_t code = (pre && tid < Ls) ? pre->b : (tid < Ls ? cx.codes[tid] : 0u);
-                for (int k = tid; k < Ls; k += nthr) {
-                    const uint32_t nxt = k + nthr < Ls ? cx.codes[k + nthr] : 0u;
+                int q = 0;
+                for (int k = tid; k < Ls; k += nthr, ++q) {
+                    uint32_t nxt = 0u;
+                    bool have = false;
+                    if constexpr (NB > 1) {              // codes fetched before the evaluation (register array: constant indices)
+                        if (pre && q < NB - 1) {
+                            have = true;
+#pragma unroll
+                            for (int e = 0; e < NB - 1; ++e)
+                                if (e == q) nxt = pre->more[e];
+                        }
+                    }
+                    if (!have) nxt = k + nthr < Ls ? cx.codes[k + nthr] : 0u;
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);

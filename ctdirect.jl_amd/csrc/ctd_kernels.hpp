@@ -75,10 +75,11 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         return;
     }
     const BlockCtx cx = make_ctx(kp, block, ctd_lds);
-    // codes not staged in LDS (long periods): the lane's first code is fetched now, its latency hidden behind load + eval
-    EmitPre pre;
+    // codes not staged in LDS (long periods): every code the lane will need is fetched now, the latency hidden behind load + eval
+    constexpr int NB = EmitN<P, SC, S>::value;
+    EmitPreT<NB> pre;
     const bool use_pre = !cx.is_edge && !codes_staged(kp);
-    if (use_pre) pre = emit_prefetch<P>(kp, cx, tid, nthr);
+    if (use_pre) pre = emit_prefetch<P, NB>(kp, cx, tid, nthr);
     phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
     __syncthreads();
     ctd_stamp<DBG>(kp, 1);
@@ -97,7 +98,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
     }
     ctd_stamp<DBG>(kp, 3);
     if (DBG && kp.debug_stop == 4) return;
-    phase_emit<P, SC, S>(kp, cx, tid, nthr, use_pre ? &pre : nullptr);
+    phase_emit<P, SC, S, NB>(kp, cx, tid, nthr, use_pre ? &pre : nullptr);
     ctd_stamp<DBG>(kp, 4);
     if (DBG && kp.stamps) {      // diagnostics: time until this workgroup's stores have left the CU
         __builtin_amdgcn_s_waitcnt(0);

@@ -66,14 +66,17 @@ CTD_HD int edge_in_stride(const Layout& L) { return L.blk + L.n + 2 * L.m; }
 
 // ---- per-step LDS record (doubles) -------------------------------------------------------------------
 // [0] = 1.0
+// C[kNC]     per-step coefficients the emit codes multiply with (same offset in every kind of record)
 // S eval blocks (S = max(s,1)), each: F[n*n] G[n*m] W[n*nv] f[n] ft[n]
 //     F = df/dx, G = df/du at the eval point, W = total d f/d v (explicit + through time and x_ij), f = value,
 //     ft = df/dt (scratch)
 // Sv[n*nv]   d(state-equation row)/dv
 // Px[p*n] Pu[p*m] Pv[p*nv] Pt[p]   path-constraint Jacobian at the node (Pv total, Pt scratch)
 // R[cb]      constraint values of the step (c rows)
-// C[kNC]     per-step coefficients the emit codes multiply with
-// The final-path record (FP) uses the P* fields and R[0..p); the boundary record (B) uses its own fields below.
+// The final-path record (FP) uses the P* fields and R[0..p); the boundary record (B) uses its own fields below.  It is the
+// LAST record of the edge block and has a size of its own (bsize): an OCP with many boundary rows (12-state quadrotor: 23 rows
+// x 2 x 13 doubles) must not inflate the stride of every step record -- tiles of the one-point schemes held 8 steps where 17
+// fit.
 constexpr int kNC = 18;
 enum { C_ZERO = 0, C_ONE = 1, C_NEG1 = 2, C_HA = 3 /* -h a_jl at 3+3j+l */, C_HB = 12 /* -h b_j */, C_B = 15 /* b_j */,
        C_NHH = 3 /* -h/2 (trapeze, midpoint) */, C_NH = 4 /* -h (midpoint) */ };
@@ -87,7 +90,8 @@ struct RecLayout {
     int32_t oEval;                        // first eval block
     int32_t oSv, oPx, oPu, oPv, oPt, oR, oC;
     int32_t oB0, oBf, oBv, oBval;         // boundary record
-    int32_t stride;
+    int32_t stride;                       // doubles per step / node / final-path record
+    int32_t bsize;                        // doubles of the boundary record (>= stride)
 };
 
 constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
@@ -96,7 +100,8 @@ constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, 
     r.ldx = n | 1; r.ldu = m | 1;
     r.oF = 0; r.oG = n * r.ldx; r.oW = r.oG + n * r.ldu; r.of = r.oW + n * nv; r.oft = r.of + n;
     r.eval_sz = r.oft + n;
-    r.oEval = 1;
+    r.oC = 1;
+    r.oEval = 1 + kNC;
     r.oSv = r.oEval + r.S * r.eval_sz;
     r.oPx = r.oSv + n * nv;
     r.oPu = r.oPx + p * r.ldx;
@@ -104,12 +109,11 @@ constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, 
     r.oPt = r.oPv + p * nv;
     r.oR = r.oPt + p;
     int end_step = r.oR + cb;
-    r.oB0 = 1; r.oBf = r.oB0 + bc * r.ldx; r.oBv = r.oBf + bc * r.ldx; r.oBval = r.oBv + bc * nv;
+    r.oB0 = 1 + kNC; r.oBf = r.oB0 + bc * r.ldx; r.oBv = r.oBf + bc * r.ldx; r.oBval = r.oBv + bc * nv;
     int end_b = r.oBval + bc;
-    int body = end_step > end_b ? end_step : end_b;
-    r.oC = body;
-    r.stride = body + kNC;
+    r.stride = end_step;
     if ((r.stride & 1) == 0) r.stride += 1;     // odd stride: lanes that index consecutive records spread over LDS banks
+    r.bsize = end_b > r.stride ? end_b : r.stride;
     return r;
 }
 
@@ -200,6 +204,7 @@ struct KParams {
     // diagnostics only (env CTD_DEBUG_STOP): 0 = normal; k > 0: every workgroup returns after phase k (1 nothing, 2 load,
     // 3 eval, 4 fin) -- ablation timing, outputs are then incomplete
     int32_t debug_stop;
+    int32_t stage_codes;        // the emit templates are copied to LDS once per workgroup (short periods that cost no occupancy)
     // sharded iterate read in place: where the other shards' variables live (device table), or null: xu holds everything
     // this shard reads
     const XHalo* halo;

@@ -252,29 +252,43 @@ class ShardedDOCP:
         dev = x.device.index
         hbuf = (C.c_ubyte * 64)()
         off = C.c_int64()
+        # Every rank goes through the same collectives whatever fails locally (a rank that raised early would leave the
+        # others waiting): errors are collected, agreed on with one all-reduce, and raised on EVERY rank together.
+        err = None
         st = L.ctd_ipc_export(dev, C.c_void_p(x.data_ptr()), hbuf, C.byref(off))
         if st:
-            raise RuntimeError("ctd_ipc_export: " + L.ctd_last_error(None).decode())
-        mine = (bytes(hbuf), int(off.value), os.getpid(), int(x.data_ptr()))
+            err = "ctd_ipc_export: " + L.ctd_last_error(None).decode()
+        mine = (bytes(hbuf), int(off.value), os.getpid(), int(x.data_ptr()), err is None)
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
-        ptrs = []
-        for r, (hb, o, pid, raw) in enumerate(everyone):
-            if r == self.rank:
-                ptrs.append(0)
-            elif pid == os.getpid():          # same process (several ranks of a test harness): the pointer is valid as it is
-                ptrs.append(raw)
-            else:
-                base = C.c_void_p()
-                st = L.ctd_ipc_open(dev, (C.c_ubyte * 64).from_buffer_copy(hb), C.byref(base))
-                if st:
-                    raise RuntimeError("ctd_ipc_open: " + L.ctd_last_error(None).decode())
-                self._ipc_bases.append((dev, base.value))
-                ptrs.append(base.value + o)
+        ptrs, opened = [], []
+        if all(e[4] for e in everyone):
+            for r, (hb, o, pid, raw, _) in enumerate(everyone):
+                if r == self.rank:
+                    ptrs.append(0)
+                elif pid == os.getpid():      # same process (several ranks of a test harness): the pointer is valid as it is
+                    ptrs.append(raw)
+                else:
+                    base = C.c_void_p()
+                    st = L.ctd_ipc_open(dev, (C.c_ubyte * 64).from_buffer_copy(hb), C.byref(base))
+                    if st:
+                        err = f"ctd_ipc_open (rank {r}'s buffer): " + L.ctd_last_error(None).decode()
+                        break
+                    opened.append((dev, base.value))
+                    ptrs.append(base.value + o)
+        elif err is None:
+            err = "another rank could not export its buffer"
+        flat = str(dist.get_backend(self.group)).lower() in ("nccl", "rccl")
+        ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=x.device if flat else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)     # also: every rank has mapped the others before anyone evaluates
+        if ok.item() != 1.0:
+            for d_, b_ in opened:
+                L.ctd_ipc_close(d_, b_)
+            raise RuntimeError("enable_peer_x: " + (err or "another rank could not map the buffers"))
+        self._ipc_bases += opened
         self.docp.set_x_shards(begins, ptrs, self.rank)
         self._peer_tables[x.data_ptr()] = ptrs
         self._peer = x.data_ptr()
-        dist.barrier(group=self.group)        # every rank has mapped the others before anyone evaluates (or frees)
         return x
 
     def broadcast_iterate(self, x, src=0):

@@ -41,11 +41,16 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
             continue;
         }
         BlockCtx cx = make_ctx(kp, b, lds.data());
+        constexpr int NB = EmitN<P, SC, S>::value;          // (as cons_jac_body: codes of long periods prefetched per lane)
+        std::vector<EmitPreT<NB>> pre(nthr);
+        const bool use_pre = !cx.is_edge && !codes_staged(kp);
+        if (use_pre)
+            for (int t = 0; t < nthr; ++t) pre[t] = emit_prefetch<P, NB>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_load<P, SC, S>(kp, cx, xu, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_fin2<P, SC, S>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S, NB>(kp, cx, t, nthr, use_pre ? &pre[t] : nullptr);
     }
 }
 
