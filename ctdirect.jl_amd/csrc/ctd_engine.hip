@@ -126,6 +126,9 @@ struct ctd_handle {
     // sharded iterate read in place (ctd_set_x_shards): device table of the other shards' buffers, host copy of what it holds
     XHalo* d_halo = nullptr;
     XHalo halo_host{};
+    // ctd_stitch_c: padded send block and gathered blocks
+    double *d_stitch_send = nullptr, *d_stitch_recv = nullptr;
+    int64_t stitch_cap = 0;
     std::string err;
 };
 
@@ -160,6 +163,7 @@ struct DeviceGuard {
 };
 
 template <class T> static hipError_t upload(T** dst, const std::vector<T>& src) {
+    if (*dst) { (void)hipFree(*dst); }       // idempotent: a retry after a partial failure (ensure_hess) replaces, never leaks
     *dst = nullptr;
     if (src.empty()) return hipSuccess;
     hipError_t e = hipMalloc((void**)dst, src.size() * sizeof(T));
@@ -180,7 +184,7 @@ static void free_device(ctd_handle* h) {
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
-                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hssrc, (void*)h->d_hschunk, (void*)h->d_hsck, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals, (void*)h->d_halo})
+                    (void*)h->d_hptasks, (void*)h->d_hbtasks, (void*)h->d_hpair_c, (void*)h->d_hcpos, (void*)h->d_hzpos, (void*)h->d_hssrc, (void*)h->d_hschunk, (void*)h->d_hsck, (void*)h->d_hpartials, (void*)h->d_y, (void*)h->d_hvals, (void*)h->d_halo, (void*)h->d_stitch_send, (void*)h->d_stitch_recv})
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -596,6 +600,90 @@ int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_be
     HIP_TRY(h, hipMemcpy(h->d_halo, &t, sizeof(XHalo), hipMemcpyHostToDevice));
     h->halo_host = t;
     h->kp.halo = h->d_halo;
+    return CTD_OK;
+}
+
+// ---- the stitched constraint vector for one-process-per-GPU hosts: RCCL all-gather inside the library --------------------
+// RCCL is reached through the copy of librccl the host process already has (a Julia / Python host created the communicator
+// with it): resolved with dlopen at first use, no link-time dependency.  CTD_RCCL_LIB names the library explicitly.
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+nccl_allgather_fn g_nccl_allgather = nullptr;
+nccl_errstr_fn g_nccl_errstr = nullptr;
+std::once_flag g_nccl_once;
+void nccl_resolve() {
+    std::call_once(g_nccl_once, [] {
+        void* lib = nullptr;
+        if (const char* p = std::getenv("CTD_RCCL_LIB")) lib = dlopen(p, RTLD_NOW);
+        for (const char* nm : {"librccl.so.1", "librccl.so"})            // the copy already in the process, whoever loaded it
+            if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if (!lib) lib = dlopen(nm, RTLD_NOW);
+        if (!lib) return;
+        g_nccl_allgather = (nccl_allgather_fn)dlsym(lib, "ncclAllGather");
+        g_nccl_errstr = (nccl_errstr_fn)dlsym(lib, "ncclGetErrorString");
+    });
+}
+__global__ void stitch_pack_kernel(const double* __restrict__ c, double* __restrict__ send, int64_t row0, int64_t own, int64_t tail0, int64_t tail) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < own) send[e] = c[row0 + e];
+    else if (e < own + tail) send[e] = c[tail0 + (e - own)];
+}
+__global__ void stitch_unpack_kernel(const double* __restrict__ recv, double* __restrict__ c, int64_t ncon, int64_t N, int cb, int G, int64_t smax) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < ncon) c[r] = recv[stitch_src(r, N, cb, G, smax)];
+}
+}  // namespace
+
+int32_t ctd_shard_steps(int64_t N, int32_t n_shards, int32_t k, int64_t* begin, int64_t* end) {
+    if (N < 1 || n_shards < 1 || n_shards > N || k < 0 || k >= n_shards || !begin || !end) return CTD_EINVAL;
+    *begin = shard_begin(N, n_shards, k);
+    *end = k + 1 == n_shards ? N : shard_begin(N, n_shards, k + 1);
+    return CTD_OK;
+}
+
+int32_t ctd_stitch_c(ctd_handle* h, void* nccl_comm, int32_t n_ranks, int32_t rank, double* c_dev) {
+    if (!h) return CTD_EINVAL;
+    if (h->device < 0) return fail(h, CTD_ENODEVICE, "host-only handle");
+    if (!nccl_comm || !c_dev || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, CTD_EINVAL, "ctd_stitch_c: bad argument");
+    const Layout& L = h->model.L;
+    const int64_t N = L.N;
+    const int G = n_ranks;
+    if (G > N || h->step_begin != shard_begin(N, G, rank) || h->step_end != (rank + 1 == G ? N : shard_begin(N, G, rank + 1)))
+        return fail(h, CTD_EINVAL, "ctd_stitch_c: the handle's shard is not block `rank` of the balanced split of the grid over n_ranks (ctd_shard_steps)");
+    nccl_resolve();
+    if (!g_nccl_allgather) return fail(h, CTD_ERCCL, "ctd_stitch_c: librccl (ncclAllGather) not found in this process; set CTD_RCCL_LIB");
+    DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
+    const int64_t tail = L.ncon - N * L.cb;
+    auto check = [&](int rc, const char* what) -> int32_t {
+        if (rc == 0) return CTD_OK;
+        return fail(h, CTD_ERCCL, std::string(what) + ": " + (g_nccl_errstr ? g_nccl_errstr(rc) : "RCCL error ") + " (" + std::to_string(rc) + ")");
+    };
+    constexpr int kNcclDouble = 8;       // ncclFloat64
+    if (N % G == 0 && tail == 0) {       // equal blocks, nothing after them: gathered in place
+        const int64_t S = (N / G) * L.cb;
+        return check(g_nccl_allgather(c_dev + rank * S, c_dev, (size_t)S, kNcclDouble, nccl_comm, h->stream), "ncclAllGather");
+    }
+    const int64_t smax = ((N + G - 1) / G) * L.cb + tail;
+    if (h->stitch_cap < (int64_t)G * smax) {
+        if (h->d_stitch_send) (void)hipFree(h->d_stitch_send);
+        if (h->d_stitch_recv) (void)hipFree(h->d_stitch_recv);
+        h->d_stitch_send = h->d_stitch_recv = nullptr;
+        h->stitch_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->d_stitch_send, sizeof(double) * smax));
+        HIP_TRY(h, hipMalloc((void**)&h->d_stitch_recv, sizeof(double) * G * smax));
+        HIP_TRY(h, hipMemsetAsync(h->d_stitch_send, 0, sizeof(double) * smax, h->stream));
+        h->stitch_cap = (int64_t)G * smax;
+    }
+    const int64_t own = (h->step_end - h->step_begin) * L.cb, mytail = rank + 1 == G ? tail : 0;
+    const int64_t np = own + mytail;
+    stitch_pack_kernel<<<(unsigned)((np + 255) / 256), 256, 0, h->stream>>>(c_dev, h->d_stitch_send, h->step_begin * L.cb, own, N * L.cb, mytail);
+    HIP_TRY(h, hipGetLastError());
+    const int32_t st = check(g_nccl_allgather(h->d_stitch_send, h->d_stitch_recv, (size_t)smax, kNcclDouble, nccl_comm, h->stream), "ncclAllGather");
+    if (st) return st;
+    stitch_unpack_kernel<<<(unsigned)((L.ncon + 255) / 256), 256, 0, h->stream>>>(h->d_stitch_recv, c_dev, L.ncon, N, L.cb, G, smax);
+    HIP_TRY(h, hipGetLastError());
     return CTD_OK;
 }
 
@@ -1025,6 +1113,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     }
     const int step_wgs = h->hess_step ? (int)((h->hp.step_end - h->hp.step_begin + kStepBlock - 1) / kStepBlock) : 0;
     const int edge_step = 32;      // (upper bound of the edge workgroups of the step launch)
+    if (h->d_hpartials) { (void)hipFree(h->d_hpartials); h->d_hpartials = nullptr; }
     HIP_TRY(h, hipMalloc((void**)&h->d_hpartials, sizeof(double) * (size_t)(std::max(h->hp.ntiles, step_wgs) + std::max(h->hp.n_edge_blocks, edge_step)) *
                                                        (H.nvv > 0 ? H.nvv : 1)));
     HParams& hp = h->hp;

@@ -862,8 +862,6 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
     build_bounds(mo);
     build_tail_blocks(mo);
     compute_dep_masks(mo);          // operator-level dependence masks: the OPTIMIZED pattern, and the count of dropped nonzeros
-    if (mo.pattern_mode == 2) {
-    }
     st = build_tables(mo, err);
     if (st) return st;
     return build_hess_model(mo, err);

@@ -155,6 +155,26 @@ struct XHalo {
     int64_t vbegin[kMaxShards + 1];    // shard k owns the variables [vbegin[k], vbegin[k+1]); vbegin[G] = v_off (v is replicated)
     const double* x[kMaxShards];       // full-length iterate buffer of shard k (entry `self` is not used: the kernel's own xu)
 };
+// Balanced split of N steps over G shards (the rule of ctd_create_sharded, ctd_shard_steps, dist.shard_steps): the first N % G
+// shards hold one step more.  shard_of_step inverts it.
+CTD_HD int64_t shard_begin(int64_t N, int G, int k) { const int64_t base = N / G, rem = N % G; return k * base + (k < rem ? k : rem); }
+CTD_HD int shard_of_step(int64_t N, int G, int64_t step) {
+    const int64_t base = N / G, rem = N % G, cut = rem * (base + 1);
+    return step < cut ? (int)(step / (base + 1)) : (int)(rem + (step - cut) / base);
+}
+// Stitching the constraint vector (ctd_stitch_c): every rank sends its row block padded to `smax` = the longest block + the p + bc
+// tail rows; position of global row r inside the gathered buffer [G][smax] (the tail rows come from the LAST rank: the only one
+// that holds everything they read when the iterate is sharded)
+CTD_HD int64_t stitch_src(int64_t r, int64_t N, int cb, int G, int64_t smax) {
+    if (r < N * cb) {
+        const int64_t step = r / cb;
+        const int k = shard_of_step(N, G, step);
+        return k * smax + (step - shard_begin(N, G, k)) * cb + (r - step * cb);
+    }
+    const int64_t last_rows = (N - shard_begin(N, G, G - 1)) * cb;
+    return (int64_t)(G - 1) * smax + last_rows + (r - N * cb);
+}
+
 // buffer that holds variable g
 CTD_HD const double* xsrc(const XHalo* hl, const double* xu, int64_t g) {
     const int G = hl->G;

@@ -363,6 +363,13 @@ class DOCP:
         arr = (C.c_void_p * G)(*[int(p) if p else None for p in x_ptrs])
         self._ck(L.ctd_set_x_shards(self._h, G, _ip(sb), arr, int(self_index)))
 
+    def stitch_c(self, comm, n_ranks, rank, c):
+        """`ctd_stitch_c`: all-gather of the row blocks of the device tensor c over the ncclComm_t `comm` (an integer / c_void_p:
+        the host's RCCL communicator), inside the library -- the one-process-per-GPU route that needs no torch.distributed."""
+        self._ck(_lib.lib().ctd_stitch_c(self._h, C.c_void_p(int(comm)), int(n_ranks), int(rank),
+                                         self._dev_ptr(c, self.dim_NLP_constraints, "c")))
+        return c
+
     def cons(self, x, c=None):
         """cons!(nlp, x, c) = __constraints!(c, x, docp); returns c (the reference's closure must return c too)."""
         L = _lib.lib()

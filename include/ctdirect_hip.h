@@ -366,6 +366,17 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
  * handle's stream) when an evaluation is enqueued -- the acceptance test of a solver iteration is a collective already.
  * (Objective, gradient and Hessian callbacks read the x they are given: use CTD_X_SHARDED_COPY / an exchange for those.) */
 int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self);
+/* One process per GPU (e.g. a Julia host under MPI): the "RCCL all-gather over xGMI for the stitched constraint vector" of the
+ * north star, inside the library.  comm is an ncclComm_t of n_ranks ranks created by the host with ITS copy of librccl (found
+ * with dlopen at first use; no link-time dependency; CTD_RCCL_LIB overrides); rank r evaluates block r of the balanced split
+ * (ctd_shard_steps gives the [begin, end) to put into ctd_desc).  c_dev is the full-length constraint vector in which this
+ * rank's rows are already written (ctd_cons_jac_dev_async); on return of the stream every rank holds all N cb step rows, and the
+ * p + bc tail rows as computed by the LAST rank.  Equal blocks without tail rows: ONE in-place ncclAllGather; otherwise padded
+ * blocks + one index kernel.  Enqueue-only on the handle's stream.  A failing collective returns CTD_ERCCL. */
+int32_t ctd_stitch_c(ctd_handle* h, void* nccl_comm, int32_t n_ranks, int32_t rank, double* c_dev);
+/* block k of the balanced split of N steps over n_shards (the first N % n_shards blocks hold one step more) */
+int32_t ctd_shard_steps(int64_t N, int32_t n_shards, int32_t k, int64_t* begin, int64_t* end);
+
 /* One process per GPU: export a device buffer (any pointer inside a hipMalloc'ed allocation, e.g. a tensor of a caching
  * allocator: `handle64` names the allocation, `offset` the pointer's byte offset in it) and map it in another process of the
  * node (ctd_ipc_open returns the allocation's base in this process; add the offset).  hipIpcGetMemHandle / hipIpcOpenMemHandle. */

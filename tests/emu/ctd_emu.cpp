@@ -197,6 +197,11 @@ int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, c
     return 0;
 }
 
+// index map of ctd_stitch_c's unpack kernel (ctd_layout.hpp stitch_src): out[r] = position of global row r in the gathered blocks
+void emu_stitch_src(int64_t N, int cb, int G, int64_t smax, int64_t ncon, int64_t* out) {
+    for (int64_t r = 0; r < ncon; ++r) out[r] = stitch_src(r, N, cb, G, smax);
+}
+
 int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen) {
     Model mo;
     HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};

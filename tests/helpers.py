@@ -19,6 +19,22 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
 
 
+def hess_err(o, x, y, obj_weight, got, ref=None, idx=None):
+    """Error of Hessian-of-the-Lagrangian values against the oracle on the backward-error scale: entries are sums of terms
+    y_r d2c_r that cancel when the multipliers change sign from row to row (Goddard's drag: per-stage terms ~1e5 cancel to
+    ~20), so two double-precision evaluations cannot agree to 1e-10 of the RESULT there.  Each entry is measured against
+    max(1, |ref|, the same sum with |y| and |obj_weight|) -- the magnitude of what is summed (tests/test_gpu_hessian.py) --
+    which keeps the 1e-10 bar.  `idx`: compare only these positions."""
+    ref = o.hess_coord(x, y, obj_weight) if ref is None else ref
+    mag = o.hess_coord(x, np.abs(y), abs(obj_weight))
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    if idx is not None:
+        got, ref, mag = got[idx], ref[idx], mag[idx]
+    if got.size == 0:
+        return 0.0
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.maximum(np.abs(ref), np.abs(mag)))))
+
+
 def fx(h):
     return float.fromhex(h)
 

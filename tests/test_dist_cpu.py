@@ -117,3 +117,27 @@ def test_stitch_constraints_world2_gloo(N, prob, sch):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert all(tot == 3.0 for _, _, tot in res)
+
+
+def test_library_stitch_index_map_equals_the_python_stitcher():
+    """ctd_stitch_c (the RCCL all-gather inside the library) unpacks the gathered padded blocks with the index map
+    stitch_src (csrc/ctd_layout.hpp); the Python route (`_Stitcher`) builds the same map as a tensor.  They must agree for
+    ragged and equal splits, with and without tail rows -- and the library's split rule must be dist.shard_steps."""
+    import ctypes as C
+    from emu import emu
+    import ctdirect_jl_amd as ct
+    L = emu.lib()
+    for N, cb, tail, G in ((10, 3, 4, 3), (7, 2, 0, 7), (12, 5, 6, 4), (1001, 9, 7, 8), (9, 4, 0, 2)):
+        ncon = N * cb + tail
+        blocks = [ctdist.shard_steps(N, G, r) for r in range(G)]
+        for r, (b, e) in enumerate(blocks):
+            bb, ee = C.c_int64(), C.c_int64()
+            assert ct._lib.lib().ctd_shard_steps(N, G, r, C.byref(bb), C.byref(ee)) == 0 and (bb.value, ee.value) == (b, e)
+        smax = max(e - b for b, e in blocks) * cb + tail
+        out = np.zeros(ncon, dtype=np.int64)
+        L.emu_stitch_src(C.c_int64(N), cb, G, C.c_int64(smax), C.c_int64(ncon), out.ctypes.data_as(C.c_void_p))
+        want = np.empty(ncon, dtype=np.int64)
+        for r, (b, e) in enumerate(blocks):
+            want[b * cb:e * cb] = r * smax + np.arange((e - b) * cb)
+        want[N * cb:] = (G - 1) * smax + (blocks[-1][1] - blocks[-1][0]) * cb + np.arange(tail)
+        assert np.array_equal(out, want), (N, cb, tail, G)
