@@ -19,7 +19,7 @@ class ctd_desc(C.Structure):
     _fields_ = [("problem", C.c_int32), ("scheme", C.c_int32), ("pattern_mode", C.c_int32), ("device", C.c_int32),
                 ("grid_size", C.c_int64), ("time_grid", C.POINTER(C.c_double)), ("time_grid_len", C.c_int64),
                 ("step_begin", C.c_int64), ("step_end", C.c_int64), ("stream", C.c_void_p),
-                ("stream_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("stream_mode", C.c_int32), ("control_steps", C.c_int32)]
 
 
 class ctd_init(C.Structure):

@@ -256,8 +256,9 @@ int32_t jit_compile(const RtOcp& ro, const char* header, const std::vector<std::
     return CTD_OK;
 }
 
+// s: stages of a Gauss-Legendre scheme; for the midpoint scheme the controls per step (control_steps)
 std::vector<std::string> jit_first_exprs(int sc, int s) {
-    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
+    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string((sc == SC_IRK || sc == SC_MIDPOINT) && s > 0 ? s : 1);
     return {"ctd::cons_jac_kernel<" + P + ", " + a + ", " + b + ", false>", "ctd::obj_partial_kernel<" + P + ", " + a + ">",
             "ctd::obj_finish_kernel<" + P + ">", "ctd::grad_units_kernel<" + P + ", " + a + ", " + b + ">",
             "ctd::grad_finish_kernel<" + P + ">"};
@@ -278,7 +279,8 @@ hipError_t jit_launch(hipFunction_t f, int grid, int block, size_t lds, hipStrea
 static int32_t jit_load_first(ctd_handle* h) {
     std::string code, err;
     std::vector<std::string> names;
-    int32_t st = jit_compile(*h->rt, "ctd_kernels.hpp", jit_first_exprs(h->model.L.sc, h->model.L.s), "off", code, names, err);
+    const Layout& Lj = h->model.L;
+    int32_t st = jit_compile(*h->rt, "ctd_kernels.hpp", jit_first_exprs(Lj.sc, Lj.sc == SC_MIDPOINT ? Lj.cs : Lj.s), "off", code, names, err);
     if (st) return fail(nullptr, st, err);
     HIP_TRY(nullptr, hipModuleLoadData(&h->jit_mod, code.data()));
     hipFunction_t* f[] = {&h->f_cons_jac, &h->f_obj_partial, &h->f_obj_finish, &h->f_grad_units, &h->f_grad_finish};
@@ -321,7 +323,8 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     struct Del { void operator()(ctd_handle* p) const { if (p) { free_device(p); delete p; } } };
     std::unique_ptr<ctd_handle, Del> h(new (std::nothrow) ctd_handle());
     if (!h) return fail(nullptr, CTD_ENOMEM, "ctd_create: out of memory");
-    HostDesc hd{desc->problem, desc->scheme, desc->pattern_mode, desc->grid_size, desc->time_grid, desc->time_grid_len};
+    HostDesc hd{desc->problem, desc->scheme, desc->pattern_mode, desc->grid_size, desc->time_grid, desc->time_grid_len,
+                desc->control_steps > 1 ? desc->control_steps : 1};
     std::string err;
     int st;
     try {
@@ -331,6 +334,8 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     }
     if (st) return fail(nullptr, st, err);
     const Model& mo = h->model;
+    if (mo.L.cs > 3 && desc->device >= 0 && !runtime_ocp(mo.problem))      // (host-only handles -- sizes, bounds, patterns -- take any)
+        return fail(nullptr, CTD_EINVAL, "ctd_create: control_steps > 3 needs an OCP registered at run time (ctd_register_ocp); the compiled registry holds the midpoint kernels for 1, 2 and 3 controls per step");
     h->step_begin = desc->step_begin;
     h->step_end = desc->step_end;
     if (h->step_begin == 0 && h->step_end == 0) h->step_end = mo.L.N;
@@ -1066,6 +1071,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_ready) return CTD_OK;
     const Model& mo = h->model;
     const HessModel& H = mo.H;
+    if (!H.values) return fail(h, CTD_EPATTERN, "hess_coord is not available with control_steps > 1 (hess_structure is); use a quasi-Newton solver or control_steps = 1");
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     h->hess_tile = env_int("CTD_HESS_TILE", 0);
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);
@@ -1246,7 +1252,7 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     int32_t st = CTD_OK;
     if (hvals_dev) { st = ensure_hess(h); if (st) return st; }      // first use uploads the tables (not capturable)
-    if (h->rt || env_int("CTD_ITER_SERIAL", 0)) {
+    if (h->rt || h->model.L.cs > 1 || env_int("CTD_ITER_SERIAL", 0)) {
         if (f_dev) st = enqueue_obj(h, x_dev, f_dev);
         if (!st && g_dev) st = enqueue_grad(h, x_dev, g_dev);
         if (!st && (c_dev || vals_dev)) st = enqueue_cons_jac(h, x_dev, c_dev, vals_dev);

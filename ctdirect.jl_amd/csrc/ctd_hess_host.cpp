@@ -105,7 +105,7 @@ void Model::hess_gen_column(int64_t j, std::vector<int64_t>& rows) const {
     for (auto& p : iv) {
         int64_t r = std::max(p.first, next);
         for (; r < p.second; ++r)
-            if (pattern_mode != 2 || hess_opt_keep(*this, r, j)) rows.push_back(r);
+            if (pattern_mode != 2 || !H.values || hess_opt_keep(*this, r, j)) rows.push_back(r);
         next = std::max(next, p.second);
     }
 }
@@ -504,6 +504,31 @@ int build_hess_model(Model& mo, std::string& err) {
     HessModel& H = mo.H;
     const int64_t N = L.N;
     H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, L.s, L.free_time != 0);
+    if (L.cs > 1) {
+        // control_steps > 1 (direct shooting layout): hess_structure! is served -- the blocks of DOCP_Hessian_pattern
+        // (midpoint.jl:240-300 are written in terms of the step block, whatever its size; with the optimized mode the same
+        // blocks: a superset of what a tracer would keep) -- hess_coord! is not: its evaluation points are not restated for
+        // several controls per step (ctd_hess_coord* return CTD_EPATTERN).
+        H.values = false;
+        build_hess_tail(mo);
+        H.reg_first = H.reg_last = N;
+        H.Lseg = 0;
+        H.tptr.assign(1, 0); H.terms.clear(); H.cp_tmpl.assign(L.blk + 1, 0);
+        std::vector<int64_t> rows;
+        const int64_t head_cols = N * (int64_t)L.blk, tail_cols = L.nvar - head_cols;
+        H.cp_head.assign(head_cols + 1, 0);
+        int64_t nz = 0;
+        for (int64_t j = 0; j < head_cols; ++j) { H.cp_head[j] = nz; mo.hess_gen_column(j, rows); nz += (int64_t)rows.size(); }
+        H.cp_head[head_cols] = nz;
+        H.seg_base = nz;
+        H.cp_tail.assign(tail_cols + 1, 0);
+        for (int64_t jj = 0; jj < tail_cols; ++jj) { H.cp_tail[jj] = nz; mo.hess_gen_column(head_cols + jj, rows); nz += (int64_t)rows.size(); }
+        H.cp_tail[tail_cols] = nz;
+        H.nnzh = nz;
+        H.nvv = 0;
+        H.head_ptr.assign(1, 0);
+        return ST_OK;
+    }
     if (H.R.stride >= 65536) { err = "per-step Hessian record too large for 16-bit data indices"; return ST_EPATTERN; }
     H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
     H.HH = (L.euler == 2 && L.p > 0) ? 1 : 0;       // implicit Euler: the path point of node i+1 couples X_{i+1} with U_i

@@ -41,11 +41,16 @@ static void set_butcher(Layout& L, int s) {
     }
 }
 
-static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
+static int build_layout(Model& mo, int scheme, int64_t N, int control_steps, std::string& err) {
     Layout& L = mo.L;
     const ProblemInfo& pi = mo.info;
     std::memset(&L, 0, sizeof(L));
     L.scheme = scheme;
+    L.cs = control_steps < 1 ? 1 : control_steps;
+    // control_steps > 1: the reference sizes every scheme's block with it (trapeze.jl:20, euler.jl:22, irk.jl:141) but only the
+    // midpoint scheme integrates over the control sub-steps (midpoint.jl:47-72,99-116,137-155); elsewhere the extra controls would
+    // be variables nothing reads.  Offered where it means something.
+    if (L.cs > 1 && scheme != 1) { err = "control_steps > 1 is only available with the :midpoint scheme (the only one whose step integrates over the control sub-steps, src/ode/midpoint.jl:137-155)"; return ST_ESCHEME; }
     L.n = pi.n; L.m = pi.m; L.nv = pi.nv; L.p = pi.npath; L.bc = pi.nbc;
     L.N = N;
     L.it0 = pi.it0; L.itf = pi.itf; L.t0 = pi.t0; L.tf = pi.tf;
@@ -56,9 +61,9 @@ static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
             L.blk = L.n + L.m; L.eqs = L.n;
             L.nvar = N * L.blk + L.n + L.nv + L.m;
             break;
-        case 1:   // Midpoint: midpoint.jl:17-39
-            L.sc = SC_MIDPOINT; L.s = 0; L.cu = L.m;
-            L.blk = L.n + L.m; L.eqs = L.n;
+        case 1:   // Midpoint: midpoint.jl:17-39 (block = state + control_steps controls, :20)
+            L.sc = SC_MIDPOINT; L.s = 0; L.cu = L.m * L.cs;
+            L.blk = L.n + L.cu; L.eqs = L.n;
             L.nvar = N * L.blk + L.n + L.nv;
             break;
         case 7: case 8:           // Euler explicit / implicit: euler.jl:19-49 (midpoint's layout, evaluation at t_i or t_{i+1})
@@ -85,7 +90,7 @@ static int build_layout(Model& mo, int scheme, int64_t N, std::string& err) {
     L.cb = L.eqs + L.p;
     L.ncon = N * L.cb + L.p + L.bc;
     L.v_off = L.nvar - L.nv;
-    mo.R = make_rec_layout(L.n, L.m, L.nv, L.p, L.bc, L.s, L.cb);
+    mo.R = make_rec_layout(L.n, L.m, L.nv, L.p, L.bc, L.s, L.cb, scheme == 1 ? L.cu : L.m);
     return ST_OK;
 }
 
@@ -148,7 +153,11 @@ static void build_bounds(Model& mo) {
         } else {
             const int64_t last = L.final_control ? L.N : L.N - 1;     // set_control_at_time_step!, common.jl:209-223
             for (int64_t i = 0; i <= last; ++i)
-                for (int k = 0; k < L.m; ++k) { mo.var_l[i * L.blk + L.n + k] = ul[k]; mo.var_u[i * L.blk + L.n + k] = uu[k]; }
+                for (int j = 0; j < L.cs; ++j)                        // DOCP_variables.jl:44-47: every control of the step
+                    for (int k = 0; k < L.m; ++k) {
+                        mo.var_l[i * L.blk + L.n + j * L.m + k] = ul[k];
+                        mo.var_u[i * L.blk + L.n + j * L.m + k] = uu[k];
+                    }
         }
     }
     if (L.nv > 0) {
@@ -205,7 +214,9 @@ void model_initial_guess(const Model& mo, double* X, bool use_default, const dou
         const double ti = grid(i);
         if (get_state(ti, tmp.data())) for (int k = 0; k < L.n; ++k) X[i * L.blk + k] = tmp[k];
         if (L.m > 0 && !L.stagewise && (i < L.N || L.final_control))
-            if (get_control(ti, tmp.data())) for (int k = 0; k < L.m; ++k) X[i * L.blk + L.n + k] = tmp[k];
+            if (get_control(ti, tmp.data()))
+                for (int j = 0; j < L.cs; ++j)                        // DOCP_variables.jl:138-140: init.control(t_i) for every control of the step
+                    for (int k = 0; k < L.m; ++k) X[i * L.blk + L.n + j * L.m + k] = tmp[k];
     }
     if (L.m > 0 && L.stagewise) {
         for (int64_t i = 0; i < L.N; ++i) {
@@ -269,7 +280,7 @@ static void build_tail_blocks(Model& mo) {
     const int64_t xf0 = N * L.blk, xf1 = xf0 + n;
     push_block(out, fp0, fp1, xf0, xf1);
     if (L.sc == SC_TRAPEZE) push_block(out, fp0, fp1, xf1, xf1 + m);
-    else push_block(out, fp0, fp1, (N - 1) * L.blk + n, (N - 1) * L.blk + n + L.cu);    // u(tf) = U_N convention
+    else push_block(out, fp0, fp1, (N - 1) * L.blk + n, (N - 1) * L.blk + n + (L.stagewise ? L.cu : m));    // u(tf) = U_N convention (its first control: common.jl:140-155)
     push_block(out, fp0, fp1, L.v_off, L.nvar);
     // 3. boundary constraints (x0, xf, v)
     const int64_t b0 = fp1, b1 = L.ncon;
@@ -338,7 +349,7 @@ bool Model::opt_dep(int64_t row, int64_t col) const {
         if (q >= 0 && q < n) return xbit(mk, (int)q);
         if (L.sc == SC_TRAPEZE) return q >= n && q < n + m && ubit(mk, (int)(q - n));
         const int64_t o = col - ((N - 1) * L.blk + n);                       // u(t_f) := controls of step N
-        return o >= 0 && o < L.cu && ubit(mk, (int)(L.stagewise ? o % m : o));
+        return o >= 0 && o < (L.stagewise ? L.cu : m) && ubit(mk, (int)(L.stagewise ? o % m : o));
     }
     const int64_t i = row / L.cb;
     const int lr = (int)(row % L.cb);
@@ -354,7 +365,7 @@ bool Model::opt_dep(int64_t row, int64_t col) const {
         const uint32_t mk = dep_g[lr - L.eqs];
         if (isv) return vbit(mk, kv);
         if (q < n) return xbit(mk, (int)q);
-        if (q < n + L.cu) return ubit(mk, (int)(L.stagewise ? (q - n) % m : q - n));     // stagewise: every stage control (average)
+        if (q < n + (L.stagewise ? L.cu : m)) return ubit(mk, (int)(L.stagewise ? (q - n) % m : q - n));     // stagewise: every stage control (average)
         return false;
     }
     if (L.sc == SC_IRK) {
@@ -389,7 +400,7 @@ bool Model::opt_dep(int64_t row, int64_t col) const {
     const bool at_i = (L.sc == SC_TRAPEZE) || L.euler == 0 || L.euler == 1;       // f reads X_i (U_i always)
     const bool at_ip1 = (L.sc == SC_TRAPEZE) || L.euler == 0 || L.euler == 2;     // f reads X_{i+1}
     if (q < n) return q == r || (at_i && xbit(mk, (int)q));
-    if (q < L.blk) return ubit(mk, (int)(q - n));
+    if (q < L.blk) return ubit(mk, (int)((q - n) % (m > 0 ? m : 1)));                 // (every control of the step: control_steps)
     if (q < L.blk + n) return q - L.blk == r || (at_ip1 && xbit(mk, (int)(q - L.blk)));
     return L.sc == SC_TRAPEZE && ubit(mk, (int)(q - L.blk - n));                   // U_{i+1}
 }
@@ -409,7 +420,7 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     const RecLayout& R = mo.R;
     const int n = L.n, m = L.m;
     auto F = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oF + r * R.ldx + c; };
-    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * R.ldu + c; };
+    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * R.ldg + c; };
     const bool is_path = lr >= L.eqs;
     if (L.sc == SC_IRK) {
         // column kind
@@ -450,7 +461,7 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
         if (kind == 0) return Loc{C_ONE, R.oPx + pq * R.ldx + c, 0, false};
         // implicit Euler evaluates the path constraints of node i >= 1 with U_{i-1} (euler.jl:59-72): the pattern's
         // (path_i, U_i) entries are structural zeros there
-        if (kind == 1) return (L.euler == 2 && step >= 1) ? kZero : Loc{C_ONE, R.oPu + pq * R.ldu + c, 0, false};
+        if (kind == 1) return ((L.euler == 2 && step >= 1) || c >= m) ? kZero : Loc{C_ONE, R.oPu + pq * R.ldu + c, 0, false};
         return kZero;
     }
     const int r = lr;
@@ -528,7 +539,7 @@ Model::Entry Model::classify(int64_t row, int64_t col) const {
             return e;
         }
         const int64_t u0 = (N - 1) * L.blk + n;
-        if (col >= u0 && col < u0 + L.cu) {
+        if (col >= u0 && col < u0 + (L.stagewise ? L.cu : m)) {
             const int o = (int)(col - u0);
             if (L.stagewise) { e.ci = C_B + o / m; e.di = Rr.oPu + pq * Rr.ldu + o % m; }
             else { e.ci = C_ONE; e.di = Rr.oPu + pq * Rr.ldu + o; }
@@ -853,7 +864,7 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
     int64_t N = 0;
     int st = build_time(mo, d, N, err);
     if (st) return st;
-    st = build_layout(mo, d.scheme, N, err);
+    st = build_layout(mo, d.scheme, N, d.control_steps, err);
     if (st) return st;
     // fixed grid (DOCP_data.jl:201-211): only meaningful when no time is free
     mo.fixed_grid.assign(N + 1, 0.0);

@@ -17,6 +17,7 @@ struct HostDesc {
     int64_t grid_size;
     const double* time_grid;
     int64_t time_grid_len;
+    int control_steps = 1;            // DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293
 };
 
 struct Block { int64_t r0, r1, c0, c1; };   // rows [r0,r1) x cols [c0,c1), 0-based
@@ -27,6 +28,7 @@ struct HessModel {
     HessRecLayout R;
     int hk = 4;                       // inner directions per eval lane (ctd::HessK<P>)
     bool sym_stage = false;           // stage points use the OCP's symbolic second derivatives (run-time OCPs, ctd_sym.hpp)
+    bool values = true;               // false: pattern only (control_steps > 1: hess_coord is not implemented, hess_structure is)
     int64_t nnzh = 0;
     std::vector<Block> tail;          // blocks that do not belong to one step (already symmetrised)
     // regular part

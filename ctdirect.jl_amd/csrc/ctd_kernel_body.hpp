@@ -240,10 +240,15 @@ template <class P> CTD_HD double dtime_of(double tau, int k) {
 
 // record layout of (OCP, scheme class, stages): a compile-time constant, so every LDS access of the kernels uses an
 // immediate offset (the host builds its emit codes from the same function, ctd_host.cpp)
+// S: stages of a Gauss-Legendre scheme; for the midpoint scheme the number of controls per step (control_steps, 1 in collocation)
 template <class P, int SC, int S> struct RL {
     static constexpr int cb = (SC == SC_IRK ? P::NX * (1 + S) : P::NX) + P::NPATH;
-    static constexpr RecLayout R = make_rec_layout(P::NX, P::NU, P::NV, P::NPATH, P::NBC, SC == SC_IRK ? S : 0, cb);
+    static constexpr RecLayout R = make_rec_layout(P::NX, P::NU, P::NV, P::NPATH, P::NBC, SC == SC_IRK ? S : 0, cb,
+                                                   SC == SC_MIDPOINT ? P::NU * S : P::NU);
 };
+// evaluation points per step that get a lane (and an eval block) of their own: the stages; the control sub-steps of the midpoint
+// scheme are walked by ONE lane (their partials are summed)
+template <int SC, int S> struct StagePoints { static constexpr int value = SC == SC_IRK ? S : 1; };
 
 template <class P> struct Dirs {
     static constexpr int DYN = P::NX + P::NU + (P::DYN_T ? 1 : 0) + (P::DYN_V ? P::NV : 0);
@@ -402,8 +407,8 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k, int row = -1)
             }
         }
     } else if (SC == SC_MIDPOINT) {
-        C[C_NHH] = -(0.5 * (h / 1.0));
-        C[C_NH] = -(h / 1.0);
+        C[C_NHH] = -(0.5 * (h / (double)S));      // h_i = (t_{i+1} - t_i) / control_steps   (midpoint.jl:134)
+        C[C_NH] = -(h / (double)S);
     } else {
         C[C_NHH] = -(0.5 * h);
     }
@@ -458,7 +463,9 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
             }
         }
     } else if (SC == SC_MIDPOINT) {
-        const double h = (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0)) / 1.0;
+        // S = control_steps: f, W, ft hold the sums over the sub-steps (same t_s, x_s for all of them, midpoint.jl:53-69), so
+        // x_{i+1} - (x_i + h_i sum_j f_j) with h_i = (t_{i+1} - t_i) / S  (:134-153; S = 1: :139)
+        const double h = (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0)) / (double)S;
         const double* nxt = slot_next(kp, cx, k);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
@@ -470,7 +477,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
                 if (P::DYN_T && FREE)
                     w = w + ev[R.oft + r] * (L.euler == 0 ? 0.5 * (dti[kk] + (dti[kk] + dh[kk])) : (L.euler == 1 ? dti[kk] : dti[kk] + dh[kk]));
                 ev[R.oW + r * nv + kk] = w;
-                rec[R.oSv + r * nv + kk] = -(dh[kk] * f + h * w);
+                rec[R.oSv + r * nv + kk] = -((S > 1 ? dh[kk] / (double)S : dh[kk]) * f + h * w);
             }
         }
     } else {  // SC_TRAPEZE: node-level total d f / d v; the step residual needs the next node (fin_trapeze_step)
@@ -616,57 +623,16 @@ template <class P> struct SymStage;
 // symbolic second derivatives of the path point (lane-per-step Hessian kernel, ctd_hess_step.hpp)
 template <class P> struct SymPathH { static constexpr bool value = false; CTD_HD static void eval(const double*, double*) {} };
 
-// one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
+// The OCP dynamics and all their first partials at ONE point (t, x, u, v) into the eval block `ev` (layout RLT::R, offsets
+// relative to the block): generated straight-line code when the OCP has it, forward duals (chunk q of the directions) otherwise.
 // SPLIT: the caller runs the NCH_DYN lanes of this point in different waves (uniform q per wave), so the generated code may be
 // split over them by rows; otherwise the lane of chunk 0 evaluates all of it
-template <class P, int SC, int S, bool SPLIT = false>
-CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q, double* ev) {
+template <class P, class RLT, bool SPLIT>
+CTD_HD void eval_point(const KParams& kp, const double* vv, int q, double t, const double* xv, const double* uv, double* ev) {
     constexpr int n = P::NX, m = P::NU, nv = P::NV, DC = P::DC;
     using D = Dual<DC>;
-    const Layout& L = kp.L;
-    constexpr RecLayout R = RL<P, SC, S>::R;
-    const int64_t i = slot_index(kp, cx, k);
-    if (i < 0) return;
-    if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
-    const double* base = slot_base(kp, cx, k);
-    const double ti = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 0));
-    double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
-    double t;
-    if (SC == SC_TRAPEZE) {                       // f(t_i, X_i, U_i, v): trapeze.jl:60-69
-        t = ti;
-#pragma unroll
-        for (int c = 0; c < n; ++c) xv[c] = base[c];
-#pragma unroll
-        for (int c = 0; c < m; ++c) uv[c] = base[n + c];
-    } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
-        const double tip1 = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1));
-        const double* nxt = slot_next(kp, cx, k);
-        if (L.euler == 0) {
-            t = 0.5 * (ti + tip1);
-#pragma unroll
-            for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + nxt[c]);
-        } else {                                  // Euler: f(t_i, X_i, U_i, v) or f(t_{i+1}, X_{i+1}, U_i, v): euler.jl:86-102
-            t = (L.euler == 1) ? ti : tip1;
-#pragma unroll
-            for (int c = 0; c < n; ++c) xv[c] = (L.euler == 1) ? base[c] : nxt[c];
-        }
-#pragma unroll
-        for (int c = 0; c < m; ++c) uv[c] = base[n + c];
-    } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
-        const double h = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1)) - ti;
-        t = ti + butcher_c<S>(L, j) * h;
-        const double* K = base + n + L.cu;
-#pragma unroll
-        for (int c = 0; c < n; ++c) {
-            double x = base[c];
-#pragma unroll
-            for (int l = 0; l < S; ++l) x = x + h * butcher_a<S>(L, j, l) * K[l * n + c];
-            xv[c] = x;
-        }
-        const double* U = base + n + (L.stagewise ? j * m : 0);
-#pragma unroll
-        for (int c = 0; c < m; ++c) uv[c] = U[c];
-    }
+    constexpr RecLayout R = RLT::R;
+    struct { const double* v; } cx{vv};
     if constexpr (SymDyn<P>::value) {
         // every partial of the point by the generated straight-line code: on the lane of the first direction chunk, or split
         // by rows over the lanes of all chunks when the generator provides the parts
@@ -720,7 +686,7 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
             for (int r = 0; r < n; ++r) ev[R.oF + r * R.ldx + g] = out[r].d[d];
         } else if (g < n + m) {
 #pragma unroll
-            for (int r = 0; r < n; ++r) ev[R.oG + r * R.ldu + (g - n)] = out[r].d[d];
+            for (int r = 0; r < n; ++r) ev[R.oG + r * R.ldg + (g - n)] = out[r].d[d];
         } else if (P::DYN_T && g == n + m) {
 #pragma unroll
             for (int r = 0; r < n; ++r) ev[R.oft + r] = out[r].d[d];
@@ -734,6 +700,97 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
 #pragma unroll
         for (int r = 0; r < n; ++r) ev[R.of + r] = out[r].v;
     }
+}
+
+// one dynamics evaluation on duals: slot k (step or node i), eval point j, direction chunk q
+template <class P, int SC, int S, bool SPLIT = false>
+CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, int q, double* ev) {
+    constexpr int n = P::NX, m = P::NU, nv = P::NV;
+    const Layout& L = kp.L;
+    constexpr RecLayout R = RL<P, SC, S>::R;
+    const int64_t i = slot_index(kp, cx, k);
+    if (i < 0) return;
+    if (SC == SC_TRAPEZE ? (i > L.N) : (i >= L.N)) return;
+    const double* base = slot_base(kp, cx, k);
+    const double ti = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 0));
+    double xv[n > 0 ? n : 1], uv[m > 0 ? m : 1];
+    double t;
+    if (SC == SC_TRAPEZE) {                       // f(t_i, X_i, U_i, v): trapeze.jl:60-69
+        t = ti;
+#pragma unroll
+        for (int c = 0; c < n; ++c) xv[c] = base[c];
+#pragma unroll
+        for (int c = 0; c < m; ++c) uv[c] = base[n + c];
+    } else if (SC == SC_MIDPOINT) {               // f(0.5(t_i+t_{i+1}), 0.5(X_i+X_{i+1}), U_i, v): midpoint.jl:53-66
+        const double tip1 = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1));
+        const double* nxt = slot_next(kp, cx, k);
+        if (L.euler == 0) {
+            t = 0.5 * (ti + tip1);
+#pragma unroll
+            for (int c = 0; c < n; ++c) xv[c] = 0.5 * (base[c] + nxt[c]);
+        } else {                                  // Euler: f(t_i, X_i, U_i, v) or f(t_{i+1}, X_{i+1}, U_i, v): euler.jl:86-102
+            t = (L.euler == 1) ? ti : tip1;
+#pragma unroll
+            for (int c = 0; c < n; ++c) xv[c] = (L.euler == 1) ? base[c] : nxt[c];
+        }
+#pragma unroll
+        for (int c = 0; c < m; ++c) uv[c] = base[n + c];
+    } else {                                      // f(t_i + c_j h, X_i + h sum_l a_jl K^l, U_i^j | U_i, v): irk_stagewise.jl:424-446
+        const double h = time_of<P>(kp, cx.v, slot_tau(kp, cx, k, 1)) - ti;
+        t = ti + butcher_c<S>(L, j) * h;
+        const double* K = base + n + L.cu;
+#pragma unroll
+        for (int c = 0; c < n; ++c) {
+            double x = base[c];
+#pragma unroll
+            for (int l = 0; l < S; ++l) x = x + h * butcher_a<S>(L, j, l) * K[l * n + c];
+            xv[c] = x;
+        }
+        const double* U = base + n + (L.stagewise ? j * m : 0);
+#pragma unroll
+        for (int c = 0; c < m; ++c) uv[c] = U[c];
+    }
+    if constexpr (SC == SC_MIDPOINT && S > 1) {
+        // control_steps = S > 1 (direct shooting, midpoint.jl:47-72): the dynamics at the SAME (t_s, x_s) once per control U_i^jj of
+        // the step.  The step residual and its Jacobian only need the sums over the sub-steps of F, W, f, f_t and the blocks G_jj
+        // side by side (n x m S), so this lane walks the sub-steps and adds its share: everything (generated code, chunk 0), its
+        // rows (generated code split by rows), or its direction columns (forward duals, chunk q).
+        using RL1 = RL<P, SC_MIDPOINT, 1>;
+        constexpr RecLayout R1 = RL1::R;
+        constexpr int DC = P::DC, NP = Dirs<P>::NCH_DYN;
+        constexpr bool sym = SymDyn<P>::value;
+        constexpr bool symsplit = sym && SPLIT && SymDyn<P>::parts > 1 && SymDyn<P>::parts == NP;
+        constexpr int gT = n + m, gV = n + m + (P::DYN_T ? 1 : 0);
+        if (sym && !symsplit && q != 0) return;
+        auto dir = [&](int g) { return sym || (g >= q * DC && g < (q + 1) * DC); };
+        for (int jj = 0; jj < S; ++jj) {
+            double tmp[R1.eval_sz];
+#pragma unroll
+            for (int e = 0; e < R1.eval_sz; ++e) tmp[e] = 0.0;
+#pragma unroll
+            for (int c = 0; c < m; ++c) uv[c] = base[n + jj * m + c];
+            eval_point<P, RL1, SPLIT>(kp, cx.v, q, t, xv, uv, tmp);
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                if (symsplit && (r % NP) != q) continue;
+#pragma unroll
+                for (int c = 0; c < n; ++c)
+                    if (dir(c)) ev[R.oF + r * R.ldx + c] = (jj == 0 ? 0.0 : ev[R.oF + r * R.ldx + c]) + tmp[R1.oF + r * R1.ldx + c];
+#pragma unroll
+                for (int c = 0; c < m; ++c)
+                    if (dir(n + c)) ev[R.oG + r * R.ldg + jj * m + c] = tmp[R1.oG + r * R1.ldg + c];
+                if (P::DYN_T && dir(gT)) ev[R.oft + r] = (jj == 0 ? 0.0 : ev[R.oft + r]) + tmp[R1.oft + r];
+                if (P::DYN_V) {
+#pragma unroll
+                    for (int kk = 0; kk < nv; ++kk)
+                        if (dir(gV + kk)) ev[R.oW + r * nv + kk] = (jj == 0 ? 0.0 : ev[R.oW + r * nv + kk]) + tmp[R1.oW + r * nv + kk];
+                }
+                if (sym || q == 0) ev[R.of + r] = (jj == 0 ? 0.0 : ev[R.of + r]) + tmp[R1.of + r];
+            }
+        }
+        return;
+    }
+    eval_point<P, RL<P, SC, S>, SPLIT>(kp, cx.v, q, t, xv, uv, ev);
 }
 
 // path constraints g(t, x, u, v) on duals into record `rec`: stepPathConstraints!, DOCP_functions.jl:122-140
@@ -911,8 +968,8 @@ CTD_HD void eval_boundary(const KParams& kp, const BlockCtx& cx, int q) {
 
 // REG (direct tiles of small FUSED problems): a lane composes its eval block in registers and stores it to the LDS record
 // once, instead of writing the partials to LDS and finishing the chain rule with reads and writes of the same words
-template <class P, int SC> struct RegEval {
-    static constexpr bool value = DirectTile<P, SC>::value && (P::NX * (P::NX + P::NU + P::NV + 2) <= 64);
+template <class P, int SC, int S = 1> struct RegEval {
+    static constexpr bool value = DirectTile<P, SC>::value && (P::NX * (P::NX + P::NU * (SC == SC_MIDPOINT ? S : 1) + P::NV + 2) <= 64);
 };
 
 // Wide OCPs: the symbolic code of one evaluation point is long (12 states: ~1300 instructions) and only S * ns lanes would run
@@ -931,7 +988,7 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
     // lanes of a wave: S ns dynamics points | ns path points | lead tasks (Gauss-Legendre: (step, state row) tasks dealt round
     // robin over the NP waves; one-point schemes: one cheap task per step on the last wave)
     const int lead = SC == SC_IRK ? (cx.nslots * P::NX + NP - 1) / NP : cx.nslots;
-    return ok && !cx.is_edge && S * cx.nslots + cx.nslots + lead <= 64 && r_path <= NP && NP * 64 <= nthr;
+    return ok && !cx.is_edge && StagePoints<SC, S>::value * cx.nslots + cx.nslots + lead <= 64 && r_path <= NP && NP * 64 <= nthr;
 #endif
 }
 
@@ -940,7 +997,7 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     constexpr bool FUSED = Dirs<P>::FUSED;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
-    constexpr int r_dyn = S * Dirs<P>::NCH_DYN;
+    constexpr int r_dyn = StagePoints<SC, S>::value * Dirs<P>::NCH_DYN;
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
     constexpr int r_lead = FUSED ? 1 : 0;
     if (cx.is_edge) {
@@ -1004,7 +1061,7 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     if constexpr (SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !FUSED) {
         if (split_eval<P, SC, S>(cx, nthr)) {
             constexpr int NP = Dirs<P>::NCH_DYN;
-            const int nd = S * ns;
+            const int nd = StagePoints<SC, S>::value * ns;
             const int wave = tid >> 6, l = tid & 63;
             if (wave < NP) {
                 if (l < nd) {
@@ -1085,7 +1142,7 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
     // after a split evaluation the lead role is done, and the path rows' total d/dv rides with the first stage task of its step:
     // 12-state quadrotor, 7 steps x 3 stages x 12 rows = 252 tasks: one pass of 256 lanes (266 tasks before: two)
     const bool split = split_eval<P, SC, S>(cx, nthr);
-    const int n_stage = S * ns * rows, n_lead = split ? 0 : ns, n_path = (P::NPATH > 0 && !split) ? ns : 0;
+    const int n_stage = StagePoints<SC, S>::value * ns * rows, n_lead = split ? 0 : ns, n_path = (P::NPATH > 0 && !split) ? ns : 0;
     const int n_fp = (cx.is_edge && P::NPATH > 0) ? 1 : 0;
     for (int task = tid; task < n_stage + n_lead + n_path + n_fp; task += nthr) {
         int t = task;
@@ -1224,7 +1281,7 @@ using EmitPre = EmitPreT<1>;     // edge block: b = the code of edge entry `tid`
 template <class P, int SC, int S> struct EmitN {
     static constexpr int n = P::NX, m = P::NU, nv = P::NV, p = P::NPATH, s = SC == SC_IRK ? S : 0;
     static constexpr int seg = SC == SC_IRK ? n * (2 * n + s * n + nv) + s * n * (n + s * m + s * n + nv) + p * (n + s * m + nv)
-                                            : n * (2 * n + 2 * m + nv) + p * (n + 2 * m + nv);
+                                            : n * (2 * n + 2 * m * (SC == SC_MIDPOINT ? S : 1) + nv) + p * (n + 2 * m + nv);
 #ifndef CTD_PRE_MAX
 #define CTD_PRE_MAX 1      /* measured on MI355X: holding all codes of a long period in registers is SLOWER (12-state quadrotor, Gauss-Legendre 3: +7 %) */
 #endif

@@ -60,7 +60,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         const BlockCtx cx = make_direct_ctx(kp, block, ctd_lds, xu);
         const EmitPre pre = emit_prefetch<P>(kp, cx, tid, nthr);
         ctd_stamp<DBG>(kp, 1);
-        phase_eval<P, SC, S, RegEval<P, SC>::value>(kp, cx, tid, nthr);
+        phase_eval<P, SC, S, RegEval<P, SC, S>::value>(kp, cx, tid, nthr);
         __syncthreads();
         ctd_stamp<DBG>(kp, 2);
         ctd_stamp<DBG>(kp, 3);
@@ -152,6 +152,17 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     const double ti = obj_time<P>(op, v, i), tip1 = obj_time<P>(op, v, i + 1);
     const double h = tip1 - ti;
     if (SC == SC_MIDPOINT) {           // midpoint.jl:87-97; Euler (euler.jl:112-134): (t_i, X_i, U_i) or (t_{i+1}, X_{i+1}, U_i)
+        if (L.cs > 1) {                // control_steps > 1 (midpoint.jl:99-116): h_i = h / cs, l(t_i + (j - 1/2) h_i, x_s, U_i^j, v), j = 1..cs
+            const double hi = h / (double)L.cs;
+            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+            double val = 0.0;
+            for (int j = 1; j <= L.cs; ++j) {
+                for (int c = 0; c < m; ++c) u[c] = base[n + (j - 1) * m + c];
+                const double term = hi * P::template lagrange<double>(ti + ((double)j - 0.5) * hi, x, u, v);
+                val = (j == 1) ? term : val + term;
+            }
+            return val;
+        }
         for (int c = 0; c < m; ++c) u[c] = base[n + c];
         if (L.euler == 0) {
             for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
@@ -391,6 +402,33 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
             const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = L.euler == 0 ? 0.5 : (L.euler == 1 ? 0.0 : 1.0);
             double gx[n > 0 ? n : 1];
             for (int c = 0; c < n; ++c) gx[c] = 0.0;
+            if (L.cs > 1) {
+                // control_steps > 1 (midpoint.jl:99-116): the step's cost is sum_j h_i l(t_ij, x_s, U_i^j, v), h_i = h / cs,
+                // t_ij = t_i + (j - 1/2) h_i; node i owns x_i (half of x_s of its own step and of the previous one) and its U_i^j
+                const double cs = (double)L.cs;
+                for (int side = 0; side < 2; ++side) {           // 0: own step i, 1: previous step i - 1
+                    const int64_t st = side == 0 ? i : i - 1;
+                    if (st < 0 || st >= L.N) continue;
+                    const double* sb = xu + st * (int64_t)L.blk;
+                    const double t0 = grad_tau<P>(gp, st), t1 = grad_tau<P>(gp, st + 1);
+                    const double ta = grad_time<P>(gp, v, t0), hi = (grad_time<P>(gp, v, t1) - ta) / cs;
+                    for (int c = 0; c < n; ++c) x[c] = 0.5 * (sb[c] + sb[L.blk + c]);
+                    for (int j = 1; j <= L.cs; ++j) {
+                        for (int c = 0; c < m; ++c) u[c] = sb[n + (j - 1) * m + c];
+                        const double w = (double)j - 0.5;
+                        lagrange_partials<P, 0>(ta + w * hi, x, u, v, val, lx, lu, lt, lv);
+                        for (int c = 0; c < n; ++c) gx[c] = gx[c] + hi * (0.5 * lx[c]);
+                        if (side == 0) {
+                            for (int c = 0; c < m; ++c) g[i * L.blk + n + (j - 1) * m + c] = hi * lu[c];
+                            for (int k = 0; k < nv; ++k) {
+                                const double d0 = FREE ? dtime_of<P>(t0, k) : 0.0, d1 = FREE ? dtime_of<P>(t1, k) : 0.0;
+                                const double dhi = (d1 - d0) / cs;
+                                gv[k] = gv[k] + dhi * val + hi * ((P::LAG_V ? lv[k] : 0.0) + ((P::LAG_T && FREE) ? lt * (d0 + w * dhi) : 0.0));
+                            }
+                        }
+                    }
+                }
+            } else {
             if (i < L.N) {
                 const double t0 = grad_tau<P>(gp, i), t1 = grad_tau<P>(gp, i + 1);
                 const double ta = grad_time<P>(gp, v, t0), tb = grad_time<P>(gp, v, t1), h = tb - ta;
@@ -414,6 +452,7 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
                 double val2 = 0.0, lt2 = 0.0, lu2[m > 0 ? m : 1], lv2[nv > 0 ? nv : 1];
                 lagrange_partials<P, 0>(L.euler == 0 ? 0.5 * (ta + tb) : tb, x, u, v, val2, lx, lu2, lt2, lv2);
                 for (int c = 0; c < n; ++c) gx[c] = gx[c] + h * (wb * lx[c]);
+            }
             }
             for (int c = 0; c < n; ++c) g[i * L.blk + c] = gx[c];
         } else {
@@ -563,7 +602,12 @@ template <class P>
 hipError_t launch_cons_jac(int sc, const KParams& kp, const double* xu, int grid, int block, size_t lds_bytes, hipStream_t st,
                            hipEvent_t e0, hipEvent_t e1) {
     if (sc == SC_TRAPEZE) return launch_variant<P, SC_TRAPEZE, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
-    if (sc == SC_MIDPOINT) return launch_variant<P, SC_MIDPOINT, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    if (sc == SC_MIDPOINT) {       // (midpoint: the template's stage count is control_steps -- 1 in collocation, up to 3 compiled in)
+        if (kp.L.cs == 2) return launch_variant<P, SC_MIDPOINT, 2>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+        if (kp.L.cs == 3) return launch_variant<P, SC_MIDPOINT, 3>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+        if (kp.L.cs > 3) return hipErrorInvalidValue;
+        return launch_variant<P, SC_MIDPOINT, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
+    }
     if (kp.L.s == 1) return launch_variant<P, SC_IRK, 1>(kp, xu, grid, block, lds_bytes, st, e0, e1);
     if (kp.L.s == 2) return launch_variant<P, SC_IRK, 2>(kp, xu, grid, block, lds_bytes, st, e0, e1);
     return launch_variant<P, SC_IRK, 3>(kp, xu, grid, block, lds_bytes, st, e0, e1);

@@ -37,7 +37,8 @@ struct Layout {
     double t0, tf;         // fixed values
     double a[9], b[3], c[3];   // Butcher tables (row-major a), Float64 arithmetic as in irk_stagewise.jl:61-64,103-109
     int32_t euler;         // SC_MIDPOINT class only: 0 midpoint, 1 explicit Euler, 2 implicit Euler (src/ode/euler.jl:10-50)
-    int32_t pad_;
+    int32_t cs;            // control_steps (DOCPtime, src/DOCP_data.jl:149): controls per time step, > 1 only for :midpoint
+                           // (direct shooting, src/direct_shooting.jl:55-71; sub-step dynamics midpoint.jl:137-155)
 };
 
 // Butcher entries for a stage index j that differs between the lanes of a wave.  The tables sit in the kernel arguments:
@@ -83,6 +84,7 @@ enum { C_ZERO = 0, C_ONE = 1, C_NEG1 = 2, C_HA = 3 /* -h a_jl at 3+3j+l */, C_HB
 
 struct RecLayout {
     int32_t S, eval_sz;
+    int32_t ldg;                          // row pitch of G: ldu, or (m control_steps) | 1 for the midpoint scheme with several controls per step
     int32_t ldx, ldu;                     // row pitch of the (rows x n) and (rows x m) derivative blocks: n, m rounded up to odd.
                                           // The CSC emission walks DOWN a column (fixed c, consecutive rows r): with an even
                                           // pitch the lanes of a wave hit a few LDS banks only (8-way conflicts for n = 8)
@@ -94,11 +96,13 @@ struct RecLayout {
     int32_t bsize;                        // doubles of the boundary record (>= stride)
 };
 
-constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb) {
+// gcols: columns of the control blocks G / Pu -- m, or m * control_steps for the midpoint scheme with several controls per step
+// (one eval block per step then holds the SUM over the sub-steps of F, W, f, ft and the n x (m control_steps) block [G_1 .. G_cs])
+constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb, int gcols = -1) {
     RecLayout r{};
     r.S = s > 0 ? s : 1;
-    r.ldx = n | 1; r.ldu = m | 1;
-    r.oF = 0; r.oG = n * r.ldx; r.oW = r.oG + n * r.ldu; r.of = r.oW + n * nv; r.oft = r.of + n;
+    r.ldx = n | 1; r.ldu = m | 1; r.ldg = (gcols > 0 ? gcols : m) | 1;
+    r.oF = 0; r.oG = n * r.ldx; r.oW = r.oG + n * r.ldg; r.of = r.oW + n * nv; r.oft = r.of + n;
     r.eval_sz = r.oft + n;
     r.oC = 1;
     r.oEval = 1 + kNC;

@@ -160,7 +160,7 @@ def jit_check(name, scheme):
 
 
 class DOCP:
-    """Discretised OCP handle; mirrors `CTDirect.DOCP(ocp, grid_size, 1, scheme, time_grid)`.
+    """Discretised OCP handle; mirrors `CTDirect.DOCP(ocp, grid_size, control_steps, scheme, time_grid)` (src/DOCP_data.jl:293).
 
     `ocp` is the name (or id) of a problem of the compiled registry (include/ctdirect_hip.h) -- the reference takes
     a CTModels.Model with Julia closures, which cannot cross the C ABI to the GPU.
@@ -169,10 +169,12 @@ class DOCP:
     `stream`: "torch" (default) launches on torch's current stream of `device` when torch sees that GPU, so the
     callbacks are ordered with the caller's tensor work; "own" gives the handle a private stream; an integer is a raw
     hipStream_t.
+    `control_steps` > 1: the direct-shooting layout (src/direct_shooting.jl:55-71; :midpoint only): `control_steps` controls per
+    time step, dynamics summed over the control sub-steps (midpoint.jl:137-155).
     """
 
     def __init__(self, ocp, grid_size=250, scheme="midpoint", time_grid=None, *, pattern="manual", device=0,
-                 steps=None, stream="torch"):
+                 steps=None, stream="torch", control_steps=1):
         L = _lib.lib()
         self.problem_name = ocp if isinstance(ocp, str) else {v: k for k, v in PROBLEMS.items()}.get(int(ocp), str(ocp))
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
@@ -201,6 +203,8 @@ class DOCP:
         if steps is not None:
             d.step_begin, d.step_end = int(steps[0]), int(steps[1])
         d.stream, d.stream_mode = None, 0
+        d.control_steps = int(control_steps)
+        self.control_steps = max(1, int(control_steps))
         if int(device) >= 0 and stream != "own":
             if stream == "torch":
                 try:
@@ -248,7 +252,7 @@ class DOCP:
         nrm = np.zeros(steps + 1)
         fx = np.zeros(steps + 1)
         self._ck(L.ctd_time_grid(self._h, _dp(nrm), _dp(fx)))
-        self.time = SimpleNamespace(steps=steps, control_steps=1, normalized_grid=nrm, fixed_grid=fx)
+        self.time = SimpleNamespace(steps=steps, control_steps=getattr(self, "control_steps", 1), normalized_grid=nrm, fixed_grid=fx)
         if stage > 0:
             a = np.zeros(stage * stage); b = np.zeros(stage); c = np.zeros(stage)
             self._ck(L.ctd_butcher(self._h, _dp(a), _dp(b), _dp(c)))
@@ -680,6 +684,16 @@ def _state_control_variable(docp, data):
     X = np.stack([data[i * blk:i * blk + n] for i in range(N + 1)])
     stage = docp.discretization.stage
     stagewise = docp.scheme in ("gauss_legendre_2", "gauss_legendre_3")
+    cs = getattr(docp.time, "control_steps", 1)
+    if cs > 1:
+        # getter(...; val = :control) with several controls per step (src/ode/common.jl:84-98): N control_steps + 1 rows, the
+        # controls of every step in order, then get_OCP_control_at_time_step(N + 1) = the first control of the last step
+        U = np.zeros((N * cs + 1, m))
+        for i in range(N):
+            for j in range(cs):
+                U[i * cs + j] = data[i * blk + n + j * m:i * blk + n + (j + 1) * m]
+        U[N * cs] = data[(N - 1) * blk + n:(N - 1) * blk + n + m]
+        return X, U, data[len(data) - nv:].copy()
     U = np.zeros((N + 1, m))
     if m:
         b = docp.discretization.butcher_b if stagewise else None
@@ -704,6 +718,9 @@ def unpack_solution(docp, x, multipliers=None, multipliers_L=None, multipliers_U
     T = get_time_grid(x, docp)
     X, U, v = _state_control_variable(docp, x)
     out = dict(T=T, X=X, U=U, v=v)
+    cs = getattr(docp.time, "control_steps", 1)
+    # time grid of the control rows (src/DOCP_data.jl:557-567): T_control[k] = T[i] + (j - 1) h_i / control_steps, last = T[end]
+    out["T_control"] = np.concatenate([(T[:-1, None] + np.arange(cs)[None, :] * (np.diff(T)[:, None] / cs)).ravel(), T[-1:]]) if cs > 1 else T
     for z, tag in ((multipliers_L, "lb"), (multipliers_U, "ub")):
         zz = np.zeros_like(x) if z is None else np.ascontiguousarray(z, dtype=np.float64)
         ZX, ZU, Zv = _state_control_variable(docp, zz)

@@ -104,8 +104,16 @@ typedef struct ctd_desc {
     int64_t step_end;         /*   0-based; 0,0 = all N steps (single GPU)                                    */
     void* stream;             /* hipStream_t to launch on when stream_mode == CTD_STREAM_GIVEN                */
     int32_t stream_mode;      /* CTD_STREAM_OWN: the handle creates a private non-blocking stream (default);  */
-    int32_t reserved;         /* CTD_STREAM_GIVEN: launch on `stream` (NULL = the device's default stream),   */
+                              /* CTD_STREAM_GIVEN: launch on `stream` (NULL = the device's default stream),   */
                               /* so launches are ordered with the caller's other work on that stream          */
+    int32_t control_steps;    /* controls per time step: DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293.
+                               * 0 or 1: collocation (src/collocation.jl:65).  > 1: the direct-shooting layout of
+                               * src/direct_shooting.jl:55-71 -- step block [X_i, U_i^1 .. U_i^cs] (midpoint.jl:20), dynamics summed over
+                               * the control sub-steps (midpoint.jl:47-72,137-155), cost midpoint.jl:99-116, bounds / initial guess for
+                               * every control (DOCP_variables.jl:44,138); path constraints see U_i^1 (common.jl:140-155).  CTD_SCHEME_MIDPOINT
+                               * only (CTD_ESCHEME otherwise: no other scheme of the reference reads the extra controls).  Compiled problems:
+                               * control_steps <= 3; problems registered at run time: any.  Constraints, Jacobian (all three patterns),
+                               * objective, gradient, hess_structure; ctd_hess_coord* return CTD_EPATTERN. */
 } ctd_desc;
 
 enum { CTD_STREAM_OWN = 0, CTD_STREAM_GIVEN = 1 };

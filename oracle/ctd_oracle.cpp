@@ -94,6 +94,7 @@ struct Docp {
     Dims dims;
     Flags flags;
     int steps;
+    int control_steps = 1;                                                        // DOCPtime.control_steps, DOCP_data.jl:149 (direct shooting: >= 1 controls per step)
     std::vector<double> normalized_grid, fixed_grid;                              // DOCP_data.jl:147-152
     Disc disc;
     int64_t dim_NLP_variables = 0, dim_NLP_constraints = 0;
@@ -146,7 +147,7 @@ static void build_scheme(Docp& p, int scheme) {
             p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v + m.NLP_u;
             break;
         case MIDPOINT:                                            // midpoint.jl:17-39
-            d.step_variables_block = m.NLP_x + m.NLP_u;
+            d.step_variables_block = m.NLP_x + m.NLP_u * p.control_steps;      // :20
             d.state_stage_eqs_block = m.NLP_x;
             d.step_pathcons_block = m.path_cons;
             p.dim_NLP_variables = N * d.step_variables_block + m.NLP_x + m.NLP_v;
@@ -184,6 +185,10 @@ static void build_scheme(Docp& p, int scheme) {
             throw std::runtime_error("Unknown discretization method");   // DOCP_data.jl:342-349
     }
     p.dim_NLP_constraints = N * (d.state_stage_eqs_block + d.step_pathcons_block) + d.step_pathcons_block + m.boundary_cons;
+    // control_steps > 1 (src/direct_shooting.jl:55-71): the other scheme structs size their blocks with it too (trapeze.jl:20,
+    // euler.jl:22, irk.jl:141) but only midpoint.jl:47-72,99-116,137-155 has sub-step dynamics -- there the extra controls would
+    // be variables nothing reads.  Restated for the midpoint scheme only.
+    if (p.control_steps > 1 && scheme != MIDPOINT) throw std::runtime_error("control_steps > 1 is restated for :midpoint only");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,9 +199,9 @@ template <class T> static const T* get_OCP_variable(const T* xu, const Docp& p) 
 // get_OCP_state_at_time_step: common.jl:124-128  (i is 1-based as in the reference)
 template <class T> static const T* get_state(const T* xu, const Docp& p, int64_t i) { return xu + (i - 1) * p.disc.step_variables_block; }
 // get_OCP_control_at_time_step (generic): common.jl:140-155
-template <class T> static const T* get_control_generic(const T* xu, const Docp& p, int64_t i) {
+template <class T> static const T* get_control_generic(const T* xu, const Docp& p, int64_t i, int j = 1) {
     if (!p.disc.final_control && i == p.steps + 1) i = p.steps;
-    return xu + (i - 1) * p.disc.step_variables_block + p.dims.NLP_x;
+    return xu + (i - 1) * p.disc.step_variables_block + p.dims.NLP_x + (j - 1) * p.dims.NLP_u;     // :150-152 (j-th control of the step)
 }
 // get_stagecontrol_at_time_step: irk_stagewise.jl:173-188
 template <class T> static const T* get_stagecontrol(const T* xu, const Docp& p, int64_t i, int j) {
@@ -267,15 +272,20 @@ template <class P, class T> static void constraints(const Docp& p, const T* xu, 
         for (int64_t i = 1; i <= N + 1; ++i) {
             P::template dynamics<T>(&work[(i - 1) * n], grid[i - 1], get_state(xu, p, i), get_control_generic(xu, p, i), v);
         }
-    } else if (d.scheme == MIDPOINT) {            // midpoint.jl:47-72: f at the N midpoints
-        work.resize((size_t)n * N);
+    } else if (d.scheme == MIDPOINT) {            // midpoint.jl:47-72: f at the N midpoints, once per control step
+        const int cs = p.control_steps;
+        work.resize((size_t)n * N * cs);
         std::vector<T> xs(n);
+        size_t offset = 0;
         for (int64_t i = 1; i <= N; ++i) {
             T ts = 0.5 * (grid[i - 1] + grid[i]);
             const T* xi = get_state(xu, p, i);
             const T* xip1 = get_state(xu, p, i + 1);
             for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
-            P::template dynamics<T>(&work[(i - 1) * n], ts, xs.data(), get_control_generic(xu, p, i), v);
+            for (int j = 1; j <= cs; ++j) {       // :61-69 (the same t_s, x_s for every control of the step)
+                P::template dynamics<T>(&work[offset], ts, xs.data(), get_control_generic(xu, p, i, j), v);
+                offset += n;
+            }
         }
     } else if (d.euler) {                         // euler.jl:79-105: f at (t_i, x_i, u_i) or (t_i+1, x_i+1, u(t_i+1) = U_i)
         work.resize((size_t)n * N);
@@ -305,10 +315,21 @@ template <class P, class T> static void constraints(const Docp& p, const T* xu, 
                 T x_next = xi[k] + half_hi * (fi[k] + fip1[k]);
                 c[offset + k] = xip1[k] - x_next;
             }
-        } else if (d.scheme == MIDPOINT) {        // midpoint.jl:124-140 (control_steps == 1)
-            T hi = (tip1 - ti) / 1.0;
-            const T* fi = &work[(i - 1) * n];
-            for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * fi[k]);
+        } else if (d.scheme == MIDPOINT) {        // midpoint.jl:124-156
+            const int cs = p.control_steps;
+            T hi = (tip1 - ti) / (double)cs;      // :134
+            if (cs == 1) {                        // :138-140
+                const T* fi = &work[(i - 1) * n];
+                for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - (xi[k] + hi * fi[k]);
+            } else {                              // :146-153: x_next = x_i; x_next += h_i work_j, j = 1..control_steps
+                std::vector<T> x_next(xi, xi + n);
+                size_t offset_dyn = (size_t)(i - 1) * n * cs;
+                for (int j = 1; j <= cs; ++j) {
+                    for (int k = 0; k < n; ++k) x_next[k] = x_next[k] + hi * work[offset_dyn + k];
+                    offset_dyn += n;
+                }
+                for (int k = 0; k < n; ++k) c[offset + k] = xip1[k] - x_next[k];
+            }
         } else if (d.euler) {                     // euler.jl:141-159
             T hi = tip1 - ti;
             const T* fi = &work[(i - 1) * n];
@@ -384,6 +405,19 @@ template <class P, class T> static T objective(const Docp& p, const T* xu) {
             {
                 T hi = grid[N] - grid[N - 1];
                 value = value + hi / 2.0 * P::template lagrange<T>(grid[N], get_state(xu, p, N + 1), get_control_generic(xu, p, N + 1), v);
+            }
+        } else if (d.scheme == MIDPOINT && p.control_steps > 1) {     // midpoint.jl:99-116
+            const int cs = p.control_steps;
+            std::vector<T> xs(n);
+            for (int64_t i = 1; i <= N; ++i) {
+                T hi = (grid[i] - grid[i - 1]) / (double)cs;
+                const T* xi = get_state(xu, p, i);
+                const T* xip1 = get_state(xu, p, i + 1);
+                for (int k = 0; k < n; ++k) xs[k] = 0.5 * (xi[k] + xip1[k]);
+                for (int j = 1; j <= cs; ++j) {
+                    T tij = grid[i - 1] + (j - 0.5) * hi;          // :110
+                    value = value + hi * P::template lagrange<T>(tij, xs.data(), get_control_generic(xu, p, i, j), v);
+                }
             }
         } else if (d.scheme == MIDPOINT) {        // midpoint.jl:79-97
             std::vector<T> xs(n);
@@ -463,8 +497,10 @@ template <class P> static void variables_bounds(Docp& p) {
         } else {                                                 // DOCP_variables.jl:40-49 + setter common.jl:209-223
             for (int64_t i = 1; i <= N + 1; ++i) {
                 if (i <= N || (d.final_control && i <= N + 1)) {
-                    int64_t off = (i - 1) * d.step_variables_block + n;
-                    for (int k = 0; k < m; ++k) { p.var_l[off + k] = u_lb[k]; p.var_u[off + k] = u_ub[k]; }
+                    for (int j = 1; j <= p.control_steps; ++j) {     // DOCP_variables.jl:44-47
+                        int64_t off = (i - 1) * d.step_variables_block + n + (j - 1) * m;
+                        for (int k = 0; k < m; ++k) { p.var_l[off + k] = u_lb[k]; p.var_u[off + k] = u_ub[k]; }
+                    }
                 }
             }
         }
@@ -520,8 +556,10 @@ template <class P> static void initial_guess(const Docp& p, bool use_problem_ini
         if (m > 0 && !d.stagewise) {
             if (i <= N || d.final_control) {
                 if (P::init_control(ti, tmp.data())) {
-                    int64_t off = (i - 1) * d.step_variables_block + n;
-                    for (int k = 0; k < m; ++k) X[off + k] = tmp[k];
+                    for (int j = 1; j <= p.control_steps; ++j) {     // DOCP_variables.jl:138-140: init.control(t_i) for every control of the step
+                        int64_t off = (i - 1) * d.step_variables_block + n + (j - 1) * m;
+                        for (int k = 0; k < m; ++k) X[off + k] = tmp[k];
+                    }
                 }
             }
         }
@@ -941,6 +979,7 @@ template <class P, int CAP> static void cons_jac_block_cap(const Docp& cp, const
     {
         Docp p1;
         p1.problem = cp.problem;
+        p1.control_steps = cp.control_steps;
         make_docp<P>(p1, d.scheme, 1, nullptr, 0);
         const int W = (int)p1.dim_NLP_variables;            // local variables of one step
         const int nloc = W - nv;                             // contiguous in xu from (i-1) * blk
@@ -1131,6 +1170,7 @@ template <class P> static bool hessian_block(Docp& p, const double* xu, const do
     {
         Docp p1;
         p1.problem = cp.problem;
+        p1.control_steps = cp.control_steps;
         make_docp<P>(p1, d.scheme, 1, nullptr, 0);
         p1.flags.mayer = false;                              // the Mayer term belongs to the boundary point below
         const int W = (int)p1.dim_NLP_variables, nloc = W - nv;
@@ -1217,6 +1257,7 @@ static void traced_patterns(Docp& p, IJ& jac, std::vector<std::pair<int64_t, int
 }
 
 template <class P> static void make_docp(Docp& p, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len) {
+    if (p.control_steps < 1) throw std::runtime_error("control_steps must be >= 1");
     p.dims = Dims{P::n, P::m, P::nv, P::p, P::bc};
     p.flags = Flags{P::freet0, P::freetf, P::has_lagrange, P::has_mayer, P::maximize};
     // DOCPtime  (DOCP_data.jl:176-214)
@@ -1258,10 +1299,16 @@ static std::string g_err;
 
 extern "C" {
 
+int orc_create_cs(int problem, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len, int control_steps, void** out);
 int orc_create(int problem, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len, void** out) {
+    return orc_create_cs(problem, scheme, grid_size, time_grid, time_grid_len, 1, out);
+}
+// DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293
+int orc_create_cs(int problem, int scheme, int64_t grid_size, const double* time_grid, int64_t time_grid_len, int control_steps, void** out) {
     try {
         auto p = std::make_unique<Docp>();
         p->problem = problem;
+        p->control_steps = control_steps;
         orc::dispatch(problem, [&](auto tag) { orc::make_docp<typename decltype(tag)::type>(*p, scheme, grid_size, time_grid, time_grid_len); });
         *out = p.release();
         return 0;

@@ -109,16 +109,17 @@ def _ip(a):
 class OracleDOCP:
     """CPU restatement of `CTDirect.DOCP(ocp, grid_size, 1, scheme, time_grid)` (src/DOCP_data.jl:293-365)."""
 
-    def __init__(self, problem, scheme, grid_size=None, time_grid=None):
+    def __init__(self, problem, scheme, grid_size=None, time_grid=None, control_steps=1):
         L = lib()
         pid = PROBLEMS[problem] if isinstance(problem, str) else int(problem)
         sid = SCHEMES[scheme] if isinstance(scheme, str) else int(scheme)
         h = C.c_void_p()
+        self.control_steps = int(control_steps)          # DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293
         if time_grid is not None:
             tg = np.ascontiguousarray(time_grid, dtype=np.float64)
-            st = L.orc_create(pid, sid, len(tg) - 1, _dp(tg), len(tg), C.byref(h))
+            st = L.orc_create_cs(pid, sid, len(tg) - 1, _dp(tg), len(tg), self.control_steps, C.byref(h))
         else:
-            st = L.orc_create(pid, sid, int(grid_size), None, 0, C.byref(h))
+            st = L.orc_create_cs(pid, sid, int(grid_size), None, 0, self.control_steps, C.byref(h))
         if st == 2:
             raise ValueError(L.orc_last_error().decode())       # Julia: ArgumentError (src/DOCP_data.jl:187)
         if st != 0:

@@ -36,7 +36,7 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
             BlockCtx cx = make_direct_ctx(kp, b, lds.data(), xu);
             std::vector<EmitPre> pre(nthr);
             for (int t = 0; t < nthr; ++t) pre[t] = emit_prefetch<P>(kp, cx, t, nthr);
-            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S, RegEval<P, SC>::value>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S, RegEval<P, SC, S>::value>(kp, cx, t, nthr);
             for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr, &pre[t]);
             continue;
         }
@@ -77,15 +77,18 @@ static void run_hess_blocks(const HParams& hp, const double* xu, const double* y
 }
 
 static std::string g_err;
+static int g_control_steps = 1;          // DOCP(..., control_steps, ...) of the models built below (tests set it around a call)
 
 extern "C" {
+
+void emu_set_control_steps(int cs) { g_control_steps = cs < 1 ? 1 : cs; }
 
 const char* emu_last_error() { return g_err.c_str(); }
 
 // out[0..3] = nvar, ncon, nnzj, dropped
 int emu_sizes(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* out) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     out[0] = mo.L.nvar; out[1] = mo.L.ncon; out[2] = mo.nnzj; out[3] = mo.dropped;
@@ -94,7 +97,7 @@ int emu_sizes(int problem, int scheme, int pattern_mode, int64_t N, const double
 
 int emu_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* colptr, int64_t* rowval) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     std::vector<int64_t> rows;
@@ -113,7 +116,7 @@ int emu_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* 
 int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
                  int64_t step_begin, int64_t step_end, const double* x, double* c, double* vals) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     if (step_end <= 0) { step_begin = 0; step_end = mo.L.N; }
@@ -132,7 +135,11 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {
             case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE, 1>(kp, x, nthr); break;
-            case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT, 1>(kp, x, nthr); break;
+            case SC_MIDPOINT:
+                if (mo.L.cs == 2) run_blocks<P, SC_MIDPOINT, 2>(kp, x, nthr);
+                else if (mo.L.cs == 3) run_blocks<P, SC_MIDPOINT, 3>(kp, x, nthr);
+                else run_blocks<P, SC_MIDPOINT, 1>(kp, x, nthr);
+                break;
             default:
                 if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, x, nthr);
                 else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, x, nthr);
@@ -149,7 +156,7 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
 int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
                          int G, const double* x, double* c, double* vals) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     const Layout& L = mo.L;
@@ -184,7 +191,11 @@ int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, c
             using P = typename decltype(tag)::type;
             switch (mo.L.sc) {
                 case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE, 1>(kp, xk, nthr); break;
-                case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT, 1>(kp, xk, nthr); break;
+                case SC_MIDPOINT:
+                    if (mo.L.cs == 2) run_blocks<P, SC_MIDPOINT, 2>(kp, xk, nthr);
+                    else if (mo.L.cs == 3) run_blocks<P, SC_MIDPOINT, 3>(kp, xk, nthr);
+                    else run_blocks<P, SC_MIDPOINT, 1>(kp, xk, nthr);
+                    break;
                 default:
                     if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, xk, nthr);
                     else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, xk, nthr);
@@ -204,7 +215,7 @@ void emu_stitch_src(int64_t N, int cb, int G, int64_t smax, int64_t ncon, int64_
 
 int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     if (build_model(d, mo, g_err)) return -1;
     return mo.H.nnzh;
 }
@@ -212,7 +223,7 @@ int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const
 // lower triangle of DOCP_Hessian_pattern, 0-based CSC
 int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* colptr, int64_t* rowval) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     std::vector<int64_t> rows;
@@ -231,7 +242,7 @@ int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const dou
 int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
              const double* x, const double* y, double obj_weight, double* vals, int64_t step_begin, int64_t step_end) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     if (tile <= 0) tile = default_hess_tile(mo);

@@ -133,3 +133,16 @@ def sym_check(expr, n, m, nv, point):
     if st:
         raise RuntimeError(lib().emu_last_error().decode())
     return err.value, nn.value
+
+
+class control_steps:
+    """`with emu.control_steps(cs): ...` -- the models the emulator builds inside use DOCP(..., control_steps = cs, ...)"""
+
+    def __init__(self, cs):
+        self.cs = int(cs)
+
+    def __enter__(self):
+        lib().emu_set_control_steps(self.cs)
+
+    def __exit__(self, *a):
+        lib().emu_set_control_steps(1)

@@ -26,6 +26,7 @@ Usage:  python tests/golden/gen_golden.py        (rewrites tests/golden/*.json; 
 import json
 import math
 import os
+import sys
 
 from mpmath import mp, mpf
 
@@ -312,9 +313,11 @@ SCHEMES = {
 
 
 class Docp:
-    def __init__(self, prob, scheme, N=None, time_grid=None):
+    def __init__(self, prob, scheme, N=None, time_grid=None, control_steps=1):
         self.P = prob
         self.scheme = scheme
+        self.cs = control_steps            # DOCPtime.control_steps (direct shooting): midpoint.jl:47-72, :99-116, :137-155
+        assert control_steps == 1 or scheme == "midpoint"
         self.kind, self.s, self.stagewise = SCHEMES[scheme]
         if time_grid is None:
             self.N = N
@@ -333,7 +336,7 @@ class Docp:
             self.blk, self.eqs, self.final_control = n + m, n, True
             self.nvar = self.N * self.blk + n + nv + m
         elif self.kind in ("midpoint", "euler_explicit", "euler_implicit"):
-            self.blk, self.eqs, self.final_control = n + m, n, False
+            self.blk, self.eqs, self.final_control = n + m * self.cs, n, False       # midpoint.jl:20
             self.nvar = self.N * self.blk + n + nv
         else:
             self.a, self.b, self.c = butcher(s)
@@ -347,10 +350,10 @@ class Docp:
     def V(self, xu): return xu[self.nvar - self.P.nv:]
     def X(self, xu, i): return xu[(i - 1) * self.blk:(i - 1) * self.blk + self.P.n]
 
-    def Ugen(self, xu, i):
+    def Ugen(self, xu, i, j=1):
         if not self.final_control and i == self.N + 1:
             i = self.N
-        o = (i - 1) * self.blk + self.P.n
+        o = (i - 1) * self.blk + self.P.n + (j - 1) * self.P.m        # common.jl:140-155
         return xu[o:o + self.P.m]
 
     def Ustage(self, xu, i, j):
@@ -395,7 +398,7 @@ class Docp:
             for i in range(1, N + 1):
                 ts = mpf("0.5") * (T[i - 1] + T[i])
                 xs = [mpf("0.5") * (a + b) for a, b in zip(self.X(xu, i), self.X(xu, i + 1))]
-                work.append(P.dynamics(ts, xs, self.Ugen(xu, i), v))
+                work.append([P.dynamics(ts, xs, self.Ugen(xu, i, j), v) for j in range(1, self.cs + 1)])
         elif self.kind in ("euler_explicit", "euler_implicit"):       # euler.jl:79-105
             work = []
             for i in range(1, N + 1):
@@ -407,7 +410,13 @@ class Docp:
             if self.kind == "trapeze":
                 hh = mpf("0.5") * (tip1 - ti)
                 c += [xip1[k] - (xi[k] + hh * (work[i - 1][k] + work[i][k])) for k in range(n)]
-            elif self.kind in ("midpoint", "euler_explicit", "euler_implicit"):
+            elif self.kind == "midpoint":                                 # midpoint.jl:124-156
+                hi = (tip1 - ti) / self.cs
+                x_next = list(xi)
+                for j in range(self.cs):
+                    x_next = [a + hi * f for a, f in zip(x_next, work[i - 1][j])]
+                c += [xip1[k] - x_next[k] for k in range(n)]
+            elif self.kind in ("euler_explicit", "euler_implicit"):
                 hi = tip1 - ti
                 c += [xip1[k] - (xi[k] + hi * work[i - 1][k]) for k in range(n)]
             else:
@@ -453,6 +462,13 @@ class Docp:
                 for i in range(2, N + 1):
                     val = val + (T[i] - T[i - 2]) / 2 * P.lagr(T[i - 1], self.X(xu, i), self.Ugen(xu, i), v)
                 val = val + (T[N] - T[N - 1]) / 2 * P.lagr(T[N], self.X(xu, N + 1), self.Ugen(xu, N + 1), v)
+            elif self.kind == "midpoint" and self.cs > 1:                 # midpoint.jl:99-116
+                for i in range(1, N + 1):
+                    hi = (T[i] - T[i - 1]) / self.cs
+                    xs = [mpf("0.5") * (a + b) for a, b in zip(self.X(xu, i), self.X(xu, i + 1))]
+                    for j in range(1, self.cs + 1):
+                        tij = T[i - 1] + (j - mpf("0.5")) * hi
+                        val = val + hi * P.lagr(tij, xs, self.Ugen(xu, i, j), v)
             elif self.kind == "midpoint":
                 for i in range(1, N + 1):
                     hi = T[i] - T[i - 1]
@@ -532,6 +548,9 @@ def fill_inputs(d):
         xu[o:o + P.n] = state(tau)
         if P.m > 0 and d.kind != "irk" and (i <= N or d.final_control):
             xu[o + P.n:o + P.n + P.m] = control(tau, 0)
+            for j in range(2, getattr(d, "cs", 1) + 1):           # further controls of the step (control_steps > 1)
+                tj = tau + (j - 1) / d.cs * (d.tau[i] - tau)
+                xu[o + P.n + (j - 1) * P.m:o + P.n + j * P.m] = control(tj, j - 1)
     if d.kind == "irk":
         # controls, then stage variables from a float evaluation of the dynamics at the stage points
         Du.NV = 0
@@ -561,8 +580,8 @@ def hexf(x):
     return float(x).hex()
 
 
-def run_case(tag, prob, scheme, N=None, time_grid=None, xu=None):
-    d = Docp(prob, scheme, N=N, time_grid=time_grid)
+def run_case(tag, prob, scheme, N=None, time_grid=None, xu=None, control_steps=1):
+    d = Docp(prob, scheme, N=N, time_grid=time_grid, control_steps=control_steps)
     if xu is None:
         xu = fill_inputs(d)
     assert len(xu) == d.nvar
@@ -586,6 +605,7 @@ def run_case(tag, prob, scheme, N=None, time_grid=None, xu=None):
         "dims": {"n": prob.n, "m": prob.m, "nv": prob.nv, "path": prob.p, "boundary": prob.bc,
                  "nvar": d.nvar, "ncon": d.ncon, "step_variables_block": d.blk, "state_stage_eqs_block": d.eqs},
         "xu": [hexf(x) for x in xu],
+        **({"control_steps": control_steps} if control_steps != 1 else {}),
         "c": [hexf(Du.lift(x).v) for x in c],
         "objective": hexf(obj.v),
         "gradient": [[j, hexf(g)] for j, g in enumerate(obj.d) if g != 0],
@@ -614,7 +634,20 @@ def exact_stagewise_xu(d):
     return xu
 
 
+def main_control_steps():
+    """control_steps > 1 (direct shooting layout, midpoint scheme): `python gen_golden.py cs` writes only these"""
+    run_case("cs2_goddard_midpoint_N4", Goddard(), "midpoint", N=4, control_steps=2)
+    run_case("cs3_goddard_midpoint_nonuniform", Goddard(), "midpoint", time_grid=[0.0, 0.1, 0.45, 1.0], control_steps=3)
+    run_case("cs2_dip_midpoint_N4", DoubleIntegratorPath(), "midpoint", N=4, control_steps=2)
+    run_case("cs3_dip_midpoint_nonuniform", DoubleIntegratorPath(), "midpoint", time_grid=[0.0, 0.3, 0.5, 0.6, 1.0], control_steps=3)
+    run_case("cs2_goddard_all_midpoint_N3", GoddardAll(), "midpoint", N=3, control_steps=2)
+    run_case("cs3_freet0tf_midpoint_N3", DoubleIntegratorFreeT0Tf(), "midpoint", N=3, control_steps=3)
+    run_case("cs2_quadrotor_midpoint_N2", Quadrotor8(), "midpoint", N=2, control_steps=2)
+
+
 def main():
+    if sys.argv[1:] == ["cs"]:
+        return main_control_steps()
     g = [0.0, 0.2, 0.6, 1.0]
     # G1: the reference's exact-feasible trajectory (c == 0, objective == 4/3)
     for sch in ("gauss_legendre_2", "gauss_legendre_3"):
@@ -655,6 +688,7 @@ def main():
     run_case("lsq_euler_implicit_N3", LeastSquaresConstraint(), "euler_implicit", N=3)
     run_case("freet0tf_euler_N3", DoubleIntegratorFreeT0Tf(), "euler", N=3)
     run_case("freet0tf_euler_implicit_N3", DoubleIntegratorFreeT0Tf(), "euler_implicit", N=3)
+    main_control_steps()
 
 
 if __name__ == "__main__":

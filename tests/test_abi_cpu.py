@@ -275,3 +275,59 @@ def test_optimized_pattern_reference_golden_and_oracle_parity(oracle_lib):
         a = ct.DOCP(prob, N, sch, device=-1)
         b = ct.DOCP(prob, N, sch, pattern="optimized", device=-1)
         assert b.nnzj < a.nnzj and b.nnzh <= a.nnzh
+
+
+@pytest.mark.parametrize("prob", ["goddard", "goddard_all", "double_integrator_path", "quadrotor", "double_integrator_freet0tf",
+                                  "estimate_rotation_rate"])
+def test_control_steps_host_logic_matches_oracle(oracle_lib, prob):
+    """control_steps > 1 -- the direct-shooting layout DOCP(ocp, grid_size, control_steps, :midpoint, time_grid)
+    (src/direct_shooting.jl:55-71): block n + m control_steps (midpoint.jl:20), bounds and initial guess for every control of a
+    step (DOCP_variables.jl:44,138), and all three Jacobian patterns bit-exact against the oracle (manual: midpoint.jl:163-233
+    is written in terms of the block; optimized: the oracle's traced pattern)."""
+    rng = np.random.default_rng(3)
+    for cs in (2, 3, 5):
+        for N, tg in ((1, None), (4, None), (5, None), (23, None), (9, np.cumsum(rng.uniform(0.5, 1.5, 10)))):
+            o = oracle_lib.OracleDOCP(prob, "midpoint", N, time_grid=tg, control_steps=cs)
+            for mode, name in ((0, "manual"), (1, "structural"), (2, "optimized")):
+                d = ct.DOCP(prob, N, "midpoint", time_grid=tg, device=-1, control_steps=cs, pattern=name)
+                assert d.time.control_steps == cs
+                assert (d.dim_NLP_variables, d.dim_NLP_constraints) == (o.dim_NLP_variables, o.dim_NLP_constraints)
+                assert d.discretization._step_variables_block == o.n + o.m * cs
+                lv, uv, lc, uc = o.bounds()
+                assert np.array_equal(d.bounds.var_l, lv) and np.array_equal(d.bounds.var_u, uv)
+                assert np.array_equal(d.bounds.con_l, lc) and np.array_equal(d.bounds.con_u, uc)
+                assert np.array_equal(ct.initial_guess(d), o.initial_guess(False))
+                assert np.array_equal(ct.initial_guess(d, "problem"), o.initial_guess(True))
+                o.set_pattern_mode(mode)
+                cp, rv = o.jac_pattern()
+                cp2, rv2 = ct.DOCP_Jacobian_pattern(d)
+                assert d.nnzj == o.jac_nnz() and np.array_equal(cp, cp2) and np.array_equal(rv, rv2), (cs, N, name)
+                if mode < 2:       # hess_structure: the blocks of midpoint.jl:240-300 (optimized: the same blocks, a superset)
+                    hp, hr = o.hess_pattern()
+                    hp2, hr2 = ct.DOCP_Hessian_pattern(d)
+                    assert np.array_equal(hp, hp2) and np.array_equal(hr, hr2), (cs, N, name)
+                d.close()
+
+
+def test_control_steps_errors_and_solution_unpacking():
+    # only the midpoint scheme integrates over the control sub-steps (midpoint.jl:137-155): refused elsewhere, never silently
+    # a layout with controls nothing reads
+    for sch in ("trapeze", "euler", "gauss_legendre_2", "gauss_legendre_2_constant_control"):
+        with pytest.raises(ct.CTDirectError) as e:
+            ct.DOCP("goddard", 5, sch, device=-1, control_steps=2)
+        assert e.value.status == ct._lib.CTD_ESCHEME
+    with pytest.raises(ct.CTDirectError) as e:           # compiled problems: the midpoint kernels exist for 1, 2, 3 controls per step
+        ct.DOCP("goddard", 5, "midpoint", device=0, control_steps=4)
+    assert e.value.status == ct._lib.CTD_EINVAL
+    assert ct.DOCP("goddard", 5, "midpoint", device=-1, control_steps=4).discretization._step_variables_block == 7     # (host-only: any)
+    # build_OCP_solution with several controls per step (src/DOCP_data.jl:530,557-567, src/ode/common.jl:84-98)
+    d = ct.DOCP("goddard", 3, "midpoint", time_grid=[0.0, 0.2, 0.6, 1.0], device=-1, control_steps=2)
+    x = np.arange(d.dim_NLP_variables, dtype=float)
+    x[-1] = 2.0                                          # t_f
+    s = ct.unpack_solution(d, x)
+    blk = 3 + 2
+    assert s["U"].shape == (3 * 2 + 1, 1) and s["X"].shape == (4, 3)
+    assert np.array_equal(s["U"][:, 0], [3, 4, 3 + blk, 4 + blk, 3 + 2 * blk, 4 + 2 * blk, 3 + 2 * blk])
+    assert np.allclose(s["T_control"], [0.0, 0.2, 0.4, 0.8, 1.2, 1.6, 2.0])
+    d1 = ct.DOCP("goddard", 3, "midpoint", device=-1)
+    assert np.array_equal(ct.unpack_solution(d1, np.ones(d1.dim_NLP_variables))["T_control"], ct.unpack_solution(d1, np.ones(d1.dim_NLP_variables))["T"])

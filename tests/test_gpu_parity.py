@@ -34,7 +34,8 @@ def test_fixture_parity_host_pointers(path):
     """Every golden fixture through the host-pointer entry points (ctd_cons, ctd_jac_coord, ctd_cons_jac, ctd_obj)."""
     g = load_golden(path)
     for pattern in ("manual", "structural"):
-        d = ct.DOCP(g["problem"], g["grid_size"], g["scheme"], time_grid=g["time_grid"], pattern=pattern, device=0)
+        d = ct.DOCP(g["problem"], g["grid_size"], g["scheme"], time_grid=g["time_grid"], pattern=pattern, device=0,
+                    control_steps=g.get("control_steps", 1))
         cp, rv = ct.DOCP_Jacobian_pattern(d)
         ref = dense_on_pattern(g["J"], cp, rv)
         c = np.full(d.dim_NLP_constraints, SENT)

@@ -14,17 +14,19 @@ from helpers import TOL, bench_inputs, dense_on_pattern, golden_files, load_gold
 def test_emulated_kernel_matches_fixture(oracle_lib, path):
     g = load_golden(path)
     pid, sid = ct.PROBLEMS[g["problem"]], ct.SCHEMES[g["scheme"]]
-    o = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
-    for mode in (0, 1):
-        o.set_pattern_mode(mode)
-        cp, rv = o.jac_pattern()
-        cp2, rv2 = emu.csc(pid, sid, mode, g["grid_size"], g["time_grid"])
-        assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2)
-        ref = dense_on_pattern(g["J"], cp, rv)
-        for tile, nthr in ((0, 64), (1, 3), (3, 17)):
-            c, vals = emu.cons_jac(pid, sid, mode, g["grid_size"], g["xu"], g["time_grid"], tile=tile, nthr=nthr)
-            assert relerr(c, g["c"]) <= TOL
-            assert relerr(vals, ref) <= TOL
+    cs = g.get("control_steps", 1)
+    o = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"], control_steps=cs)
+    with emu.control_steps(cs):
+        for mode in (0, 1, 2) if cs > 1 else (0, 1):
+            o.set_pattern_mode(mode)
+            cp, rv = o.jac_pattern()
+            cp2, rv2 = emu.csc(pid, sid, mode, g["grid_size"], g["time_grid"])
+            assert np.array_equal(cp, cp2) and np.array_equal(rv, rv2)
+            ref = dense_on_pattern(g["J"], cp, rv)
+            for tile, nthr in ((0, 64), (1, 3), (3, 17)):
+                c, vals = emu.cons_jac(pid, sid, mode, g["grid_size"], g["xu"], g["time_grid"], tile=tile, nthr=nthr)
+                assert relerr(c, g["c"]) <= TOL
+                assert relerr(vals, ref) <= TOL
 
 
 PAIRS = [(p, s) for p in ct.PROBLEMS for s in ct.SCHEMES]

@@ -135,7 +135,7 @@ def test_time_grid_errors(oracle_lib):
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-5])
 def test_oracle_matches_mpmath_fixture(oracle_lib, path):
     g = load_golden(path)
-    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
+    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"], control_steps=g.get("control_steps", 1))
     assert d.dim_NLP_variables == g["dims"]["nvar"] and d.dim_NLP_constraints == g["dims"]["ncon"]
     assert d.step_variables_block == g["dims"]["step_variables_block"]
     xu = g["xu"]
