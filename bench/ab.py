@@ -49,7 +49,8 @@ def main():
     res = {lib: {n: [] for n in names} for lib in libs}
     for rep in range(3):
         for lib in libs:
-            env = dict(os.environ, CTD_LIB_PATH=os.path.abspath(lib))
+            path, *kv = lib.split(",")               # "path/to/lib.so,CTD_EARLY=0": environment knobs of that side
+            env = dict(os.environ, CTD_LIB_PATH=os.path.abspath(path), **dict(x.split("=", 1) for x in kv))
             o = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + names, env=env, capture_output=True, text=True)
             line = [l for l in o.stdout.splitlines() if l.startswith("{")]
             if not line:

@@ -137,6 +137,8 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("CTD_LIB_PATH") and not hasattr(L, name):
+                continue                  # (A/B runs against an older experiment build: it may lack the newest entry points)
             f = getattr(L, name)          # AttributeError if the library does not export the symbol
             f.restype = res
             f.argtypes = args

@@ -85,6 +85,7 @@ struct ctd_handle {
     double* d_tau = nullptr;
     uint32_t* d_tmpl = nullptr;
     uint32_t* d_vtmpl = nullptr;
+    uint16_t* d_pos = nullptr;
     int64_t* d_edge_idx = nullptr;
     uint32_t* d_edge_code = nullptr;
     // staging for the host-pointer entry points
@@ -180,7 +181,7 @@ static void free_device(ctd_handle* h) {
     if (h->device < 0) return;
     DeviceGuard dg_(h->device);
     (void)hipStreamSynchronize(h->stream);      // enqueue-only calls may still be running on the tables freed below
-    for (void* p : {(void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
+    for (void* p : {(void*)h->d_pos, (void*)h->d_tau, (void*)h->d_tmpl, (void*)h->d_vtmpl, (void*)h->d_edge_idx, (void*)h->d_edge_code,
                     (void*)h->d_x, (void*)h->d_c, (void*)h->d_vals, (void*)h->d_partial, (void*)h->d_obj, (void*)h->d_g,
                     (void*)h->d_gpartial, (void*)h->d_htptr, (void*)h->d_hterms, (void*)h->d_hvptr, (void*)h->d_hvterms,
                     (void*)h->d_heptr, (void*)h->d_hevptr, (void*)h->d_heterms, (void*)h->d_hedge_idx, (void*)h->d_htasks,
@@ -391,6 +392,25 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         hp->kp.tau = hp->d_tau;
         hp->kp.tmpl = hp->d_tmpl;
         hp->kp.vtmpl = hp->d_vtmpl;
+        // early emission (ctd_layout.hpp KParams::pos): direct tiles of the Gauss-Legendre schemes, when the lead wave can hold one
+        // lane per early output of a step and the late positions fit the workgroup.  OFF by default (CTD_EARLY=1 switches it on):
+        // measured on MI355X it LOSES -- Goddard GL2 N = 10 000: 8.4 us against 6.2, GL3 optimized pattern 28.8 against 20.1
+        // (profiles/r03_experiments.md) -- the early and the late stores each write PARTS of the same 128-byte lines (the state
+        // rows and the stage rows of one CSC column interleave), and two partial-line writes cost more than the overlap gains
+        {
+            const int S = mo.L.s, r_dyn = S * mo.nch_dyn, r_path = mo.nch_path;
+            int lgT = 0;
+            while ((1 << lgT) < hp->tile) ++lgT;
+            const int leadbase = (((r_dyn + r_path) << lgT) + 63) & ~63;
+            const int early_lanes = mo.n_early + mo.c_early + mo.L.nv * mo.vr_early;
+            if (env_int("CTD_EARLY", 0) && mo.n_early > 0 && !hp->rt && mo.fused && hp->tile <= 32 && leadbase + 64 <= hp->block && early_lanes <= 64 &&
+                mo.n_late > 0 && mo.n_late <= hp->block) {
+                HIP_TRY(nullptr, upload(&hp->d_pos, mo.pos_order));
+                hp->kp.pos = hp->d_pos;
+                hp->kp.n_late = mo.n_late; hp->kp.n_early = mo.n_early; hp->kp.c_early = mo.c_early; hp->kp.vr_early = mo.vr_early;
+                hp->kp.div_late = make_fastdiv((uint32_t)mo.n_late);
+            }
+        }
         hp->kp.edge_idx = hp->d_edge_idx;
         hp->kp.edge_code = hp->d_edge_code;
         hp->obj_blocks = 256;
@@ -1264,7 +1284,11 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     size_t lds = 4 * kMaxNV * sizeof(double) + 64;
     ip.kp = h->kp;       // (Layout is read from kp / hp / gp / op by the respective bodies)
     ip.hp = h->hp;
-    if (hvals_dev) {
+    // Handles on which the lane-per-step Hessian kernel is the faster one (Gauss-Legendre 2 from 9 000 steps, 3 from 28 000:
+    // ensure_hess) keep it: the fused grid then holds objective + gradient + constraints / Jacobian, and the step kernel follows on
+    // the same stream (Goddard GL3, N = 80 000: tile body inside the fused grid 62 us; fused first-order grid + step kernel ~55)
+    const bool hess_apart = hvals_dev && h->hess_step;
+    if (hvals_dev && !hess_apart) {
         ip.hp.obj_weight = obj_weight;
         ip.hp.vals = hvals_dev;
         ip.nb_h = ip.hp.ntiles + ip.hp.n_edge_blocks;
@@ -1291,6 +1315,7 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
         e = launch_iter<P>(ip, x_dev, y_dev, lds, h->stream);
     });
     if (e != hipSuccess) return fail(h, CTD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (hess_apart) return enqueue_hess(h, x_dev, y_dev, obj_weight, hvals_dev);
     return CTD_OK;
 }
 

@@ -742,6 +742,30 @@ static int build_tables(Model& mo, std::string& err) {
     mo.edge_split2 = (int)mo.edge_idx.size();
     emit(last);
 
+    // ---- early emission (Gauss-Legendre schemes whose OCP functions are differentiated in one pass) -----------------------
+    // a position is early when its value only reads the step's own record at fields the lead role fills: the constant 1.0, the
+    // state rows R[0, n), their d/dv Sv, and any coefficient
+    mo.pos_order.clear();
+    mo.n_late = mo.Lseg; mo.n_early = mo.c_early = mo.vr_early = 0;
+    if (L.sc == SC_IRK && mo.fused && mo.Lseg > 0 && mo.Lseg < 65536) {
+        std::vector<uint16_t> late, early;
+        for (int k = 0; k < mo.Lseg; ++k) {
+            const uint32_t c = mo.tmpl[k];
+            const int di = code_di(c);
+            const bool lead_field = di == 0 || (di >= mo.R.oR && di < mo.R.oR + L.n) || (di >= mo.R.oSv && di < mo.R.oSv + L.n * L.nv);
+            (lead_field && code_drec_raw(c) == 0 && code_crec(c) == 0 ? early : late).push_back((uint16_t)k);
+        }
+        int vre = 0;
+        if (L.nv > 0 && mo.vr > 0)
+            for (int64_t r : vrows[0]) { if (r < L.n) ++vre; else break; }       // (rows of a V column are sorted: the state rows lead)
+        if (!early.empty()) {
+            mo.n_late = (int)late.size(); mo.n_early = (int)early.size();
+            mo.c_early = L.n; mo.vr_early = vre;
+            mo.pos_order = late;
+            mo.pos_order.insert(mo.pos_order.end(), early.begin(), early.end());
+        }
+    }
+
     // structural nonzeros the selected pattern leaves out (hazard H1)
     mo.dropped = 0;
     if (mo.pattern_mode == 0 && L.sc == SC_TRAPEZE && L.nv > 0 && (L.free_time || mo.dyn_v))
@@ -824,6 +848,8 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     for (int k = 0; k < kMaxEdgeSlots; ++k) kp.edge_steps[k] = edge_steps[k];
     // emit templates in LDS: short periods only, and never at the price of a resident workgroup (12-state quadrotor, optimized
     // pattern: 2 KiB of codes pushed the 7-step tile from three workgroups per CU to two -- the LDS granule is 1280 bytes)
+    kp.n_late = Lseg; kp.n_early = kp.c_early = kp.vr_early = 0;      // (the engine switches early emission on: device table + launch geometry)
+    kp.div_late = make_fastdiv((uint32_t)(Lseg > 0 ? Lseg : 1));
     kp.stage_codes = (Lseg + L.nv * vr <= kMaxStagedCodes) ? 1 : 0;
     if (kp.stage_codes) {
         const int with = wgs_per_cu(lds_doubles(kp) * 8);

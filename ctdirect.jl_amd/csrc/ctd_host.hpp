@@ -88,6 +88,9 @@ struct Model {
     int64_t seg_base = 0, reg_first = 0, reg_last = 0;
     int64_t vcol_base[kMaxNV] = {0, 0, 0, 0};
     int HL = 0, HH = 0;
+    // early emission (KParams::pos): positions of the period that only read the lead role's fields, late ones first
+    std::vector<uint16_t> pos_order;
+    int n_late = 0, n_early = 0, c_early = 0, vr_early = 0;
     // edge part: entries [0, edge_split) belong to the shards that own the leading irregular steps (step 0; every step when
     // N < 5: head_ptr), [edge_split, edge_split2) are the tail rows
     // of c (final-time path + boundary values: every shard computes them, x is replicated), the rest belongs to the owner

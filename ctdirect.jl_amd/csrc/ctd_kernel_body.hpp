@@ -992,8 +992,87 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
 #endif
 }
 
-template <class P, int SC, int S, bool REG = false>
-CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
+// stores of the emit phase: outputs are written once and not read again by this kernel.  CTD_NT_STORE=1: nontemporal stores
+// (they bypass the L2's allocation, so the next evaluation finds x still cached) -- an experiment knob, see DESIGN.md
+#ifndef CTD_NT_STORE
+#define CTD_NT_STORE 0
+#endif
+CTD_HD void emit_store(double* p, double v) {
+#if CTD_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// NB > 1 (long periods, e.g. 2904 codes per step for the 12-state quadrotor on Gauss-Legendre 3): more[q] = the code of position
+// tid + (q + 1) nthr -- ALL the positions a lane walks, fetched before the evaluation.  Read one position ahead inside the emit
+// loop instead, every code load queued behind the workgroups' own stores (microseconds under a full store queue): the emit phase
+// of that kernel was bound by those dependent loads, not by bandwidth.
+// kpos: the position of the period the lane owns behind the barrier (early emission: an entry of KParams::pos); eb / ek: code and
+// position (or row / V entry) of the early output the lane stores when it sits in the lead wave
+template <int NB> struct EmitPreT { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; uint32_t more[NB > 1 ? NB - 1 : 1]; int kpos; uint32_t eb; int ek; };
+using EmitPre = EmitPreT<1>;     // edge block: b = the code of edge entry `tid`, eidx its index
+// Early emission (KParams::pos): the lead wave of a Gauss-Legendre tile stores the outputs that only read what its own lead tasks
+// wrote -- lane l owns one early output of every step of the tile -- while the other waves still evaluate the dynamics
+template <class P, int SC, int S, int NB>
+CTD_HD void early_emit(const KParams& kp, const BlockCtx& cx, int l, const EmitPreT<NB>& pre) {
+    constexpr RecLayout R = RL<P, SC, S>::R;
+    const int stride = R.stride;
+    const int nsteps = (int)(cx.b - cx.a), slot0 = (int)(cx.a - cx.lo);
+    const int ne = kp.n_early, nc = kp.c_early, vre = kp.vr_early;
+    if (l < ne) {                                   // a position of the step-periodic CSC segment
+        if (!kp.vals) return;
+        const int64_t ra = cx.a > kp.reg_first ? cx.a : kp.reg_first, rb = cx.b < kp.reg_last ? cx.b : kp.reg_last;
+        const int nreg = (int)(rb - ra);
+        if (nreg <= 0) return;
+        const uint32_t code = pre.eb;
+        const int bt = code_beta(code);
+        const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
+        const int sl0 = (int)(ra - cx.lo);
+        const double* pc = cx.rec + sl0 * stride + R.oC + code_ci(code);
+        const double* pd = cx.rec + sl0 * stride + code_di(code);
+        double* out = kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)kp.Lseg + pre.ek;
+        const int last = nreg - 1;
+        for (int s0 = 0; s0 < nreg; s0 += 4) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u < last ? s0 + u : last;
+                a[u] = pc[s * stride];
+                b[u] = pd[s * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < nreg) emit_store(&out[(s0 + u) * kp.Lseg], a[u] * b[u] + beta);
+        }
+    } else if (l < ne + nc) {                       // a state row of c
+        if (!kp.c) return;
+        const int r = l - ne;
+        double* out = kp.c + cx.a * (int64_t)kp.L.cb + r;
+        const double* src = cx.rec + slot0 * stride + R.oR + r;
+        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.L.cb], src[s * stride]);
+    } else if (l < ne + nc + P::NV * vre) {         // d(state row) / dv of a V column
+        if (!kp.vals) return;
+        const int e = l - ne - nc, kk = e / vre;
+        const uint32_t code = pre.eb;
+        const double* pc = cx.rec + slot0 * stride + R.oC + code_ci(code);
+        const double* pd = cx.rec + slot0 * stride + code_di(code);
+        double* out = kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr + pre.ek;
+        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.vr], pc[s * stride] * pd[s * stride]);
+    }
+}
+
+// first lane of the lead wave of an early-emission tile: behind the dynamics / path lanes of a FULL tile, at a wave boundary
+template <class P, int SC, int S> CTD_HD int early_leadbase(const KParams& kp) {
+    constexpr int r_dyn = StagePoints<SC, S>::value * Dirs<P>::NCH_DYN, r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+    int lgT = 0;
+    while ((1 << lgT) < kp.T) ++lgT;
+    return (((r_dyn + r_path) << lgT) + 63) & ~63;
+}
+
+template <class P, int SC, int S, bool REG = false, int NB = 1>
+CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPreT<NB>* epre = nullptr) {
     constexpr bool FUSED = Dirs<P>::FUSED;
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
@@ -1091,6 +1170,58 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr)
     }
     const int lg = ns <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ns - 1));
     const int mask = (1 << lg) - 1;
+    if constexpr (FUSED && SC == SC_IRK) {
+        if (kp.n_early > 0 && epre != nullptr) {
+            // EARLY EMISSION: the lead tasks sit in a wave of their own (behind the dynamics / path lanes, at a wave boundary); that
+            // wave then stores the outputs which only read its records while the other waves still evaluate
+            int lgT = 0;                                    // (lanes as for a full tile: the host sized the workgroup with kp.T)
+            while ((1 << lgT) < kp.T) ++lgT;
+            const int nb = (r_dyn + r_path) << lgT, leadbase = (nb + 63) & ~63;
+            const int tmask = (1 << lgT) - 1;
+            if (tid < nb) {
+                const int k = tid & tmask, role = tid >> lgT;
+                if (k < ns) {
+                    if (role < r_dyn) {
+                        const int j = role / Dirs<P>::NCH_DYN, q = role % Dirs<P>::NCH_DYN;
+                        double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+                        if constexpr (REG) {
+                            double evr[R.eval_sz];
+#pragma unroll
+                            for (int e = 0; e < R.eval_sz; ++e) evr[e] = 0.0;
+                            eval_dynamics<P, SC, S>(kp, cx, k, j, q, evr);
+                            fin_stage<P, SC, S>(kp, cx, k, j, evr);
+                            const int64_t i = slot_index(kp, cx, k);
+                            if (i >= 0 && i < kp.L.N) {
+#pragma unroll
+                                for (int e = 0; e < R.eval_sz; ++e) ev[e] = evr[e];
+                            }
+                        } else {
+                            eval_dynamics<P, SC, S>(kp, cx, k, j, q, ev);
+                            fin_stage<P, SC, S>(kp, cx, k, j, ev);
+                        }
+                    } else {
+                        eval_step_path<P, SC, S, REG>(kp, cx, k, role - r_dyn);
+                    }
+                }
+            } else if ((tid >> 6) == (leadbase >> 6)) {
+                const int k = tid - leadbase;
+                if (k < ns) {
+                    fin_lead<P, SC, S>(kp, cx, k);
+                    cx.rec[k * R.stride] = 1.0;
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wave's LDS writes before its LDS reads below
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                early_emit<P, SC, S, NB>(kp, cx, tid & 63, *epre);
+#endif
+                // (the serial emulator of tests/emu steps the lanes one after the other: it calls early_emit for the lead wave
+                // once every lane has run this phase)
+            }
+            for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
+            return;
+        }
+    }
     const int total = (r_dyn + r_path + r_lead) << lg;
     for (int task = tid; task < total; task += nthr) {
         const int k = task & mask, role = task >> lg;
@@ -1270,12 +1401,6 @@ CTD_HD void emit_stream(const RecLayout R, const BlockCtx& cx, double* out, int 
 
 // The codes a lane needs in phase_emit when it owns ONE position of each period (period <= workgroup size): read from the
 // global tables before the evaluation starts, so their latency hides behind it and the emission starts from registers.
-// NB > 1 (long periods, e.g. 2904 codes per step for the 12-state quadrotor on Gauss-Legendre 3): more[q] = the code of position
-// tid + (q + 1) nthr -- ALL the positions a lane walks, fetched before the evaluation.  Read one position ahead inside the emit
-// loop instead, every code load queued behind the workgroups' own stores (microseconds under a full store queue): the emit phase
-// of that kernel was bound by those dependent loads, not by bandwidth.
-template <int NB> struct EmitPreT { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; uint32_t more[NB > 1 ? NB - 1 : 1]; };
-using EmitPre = EmitPreT<1>;     // edge block: b = the code of edge entry `tid`, eidx its index
 // upper bound of the CSC period of (OCP, scheme class, stages) -- the reference's dense-block patterns (Appendix A.4 of SURVEY.md)
 // -- in units of 256 positions: the codes a lane of a 256-lane workgroup may have to hold
 template <class P, int SC, int S> struct EmitN {
@@ -1306,7 +1431,21 @@ CTD_HD EmitPreT<NB> emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid
         return pre;
     }
     const int Ls = kp.Lseg;
-    if (Ls > 0 && Ls <= nthr) {
+    pre.kpos = 0; pre.eb = 0u; pre.ek = 0;
+    if (kp.n_early > 0) {
+        // early emission: the lane's late position (two dependent loads, hidden behind the evaluation) and, for the lead wave, the
+        // early output of lane l = tid & 63: [n_early positions | c_early rows of c | nv * vr_early V entries]
+        const int q = tid - (int)fast_div((uint32_t)tid, kp.div_late) * kp.n_late;
+        pre.kpos = kp.pos[q];
+        pre.b = kp.tmpl[pre.kpos];
+        const int l = tid & 63;
+        if (l < kp.n_early) { pre.ek = kp.pos[kp.n_late + l]; pre.eb = kp.tmpl[pre.ek]; }
+        else if (l >= kp.n_early + kp.c_early && l < kp.n_early + kp.c_early + P::NV * kp.vr_early) {
+            const int e = l - kp.n_early - kp.c_early, kk = e / kp.vr_early;
+            pre.ek = e - kk * kp.vr_early;
+            pre.eb = kp.vtmpl[kk * kp.vr + pre.ek];
+        }
+    } else if (Ls > 0 && Ls <= nthr) {
         const int k = tid - (int)fast_div((uint32_t)tid, kp.div_Lseg) * Ls;
         pre.b = kp.tmpl[k];
     } else if (Ls > nthr) {
@@ -1388,12 +1527,13 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             if (tid < par * cb) {
                 const int g = (int)fast_div((uint32_t)tid, kp.div_cb), r = tid - g * cb;
                 const double* src = cx.rec + (slot0 + g) * stride + R.oR + r;
-                for (int s = g; s < nsteps; s += par, src += par * stride) out[s * cb + r] = *src;
+                if (r >= kp.c_early)          // (early emission: the leading rows were stored by the lead wave)
+                    for (int s = g; s < nsteps; s += par, src += par * stride) emit_store(&out[s * cb + r], *src);
             }
         } else {
             for (int r = tid; r < cb; r += nthr) {
                 const double* src = cx.rec + slot0 * stride + R.oR + r;
-                for (int s = 0; s < nsteps; ++s, src += stride) out[s * cb + r] = *src;
+                for (int s = 0; s < nsteps; ++s, src += stride) emit_store(&out[s * cb + r], *src);
             }
         }
     }
@@ -1407,12 +1547,16 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             const int nreg = (int)(rb - ra);
             double* out = kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)Ls;
             const int sl0 = (int)(ra - cx.lo);
-            const int par = (int)fast_div((uint32_t)nthr, kp.div_Lseg);
+            // early emission: only the late positions are left (kp.pos[0 .. n_late)), more steps in flight per pass
+            const bool late_only = kp.n_early > 0;
+            const int Lw = late_only ? kp.n_late : Ls;          // positions walked here
+            const int par = (int)fast_div((uint32_t)nthr, late_only ? kp.div_late : kp.div_Lseg);
             // inner loops: uniform trip count and batches of 4 steps, so the 8 LDS reads of a batch are independent
             // and in flight together (reads past the last step are clamped, only the store is predicated)
             if (par >= 1) {
-                if (tid < par * Ls) {
-                    const int g = (int)fast_div((uint32_t)tid, kp.div_Lseg), k = tid - g * Ls;
+                if (tid < par * Lw) {
+                    const int g = (int)fast_div((uint32_t)tid, late_only ? kp.div_late : kp.div_Lseg);
+                    const int k = late_only ? (pre ? pre->kpos : (int)kp.pos[tid - g * Lw]) : tid - g * Ls;
                     const uint32_t code = pre ? pre->b : cx.codes[k];
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
@@ -1430,7 +1574,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int s = s0 + u * par;
-                            if (s < nreg) out[s * Ls + k] = a[u] * b[u] + beta;
+                            if (s < nreg) emit_store(&out[s * Ls + k], a[u] * b[u] + beta);
                         }
                     }
                 }
@@ -1467,7 +1611,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (s0 + u < nreg) out[(s0 + u) * Ls + k] = a[u] * b[u] + beta;
+                            if (s0 + u < nreg) emit_store(&out[(s0 + u) * Ls + k], a[u] * b[u] + beta);
                     }
                     code = nxt;
                 }
@@ -1489,14 +1633,15 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                     const double* pc = cx.rec + (slot0 + g) * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);
                     const int adv = par * stride;
-                    for (int s = g; s < nsteps; s += par, pc += adv, pd += adv) out[s * vr + k] = (*pc) * (*pd);
+                    if (k >= kp.vr_early)      // (early emission: the leading entries were stored by the lead wave)
+                        for (int s = g; s < nsteps; s += par, pc += adv, pd += adv) emit_store(&out[s * vr + k], (*pc) * (*pd));
                 }
             } else {
                 for (int k = tid; k < vr; k += nthr) {
                     const uint32_t code = codes[k];
                     const double* pc = cx.rec + slot0 * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + slot0 * stride + code_di(code);
-                    for (int s = 0; s < nsteps; ++s, pc += stride, pd += stride) out[s * vr + k] = (*pc) * (*pd);
+                    for (int s = 0; s < nsteps; ++s, pc += stride, pd += stride) emit_store(&out[s * vr + k], (*pc) * (*pd));
                 }
             }
         }

@@ -41,7 +41,7 @@ __device__ __forceinline__ void ctd_pin_kernargs(const KParams& kp, const double
                  "s"(kp.L.cb), "s"(kp.L.eqs), "s"(kp.L.euler), "s"(kp.tau), "s"(kp.L.t0), "s"(kp.L.tf), "s"(xu), "s"(blockDim.x));
     asm volatile("" ::"s"(kp.tmpl), "s"(kp.vtmpl), "s"(kp.Lseg), "s"(kp.vr), "s"(kp.div_cb.M), "s"(kp.div_Lseg.M), "s"(kp.div_vr.M),
                  "s"(kp.div_cb.d), "s"(kp.div_Lseg.d), "s"(kp.div_vr.d), "s"(kp.seg_base), "s"(kp.reg_first), "s"(kp.reg_last),
-                 "s"(kp.vcol_base[0]), "s"(kp.c), "s"(kp.vals), "s"(kp.halo));
+                 "s"(kp.vcol_base[0]), "s"(kp.c), "s"(kp.vals), "s"(kp.halo), "s"(kp.pos), "s"(kp.n_early), "s"(kp.n_late));
     if (S >= 1) asm volatile("" ::"s"(kp.L.a[0]), "s"(kp.L.b[0]), "s"(kp.L.c[0]));
     if (S >= 2) asm volatile("" ::"s"(kp.L.a[1]), "s"(kp.L.a[3]), "s"(kp.L.a[4]), "s"(kp.L.b[1]), "s"(kp.L.c[1]));
     if (S >= 3) asm volatile("" ::"s"(kp.L.a[2]), "s"(kp.L.a[5]), "s"(kp.L.a[6]), "s"(kp.L.a[7]), "s"(kp.L.a[8]), "s"(kp.L.b[2]), "s"(kp.L.c[2]));
@@ -60,7 +60,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         const BlockCtx cx = make_direct_ctx(kp, block, ctd_lds, xu);
         const EmitPre pre = emit_prefetch<P>(kp, cx, tid, nthr);
         ctd_stamp<DBG>(kp, 1);
-        phase_eval<P, SC, S, RegEval<P, SC, S>::value>(kp, cx, tid, nthr);
+        phase_eval<P, SC, S, RegEval<P, SC, S>::value, 1>(kp, cx, tid, nthr, &pre);
         __syncthreads();
         ctd_stamp<DBG>(kp, 2);
         ctd_stamp<DBG>(kp, 3);

@@ -229,6 +229,14 @@ struct KParams {
     // 3 eval, 4 fin) -- ablation timing, outputs are then incomplete
     int32_t debug_stop;
     int32_t stage_codes;        // the emit templates are copied to LDS once per workgroup (short periods that cost no occupancy)
+    // EARLY EMISSION (Gauss-Legendre schemes, direct tiles): outputs that only read what the lead role writes -- the state rows of
+    // c, their Jacobian entries (-1, -h b_j, +1: 36 of the 102 entries per step of Goddard / GL2) and d/dv -- are stored by the
+    // lead wave WHILE the dynamics are still being evaluated; the emit phase behind the barrier then streams the rest.
+    // pos = [late positions of the CSC period ..., early positions ...] (null: everything is emitted behind the barrier)
+    const uint16_t* pos;
+    int32_t n_late, n_early;    // positions of the period emitted behind the barrier / by the lead wave
+    int32_t c_early, vr_early;  // leading rows of every step's block of c / of every step's slice of a V column that are early
+    FastDiv div_late;
     // sharded iterate read in place: where the other shards' variables live (device table), or null: xu holds everything
     // this shard reads
     const XHalo* halo;

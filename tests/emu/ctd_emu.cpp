@@ -36,7 +36,13 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
             BlockCtx cx = make_direct_ctx(kp, b, lds.data(), xu);
             std::vector<EmitPre> pre(nthr);
             for (int t = 0; t < nthr; ++t) pre[t] = emit_prefetch<P>(kp, cx, t, nthr);
-            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S, RegEval<P, SC, S>::value>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S, RegEval<P, SC, S>::value, 1>(kp, cx, t, nthr, &pre[t]);
+            if constexpr (SC == SC_IRK) {
+                if (kp.n_early > 0 && !cx.is_edge) {          // early emission: the lead wave's stores (in lockstep on the GPU)
+                    const int lb = early_leadbase<P, SC, S>(kp);
+                    for (int l = 0; l < 64 && lb + l < nthr; ++l) early_emit<P, SC, S, 1>(kp, cx, l, pre[lb + l]);
+                }
+            }
             for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S>(kp, cx, t, nthr, &pre[t]);
             continue;
         }
@@ -131,6 +137,17 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     kp.edge_code = mo.edge_code.data();
     kp.c = c;
     kp.vals = vals;
+    // early emission as ctd_create switches it on (CTD_EMU_EARLY=1; the same conditions on the launch geometry)
+    if (std::getenv("CTD_EMU_EARLY") && std::atoi(std::getenv("CTD_EMU_EARLY")) && mo.n_early > 0 && mo.fused && tile <= 32) {
+        int lgT = 0;
+        while ((1 << lgT) < tile) ++lgT;
+        const int leadbase = ((((mo.L.s * mo.nch_dyn + mo.nch_path) << lgT)) + 63) & ~63;
+        if (leadbase + 64 <= nthr && mo.n_early + mo.c_early + mo.L.nv * mo.vr_early <= 64 && mo.n_late > 0 && mo.n_late <= nthr) {
+            kp.pos = mo.pos_order.data();
+            kp.n_late = mo.n_late; kp.n_early = mo.n_early; kp.c_early = mo.c_early; kp.vr_early = mo.vr_early;
+            kp.div_late = make_fastdiv((uint32_t)mo.n_late);
+        }
+    }
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {

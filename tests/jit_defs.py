@@ -164,10 +164,107 @@ CATALOGUE = {
 }
 
 
+def _glider():
+    """test/problems/glider.jl:8-100 (hang glider in a thermal updraft, COPS): the helper values of its `dynamics` inlined"""
+    r = "((x1/r_0 - 2.5)^2)"
+    w = f"(x4 - u_c*(1 - {r})*exp(-{r}))"
+    v = f"sqrt(x3^2 + {w}^2)"
+    D = f"(0.5*(c0 + c1*u1^2)*rho*S*{v}^2)"
+    L = f"(0.5*u1*rho*S*{v}^2)"
+    tf0 = (900.0 - 1000.0) / -1.288
+    return (dict(dynamics=["x3", "x4", f"(-{L}*({w}/{v}) - {D}*(x3/{v}))/mass", f"(({L}*(x3/{v}) - {D}*({w}/{v}))/mass) - g"],
+                 m=1, nv=1, itf=0, t0=0.0, mayer="xf_1", maximize=True,
+                 constants=dict(u_c=2.5, r_0=100.0, mass=100.0, g=9.81, c0=0.034, c1=0.069662, S=14.0, rho=1.13),
+                 boundary=["x0_1", "x0_2", "x0_3", "x0_4", "xf_2", "xf_3", "xf_4"],
+                 boundary_bounds=([0.0, 1000.0, 13.23, -1.288, 900.0, 13.23, -1.288],) * 2,
+                 state_box=([0, -INF, 0, -INF], [INF] * 4), control_box=([0.0], [1.4]), variable_box=([10.0], [INF])),
+            1.25e3,
+            dict(time=[0.0, tf0], state=[[0.0, 1000.0, 13.23, -1.288], [13.23 * tf0, 900.0, 13.23, -1.288]],
+                 control=[[0.7], [0.7]], variable=[tf0]))
+
+
+def _space_shuttle():
+    """test/problems/space_shuttle.jl:8-150 (re-entry, maximal cross range; no heating constraint)"""
+    import math
+    h, v, adeg = "(x1*1e5)", "(x4*1e4)", "(u1*180/pi)"
+    cD, cL = f"(b0 + b1*{adeg} + b2*{adeg}^2)", f"(a0 + a1*{adeg})"
+    rho = f"(rho0*exp(-{h}/hr))"
+    D, L = f"(0.5*{cD}*S*{rho}*{v}^2)", f"(0.5*{cL}*S*{rho}*{v}^2)"
+    r = f"(Re + {h})"
+    g = f"(mu/{r}^2)"
+    dyn = [f"{v}*sin(x5)/1e5", f"({v}/{r})*cos(x5)*sin(x6)/cos(x3)", f"({v}/{r})*cos(x5)*cos(x6)", f"(-({D}/mass) - {g}*sin(x5))/1e4",
+           f"({L}/(mass*{v}))*cos(u2) + cos(x5)*(({v}/{r}) - ({g}/{v}))",
+           f"(1/(mass*{v}*cos(x5)))*{L}*sin(u2) + ({v}/({r}*cos(x3)))*cos(x5)*sin(x6)*sin(x3)"]
+    d2r = math.radians
+    x0 = [2.6, 0.0, 0.0, 2.56, d2r(-1), d2r(90)]
+    xT = [0.8, 0.0, 0.0, 0.25, d2r(-5), d2r(90)]
+    return (dict(dynamics=dyn, m=2, nv=1, itf=0, t0=0.0, mayer="xf_3", maximize=True,
+                 constants=dict(pi=math.pi, mass=203000.0 / 32.174, rho0=0.002378, hr=23800.0, Re=20902900.0, mu=0.14076539e17, S=2690.0,
+                                a0=-0.20704, a1=0.029244, b0=0.07854, b1=-0.61592e-2, b2=0.621408e-3),
+                 boundary=[f"x0_{i}" for i in range(1, 7)] + ["xf_1", "xf_4", "xf_5"],
+                 boundary_bounds=(x0 + [0.8, 0.25, d2r(-5)],) * 2,
+                 state_box=([0, -INF, d2r(-89), 0, d2r(-89), -INF], [INF, INF, d2r(89), INF, d2r(89), INF]),
+                 control_box=([d2r(-90), d2r(-89)], [d2r(90), d2r(1)]), variable_box=([1750.0], [2250.0])),
+            d2r(34.18),
+            dict(time=[0.0, 500.0], state=[x0, xT], control=[[0.0, 0.0], [0.0, 0.0]], variable=[500.0]))
+
+
+def _truck_trailer():
+    """test/problems/truck_trailer.jl:6-130 (truck with two trailers, minimum time + alignment)"""
+    import math
+    b01, b12 = "(x3 - x4)", "(x4 - x5)"
+    dth0 = "(x6/L0*tan(x7))"
+    dth1 = f"(x6/L1*sin({b01}) - M0/L1*cos({b01})*{dth0})"
+    v1 = f"(x6*cos({b01}) + M0*sin({b01})*{dth0})"
+    dth2 = f"({v1}/L2*sin({b12}) - M1/L2*cos({b12})*{dth1})"
+    v2 = f"({v1}*cos({b12}) + M1*sin({b12})*{dth1})"
+    hp = math.pi / 2
+    return (dict(dynamics=[f"{v2}*cos(x5)", f"{v2}*sin(x5)", dth0, dth1, dth2, "u1", "u2"], m=2, nv=1, itf=0, t0=0.0,
+                 lagrange=f"{b01}^2 + {b12}^2", mayer="v1", constants=dict(L0=0.4, M0=0.1, L1=1.1, M1=0.2, L2=0.8),
+                 path=[b01, b12], path_bounds=([-hp, -hp], [hp, hp]),
+                 boundary=["x0_1", "x0_2", "x0_3", "x0_4", "x0_5", "xf_1", "xf_2", "xf_5", "xf_3 - xf_4", "xf_4 - xf_5"],
+                 boundary_bounds=([0, 0, 0, 0, 0, 0.0, -2.0, hp, 0.0, 0.0],) * 2,
+                 state_box=([-INF, -INF, -hp, -hp, -INF, -0.2, -math.pi / 6], [INF, INF, hp, hp, INF, 0.2, math.pi / 6]),
+                 control_box=([-1.0, -math.pi / 10], [1.0, math.pi / 10]), variable_box=([1.0], [1000.0])),
+            59.28, dict(variable=[10.0]))
+
+
+CATALOGUE.update({
+    # test/problems/double_integrator.jl:100-113
+    "double_integrator_nobounds": (dict(dynamics=["x2", "u1"], m=1, lagrange="0.5*u1^2", boundary=["x0_1", "x0_2", "xf_1", "xf_2"],
+                                        t0=0.0, tf=1.0, boundary_bounds=([1, -2, 0, 0], [1, -2, 0, 0])), 2.0),
+    # test/problems/electric_vehicle.jl:8-63
+    "electric_vehicle": (dict(dynamics=["x2", "h1*u1 - h2*x2^2 - h0 - (p0 + p1*x1 + p2*x1^2 + p3*x1^3)"], m=1,
+                              lagrange="b1*u1*x2 + b2*u1^2", t0=0.0, tf=1.0,
+                              constants=dict(b1=1e3, b2=1e3, h0=0.1, h1=1.0, h2=1e-3, p0=3.0, p1=0.4, p2=-1.0, p3=0.1),
+                              boundary=["x0_1", "x0_2", "xf_1", "xf_2"], boundary_bounds=([0, 0, 10.0, 0], [0, 0, 10.0, 0]),
+                              state_box=([0, 0], [INF, INF])), 1.23e6,
+                         dict(time=[0.0, 1.0], state=[[0.0, 1.0], [10.0, 1.0]], control=[[0.5], [0.5]])),
+    "glider": _glider(),
+    # test/problems/insurance.jl:7-62 (Bocop's non-audit insurance example; the reference solves it with :trapeze only).
+    # alpha = 4: m^(alpha/2) = m^2, m^(alpha/2 - 1) = m;  k = 0: epsilon = 0;  sigma = 0
+    "insurance": (dict(dynamics=["(1 - gamma*t*(2*x2/(1 + x2^2)^2)/u5)*u1", "u1", "x1*(lambda*exp(-lambda*t) + exp(-lambda*10)/10)"],
+                       m=5, nv=1, t0=0.0, tf=10.0, lagrange="u4*(lambda*exp(-lambda*t) + exp(-lambda*10)/10)", maximize=True,
+                       constants={"gamma": 0.2, "lambda": 0.25, "h0": 1.5, "w": 1.0, "s": 10.0},
+                       path=["u2 - (w - v1 + x1 - x2)", "u3 - (h0 - gamma*t*(1 - x2^2/(1 + x2^2)))", "u4 - (1 - exp(-s*u2) + u3)",
+                             "u5 - s*exp(-s*u2)"], path_bounds=([0] * 4, [0] * 4),
+                       boundary=["x0_1", "x0_2", "x0_3", "v1 - xf_3"], boundary_bounds=([0, 0.001, 0, 0], [0, 0.001, 0, 0]),
+                       state_box=([0, 0, -INF], [1.1, 1.1, INF]), control_box=([0, 0, 0, 0, 1e-8], [25, INF, INF, INF, INF]),
+                       variable_box=([0], [INF])), 2.059511),
+    "space_shuttle": _space_shuttle(),
+    "truck_trailer": _truck_trailer(),
+    # problems of the catalogue that are in the compiled registry (solved through the built-in kernels)
+    "goddard_all": ("registry:goddard_all", 1.01257, "problem"),                         # test/problems/goddard.jl:87-158
+    "double_integrator_freet0tf": ("registry:double_integrator_freet0tf", 8.0, None),     # test/problems/double_integrator.jl:79-99
+})
+
+
 def catalogue(name):
     """(run-time problem name, catalogued objective, init of the problem file or None)"""
     key = name + "_cat"
     entry = CATALOGUE[name]
+    if isinstance(entry[0], str):                     # a registry problem
+        return entry[0].split(":", 1)[1], entry[1], entry[2]
     if key not in _registered:
         _registered[key] = ct.register_ocp(key, **entry[0])
     return _registered[key], entry[1], (entry[2] if len(entry) > 2 else None)
