@@ -318,7 +318,8 @@ def _main(real_stdout):
     others, hessian, optimized = [], [], []
     if world == 1 and not args.no_extras:
         for prob, sch, n in (("double_integrator_path", "midpoint", 100000), ("goddard", "gauss_legendre_3", 80000),
-                             ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000)):
+                             ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000),
+                             ("quadrotor12", "midpoint", 20000)):
             d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch")
             x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
             c2 = torch.zeros(d2.dim_NLP_constraints, dtype=torch.float64, device=dev)
@@ -358,6 +359,23 @@ def _main(real_stdout):
                             "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
             d2.close()
             del x2, y2, h2
+
+    # per-workload rocprofv3 rows (profiles/collect_workloads.sh: one process per workload, so a row is ONE workload): IMPORTED
+    # from the committed summary, not measured in this run
+    wl_rows = {}
+    try:
+        for r in json.load(open(os.path.join(ROOT, "profiles", "r03_workloads.json")))["workloads"]:
+            wl_rows[(r["problem"], r["scheme"], r["N"], r["pattern"], r["kernel"])] = {
+                k: r[k] for k in ("rocprof_avg_ns", "frac_of_8TBs", "hbm_bytes_per_launch", "traffic_over_algorithmic")}
+    except Exception:
+        pass
+    for lst, pat, kern in ((others, "manual", "cons_jac"), (optimized, "optimized", "cons_jac"), (hessian, "manual", "hess")):
+        for e in lst:
+            prob_sch, n_ = e["workload"].split(",")[0].split(" N=")
+            prob_, sch_ = prob_sch.split("/")
+            row = wl_rows.get((prob_, sch_, int(n_), pat, kern))
+            if row:
+                e["rocprof_imported_from_profiles_r03_workloads"] = row
 
     if rank == 0:
         shard_txt = (f"{cfg['steps']} time steps per GPU (global grid {N} steps, time-step sharded)" if cfg["per_gpu"]

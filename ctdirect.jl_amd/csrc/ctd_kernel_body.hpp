@@ -988,7 +988,11 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
     // lanes of a wave: S ns dynamics points | ns path points | lead tasks (Gauss-Legendre: (step, state row) tasks dealt round
     // robin over the NP waves; one-point schemes: one cheap task per step on the last wave)
     const int lead = SC == SC_IRK ? (cx.nslots * P::NX + NP - 1) / NP : cx.nslots;
-    return ok && !cx.is_edge && StagePoints<SC, S>::value * cx.nslots + cx.nslots + lead <= 64 && r_path <= NP && NP * 64 <= nthr;
+    // a workgroup with a wave beyond the NP dynamics waves gives the symbolic path rows (and the one-point schemes' lead tasks) that
+    // wave: no path lanes behind the dynamics lanes then
+    const bool extra = SymPath<P>::value && nthr >= (NP + 1) * 64;
+    return ok && !cx.is_edge && StagePoints<SC, S>::value * cx.nslots + (extra ? 0 : cx.nslots) + lead <= 64 && 2 * cx.nslots <= 64 &&
+           r_path <= NP && NP * 64 <= nthr;
 #endif
 }
 
@@ -1142,6 +1146,27 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             constexpr int NP = Dirs<P>::NCH_DYN;
             const int nd = StagePoints<SC, S>::value * ns;
             const int wave = tid >> 6, l = tid & 63;
+            // Five waves (320 lanes: the one-point kernels of the 12-state quadrotor need 97 registers, four waves per SIMD fit): the
+            // symbolic path rows of every step run in wave NP beside the dynamics parts instead of behind one of them (4400 cycles
+            // behind part 1's 5000), the cheap lead tasks of the one-point schemes too
+            const bool extra = SymPath<P>::value && nthr >= (NP + 1) * 64;
+            if (extra) {
+                if (wave < NP) {
+                    if (l < nd) {
+                        const int j = l / ns, k = l - j * ns;
+                        eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+                    }
+                    if (SC == SC_IRK) {
+                        const int t = (l - nd) * NP + wave;
+                        if (l >= nd && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
+                    }
+                } else if (wave == NP) {
+                    if (l < ns) { if (r_path > 0) eval_step_path<P, SC, S>(kp, cx, l, 0); }
+                    else if (SC != SC_IRK && l < 2 * ns) fin_lead<P, SC, S>(kp, cx, l - ns);
+                }
+                for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
+                return;
+            }
             if (wave < NP) {
                 if (l < nd) {
                     const int j = l / ns, k = l - j * ns;

@@ -172,7 +172,7 @@ struct QuadrotorOCP {
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
-    static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
+    static constexpr int MAXB = 320;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
@@ -231,7 +231,7 @@ struct Quadrotor12OCP {
     static constexpr bool DYN_T = false, DYN_V = false, PATH_T = false, PATH_V = false;
     static constexpr bool LAG_T = false, LAG_V = false;      // explicit dependence of the Lagrange cost on t / v
     static constexpr int DC = CTD_DC(4);
-    static constexpr int MAXB = 256;                       // largest workgroup the kernels are compiled for (register budget)
+    static constexpr int MAXB = 320;                       // largest workgroup the kernels are compiled for (register budget)
     static constexpr bool HAS_SYM = false, HAS_SYM_DYN = false, HAS_SYM_PATH = false, HAS_SYM_LAG = false;   // symbolic functions: generated specialisations (ctd_sym_registry.hpp)
     static constexpr double t0_fixed() { return 0.0; }
     static constexpr double tf_fixed() { return 0.0; }
