@@ -834,6 +834,7 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.div_cb = make_fastdiv((uint32_t)L.cb);
     kp.div_Lseg = make_fastdiv((uint32_t)(Lseg > 0 ? Lseg : 1));
     kp.div_vr = make_fastdiv((uint32_t)(vr > 0 ? vr : 1));
+    kp.div_blk = make_fastdiv((uint32_t)(L.blk > 0 ? L.blk : 1));
     kp.seg_base = seg_base; kp.reg_first = reg_first; kp.reg_last = reg_last;
     for (int k = 0; k < kMaxNV; ++k) kp.vcol_base[k] = vcol_base[k];
     const bool owns_last = step_end == L.N;

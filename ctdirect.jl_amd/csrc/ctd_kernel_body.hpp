@@ -121,9 +121,9 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.b = cx.a + kp.T < kp.step_end ? cx.a + kp.T : kp.step_end;
         cx.lo = cx.a - kp.HL;
         cx.nslots = (int)(cx.b - cx.a) + kp.HL + kp.HH;
-        cx.in_stride = L.blk;
+        cx.in_stride = tile_in_stride(L);
         cx.in = lds;
-        cx.v = cx.in + (cap + 1) * L.blk + L.n + L.m;
+        cx.v = cx.in + (cap + 1) * tile_in_stride(L) + L.n + L.m;
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + cap + 2;
     }
@@ -188,7 +188,7 @@ CTD_HD const double* slot_next(const KParams& kp, const BlockCtx& cx, int k) {
         const int64_t g = (slot_index(kp, cx, k) + 1) * (int64_t)cx.in_stride;
         return xsrc(cx.halo, cx.xu, g) + g;
     }
-    return slot_base(kp, cx, k) + kp.L.blk;
+    return slot_base(kp, cx, k) + ((cx.direct || cx.is_edge) ? kp.L.blk : cx.in_stride);     // (staged tile: the next slot)
 }
 // block of step i - 1 (implicit Euler's path control U_{i-1}); direct blocks only
 CTD_HD const double* slot_prev(const KParams& kp, const BlockCtx& cx, int k) {
@@ -196,14 +196,14 @@ CTD_HD const double* slot_prev(const KParams& kp, const BlockCtx& cx, int k) {
         const int64_t g = (slot_index(kp, cx, k) - 1) * (int64_t)cx.in_stride;
         return xsrc(cx.halo, cx.xu, g) + g;
     }
-    return slot_base(kp, cx, k) - kp.L.blk;
+    return slot_base(kp, cx, k) - ((cx.direct || cx.is_edge) ? kp.L.blk : cx.in_stride);
 }
 
 // LDS doubles a block needs (host uses this to size the launch)
 inline int64_t lds_doubles(const KParams& kp) {
     const Layout& L = kp.L;
     const int64_t cap = kp.T + kp.HL + kp.HH;
-    int64_t tile = code_doubles(kp) + (cap + 1) * L.blk + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
+    int64_t tile = code_doubles(kp) + (cap + 1) * tile_in_stride(L) + L.n + L.m + kMaxNV + cap + 2 + cap * kp.R.stride;
     int64_t edge = code_doubles(kp) + (int64_t)kp.n_edge_slots * edge_in_stride(L) + kMaxNV + 2 * kMaxEdgeSlots + 2 +
                    (int64_t)(kp.n_edge_slots + 1) * kp.R.stride + kp.R.bsize;      // step slots, final-path record, boundary record
     return tile > edge ? tile : edge;
@@ -300,15 +300,17 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         if (g1 > L.v_off) g1 = L.v_off;
         // 32-bit lane-relative indices: the 64-bit part of the addresses is wave-uniform
         const double* __restrict__ src = xu + g0;
-        double* dst = cx.in + (int)(g0 - cx.lo * (int64_t)L.blk);
         const int cnt = (int)(g1 - g0);
+        // element e of the slice (offset eo from the first slot's block) -> slot eo / blk of the staged copy, pitch in_stride
+        const int eo0 = (int)(g0 - cx.lo * (int64_t)L.blk), padw = cx.in_stride - L.blk;
+        auto at = [&](int e) -> double& { const int eo = eo0 + e; return cx.in[eo + (int)fast_div((uint32_t)eo, kp.div_blk) * padw]; };
         // A lane first ISSUES its global loads of every stream (two elements of the xu slice, its optimisation variable, its
         // share of the emit templates), then stores them to LDS: one exposed memory latency instead of one per copy loop
         const bool codes = LOAD_V && codes_staged(kp);
         const int nvc = kp.L.nv * kp.vr;
         if (cx.halo) {
             // first / last tile of a shard with the iterate sharded: every element from the buffer of the shard that owns it
-            for (int e = tid; e < cnt; e += nthr) dst[e] = xsrc(cx.halo, xu, g0 + e)[g0 + e];
+            for (int e = tid; e < cnt; e += nthr) at(e) = xsrc(cx.halo, xu, g0 + e)[g0 + e];
             if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
             if (codes) {
                 uint32_t* cd = const_cast<uint32_t*>(cx.codes);
@@ -324,8 +326,8 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const uint32_t c0 = (codes && tid < kp.Lseg) ? kp.tmpl[tid] : 0u;
         const uint32_t c1 = (codes && tid < nvc) ? kp.vtmpl[tid] : 0u;
         const double tau_e = tid <= cx.nslots + 1 ? tau_global(kp, cx.lo + tid) : 0.0;      // (table load: issued with the rest)
-        if (tid < cnt) dst[tid] = x0;
-        if (tid + nthr < cnt) dst[tid + nthr] = x1;
+        if (tid < cnt) at(tid) = x0;
+        if (tid + nthr < cnt) at(tid + nthr) = x1;
         if (LOAD_V && tid < kMaxNV) cx.v[tid] = vv;
         if (codes) {
             uint32_t* cd = const_cast<uint32_t*>(cx.codes);
@@ -334,7 +336,7 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
             for (int e = tid + nthr; e < kp.Lseg; e += nthr) cd[e] = kp.tmpl[e];
             for (int e = tid + nthr; e < nvc; e += nthr) cd[kp.Lseg + e] = kp.vtmpl[e];
         }
-        for (int e = tid + 2 * nthr; e < cnt; e += nthr) dst[e] = src[e];
+        for (int e = tid + 2 * nthr; e < cnt; e += nthr) at(e) = src[e];
         if (tid <= cx.nslots + 1) cx.tau[tid] = tau_e;
         for (int e = tid + nthr; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
         return;
@@ -553,6 +555,7 @@ CTD_HD void fin_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
     double* rec = cx.rec + k * R.stride;
     const double* nxt = rec + R.stride;
     const double* base = slot_base(kp, cx, k);
+    const double* xnext = slot_next(kp, cx, k);
     const double tau0 = slot_tau(kp, cx, k, 0), tau1 = slot_tau(kp, cx, k, 1);
     const double half_h = 0.5 * (time_of<P>(kp, cx.v, tau1) - time_of<P>(kp, cx.v, tau0));
     const double* e0 = rec + R.oEval;
@@ -560,7 +563,7 @@ CTD_HD void fin_trapeze_step(const KParams& kp, const BlockCtx& cx, int k) {
 #pragma unroll
     for (int r = 0; r < n; ++r) {
         const double fs = e0[R.of + r] + e1[R.of + r];
-        rec[R.oR + r] = base[L.blk + r] - (base[r] + half_h * fs);
+        rec[R.oR + r] = xnext[r] - (base[r] + half_h * fs);
 #pragma unroll
         for (int kk = 0; kk < nv; ++kk) {
             const double dhalf = Dirs<P>::FREE ? 0.5 * (dtime_of<P>(tau1, kk) - dtime_of<P>(tau0, kk)) : 0.0;
@@ -1168,24 +1171,30 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                 return;
             }
             if (wave < NP) {
+#if !defined(CTD_ABL) || CTD_ABL != 2          /* (ablation builds, never shipped: 1 no path rows, 2 no dynamics, 3 no lead) */
                 if (l < nd) {
                     const int j = l / ns, k = l - j * ns;
                     eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
                 }
+#endif
                 CTD_SUB(kp, 2);
+#if !defined(CTD_ABL) || CTD_ABL != 1
                 if (l >= nd && l < nd + ns) {
                     // symbolic path rows: ONE pass per point (chunk 0), on the wave whose part of the dynamics is the lightest
                     // (part 1 of the 12-state quadrotor: 4100 cycles against 5100; the pass costs 3000); forward duals: chunk q on wave q
                     constexpr int PW = NP > 1 ? 1 : 0;
                     if (SymPath<P>::value ? wave == PW : wave < r_path) eval_step_path<P, SC, S>(kp, cx, l - nd, SymPath<P>::value ? 0 : wave);
                 }
+#endif
                 CTD_SUB(kp, 3);
+#if !defined(CTD_ABL) || CTD_ABL != 3
                 if (SC == SC_IRK) {       // lead role by (step, state row): task t = wave, wave + NP, ... on lane nd + ns + t / NP
                     const int t = (l - nd - ns) * NP + wave;
                     if (l >= nd + ns && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
                 } else if (l >= nd + ns && l < nd + 2 * ns && wave == NP - 1) {
                     fin_lead<P, SC, S>(kp, cx, l - nd - ns);
                 }
+#endif
                 CTD_SUB(kp, 4);
             }
             for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;

@@ -64,6 +64,10 @@ CTD_HD int xcd_tile(int b, int nt) {
 
 // doubles per record input of the edge block: own step block | X_{i+1} | U_{i+1} (trapeze) | U_{i-1} (implicit Euler's path control)
 CTD_HD int edge_in_stride(const Layout& L) { return L.blk + L.n + 2 * L.m; }
+// doubles between the staged step blocks of a tile: the block size rounded up to ODD.  The evaluating lanes read the same field
+// of consecutive steps; with an even pitch they meet in a few LDS banks (12-state quadrotor, midpoint: 16 doubles = 128 bytes:
+// every lane in one of two bank pairs, a 9-way conflict on each of the ~30 input reads of a lane)
+CTD_HD int tile_in_stride(const Layout& L) { return L.blk | 1; }
 
 // ---- per-step LDS record (doubles) -------------------------------------------------------------------
 // [0] = 1.0
@@ -204,7 +208,7 @@ struct KParams {
     const uint32_t* tmpl;
     int32_t Lseg;
     int32_t vr;                 // rows per step inside each V column
-    FastDiv div_cb, div_Lseg, div_vr;
+    FastDiv div_cb, div_Lseg, div_vr, div_blk;
     int64_t seg_base;
     int64_t reg_first, reg_last;
     // V columns: column k holds, for step i, vals[vcol_base[k] + i * vr, +vr) with codes vtmpl[k * vr ...]
