@@ -1290,10 +1290,11 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     size_t lds = 4 * kMaxNV * sizeof(double) + 64;
     ip.kp = h->kp;       // (Layout is read from kp / hp / gp / op by the respective bodies)
     ip.hp = h->hp;
-    // Handles on which the lane-per-step Hessian kernel is the faster one (Gauss-Legendre 2 from 9 000 steps, 3 from 28 000:
-    // ensure_hess) keep it: the fused grid then holds objective + gradient + constraints / Jacobian, and the step kernel follows on
-    // the same stream (Goddard GL3, N = 80 000: tile body inside the fused grid 62 us; fused first-order grid + step kernel ~55)
-    const bool hess_apart = hvals_dev && h->hess_step;
+    // The fused grid always carries the TILE body of the Hessian, also on handles whose stand-alone hess_coord runs the
+    // lane-per-step kernel (Gauss-Legendre 2 from 9 000 steps, 3 from 28 000: ensure_hess).  Measured (CTD_ITER_HESS_APART=1: fused
+    // first-order grid, then the step kernel and its finish as two more launches): Goddard GL2 N = 10 000 22.9 us against 14-16,
+    // GL3 N = 80 000 64.0 against 62.6 -- the two extra launches cost what the faster kernel gains
+    const bool hess_apart = hvals_dev && h->hess_step && env_int("CTD_ITER_HESS_APART", 0);
     if (hvals_dev && !hess_apart) {
         ip.hp.obj_weight = obj_weight;
         ip.hp.vals = hvals_dev;
