@@ -107,6 +107,7 @@ SYMBOLS = {
     "ctd_ipc_export": (C.c_int32, [C.c_int32, _vp, _vp, _ip]),
     "ctd_ipc_open": (C.c_int32, [C.c_int32, _vp, C.POINTER(_vp)]),
     "ctd_ipc_close": (C.c_int32, [C.c_int32, _vp]),
+    "ctd_ipc_probe": (C.c_int32, [C.c_int32, _vp, C.c_size_t]),
     "ctd_stitch_c": (C.c_int32, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     "ctd_shard_steps": (C.c_int32, [C.c_int64, C.c_int32, C.c_int32, _ip, _ip]),
 }

@@ -747,6 +747,20 @@ int32_t ctd_ipc_open(int32_t device, const void* handle64, void** base) {
     if (e != hipSuccess) { g_create_err = std::string("ctd_ipc_open: ") + hipGetErrorString(e); (void)hipGetLastError(); return CTD_ERCCL; }
     return CTD_OK;
 }
+// reads `bytes` (<= 64) at a mapped pointer with a device-to-device copy on `device`: a mapping the device cannot reach comes back
+// as an error code here instead of as a fault inside a kernel
+int32_t ctd_ipc_probe(int32_t device, const void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0 || bytes > 64) return CTD_EINVAL;
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&tmp, 64);
+    if (e == hipSuccess) e = hipMemcpy(tmp, ptr, bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) { g_create_err = std::string("ctd_ipc_probe: ") + hipGetErrorString(e); (void)hipGetLastError(); return CTD_ERCCL; }
+    return CTD_OK;
+}
 int32_t ctd_ipc_close(int32_t device, void* base) {
     if (!base) return CTD_OK;
     DeviceGuard dg(device);

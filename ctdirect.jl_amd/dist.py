@@ -276,6 +276,11 @@ class ShardedDOCP:
                         break
                     opened.append((dev, base.value))
                     ptrs.append(base.value + o)
+                    # one read through the mapping by a plain device copy: an unreachable mapping is an error here, not a fault
+                    # inside the evaluation kernel
+                    if L.ctd_ipc_probe(dev, C.c_void_p(base.value + o), 8):
+                        err = f"ctd_ipc_probe (rank {r}'s buffer): " + L.ctd_last_error(None).decode()
+                        break
         elif err is None:
             err = "another rank could not export its buffer"
         flat = str(dist.get_backend(self.group)).lower() in ("nccl", "rccl")

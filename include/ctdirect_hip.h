@@ -392,6 +392,9 @@ int32_t ctd_shard_steps(int64_t N, int32_t n_shards, int32_t k, int64_t* begin, 
 int32_t ctd_ipc_export(int32_t device, const void* dev_ptr, void* handle64, int64_t* offset);
 int32_t ctd_ipc_open(int32_t device, const void* handle64, void** base);
 int32_t ctd_ipc_close(int32_t device, void* base);
+/* reads `bytes` (<= 64) at a mapped pointer with a device-to-device copy: CTD_ERCCL if `device` cannot reach it (an error code
+ * here instead of a fault inside a kernel); hosts call it once per mapping before ctd_set_x_shards */
+int32_t ctd_ipc_probe(int32_t device, const void* ptr, size_t bytes);
 
 /* waits for every shard's stream */
 int32_t ctd_sharded_sync(ctd_sharded* s);

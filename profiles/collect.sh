@@ -8,7 +8,7 @@
 # committed).
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
