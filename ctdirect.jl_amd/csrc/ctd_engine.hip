@@ -429,6 +429,34 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             int32_t jst = jit_load_first(hp);
             if (jst) return jst;
         }
+        // Multi-tile workgroups (staged driver only; KParams::wg_stride): when the tiles need several rounds of resident
+        // workgroups, launch ONE round and let every workgroup walk its share of the tiles -- templates / v / codes fetched once
+        // per workgroup, the next tile's x slice in flight during the emission.  The round is what the runtime says is resident
+        // (registers and LDS of this very kernel).  EXPERIMENT: builds with -DCTD_MULTI_TILE_LOOP=1 and CTD_MULTI_TILE=1 (k > 1: k
+        // workgroups per CU) only -- measured slower than the hardware's own dispatch of one tile per workgroup (ctd_kernels.hpp).
+        {
+            const bool direct = mo.fused && mo.L.sc != SC_TRAPEZE;
+            const int mt = env_int("CTD_MULTI_TILE", 0);
+            if (!direct && mt > 0 && kMultiTileLoop && !hp->rt) {
+                int per_cu = mt > 1 ? mt : 0, cus = 256;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hp->device) != hipSuccess) cus = 256;
+                if (per_cu == 0) {
+                    if (hp->rt) {
+                        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hp->f_cons_jac, hp->block, hp->lds_bytes) != hipSuccess) per_cu = 0;
+                    } else {
+                        for_problem(mo.problem, [&](auto tag) {
+                            using P = typename decltype(tag)::type;
+                            per_cu = occupancy_cons_jac<P>(mo.L.sc, hp->kp, hp->block, hp->lds_bytes);
+                        });
+                    }
+                }
+                const int64_t cap = (int64_t)per_cu * cus - (hp->kp.has_edge ? 1 : 0);      // (the edge block holds a slot of its own)
+                if (cap > 0 && hp->kp.ntiles > cap) {
+                    hp->kp.wg_stride = (int)cap;
+                    hp->grid = hp->kp.wg_stride + (hp->kp.has_edge ? 1 : 0);
+                }
+            }
+        }
     }
     *out = h.release();
     return CTD_OK;

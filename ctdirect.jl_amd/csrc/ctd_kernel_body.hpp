@@ -344,6 +344,44 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
     if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
 }
 
+// The x slice of a tile in two halves (multi-tile workgroups, KParams::wg_stride): load_issue reads the lane's elements of the
+// NEXT tile into registers before the current tile is emitted, load_commit stores them to the staged copy afterwards -- the
+// global-memory latency of the slice hides behind the emission.  Tiles at a shard boundary of a sharded iterate (cx.halo) and
+// slices longer than two elements per lane fall back to plain loads in load_commit.
+struct TileIn { double x0, x1, tau; };
+template <class P>
+CTD_HD TileIn load_issue(const KParams& kp, const BlockCtx& cx, const double* __restrict__ xu, int tid, int nthr) {
+    TileIn t{0.0, 0.0, 0.0};
+    if (cx.halo) return t;
+    const Layout& L = kp.L;
+    const int64_t g0 = (cx.lo < 0 ? 0 : cx.lo) * (int64_t)L.blk;
+    int64_t g1 = (cx.lo + cx.nslots) * (int64_t)L.blk + L.n + L.m;
+    if (g1 > L.v_off) g1 = L.v_off;
+    const double* __restrict__ src = xu + g0;
+    const int cnt = (int)(g1 - g0);
+    if (tid < cnt) t.x0 = src[tid];
+    if (tid + nthr < cnt) t.x1 = src[tid + nthr];
+    if (tid <= cx.nslots + 1) t.tau = tau_global(kp, cx.lo + tid);
+    return t;
+}
+template <class P, int SC, int S>
+CTD_HD void load_commit(const KParams& kp, const BlockCtx& cx, const double* __restrict__ xu, const TileIn& t, int tid, int nthr) {
+    if (cx.halo) { phase_load<P, SC, S, false>(kp, cx, xu, tid, nthr); return; }
+    const Layout& L = kp.L;
+    const int64_t g0 = (cx.lo < 0 ? 0 : cx.lo) * (int64_t)L.blk;
+    int64_t g1 = (cx.lo + cx.nslots) * (int64_t)L.blk + L.n + L.m;
+    if (g1 > L.v_off) g1 = L.v_off;
+    const double* __restrict__ src = xu + g0;
+    const int cnt = (int)(g1 - g0);
+    const int eo0 = (int)(g0 - cx.lo * (int64_t)L.blk), padw = cx.in_stride - L.blk;
+    auto at = [&](int e) -> double& { const int eo = eo0 + e; return cx.in[eo + (int)fast_div((uint32_t)eo, kp.div_blk) * padw]; };
+    if (tid < cnt) at(tid) = t.x0;
+    if (tid + nthr < cnt) at(tid + nthr) = t.x1;
+    for (int e = tid + 2 * nthr; e < cnt; e += nthr) at(e) = src[e];
+    if (tid <= cx.nslots + 1) cx.tau[tid] = t.tau;
+    for (int e = tid + nthr; e <= cx.nslots + 1; e += nthr) cx.tau[e] = tau_global(kp, cx.lo + e);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // finishing pieces (called from the eval lanes when Dirs<P>::FUSED, from phase_fin otherwise)
 // ------------------------------------------------------------------------------------------------------
@@ -418,9 +456,12 @@ CTD_HD void fin_lead(const KParams& kp, const BlockCtx& cx, int k, int row = -1)
 
 // the part of the chain rule that needs all partials of one eval point
 // `ev`: the eval block of (slot k, point j) -- its place in the LDS record, or a register copy the caller stores afterwards
+// (r0, rstep): the rows r0, r0 + rstep, ... only -- the lane that evaluated those rows of the dynamics (split evaluation: one
+// part per wave, so the row tests are wave-uniform branches) finishes them itself
 template <class P, int SC, int S>
-CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, double* ev) {
+CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, double* ev, int r0 = 0, int rstep = 1) {
     constexpr int n = P::NX, nv = P::NV;
+    auto mine = [&](int r) { return rstep == 1 || (r % rstep) == r0; };
     constexpr bool FREE = Dirs<P>::FREE;
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
@@ -440,7 +481,8 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
         const double* K = base + n + L.cu;
         // stage rows: K_i^j - f(...)   (irk_stagewise.jl:448-451)
 #pragma unroll
-        for (int r = 0; r < n; ++r) rec[R.oR + n + j * n + r] = K[j * n + r] - ev[R.of + r];
+        for (int r = 0; r < n; ++r)
+            if (mine(r)) rec[R.oR + n + j * n + r] = K[j * n + r] - ev[R.of + r];
 #pragma unroll
         for (int kk = 0; kk < nv; ++kk) {
             // d x_ij / d v_kk = dh * sum_l a_jl K^l  (x_i itself does not depend on v)
@@ -455,6 +497,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
             const double dtij = dti[kk] + butcher_c<S>(L, j) * dh[kk];
 #pragma unroll
             for (int r = 0; r < n; ++r) {
+                if (!mine(r)) continue;
                 double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
                 if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dtij;
                 if (FREE) {
@@ -471,6 +514,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
         const double* nxt = slot_next(kp, cx, k);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
+            if (!mine(r)) continue;
             const double f = ev[R.of + r];
             rec[R.oR + r] = nxt[r] - (base[r] + h * f);    // midpoint.jl:139
 #pragma unroll
@@ -487,6 +531,7 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
         for (int r = 0; r < n; ++r)
 #pragma unroll
             for (int kk = 0; kk < nv; ++kk) {
+                if (!mine(r)) continue;
                 double w = P::DYN_V ? ev[R.oW + r * nv + kk] : 0.0;
                 if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dti[kk];
                 ev[R.oW + r * nv + kk] = w;
@@ -979,6 +1024,21 @@ template <class P, int SC, int S = 1> struct RegEval {
 // it.  It comes split by rows into NCH_DYN parts: part q of every point runs in wave q (uniform code per wave, the parts side by
 // side on different SIMDs); the path passes and the lead role (per-step coefficients, state rows: inputs only) take the next
 // lanes of the same waves, so the fin phase that follows is ONE pass of one task per lane.
+// FOLDED FIN: OCPs whose dynamics come as generated straight-line code (every partial of a point, or of its rows, on ONE lane) and
+// whose path rows need one pass finish the chain rule on the evaluating lanes -- stage rows and total d/dv behind the dynamics,
+// the path rows' d/dv behind the path pass, the lead role on a lane of its own -- so a tile has no fin phase and one barrier
+// less (12-state quadrotor, Gauss-Legendre 3: the fin phase was 1.8 of the tile's 10.9 us; midpoint 1.5 of 11.5).  Edge blocks
+// keep the fin phase (final-time path record, one lane per kind of task).
+template <class P, int SC, int S>
+CTD_HD bool fin_folded(const BlockCtx& cx) {
+#ifdef CTD_NO_FOLD
+    return false;
+#else
+    constexpr bool path_ok = P::NPATH == 0 || SymPath<P>::value || Dirs<P>::NCH_PATH == 1;
+    return !Dirs<P>::FUSED && SymDyn<P>::value && path_ok && !cx.is_edge;
+#endif
+}
+
 template <class P, int SC, int S>
 CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
 #ifdef CTD_NO_SPLIT
@@ -1018,7 +1078,9 @@ CTD_HD void emit_store(double* p, double v) {
 // of that kernel was bound by those dependent loads, not by bandwidth.
 // kpos: the position of the period the lane owns behind the barrier (early emission: an entry of KParams::pos); eb / ek: code and
 // position (or row / V entry) of the early output the lane stores when it sits in the lead wave
-template <int NB> struct EmitPreT { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; uint32_t more[NB > 1 ? NB - 1 : 1]; int kpos; uint32_t eb; int ek; };
+// have: the fields are filled (a caller that does not prefetch passes a zeroed struct, NOT a null pointer chosen at run time: a
+// struct whose address is selected against nullptr lives in scratch memory)
+template <int NB> struct EmitPreT { uint32_t b; uint32_t v[kMaxNV]; int64_t eidx; uint32_t more[NB > 1 ? NB - 1 : 1]; int kpos; uint32_t eb; int ek; int have; };
 using EmitPre = EmitPreT<1>;     // edge block: b = the code of edge entry `tid`, eidx its index
 // Early emission (KParams::pos): the lead wave of a Gauss-Legendre tile stores the outputs that only read what its own lead tasks
 // wrote -- lane l owns one early output of every step of the tile -- while the other waves still evaluate the dynamics
@@ -1153,18 +1215,25 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             // symbolic path rows of every step run in wave NP beside the dynamics parts instead of behind one of them (4400 cycles
             // behind part 1's 5000), the cheap lead tasks of the one-point schemes too
             const bool extra = SymPath<P>::value && nthr >= (NP + 1) * 64;
+            const bool fold = fin_folded<P, SC, S>(cx);
+            auto fin_path_slot = [&](int k) {          // total d/dv of the path rows of slot k (phase_fin's path task)
+                const int64_t i = slot_index(kp, cx, k);
+                if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + k * R.stride, slot_tau(kp, cx, k, 0));
+            };
             if (extra) {
                 if (wave < NP) {
                     if (l < nd) {
                         const int j = l / ns, k = l - j * ns;
-                        eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+                        double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+                        eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, ev);
+                        if (fold) fin_stage<P, SC, S>(kp, cx, k, j, ev, wave, NP);
                     }
                     if (SC == SC_IRK) {
                         const int t = (l - nd) * NP + wave;
                         if (l >= nd && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
                     }
                 } else if (wave == NP) {
-                    if (l < ns) { if (r_path > 0) eval_step_path<P, SC, S>(kp, cx, l, 0); }
+                    if (l < ns) { if (r_path > 0) { eval_step_path<P, SC, S>(kp, cx, l, 0); if (fold) fin_path_slot(l); } }
                     else if (SC != SC_IRK && l < 2 * ns) fin_lead<P, SC, S>(kp, cx, l - ns);
                 }
                 for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
@@ -1174,7 +1243,9 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
 #if !defined(CTD_ABL) || CTD_ABL != 2          /* (ablation builds, never shipped: 1 no path rows, 2 no dynamics, 3 no lead) */
                 if (l < nd) {
                     const int j = l / ns, k = l - j * ns;
-                    eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, cx.rec + k * R.stride + R.oEval + j * R.eval_sz);
+                    double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+                    eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, ev);
+                    if (fold) fin_stage<P, SC, S>(kp, cx, k, j, ev, wave, NP);      // the rows this wave's part evaluated
                 }
 #endif
                 CTD_SUB(kp, 2);
@@ -1183,7 +1254,10 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                     // symbolic path rows: ONE pass per point (chunk 0), on the wave whose part of the dynamics is the lightest
                     // (part 1 of the 12-state quadrotor: 4100 cycles against 5100; the pass costs 3000); forward duals: chunk q on wave q
                     constexpr int PW = NP > 1 ? 1 : 0;
-                    if (SymPath<P>::value ? wave == PW : wave < r_path) eval_step_path<P, SC, S>(kp, cx, l - nd, SymPath<P>::value ? 0 : wave);
+                    if (SymPath<P>::value ? wave == PW : wave < r_path) {
+                        eval_step_path<P, SC, S>(kp, cx, l - nd, SymPath<P>::value ? 0 : wave);
+                        if (fold) fin_path_slot(l - nd);
+                    }
                 }
 #endif
                 CTD_SUB(kp, 3);
@@ -1256,7 +1330,8 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             return;
         }
     }
-    const int total = (r_dyn + r_path + r_lead) << lg;
+    const bool fold_g = fin_folded<P, SC, S>(cx);          // (then with a lead role, as in fused mode)
+    const int total = (r_dyn + r_path + ((FUSED || fold_g) ? 1 : 0)) << lg;
     for (int task = tid; task < total; task += nthr) {
         const int k = task & mask, role = task >> lg;
         if (k >= ns) continue;
@@ -1280,10 +1355,15 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                 CTD_SUB(kp, 4);
             } else {
                 eval_dynamics<P, SC, S>(kp, cx, k, j, q, ev);
-                if (FUSED) fin_stage<P, SC, S>(kp, cx, k, j, ev);
+                // (folded fin: the generated code put every partial of the point on the lane of chunk 0)
+                if (FUSED || (fold_g && q == 0)) fin_stage<P, SC, S>(kp, cx, k, j, ev);
             }
         } else if (role < r_dyn + r_path) {
             eval_step_path<P, SC, S, REG>(kp, cx, k, role - r_dyn);
+            if (fold_g) {
+                const int64_t i = slot_index(kp, cx, k);
+                if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + k * R.stride, slot_tau(kp, cx, k, 0));
+            }
         } else {
             CTD_SUB(kp, 1);
             fin_lead<P, SC, S>(kp, cx, k);
@@ -1301,6 +1381,7 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
 template <class P, int SC, int S>
 CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) {
     if (Dirs<P>::FUSED) return;
+    if (fin_folded<P, SC, S>(cx)) return;                  // (the evaluating lanes did it)
     constexpr RecLayout R = RL<P, SC, S>::R;
     const int ns = cx.nslots;
     constexpr int rows = (SC == SC_IRK && P::NX > 4) ? P::NX : 1;    // rows of a stage per lane: 1 row each for wide states
@@ -1451,6 +1532,8 @@ CTD_HD EmitPreT<NB> emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid
     EmitPreT<NB> pre;
     pre.b = 0u;
     pre.eidx = 0;
+    pre.have = 1;
+    pre.kpos = 0; pre.eb = 0u; pre.ek = 0;
 #pragma unroll
     for (int q = 0; q < (NB > 1 ? NB - 1 : 1); ++q) pre.more[q] = 0u;
 #pragma unroll
@@ -1502,16 +1585,17 @@ CTD_HD EmitPreT<NB> emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid
 }
 
 template <class P, int SC, int S, int NB = 1>
-CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPreT<NB>* pre = nullptr) {
+CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPreT<NB> pre_v, const bool hp) {
     const Layout& L = kp.L;
     constexpr RecLayout R = RL<P, SC, S>::R;
+    const EmitPreT<NB>* pre_ = &pre_v;                     // hp: the lane's codes were prefetched (pre_v holds them)
     if (cx.is_edge) {
         const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
         for (int w = tid; w < ntot; w += nthr) {
             const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
-            const bool have = pre != nullptr && w == tid;          // first pass: prefetched before the evaluation
-            const uint32_t code = have ? pre->b : kp.edge_code[e];
-            const int64_t idx = have ? pre->eidx : kp.edge_idx[e];
+            const bool have = hp && w == tid;          // first pass: prefetched before the evaluation
+            const uint32_t code = have ? pre_->b : kp.edge_code[e];
+            const int64_t idx = have ? pre_->eidx : kp.edge_idx[e];
             const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec_raw(code) * R.stride, code);
             if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
             else if (kp.vals) kp.vals[idx] = val;
@@ -1590,8 +1674,8 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             if (par >= 1) {
                 if (tid < par * Lw) {
                     const int g = (int)fast_div((uint32_t)tid, late_only ? kp.div_late : kp.div_Lseg);
-                    const int k = late_only ? (pre ? pre->kpos : (int)kp.pos[tid - g * Lw]) : tid - g * Ls;
-                    const uint32_t code = pre ? pre->b : cx.codes[k];
+                    const int k = late_only ? (hp ? pre_->kpos : (int)kp.pos[tid - g * Lw]) : tid - g * Ls;
+                    const uint32_t code = hp ? pre_->b : cx.codes[k];
                     const int bt = code_beta(code);
                     const double beta = bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0);
                     const double* pc = cx.rec + (sl0 - code_crec(code)) * stride + R.oC + code_ci(code);
@@ -1616,17 +1700,17 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                 // long periods (more positions than lanes): a lane owns positions tid, tid + nthr, ...; the code of the NEXT
                 // position is fetched while the current one is streamed out (the table is read from global memory / L2 here:
                 // a dependent load at the top of every position would expose its latency a dozen times per tile)
-                uint32_t code = (pre && tid < Ls) ? pre->b : (tid < Ls ? cx.codes[tid] : 0u);
+                uint32_t code = (hp && tid < Ls) ? pre_->b : (tid < Ls ? cx.codes[tid] : 0u);
                 int q = 0;
                 for (int k = tid; k < Ls; k += nthr, ++q) {
                     uint32_t nxt = 0u;
                     bool have = false;
                     if constexpr (NB > 1) {              // codes fetched before the evaluation (register array: constant indices)
-                        if (pre && q < NB - 1) {
+                        if (hp && q < NB - 1) {
                             have = true;
 #pragma unroll
                             for (int e = 0; e < NB - 1; ++e)
-                                if (e == q) nxt = pre->more[e];
+                                if (e == q) nxt = pre_->more[e];
                         }
                     }
                     if (!have) nxt = k + nthr < Ls ? cx.codes[k + nthr] : 0u;
@@ -1663,7 +1747,7 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             if (par >= 1) {
                 if (tid < par * vr) {
                     const int g = (int)fast_div((uint32_t)tid, kp.div_vr), k = tid - g * vr;
-                    const uint32_t code = pre ? pre->v[kk] : codes[k];
+                    const uint32_t code = hp ? pre_->v[kk] : codes[k];
                     const double* pc = cx.rec + (slot0 + g) * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);
                     const int adv = par * stride;
@@ -1681,6 +1765,12 @@ CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
         }
     }
 #endif
+}
+// (pointer form: the drivers that always prefetch, and the emulator)
+template <class P, int SC, int S, int NB = 1>
+CTD_HD void phase_emit(const KParams& kp, const BlockCtx& cx, int tid, int nthr, const EmitPreT<NB>* pre = nullptr) {
+    if (pre != nullptr) phase_emit_impl<P, SC, S, NB>(kp, cx, tid, nthr, *pre, pre->have != 0);
+    else phase_emit_impl<P, SC, S, NB>(kp, cx, tid, nthr, EmitPreT<NB>{}, false);
 }
 
 }  // namespace ctd

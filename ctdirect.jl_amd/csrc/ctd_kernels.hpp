@@ -18,6 +18,11 @@ namespace ctd {
 // kp.has_edge).  Dynamic LDS = lds_doubles(kp) * 8 bytes.
 // DBG = true is the diagnostics instantiation (ctd_debug_stamps, env CTD_DEBUG_STOP): phase stamps and early returns.  The
 // default instantiation holds neither, so no launch pays for their branches or their kernel-argument loads.
+#ifndef CTD_MULTI_TILE_LOOP
+#define CTD_MULTI_TILE_LOOP 0
+#endif
+constexpr bool kMultiTileLoop = CTD_MULTI_TILE_LOOP != 0;
+
 template <bool DBG>
 __device__ __forceinline__ void ctd_stamp(const KParams& kp, int slot) {
     if constexpr (DBG) {
@@ -74,32 +79,54 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         }
         return;
     }
-    const BlockCtx cx = make_ctx(kp, block, ctd_lds);
+    BlockCtx cx = make_ctx(kp, block, ctd_lds);
     // codes not staged in LDS (long periods): every code the lane will need is fetched now, the latency hidden behind load + eval
     constexpr int NB = EmitN<P, SC, S>::value;
-    EmitPreT<NB> pre;
+    EmitPreT<NB> pre = {};
     const bool use_pre = !cx.is_edge && !codes_staged(kp);
     if (use_pre) pre = emit_prefetch<P, NB>(kp, cx, tid, nthr);
     phase_load<P, SC, S>(kp, cx, xu, tid, nthr);
-    __syncthreads();
-    ctd_stamp<DBG>(kp, 1);
-    if (DBG && kp.debug_stop == 2) return;
-    phase_eval<P, SC, S>(kp, cx, tid, nthr);
-    __syncthreads();
-    ctd_stamp<DBG>(kp, 2);
-    if (DBG && kp.debug_stop == 3) return;
-    if (!Dirs<P>::FUSED) {
-        phase_fin<P, SC, S>(kp, cx, tid, nthr);
+    // multi-tile workgroups (kp.wg_stride > 0; EXPERIMENT, compiled with -DCTD_MULTI_TILE_LOOP=1 only): this workgroup goes on with
+    // block + wg_stride, ... -- the templates, v and the lane's codes stay where they are (the period of the tables is the step:
+    // the same for every tile), the x slice of the next tile travels while this one is emitted.  One barrier per tile boundary: it
+    // orders the emission's reads of the records and the staged copy of the next slice before the next evaluation.
+    // Measured on MI355X (profiles/r03_experiments.md): SLOWER than one tile per workgroup -- 12-state quadrotor GL3 124 us against
+    // 106, optimized pattern 55.5 against 42.4.  A resident round of workgroups that all start together stays in lock-step (every
+    // workgroup evaluates, then every workgroup stores: the memory system idles, then saturates), while the hardware dispatcher
+    // starts the next tile whenever a slot frees and so spreads the phases; the loop also costs 30 - 55 registers.
+    const int nblk = kp.ntiles + (kp.has_edge ? 1 : 0);
+    for (;;) {
         __syncthreads();
-    }
-    if (SC == SC_TRAPEZE) {
-        phase_fin2<P, SC, S>(kp, cx, tid, nthr);
+        ctd_stamp<DBG>(kp, 1);
+        if (DBG && kp.debug_stop == 2) return;
+        phase_eval<P, SC, S>(kp, cx, tid, nthr);
         __syncthreads();
+        ctd_stamp<DBG>(kp, 2);
+        if (DBG && kp.debug_stop == 3) return;
+        if (!Dirs<P>::FUSED && !fin_folded<P, SC, S>(cx)) {     // (block-uniform)
+            phase_fin<P, SC, S>(kp, cx, tid, nthr);
+            __syncthreads();
+        }
+        if (SC == SC_TRAPEZE) {
+            phase_fin2<P, SC, S>(kp, cx, tid, nthr);
+            __syncthreads();
+        }
+        ctd_stamp<DBG>(kp, 3);
+        if (DBG && kp.debug_stop == 4) return;
+        block += kp.wg_stride;
+        const bool more = kMultiTileLoop && kp.wg_stride > 0 && !cx.is_edge && block < nblk;
+        BlockCtx nx = cx;
+        TileIn tin{0.0, 0.0, 0.0};
+        if (more) {
+            nx = make_ctx(kp, block, ctd_lds);
+            tin = load_issue<P>(kp, nx, xu, tid, nthr);
+        }
+        phase_emit_impl<P, SC, S, NB>(kp, cx, tid, nthr, pre, use_pre);
+        ctd_stamp<DBG>(kp, 4);
+        if (!more) break;
+        load_commit<P, SC, S>(kp, nx, xu, tin, tid, nthr);
+        cx = nx;
     }
-    ctd_stamp<DBG>(kp, 3);
-    if (DBG && kp.debug_stop == 4) return;
-    phase_emit<P, SC, S, NB>(kp, cx, tid, nthr, use_pre ? &pre : nullptr);
-    ctd_stamp<DBG>(kp, 4);
     if (DBG && kp.stamps) {      // diagnostics: time until this workgroup's stores have left the CU
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -613,6 +640,29 @@ hipError_t launch_cons_jac(int sc, const KParams& kp, const double* xu, int grid
     return launch_variant<P, SC_IRK, 3>(kp, xu, grid, block, lds_bytes, st, e0, e1);
 }
 
+// resident workgroups per CU of the kernel launch_cons_jac would run (registers and LDS): sizes the multi-tile grid
+template <class P, int SC, int S>
+int occupancy_variant(int block, size_t lds_bytes) {
+    int nb = 0;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)cons_jac_kernel<P, SC, S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cons_jac_kernel<P, SC, S, false>, block, lds_bytes) != hipSuccess) return 0;
+    return nb;
+}
+template <class P>
+int occupancy_cons_jac(int sc, const KParams& kp, int block, size_t lds_bytes) {
+    if (sc == SC_TRAPEZE) return occupancy_variant<P, SC_TRAPEZE, 1>(block, lds_bytes);
+    if (sc == SC_MIDPOINT) {
+        if (kp.L.cs == 2) return occupancy_variant<P, SC_MIDPOINT, 2>(block, lds_bytes);
+        if (kp.L.cs == 3) return occupancy_variant<P, SC_MIDPOINT, 3>(block, lds_bytes);
+        return occupancy_variant<P, SC_MIDPOINT, 1>(block, lds_bytes);
+    }
+    if (kp.L.s == 1) return occupancy_variant<P, SC_IRK, 1>(block, lds_bytes);
+    if (kp.L.s == 2) return occupancy_variant<P, SC_IRK, 2>(block, lds_bytes);
+    return occupancy_variant<P, SC_IRK, 3>(block, lds_bytes);
+}
+
 template <class P>
 hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, int block, hipStream_t st) {
     if (grid <= 0) {}      // Mayer-only cost: nothing to integrate
@@ -627,11 +677,13 @@ hipError_t launch_obj(int sc, const ObjParams& op, const double* xu, int grid, i
     template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t, hipEvent_t, \
                                            hipEvent_t);                                                                    \
     template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);                       \
+    template int occupancy_cons_jac<P>(int, const KParams&, int, size_t);                                                 \
     template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 #define CTD_EXTERN_LAUNCHERS(P)                                                                                            \
     extern template hipError_t launch_cons_jac<P>(int, const KParams&, const double*, int, int, size_t, hipStream_t,      \
                                                   hipEvent_t, hipEvent_t);                                                 \
     extern template hipError_t launch_obj<P>(int, const ObjParams&, const double*, int, int, hipStream_t);               \
+    extern template int occupancy_cons_jac<P>(int, const KParams&, int, size_t);                                         \
     extern template hipError_t launch_grad<P>(int, int, const GradParams&, const double*, int, hipStream_t);
 
 #endif  // !__HIPCC_RTC__

@@ -244,6 +244,12 @@ struct KParams {
     // sharded iterate read in place: where the other shards' variables live (device table), or null: xu holds everything
     // this shard reads
     const XHalo* halo;
+    // MULTI-TILE WORKGROUPS (staged driver, grids of several rounds): workgroup w walks the blocks w, w + wg_stride, ... of the
+    // evaluation instead of one (0: one block per workgroup).  The emit templates, the optimisation variable and the lane's codes
+    // are fetched once per workgroup, and the x slice of the NEXT tile is loaded into registers while the current one is emitted
+    // (ctd_kernels.hpp: cons_jac_body).  The edge block (block 0) is never followed by a tile: it is the longest block.
+    int32_t wg_stride;
+    int32_t pad_;
 };
 
 }  // namespace ctd

@@ -29,7 +29,11 @@ template <class P, int SC, int S>
 static void run_blocks(const KParams& kp, const double* xu, int nthr) {
     const int nblocks = kp.ntiles + (kp.has_edge ? 1 : 0);
     const int64_t nlds = lds_doubles(kp);
-    for (int b = 0; b < nblocks; ++b) {
+    // multi-tile workgroups (KParams::wg_stride, staged driver): workgroup w walks the blocks w, w + wg_stride, ... on ONE LDS image
+    const int stride = DirectTile<P, SC>::value ? 0 : kp.wg_stride;
+    const int nwg = stride > 0 ? std::min(nblocks, stride + (kp.has_edge ? 1 : 0)) : nblocks;
+    for (int w = 0; w < nwg; ++w) {
+        int b = w;
         std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
         if (DirectTile<P, SC>::value) {
             // direct driver (cons_jac_kernel): no staging of xu, codes prefetched per lane, one barrier before the emission
@@ -53,10 +57,23 @@ static void run_blocks(const KParams& kp, const double* xu, int nthr) {
         if (use_pre)
             for (int t = 0; t < nthr; ++t) pre[t] = emit_prefetch<P, NB>(kp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) phase_load<P, SC, S>(kp, cx, xu, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_fin2<P, SC, S>(kp, cx, t, nthr);
-        for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S, NB>(kp, cx, t, nthr, use_pre ? &pre[t] : nullptr);
+        for (;;) {                                           // (the loop of cons_jac_body)
+            for (int t = 0; t < nthr; ++t) phase_eval<P, SC, S>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_fin<P, SC, S>(kp, cx, t, nthr);
+            for (int t = 0; t < nthr; ++t) phase_fin2<P, SC, S>(kp, cx, t, nthr);
+            b += stride;
+            const bool more = stride > 0 && !cx.is_edge && b < nblocks;
+            BlockCtx nx = cx;
+            std::vector<TileIn> tin(nthr);
+            if (more) {
+                nx = make_ctx(kp, b, lds.data());
+                for (int t = 0; t < nthr; ++t) tin[t] = load_issue<P>(kp, nx, xu, t, nthr);
+            }
+            for (int t = 0; t < nthr; ++t) phase_emit<P, SC, S, NB>(kp, cx, t, nthr, use_pre ? &pre[t] : nullptr);
+            if (!more) break;
+            for (int t = 0; t < nthr; ++t) load_commit<P, SC, S>(kp, nx, xu, tin[t], t, nthr);
+            cx = nx;
+        }
     }
 }
 
@@ -130,6 +147,7 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
     KParams kp;
     mo.fill_kparams(kp, step_begin, step_end, tile);
     if (const char* e = std::getenv("CTD_XCD")) kp.xcd_remap = std::atoi(e);      // same ablation knob as the engine
+    if (const char* e = std::getenv("CTD_EMU_WG_STRIDE")) kp.wg_stride = std::atoi(e);      // multi-tile workgroups
     kp.tau = mo.uniform ? nullptr : mo.tau.data();
     kp.tmpl = mo.tmpl.data();
     kp.vtmpl = mo.vtmpl.data();
@@ -195,6 +213,7 @@ int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, c
         hl.vbegin[G] = L.v_off;
         KParams kp;
         mo.fill_kparams(kp, sb[k], sb[k + 1], tile);
+        if (const char* e = std::getenv("CTD_EMU_WG_STRIDE")) kp.wg_stride = std::atoi(e);
         kp.tau = mo.uniform ? nullptr : mo.tau.data();
         kp.tmpl = mo.tmpl.data();
         kp.vtmpl = mo.vtmpl.data();

@@ -163,3 +163,30 @@ def test_xcd_tile_order_is_a_pure_permutation(monkeypatch):
         vv[np.array(d.hess_shard_info()[2], dtype=int)] = True
         assert np.array_equal(h0[~vv], h1[~vv]) and np.allclose(h0[vv], h1[vv], rtol=1e-13, atol=0)
         d.close()
+
+
+@pytest.mark.parametrize("prob", ["goddard_all", "quadrotor", "quadrotor12", "goddard", "double_integrator_path"])
+def test_multi_tile_workgroups_write_the_same_outputs(monkeypatch, prob):
+    """KParams::wg_stride (staged driver): a workgroup walks the blocks w, w + stride, ... on one LDS image -- templates, v and the
+    lane's codes fetched once, the x slice of the next tile loaded before the current one is emitted (load_issue / load_commit).
+    Bit-identical to one block per workgroup for every scheme and pattern, strides that leave full, ragged and single rounds,
+    also on a sharded iterate (first / last tiles read through the XHalo table)."""
+    N = 29
+    pid = ct.PROBLEMS[prob]
+    for sch in ct.SCHEMES:
+        sid = ct.SCHEMES[sch]
+        d = ct.DOCP(prob, N, sch, device=-1, pattern="structural")
+        x = bench_inputs(describe(d, prob, sch), perturb=1e-3)
+        d.close()
+        for mode in (0, 1):
+            monkeypatch.delenv("CTD_EMU_WG_STRIDE", raising=False)
+            c0, v0 = emu.cons_jac(pid, sid, mode, N, x, tile=3, nthr=64)
+            for stride, tile, nthr in ((1, 3, 64), (3, 3, 64), (4, 2, 33), (7, 1, 5), (50, 3, 64)):
+                monkeypatch.setenv("CTD_EMU_WG_STRIDE", str(stride))
+                c1, v1 = emu.cons_jac(pid, sid, mode, N, x, tile=tile, nthr=nthr)
+                assert np.array_equal(c0, c1) and np.array_equal(v0, v1), (sch, mode, stride)
+        monkeypatch.setenv("CTD_EMU_WG_STRIDE", "2")
+        c2, v2 = emu.cons_jac_sharded(pid, sid, 1, N, x, 3, tile=2, nthr=64)
+        monkeypatch.delenv("CTD_EMU_WG_STRIDE")
+        c3, v3 = emu.cons_jac(pid, sid, 1, N, x, tile=3, nthr=64)
+        assert np.array_equal(c2, c3) and np.array_equal(v2, v3), sch
