@@ -355,12 +355,8 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         h->block = 256;
         const int64_t ntl = (h->step_end - h->step_begin + h->tile - 1) / h->tile;
         if (ntl <= 512 && mo.Lseg > 0 && 320 / mo.Lseg > 256 / mo.Lseg && mo.Lseg * (320 / mo.Lseg) * 10 >= 320 * 9) h->block = 320;
-        // wide OCPs whose dynamics run as four parts in four waves (the 12-state quadrotor): a fifth wave can take the symbolic path
-        // rows (split_eval, ctd_kernel_body.hpp).  EXPERIMENT, off by default (CTD_WIDE5=1 one-point schemes, 2 all): measured slower
-        // on MI355X -- quadrotor12 midpoint N = 20 000 30.1 us against 24.4, Gauss-Legendre 3 168 against 119 -- three five-wave
-        // workgroups do not stay resident per CU (profiles/r03_experiments.md)
-        const int wide5 = env_int("CTD_WIDE5", 0);
-        if (mo.nch_dyn >= 4 && !mo.fused && !h->rt && wide5 && (mo.L.sc != SC_IRK || wide5 == 2)) h->block = 320;
+        // (a fifth wave for the symbolic path rows of the wide OCPs was measured slower -- quadrotor12 midpoint N = 20 000 30.1 us
+        // against 24.4 -- and is gone: profiles/r03_experiments.md)
     }
     if (h->block < 64 || (h->block % 64)) h->block = 256;
     if (h->block > maxb) h->block = maxb;

@@ -90,7 +90,7 @@ static int build_layout(Model& mo, int scheme, int64_t N, int control_steps, std
     L.cb = L.eqs + L.p;
     L.ncon = N * L.cb + L.p + L.bc;
     L.v_off = L.nvar - L.nv;
-    mo.R = make_rec_layout(L.n, L.m, L.nv, L.p, L.bc, L.s, L.cb, scheme == 1 ? L.cu : L.m);
+    mo.R = make_rec_layout(L.n, L.m, L.nv, L.p, L.bc, L.s, L.cb, scheme == 1 ? L.cu : L.m, mo.n_f, mo.n_g);
     return ST_OK;
 }
 
@@ -419,8 +419,20 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     const Layout& L = mo.L;
     const RecLayout& R = mo.R;
     const int n = L.n, m = L.m;
-    auto F = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oF + r * R.ldx + c; };
-    auto G = [&](int j, int r, int c) { return R.oEval + j * R.eval_sz + R.oG + r * R.ldg + c; };
+    // record offset of d f_r / d x_c (d f_r / d u_c; c over all control blocks of the step) of eval block j, or -1: structurally
+    // zero -- sparse eval blocks hold no slot for it and the entry is the constant part of its code
+    auto F = [&](int j, int r, int c) {
+        if (mo.n_f < 0) return R.oEval + j * R.eval_sz + R.oF + r * R.ldx + c;
+        const int s = mo.map_f[r * n + c];
+        return s < 0 ? -1 : R.oEval + j * R.eval_sz + R.oF + s;
+    };
+    auto G = [&](int j, int r, int c) {
+        if (mo.n_g < 0) return R.oEval + j * R.eval_sz + R.oG + r * R.ldg + c;
+        const int s = mo.map_g[r * m + c % m];
+        return s < 0 ? -1 : R.oEval + j * R.eval_sz + R.oG + (c / m) * mo.n_g + s;
+    };
+    // coefficient * (a partial of the dynamics) + beta
+    auto D = [&](int ci, int di, int beta, bool next) { return di < 0 ? Loc{C_ZERO, 0, beta, false} : Loc{ci, di, beta, next}; };
     const bool is_path = lr >= L.eqs;
     if (L.sc == SC_IRK) {
         // column kind
@@ -444,9 +456,9 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
             return kZero;
         }
         const int j = (lr - n) / n, r = (lr - n) % n;   // stage equation row
-        if (kind == 0) return Loc{C_NEG1, F(j, r, c), 0, false};
-        if (kind == 1) return (!L.stagewise || l == j) ? Loc{C_NEG1, G(j, r, c), 0, false} : kZero;
-        if (kind == 2) return Loc{C_HA + 3 * j + l, F(j, r, c), (j == l && r == c) ? 1 : 0, false};
+        if (kind == 0) return D(C_NEG1, F(j, r, c), 0, false);
+        if (kind == 1) return (!L.stagewise || l == j) ? D(C_NEG1, G(j, r, c), 0, false) : kZero;
+        if (kind == 2) return D(C_HA + 3 * j + l, F(j, r, c), (j == l && r == c) ? 1 : 0, false);
         return kZero;
     }
     // trapeze / midpoint
@@ -466,27 +478,27 @@ static Loc local_entry(const Model& mo, int lr, int q, int64_t step) {
     }
     const int r = lr;
     if (L.sc == SC_MIDPOINT && L.euler == 1) {       // x_{i+1} - (x_i + h f(t_i, x_i, u_i)): euler.jl:141-159
-        if (kind == 0) return Loc{C_NH, F(0, r, c), r == c ? 2 : 0, false};
-        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
+        if (kind == 0) return D(C_NH, F(0, r, c), r == c ? 2 : 0, false);
+        if (kind == 1) return D(C_NH, G(0, r, c), 0, false);
         if (kind == 3) return Loc{C_ZERO, 0, r == c ? 1 : 0, false};
         return kZero;
     }
     if (L.sc == SC_MIDPOINT && L.euler == 2) {       // x_{i+1} - (x_i + h f(t_{i+1}, x_{i+1}, u_i))
         if (kind == 0) return Loc{C_ZERO, 0, r == c ? 2 : 0, false};
-        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
-        if (kind == 3) return Loc{C_NH, F(0, r, c), r == c ? 1 : 0, false};
+        if (kind == 1) return D(C_NH, G(0, r, c), 0, false);
+        if (kind == 3) return D(C_NH, F(0, r, c), r == c ? 1 : 0, false);
         return kZero;
     }
     if (L.sc == SC_MIDPOINT) {
-        if (kind == 0) return Loc{C_NHH, F(0, r, c), r == c ? 2 : 0, false};
-        if (kind == 1) return Loc{C_NH, G(0, r, c), 0, false};
-        if (kind == 3) return Loc{C_NHH, F(0, r, c), r == c ? 1 : 0, false};
+        if (kind == 0) return D(C_NHH, F(0, r, c), r == c ? 2 : 0, false);
+        if (kind == 1) return D(C_NH, G(0, r, c), 0, false);
+        if (kind == 3) return D(C_NHH, F(0, r, c), r == c ? 1 : 0, false);
         return kZero;
     }
-    if (kind == 0) return Loc{C_NHH, F(0, r, c), r == c ? 2 : 0, false};
-    if (kind == 1) return Loc{C_NHH, G(0, r, c), 0, false};
-    if (kind == 3) return Loc{C_NHH, F(0, r, c), r == c ? 1 : 0, true};
-    if (kind == 5) return Loc{C_NHH, G(0, r, c), 0, true};
+    if (kind == 0) return D(C_NHH, F(0, r, c), r == c ? 2 : 0, false);
+    if (kind == 1) return D(C_NHH, G(0, r, c), 0, false);
+    if (kind == 3) return D(C_NHH, F(0, r, c), r == c ? 1 : 0, true);
+    if (kind == 5) return D(C_NHH, G(0, r, c), 0, true);
     return kZero;
 }
 
@@ -793,14 +805,22 @@ int default_tile(const Model& mo, int64_t nsteps) {
     const int64_t cap = (L.sc == SC_IRK) ? 32 : 64;
     int64_t T = 1;
     while (T * 2 <= fit && T * 2 <= cap) T *= 2;
-    // wide OCPs (several direction chunks per evaluation point: the quadrotors): the emit phase runs at the chip's write rate
-    // only while the other phases of co-resident workgroups overlap it, so three workgroups per CU (52 KiB each) beat two
-    // larger ones; at most 8 steps (profiles/r02_tile_sweeps.log: 12-state quadrotor 7 steps 117 us vs 8 steps 122 us)
-    // (one-point schemes of those OCPs have light emit phases: 16 steps -- 8-state quadrotor, trapeze, N = 20 000: 16.5 vs 20.7 us)
+    // wide OCPs (several direction chunks per evaluation point: the quadrotors).  Their evaluation is bound by FP64 ISSUE, not by
+    // latency: the generated dynamics code of a point is ~500 instructions per part, a wave instruction costs 4 cycles whatever
+    // the number of active lanes, and a 7-step tile of Gauss-Legendre 3 runs it with 21 of 64 lanes.  With the sparse eval blocks
+    // (a 12-state quadrotor step record: 310 doubles instead of 926) a tile holds as many steps as the evaluating wave has lanes
+    // for: stage points + path points <= 64.  What limits the tile from above is the OUTPUT per step: the emit phase runs at
+    // the chip's write rate only while other workgroups' evaluations overlap it, so tiles that write ~128 KiB measured best
+    // (profiles/r03_tile_sweeps.log: 12-state quadrotor GL3 N = 20 000, manual pattern (23 KiB per step) 5 - 8 steps 109 - 112 us,
+    // 16 steps 125; optimized pattern (3.7 KiB per step) 7 steps 36.3, 16 steps 25.8; 8-state quadrotor 11 KiB per step: 10 - 12
+    // steps; one-point schemes flat from 16 steps on)
     const bool wide = mo.nch_dyn > 1;
     if (wide) {
-        // the largest tile that leaves three workgroups per CU (exact LDS accounting: 1280-byte granules)
-        T = L.sc == SC_IRK ? 8 : 16;
+        const int pts = L.sc == SC_IRK ? L.s : 1;
+        const int64_t lane_cap = L.sc == SC_IRK ? 64 / (pts + 1) : 24;
+        const double out_bytes = 8.0 * (double)(mo.Lseg + L.cb + (int64_t)L.nv * mo.vr);
+        T = std::max<int64_t>(4, std::min<int64_t>(lane_cap, (int64_t)std::lround(131072.0 / std::max(out_bytes, 1.0))));
+        // ... and the largest such tile that leaves three workgroups per CU (exact LDS accounting: 1280-byte granules)
         for (; T > 4; --T) {
             KParams kp;
             mo.fill_kparams(kp, 0, std::min<int64_t>(L.N, T * 4), (int)T);
@@ -873,6 +893,15 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.nch_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
         mo.fused = Dirs<P>::FUSED;
         mo.H.hk = HessK<P>::value;
+        mo.n_f = mo.n_g = -1;
+        if (DynNZ<P>::sparse) {
+            mo.n_f = DynNZ<P>::nF; mo.n_g = DynNZ<P>::nG;
+            mo.map_f.assign(P::NX * P::NX, -1); mo.map_g.assign(P::NX * P::NU, -1);
+            for (int r = 0; r < P::NX; ++r) {
+                for (int c = 0; c < P::NX; ++c) mo.map_f[r * P::NX + c] = DynNZ<P>::fx(r, c);
+                for (int c = 0; c < P::NU; ++c) mo.map_g[r * P::NU + c] = DynNZ<P>::gu(r, c);
+            }
+        }
     });
     if (!found) {
         const RtOcp* ro = runtime_ocp(d.problem);          // registered at run time (ctd_register_ocp)
@@ -886,6 +915,8 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
         mo.nch_path = ro->info.npath > 0 ? (pth + ro->dc - 1) / ro->dc : 0;
         mo.fused = mo.nch_dyn == 1 && (ro->info.npath == 0 || mo.nch_path == 1);      // Dirs<P>::FUSED
         mo.H.hk = ro->hk;
+        mo.n_f = mo.n_g = -1;
+        if (ro->dyn_nz.sparse) { mo.n_f = ro->dyn_nz.n_f; mo.n_g = ro->dyn_nz.n_g; mo.map_f = ro->dyn_nz.map_f; mo.map_g = ro->dyn_nz.map_g; }
     }
     if (d.scheme < 0 || d.scheme > 8) { err = "Unknown discretization method"; return ST_ESCHEME; }
     int64_t N = 0;

@@ -72,6 +72,10 @@ struct Model {
     bool dyn_t = false, dyn_v = false;
     // lanes one step needs in the eval phase: dynamics passes per stage, path passes, fused lead lane (ctd_kernel_body.hpp Dirs<P>)
     int nch_dyn = 1, nch_path = 0;
+    // sparse eval blocks (DynNZ, ctd_kernel_body.hpp): slot of d f_r / d x_c, d f_r / d u_c in the F / G block, -1 = structurally zero;
+    // n_f < 0: dense blocks
+    int n_f = -1, n_g = -1;
+    std::vector<int> map_f, map_g;
     bool fused = true;
     // DOCPtime (src/DOCP_data.jl:147-152)
     bool uniform = true;

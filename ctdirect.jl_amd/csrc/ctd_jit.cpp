@@ -367,9 +367,12 @@ static bool gen_sym_pathh(const ctd_ocp_def* d, const ExprCtx& c0, std::string& 
 // `nparts` > 1: body = the cases of a switch on `part`; part k holds the outputs of the rows r = k, k + nparts, ... (the rows
 // of an OCP come in classes of similar cost -- kinematics, rotation, inertia -- so striding balances the parts); the lanes of
 // one evaluation point that would each differentiate a chunk of directions with duals split the symbolic code this way
-static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err, int nparts = 1) {
+// nz (optional): the structural nonzeros of df/dx and df/du -- map_f[r n + c] / map_g[r m + c] = slot in row-major order or -1.
+// The code stores the nonzeros only, at the offsets of the SPARSE eval block (make_rec_layout with nF, nG; DynNZ in
+// ctd_kernel_body.hpp); CTD_DENSE_EVAL=1 at generation time keeps the dense n x ldx / n x ldu blocks (every zero stored).
+static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err, int nparts = 1,
+                        DynNZMap* nz = nullptr) {
     const int n = d->n, m = d->m, nv = d->nv;
-    const RecLayout R = make_rec_layout(n, m, nv, d->npath, d->nbc, 0, n + d->npath);     // eval-block offsets depend on n, m, nv only
     sym::Graph g;
     // parameters: p[0] = t, then x[n], u[m], v[nv]; variables: the same positions
     std::vector<int> X(n), U(m > 0 ? m : 1), V(nv > 0 ? nv : 1);
@@ -388,12 +391,32 @@ static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bo
         f[r] = v.node;
         dyn_t = dyn_t || ps.uses_t; dyn_v = dyn_v || ps.uses_v;
     }
+    // first partials, and which of them vanish identically
+    std::vector<int> dfx(n * n), dfu(n * (m > 0 ? m : 1));
+    DynNZMap map;
+    const char* dense_env = std::getenv("CTD_DENSE_EVAL");
+    map.sparse = !(dense_env && std::atoi(dense_env) != 0);
+    map.n_f = map.n_g = 0;
+    map.map_f.assign(n * n, -1); map.map_g.assign(n * m, -1);
+    for (int r = 0; r < n; ++r) {
+        for (int c = 0; c < n; ++c) { dfx[r * n + c] = g.at_zero(g.diff(f[r], 1 + c)); if (!g.is_zero(dfx[r * n + c])) map.map_f[r * n + c] = map.n_f++; }
+        for (int b = 0; b < m; ++b) { dfu[r * m + b] = g.at_zero(g.diff(f[r], 1 + n + b)); if (!g.is_zero(dfu[r * m + b])) map.map_g[r * m + b] = map.n_g++; }
+    }
+    const RecLayout R = map.sparse ? make_rec_layout(n, m, nv, d->npath, d->nbc, 0, n + d->npath, -1, map.n_f, map.n_g)
+                                   : make_rec_layout(n, m, nv, d->npath, d->nbc, 0, n + d->npath);     // eval-block offsets depend on n, m, nv (and the nonzeros) only
+    if (nz) *nz = map;
     body.clear();
     for (int part = 0; part < nparts; ++part) {
         std::vector<std::pair<std::string, int>> outs;
         for (int r = part; r < n; r += nparts) {
-            for (int c = 0; c < n; ++c) outs.emplace_back("ev[" + std::to_string(R.oF + r * R.ldx + c) + "]", g.at_zero(g.diff(f[r], 1 + c)));
-            for (int b = 0; b < m; ++b) outs.emplace_back("ev[" + std::to_string(R.oG + r * R.ldu + b) + "]", g.at_zero(g.diff(f[r], 1 + n + b)));
+            for (int c = 0; c < n; ++c) {
+                if (!map.sparse) outs.emplace_back("ev[" + std::to_string(R.oF + r * R.ldx + c) + "]", dfx[r * n + c]);
+                else if (map.map_f[r * n + c] >= 0) outs.emplace_back("ev[" + std::to_string(R.oF + map.map_f[r * n + c]) + "]", dfx[r * n + c]);
+            }
+            for (int b = 0; b < m; ++b) {
+                if (!map.sparse) outs.emplace_back("ev[" + std::to_string(R.oG + r * R.ldu + b) + "]", dfu[r * m + b]);
+                else if (map.map_g[r * m + b] >= 0) outs.emplace_back("ev[" + std::to_string(R.oG + map.map_g[r * m + b]) + "]", dfu[r * m + b]);
+            }
             if (dyn_t) outs.emplace_back("ev[" + std::to_string(R.oft + r) + "]", g.at_zero(g.diff(f[r], 0)));
             if (dyn_v) for (int k = 0; k < nv; ++k) outs.emplace_back("ev[" + std::to_string(R.oW + r * nv + k) + "]", g.at_zero(g.diff(f[r], 1 + n + m + k)));
             outs.emplace_back("ev[" + std::to_string(R.of + r) + "]", g.at_zero(f[r]));
@@ -402,6 +425,20 @@ static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bo
         else body += "            case " + std::to_string(part) + ": {\n" + g.codegen(outs, "p", "                ") + "            } break;\n";
     }
     return true;
+}
+
+std::string dyn_nz_source(const std::string& type, int n, int m, const DynNZMap& nz) {
+    auto table = [](const std::vector<int>& t) {
+        std::string s;
+        for (size_t k = 0; k < t.size(); ++k) s += (k ? ", " : "") + std::to_string(t[k]);
+        return t.empty() ? std::string("-1") : s;
+    };
+    std::string s = "template <> struct DynNZ<" + type + "> {\n    static constexpr bool sparse = true;\n";
+    s += "    static constexpr int nF = " + std::to_string(nz.n_f) + ", nG = " + std::to_string(nz.n_g) + ";\n";
+    s += "    CTD_HD static constexpr int fx(int r, int c) { constexpr short t[] = {" + table(nz.map_f) + "}; return t[r * " + std::to_string(n) + " + c]; }\n";
+    s += "    CTD_HD static constexpr int gu(int r, int c) { constexpr short t[] = {" + table(nz.map_g) + "}; return t[r * " + std::to_string(m > 0 ? m : 1) + " + c]; }\n";
+    s += "};\n";
+    return s;
 }
 
 // The same for the path constraints g(t, x, u, v): Px[np x ldx] | Pu[np x ldu] | Pv[np x nv] | Pt[np] of the step record and
@@ -547,7 +584,9 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         const char* env = std::getenv("CTD_DYN_SYM");
         std::string b_dyn, e2;
         bool dt = false, dv = false;
-        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2);
+        DynNZMap nz;
+        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2, 1, &nz);
+        if (ok) o->dyn_nz = nz;
         s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
         std::string b_path;
@@ -559,7 +598,9 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         s += std::string("    static constexpr bool HAS_SYM_PATH = ") + B(okp) + ";\n";
         if (okp) s += "    CTD_HD static void path_sym(const double* p, double* px, double* val) {\n" + b_path + "    }\n";
     }
-    s += "};\n}  // namespace ctd\n";
+    s += "};\n";
+    if (o->dyn_nz.sparse) s += dyn_nz_source("UserOCP", d->n, d->m, o->dyn_nz);
+    s += "}  // namespace ctd\n";
 
     ProblemInfo& pi = o->info;
     pi.name = o->name.c_str();

@@ -27,8 +27,18 @@ enum RtOpKind : uint8_t { RT_CONST, RT_T, RT_X, RT_U, RT_V, RT_X0, RT_XF, RT_ADD
 struct RtOp { uint8_t kind; int16_t k; };
 using RtProgram = std::vector<RtOp>;
 
+// structural nonzeros of the dynamics' first partials as the code generator found them (gen_sym_dyn): row-major slots, -1 = zero
+struct DynNZMap {
+    bool sparse = false;
+    int n_f = 0, n_g = 0;
+    std::vector<int> map_f, map_g;       // [r n + c], [r m + c]
+};
+// text of the DynNZ<type> specialisation (ctd_kernel_body.hpp) for a generated functor / a registry problem
+std::string dyn_nz_source(const std::string& type, int n, int m, const DynNZMap& nz);
+
 struct RtOcp {
     std::string name;
+    DynNZMap dyn_nz;                   // sparse eval blocks of the generated dynamics code (sparse = false: forward duals, dense)
     ProblemInfo info;                  // info.name points into `name`
     bool dyn_t, dyn_v, path_t, path_v, lag_t, lag_v;
     int dc, hk, maxb;

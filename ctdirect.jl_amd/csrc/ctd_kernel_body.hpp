@@ -241,10 +241,29 @@ template <class P> CTD_HD double dtime_of(double tau, int k) {
 // record layout of (OCP, scheme class, stages): a compile-time constant, so every LDS access of the kernels uses an
 // immediate offset (the host builds its emit codes from the same function, ctd_host.cpp)
 // S: stages of a Gauss-Legendre scheme; for the midpoint scheme the number of controls per step (control_steps, 1 in collocation)
+// Structural nonzeros of the dynamics' first partials: slot of d f_r / d x_c inside the F block (fx) and of d f_r / d u_c inside a
+// G block (gu), or -1 where the derivative is identically zero.  Dense (every pair has its n x ldx / n x ldg place) for OCPs
+// evaluated with forward duals; OCPs with generated dynamics code (ctd_sym_registry.hpp at build time, the functor's text for
+// run-time OCPs) specialise it: the generator only stores -- and the records only hold -- the nonzeros.
+template <class P> struct DynNZ {
+    static constexpr bool sparse = false;
+    static constexpr int nF = -1, nG = -1;
+    CTD_HD static constexpr int fx(int, int) { return -1; }
+    CTD_HD static constexpr int gu(int, int) { return -1; }
+};
 template <class P, int SC, int S> struct RL {
     static constexpr int cb = (SC == SC_IRK ? P::NX * (1 + S) : P::NX) + P::NPATH;
     static constexpr RecLayout R = make_rec_layout(P::NX, P::NU, P::NV, P::NPATH, P::NBC, SC == SC_IRK ? S : 0, cb,
-                                                   SC == SC_MIDPOINT ? P::NU * S : P::NU);
+                                                   SC == SC_MIDPOINT ? P::NU * S : P::NU, DynNZ<P>::nF, DynNZ<P>::nG);
+    // offset of d f_r / d x_c (d f_r / d u_c of control block jb) inside an eval block, or -1: structurally zero (sparse blocks only)
+    CTD_HD static constexpr int F(int r, int c) {
+        if (DynNZ<P>::sparse) { const int s = DynNZ<P>::fx(r, c); return s < 0 ? -1 : R.oF + s; }
+        return R.oF + r * R.ldx + c;
+    }
+    CTD_HD static constexpr int G(int r, int c, int jb = 0) {
+        if (DynNZ<P>::sparse) { const int s = DynNZ<P>::gu(r, c); return s < 0 ? -1 : R.oG + jb * DynNZ<P>::nG + s; }
+        return R.oG + r * R.ldg + jb * P::NU + c;
+    }
 };
 // evaluation points per step that get a lane (and an eval block) of their own: the stages; the control sub-steps of the midpoint
 // scheme are walked by ONE lane (their partials are summed)
@@ -502,7 +521,8 @@ CTD_HD void fin_stage(const KParams& kp, const BlockCtx& cx, int k, int j, doubl
                 if (P::DYN_T && FREE) w = w + ev[R.oft + r] * dtij;
                 if (FREE) {
 #pragma unroll
-                    for (int c = 0; c < n; ++c) w = w + ev[R.oF + r * R.ldx + c] * dx[c];
+                    for (int c = 0; c < n; ++c)
+                        if (RL<P, SC, S>::F(r, c) >= 0) w = w + ev[RL<P, SC, S>::F(r, c)] * dx[c];
                 }
                 ev[R.oW + r * nv + kk] = w;
             }
@@ -566,7 +586,8 @@ CTD_HD void fin_stage_row(const KParams& kp, const BlockCtx& cx, int k, int j, i
                 double acc = 0.0;
 #pragma unroll
                 for (int l = 0; l < S; ++l) acc = acc + (dh * butcher_a<S>(L, j, l)) * K[l * n + c];
-                w = w + ev[R.oF + r * R.ldx + c] * acc;
+                const int sl = RL<P, SC_IRK, S>::F(r, c);      // (r is a lane parameter: a table lookup for sparse blocks)
+                if (sl >= 0) w = w + ev[sl] * acc;
             }
         }
         ev[R.oW + r * nv + kk] = w;
@@ -823,10 +844,11 @@ CTD_HD void eval_dynamics(const KParams& kp, const BlockCtx& cx, int k, int j, i
                 if (symsplit && (r % NP) != q) continue;
 #pragma unroll
                 for (int c = 0; c < n; ++c)
-                    if (dir(c)) ev[R.oF + r * R.ldx + c] = (jj == 0 ? 0.0 : ev[R.oF + r * R.ldx + c]) + tmp[R1.oF + r * R1.ldx + c];
+                        if (dir(c) && RL1::F(r, c) >= 0)
+                        ev[RL<P, SC, S>::F(r, c)] = (jj == 0 ? 0.0 : ev[RL<P, SC, S>::F(r, c)]) + tmp[RL1::F(r, c)];
 #pragma unroll
                 for (int c = 0; c < m; ++c)
-                    if (dir(n + c)) ev[R.oG + r * R.ldg + jj * m + c] = tmp[R1.oG + r * R1.ldg + c];
+                    if (dir(n + c) && RL1::G(r, c) >= 0) ev[RL<P, SC, S>::G(r, c, jj)] = tmp[RL1::G(r, c)];
                 if (P::DYN_T && dir(gT)) ev[R.oft + r] = (jj == 0 ? 0.0 : ev[R.oft + r]) + tmp[R1.oft + r];
                 if (P::DYN_V) {
 #pragma unroll
@@ -1048,14 +1070,10 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
     constexpr bool ok = SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !Dirs<P>::FUSED;
     constexpr int NP = Dirs<P>::NCH_DYN;
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
-    // lanes of a wave: S ns dynamics points | ns path points | lead tasks (Gauss-Legendre: (step, state row) tasks dealt round
-    // robin over the NP waves; one-point schemes: one cheap task per step on the last wave)
-    const int lead = SC == SC_IRK ? (cx.nslots * P::NX + NP - 1) / NP : cx.nslots;
-    // a workgroup with a wave beyond the NP dynamics waves gives the symbolic path rows (and the one-point schemes' lead tasks) that
-    // wave: no path lanes behind the dynamics lanes then
-    const bool extra = SymPath<P>::value && nthr >= (NP + 1) * 64;
-    return ok && !cx.is_edge && StagePoints<SC, S>::value * cx.nslots + (extra ? 0 : cx.nslots) + lead <= 64 && 2 * cx.nslots <= 64 &&
-           r_path <= NP && NP * 64 <= nthr;
+    // lanes of a wave: S ns dynamics points (the lead tasks -- Gauss-Legendre: (step, state row) pairs dealt round robin over the
+    // dynamics lanes of all waves; one-point schemes: one task per step on the last wave -- run BEHIND the dynamics on the same
+    // lanes) | ns path points
+    return ok && !cx.is_edge && StagePoints<SC, S>::value * cx.nslots + ((P::NPATH > 0) ? cx.nslots : 0) <= 64 && r_path <= NP && NP * 64 <= nthr;
 #endif
 }
 
@@ -1211,34 +1229,11 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
             constexpr int NP = Dirs<P>::NCH_DYN;
             const int nd = StagePoints<SC, S>::value * ns;
             const int wave = tid >> 6, l = tid & 63;
-            // Five waves (320 lanes: the one-point kernels of the 12-state quadrotor need 97 registers, four waves per SIMD fit): the
-            // symbolic path rows of every step run in wave NP beside the dynamics parts instead of behind one of them (4400 cycles
-            // behind part 1's 5000), the cheap lead tasks of the one-point schemes too
-            const bool extra = SymPath<P>::value && nthr >= (NP + 1) * 64;
             const bool fold = fin_folded<P, SC, S>(cx);
             auto fin_path_slot = [&](int k) {          // total d/dv of the path rows of slot k (phase_fin's path task)
                 const int64_t i = slot_index(kp, cx, k);
                 if (i >= 0 && i < kp.L.N) fin_path<P, SC, S>(kp, cx.rec + k * R.stride, slot_tau(kp, cx, k, 0));
             };
-            if (extra) {
-                if (wave < NP) {
-                    if (l < nd) {
-                        const int j = l / ns, k = l - j * ns;
-                        double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
-                        eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, ev);
-                        if (fold) fin_stage<P, SC, S>(kp, cx, k, j, ev, wave, NP);
-                    }
-                    if (SC == SC_IRK) {
-                        const int t = (l - nd) * NP + wave;
-                        if (l >= nd && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
-                    }
-                } else if (wave == NP) {
-                    if (l < ns) { if (r_path > 0) { eval_step_path<P, SC, S>(kp, cx, l, 0); if (fold) fin_path_slot(l); } }
-                    else if (SC != SC_IRK && l < 2 * ns) fin_lead<P, SC, S>(kp, cx, l - ns);
-                }
-                for (int k = tid; k < ns; k += nthr) cx.rec[k * R.stride] = 1.0;
-                return;
-            }
             if (wave < NP) {
 #if !defined(CTD_ABL) || CTD_ABL != 2          /* (ablation builds, never shipped: 1 no path rows, 2 no dynamics, 3 no lead) */
                 if (l < nd) {
@@ -1249,6 +1244,17 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                 }
 #endif
                 CTD_SUB(kp, 2);
+#if !defined(CTD_ABL) || CTD_ABL != 3
+                // lead role behind the dynamics, on the same lanes (short tasks that read the inputs only): Gauss-Legendre schemes by
+                // (step, state row) over the dynamics lanes of all waves, one-point schemes one task per step on the last wave
+                if (SC == SC_IRK) {
+                    if (l < nd)
+                        for (int t = l * NP + wave; t < ns * P::NX; t += nd * NP) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
+                } else if (l < ns && wave == NP - 1) {
+                    fin_lead<P, SC, S>(kp, cx, l);
+                }
+#endif
+                CTD_SUB(kp, 3);
 #if !defined(CTD_ABL) || CTD_ABL != 1
                 if (l >= nd && l < nd + ns) {
                     // symbolic path rows: ONE pass per point (chunk 0), on the wave whose part of the dynamics is the lightest
@@ -1258,15 +1264,6 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
                         eval_step_path<P, SC, S>(kp, cx, l - nd, SymPath<P>::value ? 0 : wave);
                         if (fold) fin_path_slot(l - nd);
                     }
-                }
-#endif
-                CTD_SUB(kp, 3);
-#if !defined(CTD_ABL) || CTD_ABL != 3
-                if (SC == SC_IRK) {       // lead role by (step, state row): task t = wave, wave + NP, ... on lane nd + ns + t / NP
-                    const int t = (l - nd - ns) * NP + wave;
-                    if (l >= nd + ns && t < ns * P::NX) fin_lead<P, SC, S>(kp, cx, t / P::NX, t % P::NX);
-                } else if (l >= nd + ns && l < nd + 2 * ns && wave == NP - 1) {
-                    fin_lead<P, SC, S>(kp, cx, l - nd - ns);
                 }
 #endif
                 CTD_SUB(kp, 4);

@@ -98,15 +98,22 @@ struct RecLayout {
     int32_t oB0, oBf, oBv, oBval;         // boundary record
     int32_t stride;                       // doubles per step / node / final-path record
     int32_t bsize;                        // doubles of the boundary record (>= stride)
+    int32_t nF, nG;                       // SPARSE eval blocks (OCPs with generated dynamics code): slots of the F / G blocks = their
+                                          // structural nonzeros (DynNZ, ctd_kernel_body.hpp); -1: dense n x ldx / n x ldg blocks
 };
 
 // gcols: columns of the control blocks G / Pu -- m, or m * control_steps for the midpoint scheme with several controls per step
 // (one eval block per step then holds the SUM over the sub-steps of F, W, f, ft and the n x (m control_steps) block [G_1 .. G_cs])
-constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb, int gcols = -1) {
+// nF, nG >= 0: the F block holds nF slots and the G block nG slots per control block (the structural nonzeros of df/dx and df/du
+// in row-major order); a 12-state quadrotor step record on Gauss-Legendre 3 shrinks from 926 to 389 doubles, so more than twice the
+// steps fit a tile and the evaluating waves run with full lanes
+constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb, int gcols = -1, int nF = -1, int nG = -1) {
     RecLayout r{};
     r.S = s > 0 ? s : 1;
     r.ldx = n | 1; r.ldu = m | 1; r.ldg = (gcols > 0 ? gcols : m) | 1;
-    r.oF = 0; r.oG = n * r.ldx; r.oW = r.oG + n * r.ldg; r.of = r.oW + n * nv; r.oft = r.of + n;
+    r.nF = nF; r.nG = nG;
+    const int gblocks = (m > 0 && gcols > 0) ? gcols / m : 1;          // control blocks side by side (control_steps)
+    r.oF = 0; r.oG = nF >= 0 ? nF : n * r.ldx; r.oW = r.oG + (nG >= 0 ? nG * gblocks : n * r.ldg); r.of = r.oW + n * nv; r.oft = r.of + n;
     r.eval_sz = r.oft + n;
     r.oC = 1;
     r.oEval = 1 + kNC;

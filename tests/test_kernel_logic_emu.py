@@ -190,3 +190,32 @@ def test_multi_tile_workgroups_write_the_same_outputs(monkeypatch, prob):
         monkeypatch.delenv("CTD_EMU_WG_STRIDE")
         c3, v3 = emu.cons_jac(pid, sid, 1, N, x, tile=3, nthr=64)
         assert np.array_equal(c2, c3) and np.array_equal(v2, v3), sch
+
+
+@pytest.mark.parametrize("prob", ["quadrotor12", "quadrotor"])
+def test_full_lane_tiles_of_the_wide_ocps(oracle_lib, prob):
+    """Sparse eval blocks (DynNZ: the records hold the structural nonzeros of df/dx, df/du only) let a tile of a wide OCP hold as
+    many steps as the evaluating waves have lanes: 16 steps on Gauss-Legendre 3 (48 stage points + 16 path points per wave), 21 on
+    GL2, 24 - 31 on the one-point schemes; the lead tasks run behind the dynamics on the same lanes.  Against the oracle, all three
+    patterns, 256- and 320-lane workgroups, grids that end in a short tile."""
+    pid = ct.PROBLEMS[prob]
+    for sch, tiles in (("gauss_legendre_3", (16,)), ("gauss_legendre_2", (21,)), ("gauss_legendre_2_constant_control", (16,)),
+                       ("midpoint", (24, 31)), ("trapeze", (30,)), ("euler_implicit", (24,))):
+        sid = ct.SCHEMES[sch]
+        N = 37
+        o = oracle_lib.OracleDOCP(prob, sch, N)
+        x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+        cref = o.constraints(x)
+        for mode in (0, 1, 2):
+            o.set_pattern_mode(mode)
+            vref = o.jac_coord(x) if mode >= 1 else None
+            for tile in tiles:
+                for nthr in (256, 320):
+                    c, vals = emu.cons_jac(pid, sid, mode, N, x, tile=tile, nthr=nthr)
+                    assert not np.any(c == 666.666) and not np.any(vals == 666.666)
+                    assert relerr(c, cref) <= TOL
+                    if vref is not None:
+                        assert relerr(vals, vref) <= TOL, (sch, mode, tile)
+                    else:
+                        c7, v7 = emu.cons_jac(pid, sid, mode, N, x, tile=7, nthr=256)
+                        assert np.array_equal(vals, v7) and np.array_equal(c, c7)
