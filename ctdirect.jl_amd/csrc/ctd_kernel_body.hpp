@@ -1061,6 +1061,24 @@ CTD_HD bool fin_folded(const BlockCtx& cx) {
 #endif
 }
 
+// EDGE BLOCK of an OCP with generated dynamics code (one workgroup of every launch: first / last steps, final-time path rows,
+// boundary rows; it is the longest workgroup of the light kernels).  One lane per (stage, slot) runs the generated code -- split
+// by rows over one wave per part where the generator provides the parts -- and finishes its rows of the chain rule; the other
+// kinds of task (path passes, final-time path passes, coefficient records, boundary passes) sit on lanes 32.. of the waves, the
+// heavy kinds on different waves.  (In index order, as the fallback below deals them, the 12-state quadrotor's edge block ran all
+// four parts of every point on ONE lane and every kind in the same two waves: 17 - 23 us of evaluation + 10 us of fin.)
+template <class P, int SC, int S>
+CTD_HD bool edge_sym_layout(const BlockCtx& cx, int nthr) {
+#ifdef CTD_NO_EDGE_SYM
+    return false;
+#else
+    constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
+    constexpr int n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
+    return SymDyn<P>::value && !Dirs<P>::FUSED && cx.is_edge && cx.nslots <= 8 && nthr >= 256 && r_path <= 4 && n_b <= 32 &&
+           StagePoints<SC, S>::value * 8 <= 32;
+#endif
+}
+
 template <class P, int SC, int S>
 CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
 #ifdef CTD_NO_SPLIT
@@ -1174,6 +1192,38 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
         // workgroup has too few waves.
         constexpr int n_fp = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
         constexpr int n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
+        if constexpr (SymDyn<P>::value && !FUSED) {
+            if (edge_sym_layout<P, SC, S>(cx, nthr)) {
+                constexpr int NP = Dirs<P>::NCH_DYN;
+                constexpr bool parts = SymDyn<P>::parts >= 4 && SymDyn<P>::parts == NP;      // one wave per part of the generated code
+                constexpr int NPW = parts ? NP : 1;
+                const int wave = tid >> 6, l = tid & 63;
+                if (wave < NPW && l < StagePoints<SC, S>::value * 8) {
+                    const int j = l >> 3, k = l & 7;
+                    if (k < ns) {
+                        double* ev = cx.rec + k * R.stride + R.oEval + j * R.eval_sz;
+                        if constexpr (parts) {
+                            eval_dynamics<P, SC, S, true>(kp, cx, k, j, wave, ev);
+                            fin_stage<P, SC, S>(kp, cx, k, j, ev, wave, NP);
+                        } else {
+                            eval_dynamics<P, SC, S>(kp, cx, k, j, 0, ev);
+                            fin_stage<P, SC, S>(kp, cx, k, j, ev);
+                        }
+                    }
+                } else if (l >= 32) {
+                    // aux kinds on lanes 32.. : path passes | final-time path passes + coefficient records | boundary passes, on the
+                    // waves 0, 1, 2 when the dynamics parts fill the first lanes of all waves, else on the waves 1, 2, 3
+                    const int a = wave - (parts ? 0 : 1), t = l - 32;
+                    if (a == 0) { if (t < r_path * 8 && (t & 7) < ns) eval_step_path<P, SC, S>(kp, cx, t & 7, t >> 3); }
+                    else if (a == 1) {
+                        if (t < n_fp) eval_final_path<P, SC, S>(kp, cx, t);
+                        else if (t >= 8 && t < 10) fill_const_coefs<P>(kp, cx.rec + (t == 8 ? kp.edge_fp : kp.edge_b) * R.stride + R.oC);
+                    } else if (a == 2) { if (t < n_b) eval_boundary<P, SC, S>(kp, cx, t); }
+                }
+                for (int k = tid; k < ns + 2; k += nthr) cx.rec[k * R.stride] = 1.0;
+                return;
+            }
+        }
         constexpr int seg0 = 0;
         constexpr int seg1 = seg0 + ((r_dyn * 8 + 63) & ~63);
         constexpr int seg2 = seg1 + ((r_path * 8 + n_fp + 63) & ~63);
@@ -1385,7 +1435,8 @@ CTD_HD void phase_fin(const KParams& kp, const BlockCtx& cx, int tid, int nthr) 
     // after a split evaluation the lead role is done, and the path rows' total d/dv rides with the first stage task of its step:
     // 12-state quadrotor, 7 steps x 3 stages x 12 rows = 252 tasks: one pass of 256 lanes (266 tasks before: two)
     const bool split = split_eval<P, SC, S>(cx, nthr);
-    const int n_stage = StagePoints<SC, S>::value * ns * rows, n_lead = split ? 0 : ns, n_path = (P::NPATH > 0 && !split) ? ns : 0;
+    const bool esl = edge_sym_layout<P, SC, S>(cx, nthr);          // (edge block: the stage rows were finished by the evaluating lanes)
+    const int n_stage = esl ? 0 : StagePoints<SC, S>::value * ns * rows, n_lead = split ? 0 : ns, n_path = (P::NPATH > 0 && !split) ? ns : 0;
     const int n_fp = (cx.is_edge && P::NPATH > 0) ? 1 : 0;
     for (int task = tid; task < n_stage + n_lead + n_path + n_fp; task += nthr) {
         int t = task;
@@ -1588,14 +1639,26 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
     const EmitPreT<NB>* pre_ = &pre_v;                     // hp: the lane's codes were prefetched (pre_v holds them)
     if (cx.is_edge) {
         const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
-        for (int w = tid; w < ntot; w += nthr) {
-            const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
-            const bool have = hp && w == tid;          // first pass: prefetched before the evaluation
-            const uint32_t code = have ? pre_->b : kp.edge_code[e];
-            const int64_t idx = have ? pre_->eidx : kp.edge_idx[e];
-            const double val = eval_code(R.oC, cx.rec + code_crec(code) * R.stride, cx.rec + code_drec_raw(code) * R.stride, code);
-            if (idx & kEdgeCBit) { if (kp.c) kp.c[idx & ~kEdgeCBit] = val; }
-            else if (kp.vals) kp.vals[idx] = val;
+        // four entries per round: their (code, index) loads are in flight together -- one dependent global load per entry, queued
+        // behind the whole chip's stores, made the 6432 edge entries of the 12-state quadrotor (Gauss-Legendre 3) a 48 us phase
+        for (int w0 = tid; w0 < ntot; w0 += 4 * nthr) {
+            uint32_t code[4];
+            int64_t idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u * nthr;
+                const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
+                const bool have = hp && w == tid;          // first entry: prefetched before the evaluation
+                code[u] = have ? pre_->b : (w < ntot ? kp.edge_code[e] : 0u);
+                idx[u] = have ? pre_->eidx : (w < ntot ? kp.edge_idx[e] : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w0 + u * nthr >= ntot) break;
+                const double val = eval_code(R.oC, cx.rec + code_crec(code[u]) * R.stride, cx.rec + code_drec_raw(code[u]) * R.stride, code[u]);
+                if (idx[u] & kEdgeCBit) { if (kp.c) kp.c[idx[u] & ~kEdgeCBit] = val; }
+                else if (kp.vals) kp.vals[idx[u]] = val;
+            }
         }
         return;
     }
