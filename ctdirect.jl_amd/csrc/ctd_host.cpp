@@ -808,7 +808,7 @@ int default_tile(const Model& mo, int64_t nsteps) {
     // wide OCPs (several direction chunks per evaluation point: the quadrotors).  Their evaluation is bound by FP64 ISSUE, not by
     // latency: the generated dynamics code of a point is ~500 instructions per part, a wave instruction costs 4 cycles whatever
     // the number of active lanes, and a 7-step tile of Gauss-Legendre 3 runs it with 21 of 64 lanes.  With the sparse eval blocks
-    // (a 12-state quadrotor step record: 310 doubles instead of 926) a tile holds as many steps as the evaluating wave has lanes
+    // (a 12-state quadrotor step record on Gauss-Legendre 3: 307 doubles instead of 857) a tile holds as many steps as the evaluating wave has lanes
     // for: stage points + path points <= 64.  What limits the tile from above is the OUTPUT per step: the emit phase runs at
     // the chip's write rate only while other workgroups' evaluations overlap it, so tiles that write ~128 KiB measured best
     // (profiles/r03_tile_sweeps.log: 12-state quadrotor GL3 N = 20 000, manual pattern (23 KiB per step) 5 - 8 steps 109 - 112 us,

@@ -105,7 +105,7 @@ struct RecLayout {
 // gcols: columns of the control blocks G / Pu -- m, or m * control_steps for the midpoint scheme with several controls per step
 // (one eval block per step then holds the SUM over the sub-steps of F, W, f, ft and the n x (m control_steps) block [G_1 .. G_cs])
 // nF, nG >= 0: the F block holds nF slots and the G block nG slots per control block (the structural nonzeros of df/dx and df/du
-// in row-major order); a 12-state quadrotor step record on Gauss-Legendre 3 shrinks from 926 to 389 doubles, so more than twice the
+// in row-major order); a 12-state quadrotor step record on Gauss-Legendre 3 shrinks from 857 to 307 doubles, so more than twice the
 // steps fit a tile and the evaluating waves run with full lanes
 constexpr RecLayout make_rec_layout(int n, int m, int nv, int p, int bc, int s, int cb, int gcols = -1, int nF = -1, int nG = -1) {
     RecLayout r{};
