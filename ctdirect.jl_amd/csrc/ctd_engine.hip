@@ -796,7 +796,22 @@ int32_t ctd_launch_info(const ctd_handle* h, int64_t* o) {
     o[0] = h->grid; o[1] = h->block; o[2] = (int64_t)h->lds_bytes; o[3] = h->tile; o[4] = h->model.Lseg;
     o[5] = (int64_t)h->model.edge_idx.size();
     o[6] = (h->model.fused && h->model.L.sc != SC_TRAPEZE) ? 1 : 0;      // DirectTile<P, SC>
+    // resident workgroups per CU of the kernel this handle launches, as the runtime computes it from the kernel's registers and
+    // LDS (0: host-only handle / query failed): the tiles' rounds = grid / (o[7] * CUs)
     o[7] = 0;
+    if (h->device >= 0) {
+        DeviceGuard dg(h->device);
+        int per_cu = 0;
+        if (dg.err == hipSuccess) {
+            if (h->rt) { if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->f_cons_jac, h->block, h->lds_bytes) != hipSuccess) per_cu = 0; }
+            else for_problem(h->model.problem, [&](auto tag) {
+                using P = typename decltype(tag)::type;
+                per_cu = occupancy_cons_jac<P>(h->model.L.sc, h->kp, h->block, h->lds_bytes);
+            });
+        }
+        (void)hipGetLastError();
+        o[7] = per_cu;
+    }
     return CTD_OK;
 }
 

@@ -134,8 +134,14 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
     }
 }
 
+// Waves per SIMD the kernel is compiled for (the second launch bound caps the registers per lane at 512 / value).  Four: the
+// 12-state quadrotor's Gauss-Legendre 3 instantiation needed 129 registers -- ONE more than four waves per SIMD allow -- and ran
+// three workgroups per CU where its 15 KiB of LDS would let ten in.  The midpoint kernels with several controls per step
+// (195 - 245 registers) and OCPs wider than the registry's keep the compiler's own choice.
+template <class P, int SC, int S> struct MinWaves { static constexpr int value = (P::NX <= 12 && !(SC == SC_MIDPOINT && S > 1)) ? 4 : 1; };
+
 template <class P, int SC, int S, bool DBG>
-__global__ void __launch_bounds__(P::MAXB) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
+__global__ void __launch_bounds__(P::MAXB, (MinWaves<P, SC, S>::value)) cons_jac_kernel(const KParams kp, const double* __restrict__ xu) {
     extern __shared__ double ctd_lds[];
     cons_jac_body<P, SC, S, DBG>(kp, xu, (int)blockIdx.x, ctd_lds);
 }

@@ -294,7 +294,7 @@ class DOCP:
         o = np.zeros(8, dtype=np.int64)
         self._ck(_lib.lib().ctd_launch_info(self._h, _ip(o)))
         return dict(grid=int(o[0]), block=int(o[1]), lds_bytes=int(o[2]), steps_per_tile=int(o[3]),
-                    csc_period=int(o[4]), edge_entries=int(o[5]), direct_tiles=int(o[6]))
+                    csc_period=int(o[4]), edge_entries=int(o[5]), direct_tiles=int(o[6]), workgroups_per_cu=int(o[7]))
 
     def dropped_nonzeros(self):
         n = C.c_int64()

@@ -266,7 +266,8 @@ int32_t ctd_time_cons_jac_dev(ctd_handle* h, const double* x_dev, double* c_dev,
 int32_t ctd_debug_stamps(ctd_handle* h, const double* x_dev, double* c_dev, double* vals_dev, uint64_t* out, int64_t cap);
 /* kernel launch geometry: out[0..7] = grid blocks, block threads, dynamic LDS bytes, steps per tile, interior
  * CSC period L (entries per regular step), number of edge entries, 1 when the tiles run the direct driver (x read
- * straight from global memory by the evaluating lanes, one workgroup barrier) and 0 for the staged one, reserved (0) */
+ * straight from global memory by the evaluating lanes, one workgroup barrier) and 0 for the staged one, resident workgroups
+ * per CU of that kernel (the runtime's occupancy query for its registers and LDS; 0 on a host-only handle) */
 int32_t ctd_launch_info(const ctd_handle* h, int64_t* out8);
 
 
