@@ -24,7 +24,9 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         # extra: OCPs whose kernels run the staged driver (path constraints in every scheme)
         "gall_trap": ("goddard_all", "trapeze", 20000), "gall_gl2": ("goddard_all", "gauss_legendre_2", 20000),
         "quad_trap": ("quadrotor", "trapeze", 20000), "q12_mid": ("quadrotor12", "midpoint", 20000),
-        "q12_trap": ("quadrotor12", "trapeze", 20000)}
+        "q12_trap": ("quadrotor12", "trapeze", 20000),
+        # one tile + the edge block: the kernel's serial latency chain without any contention
+        "cfg2_tiny": ("goddard", "gauss_legendre_2", 21), "cfg2_small": ("goddard", "gauss_legendre_2", 2100)}
 
 
 def main():

@@ -55,6 +55,18 @@ namespace ctd {
 #else
 #define CTD_SUB(kp, id) do { } while (0)
 #endif
+// the same inside the EMIT phase (make EXTRA=-DCTD_SUBSTAMPS_EMIT; the memory counters are NOT drained: issue times)
+#if defined(CTD_SUBSTAMPS_EMIT) && defined(__HIP_DEVICE_COMPILE__)
+#define CTD_SUBE(kp, id)                                                                                             \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((kp).stamps && (threadIdx.x & 63) == 0 && threadIdx.x < 128)                                             \
+            (kp).stamps[(size_t)gridDim.x * 12 + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (id)] = clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#else
+#define CTD_SUBE(kp, id) do { } while (0)
+#endif
 
 struct BlockCtx {
     int is_edge;
@@ -1664,6 +1676,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
     }
     const int nsteps = (int)(cx.b - cx.a);
     const int slot0 = (int)(cx.a - cx.lo);
+    CTD_SUBE(kp, 0);
 #if CTD_EMIT_PAIRS
     // (A) constraint rows of the tile: c[a*cb .. b*cb): entry (s, r) = record(s).R[r]
     if (kp.c) {
@@ -1715,6 +1728,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
             }
         }
     }
+    CTD_SUBE(kp, 1);
     if (!kp.vals) return;
     // (B) step-periodic CSC segments of the regular steps of the tile
     {
@@ -1796,6 +1810,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
             }
         }
     }
+    CTD_SUBE(kp, 2);
     // (C) the tile's slice of every V column
     if (kp.vr > 0) {
         const int vr = kp.vr;
@@ -1824,6 +1839,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
             }
         }
     }
+    CTD_SUBE(kp, 3);
 #endif
 }
 // (pointer form: the drivers that always prefetch, and the emulator)

@@ -53,6 +53,18 @@ __device__ __forceinline__ void ctd_pin_kernargs(const KParams& kp, const double
 #endif
 }
 
+// The same for the emit phase.  The evaluation needs every scalar register it can get, so the values pinned at the top of the
+// kernel do not survive it: the compiler re-loads each kernel argument where the emit phase first uses it -- behind a branch
+// each, i.e. one scalar-cache round trip after the other again (a dozen `s_load; s_waitcnt lgkmcnt(0)` pairs on the critical path
+// of a 1.4 us phase).  Named once more in front of the barrier, they arrive together while the waves wait for each other.
+__device__ __forceinline__ void ctd_pin_emit_kernargs(const KParams& kp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"s"(kp.c), "s"(kp.vals), "s"(kp.L.cb), "s"(kp.Lseg), "s"(kp.vr), "s"(kp.div_cb.M), "s"(kp.div_Lseg.M), "s"(kp.div_vr.M),
+                 "s"(kp.div_cb.d), "s"(kp.div_Lseg.d), "s"(kp.div_vr.d), "s"(kp.seg_base), "s"(kp.reg_first), "s"(kp.reg_last),
+                 "s"(kp.vcol_base[0]), "s"(kp.n_early), "s"(kp.c_early), "s"(kp.vr_early), "s"(kp.n_late), "s"(kp.div_late.M), "s"(kp.div_late.d));
+#endif
+}
+
 // workgroup `block` of the evaluation (the kernel below; also a branch of the fused iteration kernel, ctd_iter_kernels.hpp)
 template <class P, int SC, int S, bool DBG>
 __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* __restrict__ xu, int block, double* ctd_lds) {
@@ -66,6 +78,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         const EmitPre pre = emit_prefetch<P>(kp, cx, tid, nthr);
         ctd_stamp<DBG>(kp, 1);
         phase_eval<P, SC, S, RegEval<P, SC, S>::value, 1>(kp, cx, tid, nthr, &pre);
+        ctd_pin_emit_kernargs(kp);
         __syncthreads();
         ctd_stamp<DBG>(kp, 2);
         ctd_stamp<DBG>(kp, 3);
@@ -100,6 +113,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
         ctd_stamp<DBG>(kp, 1);
         if (DBG && kp.debug_stop == 2) return;
         phase_eval<P, SC, S>(kp, cx, tid, nthr);
+        ctd_pin_emit_kernargs(kp);
         __syncthreads();
         ctd_stamp<DBG>(kp, 2);
         if (DBG && kp.debug_stop == 3) return;
