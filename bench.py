@@ -371,6 +371,46 @@ def _main(real_stdout):
             d2.close()
             del x2, y2, h2
 
+    # "objective reported separately", "also report host-pointer mode": the other callbacks of the SAME
+    # workload (never `value`): objective, gradient, one whole solver iteration (obj + grad + cons + Jacobian + Hessian in two
+    # launches) with everything resident in HBM, and the fused evaluation through the host-pointer entry point (PCIe inclusive)
+    separately = {}
+    if world == 1 and not args.no_extras:
+        try:
+            import time as _t
+            K2 = 200
+            g_ = torch.zeros(docp.dim_NLP_variables, dtype=torch.float64, device=dev)
+            f_ = torch.zeros(1, dtype=torch.float64, device=dev)
+            y_ = torch.from_numpy(0.6 + 0.4 * np.sin(0.7 * np.arange(docp.dim_NLP_constraints) + 0.3)).to(dev)
+            h_ = torch.zeros(docp.nnzh, dtype=torch.float64, device=dev)
+
+            def rate(fn, k=K2):
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t0 = _t.perf_counter()
+                for _ in range(k):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (_t.perf_counter() - t0) / k
+            t_obj = rate(lambda: docp.eval_all(x_full, None, 1.0, f_, None, None, None, None))
+            t_grad = rate(lambda: docp.grad(x_full, g_, sync=False))
+            t_iter = rate(lambda: docp.eval_all(x_full, y_, 1.0, f_, g_, c, vals, h_))
+            xh, ch, vh = ct.pinned_empty(docp.dim_NLP_variables), ct.pinned_empty(docp.dim_NLP_constraints), ct.pinned_empty(docp.nnzj)
+            xh[:] = x_host
+            t_host = rate(lambda: docp.cons_jac(xh, ch, vh), 50)
+            separately = {"same_workload_other_callbacks": {
+                "objective_device": {"ms_per_call": t_obj * 1e3, "calls_per_s": 1.0 / t_obj},
+                "gradient_device": {"ms_per_call": t_grad * 1e3, "calls_per_s": 1.0 / t_grad},
+                "whole_iteration_device": {"ms_per_call": t_iter * 1e3, "calls_per_s": 1.0 / t_iter,
+                                           "what": "ctd_eval_all_dev_async: objective + gradient + constraints + Jacobian values + Hessian values at one (x, y), two launches"},
+                "fused_cons_jac_host_pointers_pinned": {"ms_per_call": t_host * 1e3, "calls_per_s": 1.0 / t_host,
+                                                         "bytes_over_pcie": 8 * (docp.dim_NLP_variables + docp.dim_NLP_constraints + docp.nnzj),
+                                                         "what": "ctd_cons_jac on page-locked host arrays: H2D x + kernel + D2H c, values (PCIe inclusive; never `value`)"}}}
+            del g_, f_, y_, h_
+        except Exception as e:      # a secondary figure must never cost the line
+            separately = {"same_workload_other_callbacks": {"error": repr(e)[:300]}}
+
     # per-workload rocprofv3 rows (profiles/collect_workloads.sh: one process per workload, so a row is ONE workload): IMPORTED
     # from the committed summary, not measured in this run
     wl_rows = {}
@@ -439,6 +479,7 @@ def _main(real_stdout):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(PROBLEM, SCHEME, N, x_host)
         out.update(secondary)
+        out.update(separately)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
