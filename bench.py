@@ -239,11 +239,8 @@ def _main(real_stdout):
         for _ in range(steps):
             step()
         e1.record()
-        # the host polls the closing event instead of sleeping in the synchronisation: a blocked host thread is woken by the
-        # scheduler up to one tick (10 ms) late on a busy box -- a 20-step region of 130 us of GPU work was once timed at 9.8 ms
-        # that way (profiles/r03_experiments.md).  The synchronisation the contract asks for follows and returns at once.
-        while not e1.query():
-            pass
+        # (polling the closing event before the synchronisation was tried against a once-seen 10 ms wake-up stall and costs
+        # 12 us per region -- hipEventQuery in a loop, then a synchronisation that still takes its 16 us: profiles/r03_experiments.md)
         sync_all()
         el = time.perf_counter() - t0
         region["ms_per_launch"] = e0.elapsed_time(e1) / steps
