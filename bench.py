@@ -396,7 +396,20 @@ def _main(real_stdout):
             xh, ch, vh = ct.pinned_empty(docp.dim_NLP_variables), ct.pinned_empty(docp.dim_NLP_constraints), ct.pinned_empty(docp.nnzj)
             xh[:] = x_host
             t_host = rate(lambda: docp.cons_jac(xh, ch, vh), 50)
-            separately = {"same_workload_other_callbacks": {
+            # two handles on two streams, launches alternating: independent evaluations (line-search candidates, multiple starts)
+            # overlap one kernel's launch / drain with the other's evaluation.  NOT `value`: a solver's evaluations depend on each other.
+            s2 = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s2):
+                d_b = ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, stream="torch")
+                c_b, v_b = torch.zeros_like(c), torch.zeros_like(vals)
+                l_b = d_b.bind_cons_jac(x_full, c_b, v_b, sync=False)
+            l_a = docp.bind_cons_jac(x_full, c, vals, sync=False)
+            t_two = rate(lambda: (l_a(), l_b()), 500) / 2.0
+            same2 = bool(torch.equal(c_b, c) and torch.equal(v_b, vals))
+            d_b.close()
+            separately = {"two_streams_alternating": {"ms_per_eval": t_two * 1e3, "evals_per_s": 1.0 / t_two, "outputs_identical": same2,
+                                                      "what": "independent evaluations of the same workload on two handles / two streams, launched alternately (never `value`)"},
+                          "same_workload_other_callbacks": {
                 "objective_device": {"ms_per_call": t_obj * 1e3, "calls_per_s": 1.0 / t_obj},
                 "gradient_device": {"ms_per_call": t_grad * 1e3, "calls_per_s": 1.0 / t_grad},
                 "whole_iteration_device": {"ms_per_call": t_iter * 1e3, "calls_per_s": 1.0 / t_iter,
