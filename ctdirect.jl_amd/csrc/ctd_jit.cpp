@@ -589,6 +589,13 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         if (ok) o->dyn_nz = nz;
         s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
+        // wide OCPs (four direction chunks and more, Dirs<P>::NCH_DYN): the same code split by rows, one part per wave (SymDyn::parts)
+        const int ndir = d->n + d->m + (dt ? 1 : 0) + (dv ? d->nv : 0), nparts = (ndir + o->dc - 1) / o->dc;
+        std::string b_parts;
+        bool dt2 = false, dv2 = false;
+        const bool okp4 = ok && nparts >= 4 && gen_sym_dyn(d, c0, dt2, dv2, b_parts, e2, nparts);
+        s += "    static constexpr int DYN_PARTS = " + std::to_string(okp4 ? nparts : 1) + ";\n";
+        if (okp4) s += "    CTD_HD static void dyn_sym_part(int part, const double* p, double* ev) {\n        switch (part) {\n" + b_parts + "        }\n    }\n";
         std::string b_path;
         const bool okp = ok && d->npath > 0 && gen_sym_path(d, c0, b_path, e2);
         std::string b_lag;

@@ -686,11 +686,16 @@ template <class P, int S> CTD_HD void path_control(const KParams& kp, const Bloc
 
 // Symbolic first derivatives of the dynamics (ctd_sym.hpp): member of the generated functor of a run-time OCP, explicit
 // specialisation generated at build time for a registry problem (ctd_sym_registry.hpp, included at the end of this header)
+// (this primary template serves the generated functors of run-time OCPs, which carry DYN_PARTS and, when > 1, dyn_sym_part: the same
+// split by rows as the registry's wide problems -- a 12-state run-time OCP then runs one part per wave like the built-in one)
 template <class P> struct SymDyn {
     static constexpr bool value = P::HAS_SYM_DYN;
-    static constexpr int parts = 1;       // lanes the generated code of one evaluation point is split over (registry: by rows)
+    static constexpr int parts = P::DYN_PARTS;       // lanes the generated code of one evaluation point is split over (by rows)
     CTD_HD static void eval(const double* p, double* ev) { if constexpr (P::HAS_SYM_DYN) P::dyn_sym(p, ev); }
-    CTD_HD static void eval_part(int, const double* p, double* ev) { eval(p, ev); }
+    CTD_HD static void eval_part(int q, const double* p, double* ev) {
+        if constexpr (P::HAS_SYM_DYN && P::DYN_PARTS > 1) P::dyn_sym_part(q, p, ev);
+        else eval(p, ev);
+    }
 };
 template <class P> struct SymPath {
     static constexpr bool value = P::HAS_SYM_PATH;
@@ -1086,8 +1091,9 @@ CTD_HD bool edge_sym_layout(const BlockCtx& cx, int nthr) {
 #else
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
     constexpr int n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
+    constexpr bool parts = SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN;      // then one wave per part
     return SymDyn<P>::value && !Dirs<P>::FUSED && cx.is_edge && cx.nslots <= 8 && nthr >= 256 && r_path <= 4 && n_b <= 32 &&
-           StagePoints<SC, S>::value * 8 <= 32;
+           StagePoints<SC, S>::value * 8 <= 32 && (!parts || Dirs<P>::NCH_DYN * 64 <= nthr);
 #endif
 }
 

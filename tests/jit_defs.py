@@ -39,6 +39,20 @@ TWINS = {
         control_box=([0, -3, -3, -INF], [9.18 * 5, 3, 3, INF]), variable_box=([0.1], [INF]),
         path_bounds=([math.cos(1.1 / 2)], [INF]),
         boundary_bounds=([0, 0, 2.5, 0, 0, 0, 0, 0, 0.01, 5, 2.5, 0, 0, 0], [0, 0, 2.5, 0, 0, 0, 0, 0, 0.01, 5, 2.5, 0, 0, 0])),
+    # the 12-state quadrotor (ctd_problems.hpp Quadrotor12OCP): 16 dynamics directions = four chunks -- the generated functor carries
+    # its dynamics split by rows into four parts (DYN_PARTS), one wave each, like the built-in problem
+    "quadrotor12": dict(
+        dynamics=["x4", "x5", "x6", "(cos(x9)*sin(x8)*cos(x7) + sin(x9)*sin(x7))*u1", "(sin(x9)*sin(x8)*cos(x7) - cos(x9)*sin(x7))*u1",
+                  "(cos(x8)*cos(x7))*u1 - g", "x10 + sin(x7)*(sin(x8)/cos(x8))*x11 + cos(x7)*(sin(x8)/cos(x8))*x12",
+                  "cos(x7)*x11 - sin(x7)*x12", "(sin(x7)*x11 + cos(x7)*x12)/cos(x8)", "((Jy - Jz)*x11*x12 + u2)/Jx",
+                  "((Jz - Jx)*x12*x10 + u3)/Jy", "((Jx - Jy)*x10*x11 + u4)/Jz"],
+        m=4, nv=1, lagrange="1e-8*(x7^2 + x8^2 + u1^2) + 1e-2*(u2^2 + u3^2 + u4^2) + 1e2*x9^2", mayer="v1", path=["cos(x8)*cos(x7)"],
+        boundary=[f"x0_{i}" for i in range(1, 13)] + [f"xf_{i}" for i in range(1, 9)] + [f"xf_{i}" for i in range(10, 13)],
+        constants=dict(g=9.81, Jx=0.03, Jy=0.03, Jz=0.06), itf=0,
+        state_box=([-INF] * 6 + [-math.pi / 2] * 2 + [-INF] * 4, [INF] * 6 + [math.pi / 2] * 2 + [INF] * 4),
+        control_box=([0, -1, -1, -1], [45.9, 1, 1, 1]), variable_box=([0.1], [INF]),
+        path_bounds=([math.cos(0.55)], [INF]),
+        boundary_bounds=([0, 0, 2.5] + [0] * 9 + [0.01, 5, 2.5] + [0] * 8, [0, 0, 2.5] + [0] * 9 + [0.01, 5, 2.5] + [0] * 8)),
     "double_integrator_freet0tf": dict(
         dynamics=["x2", "u1"], m=1, nv=2, mayer="v1", boundary=["x0_1", "x0_2", "xf_1", "xf_2", "v2 - v1"], it0=0, itf=1,
         maximize=True, control_box=([-1], [1]), variable_box=([0.05, 0.05], [10, 10]),

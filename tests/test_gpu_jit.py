@@ -34,6 +34,8 @@ def test_runtime_twin_matches_registry_and_oracle(oracle_lib, torch_cuda, prob, 
     torch = torch_cuda
     if prob == "quadrotor" and sch not in ("midpoint", "gauss_legendre_2", "gauss_legendre_3", "trapeze"):
         pytest.skip("quadrotor twin: four schemes are enough (compile time)")
+    if prob == "quadrotor12" and sch not in ("midpoint", "gauss_legendre_3", "trapeze"):
+        pytest.skip("quadrotor12 twin: three schemes are enough (compile time)")
     rt = jit_defs.twin(prob)
     rng = np.random.default_rng(21)
     for N in (4, 41):
