@@ -1084,6 +1084,14 @@ CTD_HD bool fin_folded(const BlockCtx& cx) {
 // kinds of task (path passes, final-time path passes, coefficient records, boundary passes) sit on lanes 32.. of the waves, the
 // heavy kinds on different waves.  (In index order, as the fallback below deals them, the 12-state quadrotor's edge block ran all
 // four parts of every point on ONE lane and every kind in the same two waves: 17 - 23 us of evaluation + 10 us of fin.)
+// generated dynamics code that comes in at least this many parts (= direction chunks) runs one part per wave.  Four: with three
+// (the 8-state quadrotor, 12 directions) the split measured SLOWER in both rounds -- round 2, 7-step tiles: +4 %; round 3, 16-step
+// tiles (48 lanes per part-wave): cfg 5' 38.6 -> 40.2 us, optimized 16.9 -> 18.5, trapeze 10.9 -> 11.7 (profiles/r03_experiments.md)
+#ifndef CTD_SPLIT_MIN_PARTS
+#define CTD_SPLIT_MIN_PARTS 4
+#endif
+constexpr int kSplitMinParts = CTD_SPLIT_MIN_PARTS;
+
 template <class P, int SC, int S>
 CTD_HD bool edge_sym_layout(const BlockCtx& cx, int nthr) {
 #ifdef CTD_NO_EDGE_SYM
@@ -1091,7 +1099,7 @@ CTD_HD bool edge_sym_layout(const BlockCtx& cx, int nthr) {
 #else
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
     constexpr int n_b = (P::NBC > 0) ? Dirs<P>::NCH_BND : 0;
-    constexpr bool parts = SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN;      // then one wave per part
+    constexpr bool parts = SymDyn<P>::parts >= kSplitMinParts && SymDyn<P>::parts == Dirs<P>::NCH_DYN;      // then one wave per part
     return SymDyn<P>::value && !Dirs<P>::FUSED && cx.is_edge && cx.nslots <= 8 && nthr >= 256 && r_path <= 4 && n_b <= 32 &&
            StagePoints<SC, S>::value * 8 <= 32 && (!parts || Dirs<P>::NCH_DYN * 64 <= nthr);
 #endif
@@ -1103,7 +1111,7 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
     return false;
 #else
     // (four parts and more: measured +2 % for the 12-state quadrotor, -4 % for the 8-state one with three, profiles/r02_tile_sweeps.log)
-    constexpr bool ok = SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !Dirs<P>::FUSED;
+    constexpr bool ok = SymDyn<P>::value && SymDyn<P>::parts >= kSplitMinParts && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !Dirs<P>::FUSED;
     constexpr int NP = Dirs<P>::NCH_DYN;
     constexpr int r_path = (P::NPATH > 0) ? Dirs<P>::NCH_PATH : 0;
     // lanes of a wave: S ns dynamics points (the lead tasks -- Gauss-Legendre: (step, state row) pairs dealt round robin over the
@@ -1213,7 +1221,7 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
         if constexpr (SymDyn<P>::value && !FUSED) {
             if (edge_sym_layout<P, SC, S>(cx, nthr)) {
                 constexpr int NP = Dirs<P>::NCH_DYN;
-                constexpr bool parts = SymDyn<P>::parts >= 4 && SymDyn<P>::parts == NP;      // one wave per part of the generated code
+                constexpr bool parts = SymDyn<P>::parts >= kSplitMinParts && SymDyn<P>::parts == NP;      // one wave per part of the generated code
                 constexpr int NPW = parts ? NP : 1;
                 const int wave = tid >> 6, l = tid & 63;
                 if (wave < NPW && l < StagePoints<SC, S>::value * 8) {
@@ -1292,7 +1300,7 @@ CTD_HD void phase_eval(const KParams& kp, const BlockCtx& cx, int tid, int nthr,
     // neighbouring lanes run the same role on neighbouring steps.  Roles: S * NCH_DYN dynamics passes, NCH_PATH path
     // passes, one lead role (coefficients + state rows, fused mode).
     CTD_SUB(kp, 0);
-    if constexpr (SymDyn<P>::value && SymDyn<P>::parts >= 4 && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !FUSED) {
+    if constexpr (SymDyn<P>::value && SymDyn<P>::parts >= kSplitMinParts && SymDyn<P>::parts == Dirs<P>::NCH_DYN && !FUSED) {
         if (split_eval<P, SC, S>(cx, nthr)) {
             constexpr int NP = Dirs<P>::NCH_DYN;
             const int nd = StagePoints<SC, S>::value * ns;
