@@ -241,8 +241,11 @@ def _main(real_stdout):
         e1.record()
         # (polling the closing event before the synchronisation was tried against a once-seen 10 ms wake-up stall and costs
         # 12 us per region -- hipEventQuery in a loop, then a synchronisation that still takes its 16 us: profiles/r03_experiments.md)
-        sync_all()
-        el = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0       # this rank's K steps are done; the MAX over the ranks (below) is when the last one was
+        if dist_on:                         # the closing barrier of the bracket: its own latency (a collective) is not a step
+            dist.barrier()
+            torch.cuda.synchronize(dev)
         region["ms_per_launch"] = e0.elapsed_time(e1) / steps
         if dist_on:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
