@@ -956,6 +956,7 @@ static int fill_obj_params(ctd_handle* h, double* f_dev, ObjParams& op) {
     op.add_mayer = last ? 1 : 0;
     op.partial = h->d_partial;
     op.out = f_dev;
+    op.halo = h->kp.halo;
     const int64_t units = op.unit_end - op.unit_begin;
     int blocks = (int)((units + 255) / 256);
     if (blocks > h->obj_blocks) blocks = h->obj_blocks;
@@ -989,6 +990,9 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, G
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
+    // (constraints / Jacobian, objective and Hessian read a sharded iterate in place; the gradient pass gathers the two steps around
+    // a node and is not restated for it: refused, never evaluated on another shard's NaNs)
+    if (h->kp.halo) return fail(h, CTD_EINVAL, "gradient on a sharded iterate (ctd_set_x_shards) is not implemented: pass the whole x and clear the shard table");
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
     const int64_t units = (L.sc == SC_IRK) ? L.N : L.N + 1;
@@ -1266,6 +1270,8 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     HParams hp = h->hp;
     hp.obj_weight = obj_weight;
     hp.vals = vals_dev;
+    hp.halo = h->kp.halo;
+    if (hp.halo) { hp.own_lo = h->halo_host.vbegin[h->halo_host.self]; hp.own_hi = h->halo_host.vbegin[h->halo_host.self + 1]; }
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
         void* args[] = {&hp, &x_dev, &y_dev};
@@ -1343,6 +1349,8 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     size_t lds = 4 * kMaxNV * sizeof(double) + 64;
     ip.kp = h->kp;       // (Layout is read from kp / hp / gp / op by the respective bodies)
     ip.hp = h->hp;
+    ip.hp.halo = h->kp.halo;
+    if (ip.hp.halo) { ip.hp.own_lo = h->halo_host.vbegin[h->halo_host.self]; ip.hp.own_hi = h->halo_host.vbegin[h->halo_host.self + 1]; }
     // The fused grid always carries the TILE body of the Hessian, also on handles whose stand-alone hess_coord runs the
     // lane-per-step kernel (Gauss-Legendre 2 from 9 000 steps, 3 from 28 000: ensure_hess).  Measured (CTD_ITER_HESS_APART=1: fused
     // first-order grid, then the step kernel and its finish as two more launches): Goddard GL2 N = 10 000 22.9 us against 14-16,

@@ -178,6 +178,11 @@ struct HParams {
     double obj_weight;
     double* vals;
     double* partials;           // (ntiles + n_edge_blocks) * nvv: V x V partial sums per workgroup (workgroup 0: the edge's)
+    // sharded iterate read in place (ctd_set_x_shards; the multipliers y stay replicated): variables outside [own_lo, own_hi) -- the
+    // previous shard's last block / the next shard's first node of a boundary tile, X_1 / X_{N+1} of the edge blocks -- are fetched
+    // from the owners' buffers; null: xu holds everything
+    const XHalo* halo;
+    int64_t own_lo, own_hi;
     // diagnostics only (env CTD_HESS_STOP): 0 normal; 1 return after load, 2 after eval (ablation timing, outputs incomplete)
     int32_t debug_stop;
     // diagnostics only (ctd_hess_debug_stamps): lane 0 of every workgroup stores 5 x {100 MHz realtime, shader cycles}

@@ -190,7 +190,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
             int64_t g = hp.edge_steps[k] * L.blk + o;
             if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
                 g = (hp.edge_steps[k] >= 1 ? hp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
-            cx.in[e] = (g < L.v_off) ? xu[g] : 0.0;
+            cx.in[e] = (g < L.v_off) ? (hp.halo ? xsrc(hp.halo, xu, g) : xu)[g] : 0.0;
         }
         for (int e = tid; e < 2 * cx.nslots * L.cb; e += nthr) {
             const int blk2 = e / L.cb, r = e - blk2 * L.cb;
@@ -243,6 +243,13 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         for (int e = tid + 2 * nthr; e < ny; e += nthr) cx.ly[e] = yval(e);
         if (tid <= cx.nslots + 2) cx.tau[tid] = tau_e;
         for (int e = tid + nthr; e <= cx.nslots + 2; e += nthr) cx.tau[e] = htau_global(hp, cx.lo - 1 + e);
+        // sharded iterate: the entries of the slice other shards own (a boundary tile: a handful) once more, from the owners' buffers
+        // (same lane, same LDS word: ordered behind the copy above)
+        if (hp.halo && (g0 < hp.own_lo || g1 > hp.own_hi))
+            for (int e = tid; e < cnt; e += nthr) {
+                const int64_t g = g0 + e;
+                if (g < hp.own_lo || g >= hp.own_hi) dst[e] = xsrc(hp.halo, xu, g)[g];
+            }
         return;
     }
     if (tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;

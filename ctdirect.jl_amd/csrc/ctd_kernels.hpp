@@ -172,6 +172,9 @@ struct ObjParams {
     double* partial;
     double* out;
     int32_t nblocks;
+    // sharded iterate read in place (ctd_set_x_shards): the next shard's first node (midpoint / Euler units of a shard's last step)
+    // and X_1 / X_{N+1} of the Mayer term come from the owners' buffers; null: xu holds everything
+    const XHalo* halo;
 };
 
 template <class P> __device__ double obj_time(const ObjParams& op, const double* v, int64_t i) {
@@ -186,6 +189,9 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     constexpr int n = P::NX, m = P::NU;
     const Layout& L = op.L;
     const double* base = xu + i * (int64_t)L.blk;
+    // X_{i+1} sits behind the step's block -- in the next shard's buffer for the last step of a shard of a sharded iterate
+    const int64_t gn = (i + 1) * (int64_t)L.blk;
+    const double* nxt = ((op.halo && i + 1 >= op.unit_end) ? xsrc(op.halo, xu, gn) : xu) + gn;      // (only the shard's last unit looks at the table)
     double x[n > 0 ? n : 1], u[m > 0 ? m : 1];
     if (SC == SC_TRAPEZE) {            // trapeze.jl:78-110: node weights h_1/2, (t_{i+1}-t_{i-1})/2, h_N/2
         double w;
@@ -201,7 +207,7 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     if (SC == SC_MIDPOINT) {           // midpoint.jl:87-97; Euler (euler.jl:112-134): (t_i, X_i, U_i) or (t_{i+1}, X_{i+1}, U_i)
         if (L.cs > 1) {                // control_steps > 1 (midpoint.jl:99-116): h_i = h / cs, l(t_i + (j - 1/2) h_i, x_s, U_i^j, v), j = 1..cs
             const double hi = h / (double)L.cs;
-            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + nxt[c]);
             double val = 0.0;
             for (int j = 1; j <= L.cs; ++j) {
                 for (int c = 0; c < m; ++c) u[c] = base[n + (j - 1) * m + c];
@@ -212,10 +218,10 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
         }
         for (int c = 0; c < m; ++c) u[c] = base[n + c];
         if (L.euler == 0) {
-            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + base[L.blk + c]);
+            for (int c = 0; c < n; ++c) x[c] = 0.5 * (base[c] + nxt[c]);
             return h * P::template lagrange<double>(0.5 * (ti + tip1), x, u, v);
         }
-        for (int c = 0; c < n; ++c) x[c] = (L.euler == 1) ? base[c] : base[L.blk + c];
+        for (int c = 0; c < n; ++c) x[c] = (L.euler == 1) ? base[c] : nxt[c];
         return h * P::template lagrange<double>(L.euler == 1 ? ti : tip1, x, u, v);
     }
     // irk.jl:179-228 / irk_stagewise.jl:344-384
@@ -276,7 +282,10 @@ __device__ __forceinline__ void obj_finish_body(const ObjParams& op, const doubl
     if (P::HAS_MAYER && op.add_mayer) {
         constexpr int n = P::NX, nv = P::NV;
         double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1];
-        for (int c = 0; c < n; ++c) { x0[c] = xu[c]; xf[c] = xu[op.L.N * (int64_t)op.L.blk + c]; }
+        const int64_t gf = op.L.N * (int64_t)op.L.blk;
+        const double* xa = op.halo ? xsrc(op.halo, xu, 0) : xu;
+        const double* xb = op.halo ? xsrc(op.halo, xu, gf) : xu;
+        for (int c = 0; c < n; ++c) { x0[c] = xa[c]; xf[c] = xb[gf + c]; }
         for (int k = 0; k < nv; ++k) v[k] = xu[op.L.v_off + k];
         mayer = P::template mayer<double>(x0, xf, v);
     }

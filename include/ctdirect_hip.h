@@ -366,14 +366,17 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
  * One shard handle (ctd_desc.step_begin / step_end) usually finds everything it reads in the x passed to the call.  With the
  * iterate sharded like the steps (a shard holds its own steps' variables and the replicated v in a
  * full-length buffer) a few entries belong to other shards: the next shard's first node, the previous shard's last step block
- * (one-point schemes), X_1 and X_{N+1} (boundary rows).  After ctd_set_x_shards the constraint / Jacobian kernels of `h` load
+ * (one-point schemes), X_1 and X_{N+1} (boundary rows).  After ctd_set_x_shards the constraint / Jacobian, objective and Hessian kernels of `h` load
  * those entries straight from x_bufs[k], the full-length buffer of shard k = steps [step_begin[k], step_begin[k+1]) -- a
  * peer-mapped pointer of another device of this process, or the mapping of another process' buffer (ctd_ipc_open below) --
  * so the evaluation of a shard contains no exchange step at all: the loop being split is src/DOCP_functions.jl:92-98, and
  * step i reads only X_i, U_i, K_i, X_{i+1}, v.  `self` = this handle's shard (x_bufs[self] is ignored: its x is the call's
  * argument); n_shards <= 16; n_shards = 0 switches back.  The writers' updates of x must be complete (or ordered before this
  * handle's stream) when an evaluation is enqueued -- the acceptance test of a solver iteration is a collective already.
- * (Objective, gradient and Hessian callbacks read the x they are given: use CTD_X_SHARDED_COPY / an exchange for those.) */
+ * The objective (src/DOCP_functions.jl:23-54: its quadrature over the shard's steps, the Mayer term on the last shard) and the
+ * Hessian callbacks (ctd_hess_coord*, ctd_eval_all_dev_async; the multipliers y are replicated) follow the same table since
+ * round 3.  The gradient pass gathers the two steps around a node and is NOT restated for a sharded iterate: ctd_grad* returns
+ * CTD_EINVAL while the table is set (never a value computed from another shard's placeholder entries). */
 int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self);
 /* One process per GPU (e.g. a Julia host under MPI): the "RCCL all-gather over xGMI for the stitched constraint vector" of the
  * north star, inside the library.  comm is an ncclComm_t of n_ranks ranks created by the host with ITS copy of librccl (found

@@ -103,6 +103,20 @@ def _worker(rank, world, port, N, prob, sch, q):
         chk['peer c tail'] = bool(np.array_equal(c3h[N * sh.cb:], c.cpu().numpy()[N * sh.cb:]))
         chk['peer J'] = bool(np.array_equal(v3h, vh))
         chk['peer x untouched'] = bool(np.array_equal(np.isnan(xp.cpu().numpy()), np.isnan(xs)))
+        # the objective and the Hessian read the same sharded iterate in place (the shard table stays on the handle); the gradient
+        # pass is not restated for it and refuses instead of evaluating on NaNs
+        f3 = sh.obj(xp)
+        chk['peer obj'] = bool(f3 == f)
+        hv3 = torch.full((d.nnzh,), 777.0, dtype=torch.float64, device="cuda")
+        sh.hess_coord(xp, torch.from_numpy(y).cuda(), 0.5, hv3)
+        torch.cuda.synchronize()
+        dist.barrier()
+        chk['peer H'] = bool(np.array_equal(hv3.cpu().numpy(), hh))
+        try:
+            d.grad(xp)
+            chk['peer grad refused'] = False
+        except ct.CTDirectError as e:
+            chk['peer grad refused'] = e.status == ct._lib.CTD_EINVAL
         sh.close()
         bad = [k for k, v_ in chk.items() if not v_]
         q.put((rank, True if not bad else bad))
