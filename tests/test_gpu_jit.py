@@ -235,3 +235,28 @@ def test_four_optimisation_variables_with_both_times_free(torch_cuda, sch):
             assert relerr(c.cpu().numpy(), c0.cpu().numpy()) <= TOL and relerr(vals.cpu().numpy(), v0.cpu().numpy()) <= TOL
             d0.close()
         d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prob,sch", [("quadrotor", "gauss_legendre_2"), ("goddard_all", "trapeze"), ("quadrotor", "midpoint")])
+def test_sparse_and_dense_eval_blocks_agree(torch_cuda, monkeypatch, prob, sch):
+    """Run-time OCPs store only the structurally nonzero partials of their dynamics (DynNZ specialisation in the generated functor);
+    CTD_DENSE_EVAL=1 at registration keeps the dense blocks.  Same values, entry for entry, in all three patterns -- and the sparse
+    variant really is sparse (smaller tiles' LDS, a DynNZ specialisation in its source)."""
+    torch = torch_cuda
+    a = jit_defs.twin(prob)
+    monkeypatch.setenv("CTD_DENSE_EVAL", "1")
+    name = prob + "_dense_rt"
+    b = name if name in ct.PROBLEMS else ct.register_ocp(name, **jit_defs.TWINS[prob])
+    monkeypatch.delenv("CTD_DENSE_EVAL")
+    assert "struct DynNZ<UserOCP>" in ct.ocp_source(a) and "struct DynNZ<UserOCP>" not in ct.ocp_source(b)
+    for pattern in ("manual", "structural", "optimized"):
+        da, db = ct.DOCP(a, 57, sch, pattern=pattern, device=0), ct.DOCP(b, 57, sch, pattern=pattern, device=0)
+        x = torch.from_numpy(bench_inputs(describe(da, prob, sch), perturb=1e-2)).cuda()
+        ca, va = da.cons_jac(x)
+        cb, vb = db.cons_jac(x)
+        assert da.nnzj == db.nnzj and torch.equal(ca, cb)
+        assert relerr(va.cpu().numpy(), vb.cpu().numpy()) <= 1e-15            # (a structural zero is 0.0 either way, possibly -0.0)
+        ia, ib = da.launch_info(), db.launch_info()
+        assert ia["lds_bytes"] / max(1, ia["steps_per_tile"]) < ib["lds_bytes"] / max(1, ib["steps_per_tile"])
+        da.close(); db.close()
