@@ -29,11 +29,6 @@
 #pragma once
 #include "ctd_layout.hpp"
 
-// emit variant: 0 = one 8-byte store per lane and entry (default, measured faster on MI355X for this kernel),
-// 1 = 16-byte stores of entry pairs (emit_stream)
-#ifndef CTD_EMIT_PAIRS
-#define CTD_EMIT_PAIRS 0
-#endif
 
 namespace ctd {
 
@@ -1505,89 +1500,6 @@ CTD_HD double eval_code(int oC, const double* rec_c, const double* rec_d, uint32
     return coef * data + beta;
 }
 
-// Streams E = nsteps * period step-periodic outputs to out[0 .. E) with 16-byte stores (two consecutive entries per
-// lane: 8-byte-per-lane stores are issue-bound at about half the chip's write bandwidth).  Entry e = s * period + k comes
-// from the record of slot (slot0 + s) through code(k).  A lane owns a fixed PAIR position inside the pair period
-// (period entries when period is even, 2 * period when odd), so its two codes are decoded once into registers and the
-// loop over steps only does 4 LDS reads, 2 multiply-adds and one store.  An odd 8-byte element in front of / behind the
-// 16-byte aligned body is written by lane 0 / the owner of the last pair.
-template <class CodeFn>
-CTD_HD void emit_stream(const RecLayout R, const BlockCtx& cx, double* out, int E, int period, int slot0, CodeFn code,
-                        int tid, int nthr) {
-    if (E <= 0) return;
-    const int stride = R.stride;
-    auto value = [&](uint32_t c, int slot) -> double {
-        const double* rc = cx.rec + (slot - code_crec(c)) * stride;
-        const double* rd = cx.rec + (slot - code_drec(c)) * stride;
-        const int bt = code_beta(c);
-        return rc[R.oC + code_ci(c)] * rd[code_di(c)] + (bt == 0 ? 0.0 : (bt == 1 ? 1.0 : -1.0));
-    };
-    const int off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 1);   // 1: out[0] is not 16-byte aligned
-    if (off && tid == 0) out[0] = value(code(0), slot0);
-    const int npairs = (E - off) >> 1;
-    const bool tail = ((E - off) & 1) != 0;
-    const int pd = (period & 1) ? 2 * period : period;     // entries after which the (k0, k1) pattern of a pair repeats
-    const int pp = pd >> 1;                                // pairs per pattern period
-    const int sp = pd / period;                            // steps per pattern period (1 or 2)
-    const int par = nthr / pp;                             // pattern periods in flight
-    if (par >= 1) {
-        if (tid < par * pp) {
-            const int g = tid / pp, j = tid - g * pp;
-            const int e0 = off + 2 * j;                    // first entry of the lane's pair inside a period
-            const int s0 = e0 / period, k0 = e0 - s0 * period;
-            const int e1 = e0 + 1;
-            const int s1 = e1 / period, k1 = e1 - s1 * period;
-            const uint32_t c0 = code(k0), c1 = code(k1);
-            const int bt0 = code_beta(c0), bt1 = code_beta(c1);
-            const double beta0 = bt0 == 0 ? 0.0 : (bt0 == 1 ? 1.0 : -1.0);
-            const double beta1 = bt1 == 0 ? 0.0 : (bt1 == 1 ? 1.0 : -1.0);
-            const int base = slot0 + g * sp;
-            const double* pc0 = cx.rec + (base + s0 - code_crec(c0)) * stride + R.oC + code_ci(c0);
-            const double* pd0 = cx.rec + (base + s0 - code_drec(c0)) * stride + code_di(c0);
-            const double* pc1 = cx.rec + (base + s1 - code_crec(c1)) * stride + R.oC + code_ci(c1);
-            const double* pd1 = cx.rec + (base + s1 - code_drec(c1)) * stride + code_di(c1);
-            const int adv = par * sp * stride;
-            double* o = out + e0 + g * pd;
-            const int oadv = par * pd;
-            int p = j + g * pp;                            // global pair index
-#pragma unroll 4
-            for (; p < npairs; p += par * pp, pc0 += adv, pd0 += adv, pc1 += adv, pd1 += adv, o += oadv) {
-                const double v0 = (*pc0) * (*pd0) + beta0;
-                const double v1 = (*pc1) * (*pd1) + beta1;
-                CTD_STORE2(o, v0, v1);
-            }
-            if (tail && p == npairs) *o = (*pc0) * (*pd0) + beta0;      // last, unpaired entry of the stream
-        }
-    } else {
-        // long periods (more pairs than lanes): a lane owns pair positions j, j + nthr, ... and walks the periods
-        const int nper = (npairs + pp - 1) / pp;
-        for (int j = tid; j < pp; j += nthr) {
-            const int e0 = off + 2 * j;
-            const int s0 = e0 / period, k0 = e0 - s0 * period;
-            const int e1 = e0 + 1;
-            const int s1 = e1 / period, k1 = e1 - s1 * period;
-            const uint32_t c0 = code(k0), c1 = code(k1);
-            const int bt0 = code_beta(c0), bt1 = code_beta(c1);
-            const double beta0 = bt0 == 0 ? 0.0 : (bt0 == 1 ? 1.0 : -1.0);
-            const double beta1 = bt1 == 0 ? 0.0 : (bt1 == 1 ? 1.0 : -1.0);
-            const double* pc0 = cx.rec + (slot0 + s0 - code_crec(c0)) * stride + R.oC + code_ci(c0);
-            const double* pd0 = cx.rec + (slot0 + s0 - code_drec(c0)) * stride + code_di(c0);
-            const double* pc1 = cx.rec + (slot0 + s1 - code_crec(c1)) * stride + R.oC + code_ci(c1);
-            const double* pd1 = cx.rec + (slot0 + s1 - code_drec(c1)) * stride + code_di(c1);
-            const int adv = sp * stride;
-            double* o = out + e0;
-            int p = j;
-#pragma unroll 4
-            for (int q = 0; q < nper && p < npairs; ++q, p += pp, pc0 += adv, pd0 += adv, pc1 += adv, pd1 += adv, o += pd) {
-                const double v0 = (*pc0) * (*pd0) + beta0;
-                const double v1 = (*pc1) * (*pd1) + beta1;
-                CTD_STORE2(o, v0, v1);
-            }
-            if (tail && p == npairs) *o = (*pc0) * (*pd0) + beta0;
-        }
-    }
-}
-
 // The codes a lane needs in phase_emit when it owns ONE position of each period (period <= workgroup size): read from the
 // global tables before the evaluation starts, so their latency hides behind it and the emission starts from registers.
 // upper bound of the CSC period of (OCP, scheme class, stages) -- the reference's dense-block patterns (Appendix A.4 of SURVEY.md)
@@ -1691,33 +1603,6 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
     const int nsteps = (int)(cx.b - cx.a);
     const int slot0 = (int)(cx.a - cx.lo);
     CTD_SUBE(kp, 0);
-#if CTD_EMIT_PAIRS
-    // (A) constraint rows of the tile: c[a*cb .. b*cb): entry (s, r) = record(s).R[r]
-    if (kp.c) {
-        const int oR = R.oR;
-        emit_stream(R, cx, kp.c + cx.a * (int64_t)L.cb, nsteps * L.cb, L.cb, slot0,
-                    [oR](int k) { return pack_code(oR + k, C_ONE, 0, 0, 0); }, tid, nthr);
-    }
-    if (!kp.vals) return;
-    // (B) step-periodic CSC segments of the regular steps of the tile
-    {
-        const int64_t ra = cx.a > kp.reg_first ? cx.a : kp.reg_first;
-        const int64_t rb = cx.b < kp.reg_last ? cx.b : kp.reg_last;
-        if (rb > ra) {
-            const uint32_t* tmpl = cx.codes;
-            emit_stream(R, cx, kp.vals + kp.seg_base + (ra - kp.reg_first) * (int64_t)kp.Lseg, (int)(rb - ra) * kp.Lseg,
-                        kp.Lseg, (int)(ra - cx.lo), [tmpl](int k) { return tmpl[k]; }, tid, nthr);
-        }
-    }
-    // (C) the tile's slice of every V column
-    if (kp.vr > 0) {
-        for (int kk = 0; kk < P::NV; ++kk) {
-            const uint32_t* codes = cx.vcodes + kk * kp.vr;
-            emit_stream(R, cx, kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr, nsteps * kp.vr, kp.vr, slot0,
-                        [codes](int k) { return codes[k]; }, tid, nthr);
-        }
-    }
-#else
     const int stride = R.stride;
     // Every output stream of the tile is step-periodic with a small period (cb rows, Lseg CSC entries, vr entries of a
     // V column).  A lane owns ONE position k of the period (its code is decoded once, into registers) and walks the
@@ -1854,7 +1739,6 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
         }
     }
     CTD_SUBE(kp, 3);
-#endif
 }
 // (pointer form: the drivers that always prefetch, and the emulator)
 template <class P, int SC, int S, int NB = 1>
