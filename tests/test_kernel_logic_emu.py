@@ -219,3 +219,21 @@ def test_full_lane_tiles_of_the_wide_ocps(oracle_lib, prob):
                     else:
                         c7, v7 = emu.cons_jac(pid, sid, mode, N, x, tile=7, nthr=256)
                         assert np.array_equal(vals, v7) and np.array_equal(c, c7)
+
+
+def test_early_emission_knob_stays_bit_identical(monkeypatch):
+    """CTD_EARLY=1 (off by default: measured slower, profiles/r03_experiments.md) lets the lead wave of a Gauss-Legendre tile store
+    the outputs that only read its own records while the dynamics are still evaluated; the emit phase then walks the late positions
+    only.  Emulated (CTD_EMU_EARLY): the same bits, all three patterns, also on the sparse eval blocks."""
+    for prob in ("goddard", "double_integrator_freet0tf", "stagewise_scalar"):
+        for sch in ("gauss_legendre_2", "gauss_legendre_3", "gauss_legendre_2_constant_control", "gauss_legendre_1"):
+            d = ct.DOCP(prob, 41, sch, device=-1, pattern="structural")
+            x = bench_inputs(describe(d, prob, sch), perturb=1e-3)
+            d.close()
+            for mode in (0, 1, 2):
+                monkeypatch.delenv("CTD_EMU_EARLY", raising=False)
+                c0, v0 = emu.cons_jac(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, 41, x, tile=8, nthr=320)
+                monkeypatch.setenv("CTD_EMU_EARLY", "1")
+                c1, v1 = emu.cons_jac(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, 41, x, tile=8, nthr=320)
+                assert np.array_equal(c0, c1) and np.array_equal(v0, v1), (prob, sch, mode)
+    monkeypatch.delenv("CTD_EMU_EARLY", raising=False)
