@@ -1284,6 +1284,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
             HParams he = h->hp_step;
             he.obj_weight = obj_weight;
             he.vals = vals_dev;
+            he.halo = hp.halo; he.own_lo = hp.own_lo; he.own_hi = hp.own_hi;       // (its edge blocks; a step lane reads its own step only)
             SParams sp = h->sp;
             sp.obj_weight = obj_weight;
             sp.vals = vals_dev;
