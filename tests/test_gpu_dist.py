@@ -128,7 +128,8 @@ def _worker(rank, world, port, N, prob, sch, q):
 
 @pytest.mark.parametrize("N,prob,sch", [(2000, "goddard", "gauss_legendre_2"), (1001, "goddard_all", "trapeze"),
                                         (3000, "double_integrator_path", "midpoint"), (501, "quadrotor", "gauss_legendre_3"),
-                                        (777, "goddard_all", "euler_implicit")])
+                                        (777, "goddard_all", "euler_implicit"),
+                                        (20000, "goddard", "gauss_legendre_2")])      # (10 000 steps per rank: the lane-per-step Hessian kernel)
 def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
     assert torch.cuda.is_available()
     world = 2
