@@ -990,9 +990,8 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, G
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
-    // (constraints / Jacobian, objective and Hessian read a sharded iterate in place; the gradient pass gathers the two steps around
-    // a node and is not restated for it: refused, never evaluated on another shard's NaNs)
-    if (h->kp.halo) return fail(h, CTD_EINVAL, "gradient on a sharded iterate (ctd_set_x_shards) is not implemented: pass the whole x and clear the shard table");
+    // (constraints / Jacobian, objective and Hessian read a sharded iterate in place; the gradient is always that of the WHOLE
+    // objective -- O(nvar) work on every rank -- and reads only the x it is given, shard table or not: it needs a whole iterate)
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
     const int64_t units = (L.sc == SC_IRK) ? L.N : L.N + 1;

@@ -375,8 +375,8 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
  * handle's stream) when an evaluation is enqueued -- the acceptance test of a solver iteration is a collective already.
  * The objective (src/DOCP_functions.jl:23-54: its quadrature over the shard's steps, the Mayer term on the last shard) and the
  * Hessian callbacks (ctd_hess_coord*, ctd_eval_all_dev_async; the multipliers y are replicated) follow the same table since
- * round 3.  The gradient pass gathers the two steps around a node and is NOT restated for a sharded iterate: ctd_grad* returns
- * CTD_EINVAL while the table is set (never a value computed from another shard's placeholder entries). */
+ * round 3.  ctd_grad* is the gradient of the WHOLE objective on every rank (see there) and ignores the table: it reads only the
+ * x it is given, which must then hold every variable (an all-gathered copy). */
 int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self);
 /* One process per GPU (e.g. a Julia host under MPI): the "RCCL all-gather over xGMI for the stitched constraint vector" of the
  * north star, inside the library.  comm is an ncclComm_t of n_ranks ranks created by the host with ITS copy of librccl (found
