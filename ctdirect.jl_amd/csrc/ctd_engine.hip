@@ -371,6 +371,13 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     }
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
     h->kp.debug_stop = debug_stop;
+    {   // write-through stores (emit_store) for launches whose outputs are small: what a kernel leaves dirty in the XCDs' L2s is written
+        // back at its end, serial with the next launch.  CTD_WT_STORE: 0 never, 1 always, unset: outputs of this handle up to
+        // CTD_WT_MB megabytes (default from the MI355X sweep in profiles/r03_experiments.md)
+        const int wt = env_int("CTD_WT_STORE", -1);
+        const double out_mb = 8.0 * ((double)(h->step_end - h->step_begin) * (mo.L.cb + mo.Lseg + (double)mo.L.nv * mo.vr)) / 1.0e6;
+        h->kp.wt_store = wt >= 0 ? (wt ? 1 : 0) : (out_mb <= (double)env_int("CTD_WT_MB", 64) ? 1 : 0);
+    }
     h->kp.xcd_remap = env_int("CTD_XCD", 0);          // 1: every XCD walks one contiguous run of tiles (measured neutral)
     h->device = desc->device;
     if (h->device >= 0) {

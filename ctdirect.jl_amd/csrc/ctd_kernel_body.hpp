@@ -1121,12 +1121,19 @@ CTD_HD bool split_eval(const BlockCtx& cx, int nthr) {
 #ifndef CTD_NT_STORE
 #define CTD_NT_STORE 0
 #endif
-CTD_HD void emit_store(double* p, double v) {
-#if CTD_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+CTD_HD void emit_store(double* p, double v, int wt = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if CTD_NT_STORE
     __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
+    return;
 #endif
+    // wt (KParams::wt_store, wave-uniform): WRITE-THROUGH store (sc1) -- the line leaves the XCD's L2 at once instead of staying dirty
+    // until the end of the kernel, where the write-back of what is left is serial with the next launch (MI355X_MICROARCH.md: a
+    // dependent kernel boundary costs + B / 6 TB/s for B dirty bytes).  Small launches gain (one round of workgroups: their stores
+    // are latency-, not throughput-bound), large ones lose (8-byte sc1 stores cost more per byte): the engine decides per handle
+    if (wt) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+#endif
+    *p = v;
 }
 
 // NB > 1 (long periods, e.g. 2904 codes per step for the 12-state quadrotor on Gauss-Legendre 3): more[q] = the code of position
@@ -1170,14 +1177,14 @@ CTD_HD void early_emit(const KParams& kp, const BlockCtx& cx, int l, const EmitP
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (s0 + u < nreg) emit_store(&out[(s0 + u) * kp.Lseg], a[u] * b[u] + beta);
+                if (s0 + u < nreg) emit_store(&out[(s0 + u) * kp.Lseg], a[u] * b[u] + beta, kp.wt_store);
         }
     } else if (l < ne + nc) {                       // a state row of c
         if (!kp.c) return;
         const int r = l - ne;
         double* out = kp.c + cx.a * (int64_t)kp.L.cb + r;
         const double* src = cx.rec + slot0 * stride + R.oR + r;
-        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.L.cb], src[s * stride]);
+        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.L.cb], src[s * stride], kp.wt_store);
     } else if (l < ne + nc + P::NV * vre) {         // d(state row) / dv of a V column
         if (!kp.vals) return;
         const int e = l - ne - nc, kk = e / vre;
@@ -1185,7 +1192,7 @@ CTD_HD void early_emit(const KParams& kp, const BlockCtx& cx, int l, const EmitP
         const double* pc = cx.rec + slot0 * stride + R.oC + code_ci(code);
         const double* pd = cx.rec + slot0 * stride + code_di(code);
         double* out = kp.vals + kp.vcol_base[kk] + cx.a * (int64_t)kp.vr + pre.ek;
-        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.vr], pc[s * stride] * pd[s * stride]);
+        for (int s = 0; s < nsteps; ++s) emit_store(&out[s * kp.vr], pc[s * stride] * pd[s * stride], kp.wt_store);
     }
 }
 
@@ -1618,12 +1625,12 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
                 const int g = (int)fast_div((uint32_t)tid, kp.div_cb), r = tid - g * cb;
                 const double* src = cx.rec + (slot0 + g) * stride + R.oR + r;
                 if (r >= kp.c_early)          // (early emission: the leading rows were stored by the lead wave)
-                    for (int s = g; s < nsteps; s += par, src += par * stride) emit_store(&out[s * cb + r], *src);
+                    for (int s = g; s < nsteps; s += par, src += par * stride) emit_store(&out[s * cb + r], *src, kp.wt_store);
             }
         } else {
             for (int r = tid; r < cb; r += nthr) {
                 const double* src = cx.rec + slot0 * stride + R.oR + r;
-                for (int s = 0; s < nsteps; ++s, src += stride) emit_store(&out[s * cb + r], *src);
+                for (int s = 0; s < nsteps; ++s, src += stride) emit_store(&out[s * cb + r], *src, kp.wt_store);
             }
         }
     }
@@ -1665,7 +1672,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int s = s0 + u * par;
-                            if (s < nreg) emit_store(&out[s * Ls + k], a[u] * b[u] + beta);
+                            if (s < nreg) emit_store(&out[s * Ls + k], a[u] * b[u] + beta, kp.wt_store);
                         }
                     }
                 }
@@ -1702,7 +1709,7 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (s0 + u < nreg) emit_store(&out[(s0 + u) * Ls + k], a[u] * b[u] + beta);
+                            if (s0 + u < nreg) emit_store(&out[(s0 + u) * Ls + k], a[u] * b[u] + beta, kp.wt_store);
                     }
                     code = nxt;
                 }
@@ -1726,14 +1733,14 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
                     const double* pd = cx.rec + (slot0 + g) * stride + code_di(code);
                     const int adv = par * stride;
                     if (k >= kp.vr_early)      // (early emission: the leading entries were stored by the lead wave)
-                        for (int s = g; s < nsteps; s += par, pc += adv, pd += adv) emit_store(&out[s * vr + k], (*pc) * (*pd));
+                        for (int s = g; s < nsteps; s += par, pc += adv, pd += adv) emit_store(&out[s * vr + k], (*pc) * (*pd), kp.wt_store);
                 }
             } else {
                 for (int k = tid; k < vr; k += nthr) {
                     const uint32_t code = codes[k];
                     const double* pc = cx.rec + slot0 * stride + R.oC + code_ci(code);
                     const double* pd = cx.rec + slot0 * stride + code_di(code);
-                    for (int s = 0; s < nsteps; ++s, pc += stride, pd += stride) emit_store(&out[s * vr + k], (*pc) * (*pd));
+                    for (int s = 0; s < nsteps; ++s, pc += stride, pd += stride) emit_store(&out[s * vr + k], (*pc) * (*pd), kp.wt_store);
                 }
             }
         }

@@ -256,7 +256,7 @@ struct KParams {
     // are fetched once per workgroup, and the x slice of the NEXT tile is loaded into registers while the current one is emitted
     // (ctd_kernels.hpp: cons_jac_body).  The edge block (block 0) is never followed by a tile: it is the longest block.
     int32_t wg_stride;
-    int32_t pad_;
+    int32_t wt_store;       // 1: the emit phase's stores are write-through (sc1): small launches, see emit_store (ctd_kernel_body.hpp)
 };
 
 }  // namespace ctd
