@@ -1222,6 +1222,11 @@ static int32_t ensure_hess(ctd_handle* h) {
     // V x V partials: added in a fixed order by a second, one-workgroup kernel (a last-workgroup finish inside the main
     // kernel measured 2-7x slower on MI355X, profiles/r01_hessian_kernel.md: device-scope release per workgroup)
     hp.debug_stop = env_int("CTD_HESS_STOP", 0);
+    {   // write-through value stores for small Hessians (as for the constraint / Jacobian kernel, ctd_create)
+        const int wt = env_int("CTD_HESS_WT", -1);
+        const double out_mb = 8.0 * (double)(h->hp.step_end - h->hp.step_begin) * (double)H.Lseg / 1.0e6;
+        hp.wt_store = wt >= 0 ? (wt ? 1 : 0) : (out_mb <= (double)std::min(16, env_int("CTD_WT_MB", 64)) ? 1 : 0);       // (sweep: gains up to ~10 MB, even at 16, losses from ~80)
+    }
     hp.xcd_remap = env_int("CTD_XCD", 0);
     if (h->hess_step) {
         HIP_TRY(h, upload(&h->d_hssrc, ssrc));
@@ -1259,6 +1264,7 @@ static int32_t ensure_hess(ctd_handle* h) {
         h->hp_step.n_edge_blocks = std::max(1, std::min(edge_step, (ntot + kStepBlock - 1) / kStepBlock));
         h->hp_step.ntiles = step_wgs;                 // (partials the finish kernel adds)
         sp.part_base = h->hp_step.n_edge_blocks;
+        sp.wt_store = hp.wt_store;
         h->hess_step_lds = std::max(hess_step_lds_bytes(snout, mo.L.nv, H.Lseg), (size_t)hess_edge_lds_doubles(h->hp_step) * sizeof(double));
     }
     h->hess_ready = true;

@@ -183,6 +183,9 @@ struct HParams {
     // from the owners' buffers; null: xu holds everything
     const XHalo* halo;
     int64_t own_lo, own_hi;
+    // 1: the value stores are write-through (sc1): small launches leave nothing dirty in the L2s for the kernel boundary
+    // (emit_store in ctd_kernel_body.hpp; profiles/r03_experiments.md)
+    int32_t wt_store;
     // diagnostics only (env CTD_HESS_STOP): 0 normal; 1 return after load, 2 after eval (ablation timing, outputs incomplete)
     int32_t debug_stop;
     // diagnostics only (ctd_hess_debug_stamps): lane 0 of every workgroup stores 5 x {100 MHz realtime, shader cycles}

@@ -654,7 +654,7 @@ CTD_HD void hess_zero_fill(const HParams& hp, const HBlockCtx& cx, int tid, int 
     double* out0 = hp.vals + hp.seg_base + (i0 - hp.reg_first) * (int64_t)hp.Lseg;
     const int n = (int)(i1 - i0) * hp.Lseg, z0 = nthr > 64 ? 64 : 0;
     if (tid >= z0)
-        for (int j = tid - z0; j < n; j += nthr - z0) out0[j] = 0.0;
+        for (int j = tid - z0; j < n; j += nthr - z0) emit_store(&out0[j], 0.0, hp.wt_store);
 }
 
 template <class P, int SC, int S>
@@ -755,7 +755,7 @@ CTD_HD int hess_wave_max(int own, int w0, int wend, const uint32_t* tptr, FastDi
 // da / db / dout: what one round adds to the two LDS offsets and to the output position (uniform).
 template <int NT>
 CTD_HD void hess_emit_steps(const double* pa, const double* pb, const uint32_t* codes, int nt, int oZero, int da, int db, double* out,
-                            int64_t dout, int nu, int n_own) {
+                            int64_t dout, int nu, int n_own, int wt) {
     constexpr int M = NT > 0 ? NT : 1;
     const double *qa[M], *qb[M];
 #pragma unroll
@@ -772,7 +772,7 @@ CTD_HD void hess_emit_steps(const double* pa, const double* pb, const uint32_t* 
             double acc = 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc = acc + a[t] * b[t];
-            out[u * dout] = acc;
+            emit_store(&out[u * dout], acc, wt);
         }
     }
 }
@@ -838,19 +838,19 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
             const uint32_t* codes = cx.terms + t0;
             double* out = out0 + (int64_t)g * hp.Lseg + e;
             switch (wmax) {
-                case 0: hess_emit_steps<0>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                case 1: hess_emit_steps<1>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                case 2: hess_emit_steps<2>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                case 3: hess_emit_steps<3>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                case 4: hess_emit_steps<4>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                case 5: hess_emit_steps<5>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
-                default: hess_emit_steps<kMaxTerms>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own); break;
+                case 0: hess_emit_steps<0>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 1: hess_emit_steps<1>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 2: hess_emit_steps<2>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 3: hess_emit_steps<3>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 4: hess_emit_steps<4>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 5: hess_emit_steps<5>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                default: hess_emit_steps<kMaxTerms>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
             }
         }
         // compact = 2: zeros at the listed positions of every step (item j = step * nz + position index)
         for (int j = tid; j < hp.nz * nreg; j += nthr) {
             const int u = (int)fast_div((uint32_t)j, hp.div_nz);
-            out0[u * (int64_t)hp.Lseg + cx.zpos[j - u * hp.nz]] = 0.0;
+            emit_store(&out0[u * (int64_t)hp.Lseg + cx.zpos[j - u * hp.nz]], 0.0, hp.wt_store);
         }
     }
     // V x V entries: one lane per (step of the tile, entry) adds up that step's terms; hess_phase_vvsum then sums the steps

@@ -78,6 +78,7 @@ struct SParams {
     double* vals;
     double* partials;               // V x V partial sums per workgroup: this launch writes rows part_base + blockIdx
     int32_t part_base;
+    int32_t wt_store;               // write-through value stores (HParams::wt_store)
 };
 
 // The workgroup is ONE wave: its LDS operations execute in program order, so the transposition through LDS needs no workgroup
@@ -227,12 +228,12 @@ __global__ __launch_bounds__(kStepBlock) __attribute__((amdgpu_waves_per_eu(CTD_
                 for (int q = 0; q < 8; ++q) t[q] = has ? t[q] : 0.0;
                 if (live) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) o[(st + q) * (int64_t)sp.Lseg] = t[q];
+                    for (int q = 0; q < 8; ++q) emit_store(&o[(st + q) * (int64_t)sp.Lseg], t[q], sp.wt_store);
                 }
             }
             for (; st < st_hi; ++st) {
                 const double t = has ? col[st * kStepBufStride] : 0.0;
-                if (live) o[st * (int64_t)sp.Lseg] = t;
+                if (live) emit_store(&o[st * (int64_t)sp.Lseg], t, sp.wt_store);
             }
         }
         step_lds_order();                                  // before the next chunk overwrites the buffer
