@@ -150,6 +150,9 @@ def _main(real_stdout):
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2_weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernel-only figures of the other configs")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time independent evaluations on two streams (overlapping kernels: keeps it out of the default run, whose rocprofv3 "
+                         "kernel statistics are the timed region's)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     PROBLEM, SCHEME = cfg["problem"], cfg["scheme"]
@@ -401,18 +404,18 @@ def _main(real_stdout):
             t_host = rate(lambda: docp.cons_jac(xh, ch, vh), 50)
             # two handles on two streams, launches alternating: independent evaluations (line-search candidates, multiple starts)
             # overlap one kernel's launch / drain with the other's evaluation.  NOT `value`: a solver's evaluations depend on each other.
-            s2 = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(s2):
+            t_two, same2 = float("nan"), None
+            s2 = torch.cuda.Stream(device=dev) if args.two_streams else None
+            if s2 is not None:
+              with torch.cuda.stream(s2):
                 d_b = ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, stream="torch")
                 c_b, v_b = torch.zeros_like(c), torch.zeros_like(vals)
                 l_b = d_b.bind_cons_jac(x_full, c_b, v_b, sync=False)
-            l_a = docp.bind_cons_jac(x_full, c, vals, sync=False)
-            t_two = rate(lambda: (l_a(), l_b()), 500) / 2.0
-            same2 = bool(torch.equal(c_b, c) and torch.equal(v_b, vals))
-            d_b.close()
-            separately = {"two_streams_alternating": {"ms_per_eval": t_two * 1e3, "evals_per_s": 1.0 / t_two, "outputs_identical": same2,
-                                                      "what": "independent evaluations of the same workload on two handles / two streams, launched alternately (never `value`)"},
-                          "same_workload_other_callbacks": {
+              l_a = docp.bind_cons_jac(x_full, c, vals, sync=False)
+              t_two = rate(lambda: (l_a(), l_b()), 500) / 2.0
+              same2 = bool(torch.equal(c_b, c) and torch.equal(v_b, vals))
+              d_b.close()
+            separately = {"same_workload_other_callbacks": {
                 "objective_device": {"ms_per_call": t_obj * 1e3, "calls_per_s": 1.0 / t_obj},
                 "gradient_device": {"ms_per_call": t_grad * 1e3, "calls_per_s": 1.0 / t_grad},
                 "whole_iteration_device": {"ms_per_call": t_iter * 1e3, "calls_per_s": 1.0 / t_iter,
@@ -420,6 +423,10 @@ def _main(real_stdout):
                 "fused_cons_jac_host_pointers_pinned": {"ms_per_call": t_host * 1e3, "calls_per_s": 1.0 / t_host,
                                                          "bytes_over_pcie": 8 * (docp.dim_NLP_variables + docp.dim_NLP_constraints + docp.nnzj),
                                                          "what": "ctd_cons_jac on page-locked host arrays: H2D x + kernel + D2H c, values (PCIe inclusive; never `value`)"}}}
+            if s2 is not None:
+                separately["two_streams_alternating"] = {
+                    "ms_per_eval": t_two * 1e3, "evals_per_s": 1.0 / t_two, "outputs_identical": same2,
+                    "what": "independent evaluations of the same workload on two handles / two streams, launched alternately (never `value`; --two-streams)"}
             del g_, f_, y_, h_
         except Exception as e:      # a secondary figure must never cost the line
             separately = {"same_workload_other_callbacks": {"error": repr(e)[:300]}}
