@@ -662,6 +662,7 @@ int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_be
     HIP_TRY(h, hipMemcpy(h->d_halo, &t, sizeof(XHalo), hipMemcpyHostToDevice));
     h->halo_host = t;
     h->kp.halo = h->d_halo;
+    h->kp.near = make_xnear(t, L.blk, L.N, L.v_off);
     return CTD_OK;
 }
 

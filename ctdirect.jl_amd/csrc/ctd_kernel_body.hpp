@@ -183,7 +183,7 @@ CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const
 CTD_HD const double* slot_base(const KParams& kp, const BlockCtx& cx, int k) {
     if (cx.direct && cx.halo) {
         const int64_t g = slot_index(kp, cx, k) * (int64_t)cx.in_stride;
-        return xsrc(cx.halo, cx.xu, g) + g;
+        return xnear(kp.near, cx.xu, g) + g;
     }
     if (cx.direct && cx.is_edge) return cx.in + kp.edge_steps[k] * (int64_t)cx.in_stride;
     return cx.in + k * cx.in_stride;
@@ -193,7 +193,7 @@ CTD_HD const double* slot_base(const KParams& kp, const BlockCtx& cx, int k) {
 CTD_HD const double* slot_next(const KParams& kp, const BlockCtx& cx, int k) {
     if (cx.direct && cx.halo) {
         const int64_t g = (slot_index(kp, cx, k) + 1) * (int64_t)cx.in_stride;
-        return xsrc(cx.halo, cx.xu, g) + g;
+        return xnear(kp.near, cx.xu, g) + g;
     }
     return slot_base(kp, cx, k) + ((cx.direct || cx.is_edge) ? kp.L.blk : cx.in_stride);     // (staged tile: the next slot)
 }
@@ -201,7 +201,7 @@ CTD_HD const double* slot_next(const KParams& kp, const BlockCtx& cx, int k) {
 CTD_HD const double* slot_prev(const KParams& kp, const BlockCtx& cx, int k) {
     if (cx.direct && cx.halo) {
         const int64_t g = (slot_index(kp, cx, k) - 1) * (int64_t)cx.in_stride;
-        return xsrc(cx.halo, cx.xu, g) + g;
+        return xnear(kp.near, cx.xu, g) + g;
     }
     return slot_base(kp, cx, k) - ((cx.direct || cx.is_edge) ? kp.L.blk : cx.in_stride);
 }
@@ -316,7 +316,7 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
             int64_t g = kp.edge_steps[k] * L.blk + o;
             if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
                 g = (kp.edge_steps[k] >= 1 ? kp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
-            cx.in[e] = (g < L.v_off) ? (cx.halo ? xsrc(cx.halo, xu, g) : xu)[g] : 0.0;
+            cx.in[e] = (g < L.v_off) ? (cx.halo ? xnear(kp.near, xu, g) : xu)[g] : 0.0;
         }
         for (int e = tid; e <= 2 * cx.nslots; e += nthr)
             cx.tau[e] = (e == 2 * cx.nslots) ? tau_global(kp, L.N) : tau_global(kp, kp.edge_steps[e >> 1] + (e & 1));
@@ -336,7 +336,7 @@ CTD_HD void phase_load(const KParams& kp, const BlockCtx& cx, const double* __re
         const int nvc = kp.L.nv * kp.vr;
         if (cx.halo) {
             // first / last tile of a shard with the iterate sharded: every element from the buffer of the shard that owns it
-            for (int e = tid; e < cnt; e += nthr) at(e) = xsrc(cx.halo, xu, g0 + e)[g0 + e];
+            for (int e = tid; e < cnt; e += nthr) at(e) = xnear(kp.near, xu, g0 + e)[g0 + e];
             if (LOAD_V && tid < kMaxNV) cx.v[tid] = (tid < P::NV) ? xu[L.v_off + tid] : 0.0;
             if (codes) {
                 uint32_t* cd = const_cast<uint32_t*>(cx.codes);

@@ -222,6 +222,7 @@ int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, c
         kp.c = c;
         kp.vals = vals;
         kp.halo = &hl;
+        kp.near = make_xnear(hl, L.blk, L.N, L.v_off);
         const double* xk = xs[k].data();
         bool ok = for_problem(problem, [&](auto tag) {
             using P = typename decltype(tag)::type;
