@@ -965,6 +965,7 @@ static int fill_obj_params(ctd_handle* h, double* f_dev, ObjParams& op) {
     op.partial = h->d_partial;
     op.out = f_dev;
     op.halo = h->kp.halo;
+    op.near = h->kp.near;
     const int64_t units = op.unit_end - op.unit_begin;
     int blocks = (int)((units + 255) / 256);
     if (blocks > h->obj_blocks) blocks = h->obj_blocks;
@@ -1284,6 +1285,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
     hp.obj_weight = obj_weight;
     hp.vals = vals_dev;
     hp.halo = h->kp.halo;
+    hp.near = h->kp.near;
     if (hp.halo) { hp.own_lo = h->halo_host.vbegin[h->halo_host.self]; hp.own_hi = h->halo_host.vbegin[h->halo_host.self + 1]; }
     hipError_t e = hipErrorInvalidValue;
     if (h->rt) {
@@ -1297,7 +1299,7 @@ static int32_t enqueue_hess(ctd_handle* h, const double* x_dev, const double* y_
             HParams he = h->hp_step;
             he.obj_weight = obj_weight;
             he.vals = vals_dev;
-            he.halo = hp.halo; he.own_lo = hp.own_lo; he.own_hi = hp.own_hi;       // (its edge blocks; a step lane reads its own step only)
+            he.halo = hp.halo; he.near = hp.near; he.own_lo = hp.own_lo; he.own_hi = hp.own_hi;       // (its edge blocks; a step lane reads its own step only)
             SParams sp = h->sp;
             sp.obj_weight = obj_weight;
             sp.vals = vals_dev;
@@ -1364,6 +1366,7 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
     ip.kp = h->kp;       // (Layout is read from kp / hp / gp / op by the respective bodies)
     ip.hp = h->hp;
     ip.hp.halo = h->kp.halo;
+    ip.hp.near = h->kp.near;
     if (ip.hp.halo) { ip.hp.own_lo = h->halo_host.vbegin[h->halo_host.self]; ip.hp.own_hi = h->halo_host.vbegin[h->halo_host.self + 1]; }
     // The fused grid always carries the TILE body of the Hessian, also on handles whose stand-alone hess_coord runs the
     // lane-per-step kernel (Gauss-Legendre 2 from 9 000 steps, 3 from 28 000: ensure_hess).  Measured (CTD_ITER_HESS_APART=1: fused

@@ -182,6 +182,7 @@ struct HParams {
     // previous shard's last block / the next shard's first node of a boundary tile, X_1 / X_{N+1} of the edge blocks -- are fetched
     // from the owners' buffers; null: xu holds everything
     const XHalo* halo;
+    XNear near;
     int64_t own_lo, own_hi;
     // 1: the value stores are write-through (sc1): small launches leave nothing dirty in the L2s for the kernel boundary
     // (emit_store in ctd_kernel_body.hpp; profiles/r03_experiments.md)

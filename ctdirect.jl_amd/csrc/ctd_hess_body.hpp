@@ -190,7 +190,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
             int64_t g = hp.edge_steps[k] * L.blk + o;
             if (o >= L.blk + L.n + L.m)        // control of the previous step (own step for step 0): implicit Euler's path control
                 g = (hp.edge_steps[k] >= 1 ? hp.edge_steps[k] - 1 : 0) * (int64_t)L.blk + L.n + (o - (L.blk + L.n + L.m));
-            cx.in[e] = (g < L.v_off) ? (hp.halo ? xsrc(hp.halo, xu, g) : xu)[g] : 0.0;
+            cx.in[e] = (g < L.v_off) ? (hp.halo ? xnear(hp.near, xu, g) : xu)[g] : 0.0;
         }
         for (int e = tid; e < 2 * cx.nslots * L.cb; e += nthr) {
             const int blk2 = e / L.cb, r = e - blk2 * L.cb;
@@ -248,7 +248,7 @@ CTD_HD void hess_phase_load(const HParams& hp, const HBlockCtx& cx, const double
         if (hp.halo && (g0 < hp.own_lo || g1 > hp.own_hi))
             for (int e = tid; e < cnt; e += nthr) {
                 const int64_t g = g0 + e;
-                if (g < hp.own_lo || g >= hp.own_hi) dst[e] = xsrc(hp.halo, xu, g)[g];
+                if (g < hp.own_lo || g >= hp.own_hi) dst[e] = xnear(hp.near, xu, g)[g];
             }
         return;
     }

@@ -175,6 +175,7 @@ struct ObjParams {
     // sharded iterate read in place (ctd_set_x_shards): the next shard's first node (midpoint / Euler units of a shard's last step)
     // and X_1 / X_{N+1} of the Mayer term come from the owners' buffers; null: xu holds everything
     const XHalo* halo;
+    XNear near;             // (the same buffers in the kernel arguments: one memory round trip per remote entry)
 };
 
 template <class P> __device__ double obj_time(const ObjParams& op, const double* v, int64_t i) {
@@ -191,7 +192,7 @@ __device__ double lagrange_unit(const ObjParams& op, const double* __restrict__ 
     const double* base = xu + i * (int64_t)L.blk;
     // X_{i+1} sits behind the step's block -- in the next shard's buffer for the last step of a shard of a sharded iterate
     const int64_t gn = (i + 1) * (int64_t)L.blk;
-    const double* nxt = ((op.halo && i + 1 >= op.unit_end) ? xsrc(op.halo, xu, gn) : xu) + gn;      // (only the shard's last unit looks at the table)
+    const double* nxt = ((op.halo && i + 1 >= op.unit_end) ? xnear(op.near, xu, gn) : xu) + gn;      // (only the shard's last unit looks at the table)
     double x[n > 0 ? n : 1], u[m > 0 ? m : 1];
     if (SC == SC_TRAPEZE) {            // trapeze.jl:78-110: node weights h_1/2, (t_{i+1}-t_{i-1})/2, h_N/2
         double w;
@@ -283,8 +284,8 @@ __device__ __forceinline__ void obj_finish_body(const ObjParams& op, const doubl
         constexpr int n = P::NX, nv = P::NV;
         double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1];
         const int64_t gf = op.L.N * (int64_t)op.L.blk;
-        const double* xa = op.halo ? xsrc(op.halo, xu, 0) : xu;
-        const double* xb = op.halo ? xsrc(op.halo, xu, gf) : xu;
+        const double* xa = op.halo ? xnear(op.near, xu, 0) : xu;
+        const double* xb = op.halo ? xnear(op.near, xu, gf) : xu;
         for (int c = 0; c < n; ++c) { x0[c] = xa[c]; xf[c] = xb[gf + c]; }
         for (int k = 0; k < nv; ++k) v[k] = xu[op.L.v_off + k];
         mayer = P::template mayer<double>(x0, xf, v);
