@@ -265,7 +265,7 @@ std::vector<std::string> jit_first_exprs(int sc, int s) {
             "ctd::grad_finish_kernel<" + P + ">"};
 }
 std::vector<std::string> jit_hess_exprs(int sc, int s) {
-    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string(sc == SC_IRK ? s : 1);
+    const std::string P = "ctd::UserOCP", a = std::to_string(sc), b = std::to_string((sc == SC_IRK || sc == SC_MIDPOINT) && s > 0 ? s : 1);
     return {"ctd::hess_kernel<" + P + ", " + a + ", " + b + ", false>", "ctd::hess_finish_kernel<" + P + ">"};
 }
 
@@ -291,7 +291,7 @@ static int32_t jit_load_first(ctd_handle* h) {
 static int32_t jit_load_hess(ctd_handle* h) {
     std::string code, err;
     std::vector<std::string> names;
-    int32_t st = jit_compile(*h->rt, "ctd_hess_kernels.hpp", jit_hess_exprs(h->model.L.sc, h->model.L.s), "fast", code, names, err);
+    int32_t st = jit_compile(*h->rt, "ctd_hess_kernels.hpp", jit_hess_exprs(h->model.L.sc, h->model.L.sc == SC_MIDPOINT ? h->model.L.cs : h->model.L.s), "fast", code, names, err);
     if (st) return fail(h, st, err);
     HIP_TRY(h, hipModuleLoadData(&h->jit_hmod, code.data()));
     HIP_TRY(h, hipModuleGetFunction(&h->f_hess, h->jit_hmod, names[0].c_str()));
@@ -491,7 +491,8 @@ int32_t ctd_jit_check(int32_t problem_id, int32_t scheme) {
     if (!ro) return fail(nullptr, CTD_EPROBLEM, "ctd_jit_check: not a run-time problem id");
     if (scheme < 0 || scheme > 8) return fail(nullptr, CTD_ESCHEME, "Unknown discretization method");
     const int sc = scheme == 0 ? SC_TRAPEZE : ((scheme == 1 || scheme >= 7) ? SC_MIDPOINT : SC_IRK);
-    const int s = (scheme < 2 || scheme >= 7) ? 0 : (scheme <= 4 ? scheme - 1 : scheme - 3);
+    int s = (scheme < 2 || scheme >= 7) ? 0 : (scheme <= 4 ? scheme - 1 : scheme - 3);
+    if (scheme == 1) s = env_int("CTD_JIT_CHECK_CS", 0);       // midpoint: controls per step of the kernels to build (default 1)
     std::string code, err;
     std::vector<std::string> names;
     int32_t st = jit_compile(*ro, "ctd_kernels.hpp", jit_first_exprs(sc, s), "off", code, names, err);
@@ -1162,7 +1163,7 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_ready) return CTD_OK;
     const Model& mo = h->model;
     const HessModel& H = mo.H;
-    if (!H.values) return fail(h, CTD_EPATTERN, "hess_coord is not available with control_steps > 1 (hess_structure is); use a quasi-Newton solver or control_steps = 1");
+    if (!H.values) return fail(h, CTD_EPATTERN, "hess_coord is not available with control_steps > 3 (hess_structure is); use a quasi-Newton solver or fewer controls per step");
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     h->hess_tile = env_int("CTD_HESS_TILE", 0);
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);

@@ -31,7 +31,7 @@ enum { HC_ONE = 0, HC_HALF = 1,
 enum { HF_ONE = 0, HF_H = 1, HF_DH = 2 };
 
 constexpr int kMaxPairs = 64;          // distinct coefficient products C[c1] * C[c2] the term tables may use
-constexpr int kMaxTerms = 6;           // terms per output entry (S stage points + path point + state-equation row)
+constexpr int kMaxTerms = 7;           // terms per output entry (S stage points of the step and of the one before + path point / state-equation row)
 constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
 
 // ---- per-slot LDS record (doubles) ---------------------------------------------------------------------

@@ -32,7 +32,8 @@ template <class P> struct HessK { static constexpr int value = (P::NX >= 8) ? 1 
 
 template <class P, int SC, int S> struct HRL {
     static constexpr HessRecLayout R =
-        make_hess_layout(P::NX, P::NU, P::NV, P::NPATH, SC, SC == SC_IRK ? S : 0, (P::IT0 >= 0) || (P::ITF >= 0));
+        make_hess_layout(P::NX, P::NU, P::NV, P::NPATH, SC, (SC == SC_IRK || (SC == SC_MIDPOINT && S > 1)) ? S : 0,
+                         (P::IT0 >= 0) || (P::ITF >= 0));      // (midpoint, S > 1: controls per step, one stage-type point each)
 };
 
 struct HBlockCtx {
@@ -331,10 +332,16 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
 #pragma unroll
     for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau1) - dt_of(q[i], tau0);
     const double hda = dt_of(p, tau1) - dt_of(p, tau0);
-    const T hh = hess_seed<K>(h, hda, sb);
     double hdb[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) hdb[i] = sb[i];
+    // midpoint with S > 1 controls per step: point j integrates over h / S (midpoint.jl:106,134)
+    constexpr double hs = (SC == SC_MIDPOINT && S > 1) ? 1.0 / (double)S : 1.0;
+    if (SC == SC_MIDPOINT && S > 1) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) sb[i] = hs * hdb[i];
+    }
+    const T hh = hess_seed<K>(hs * h, hs * hda, sb);
 
     // evaluation time
     T t;
@@ -380,7 +387,7 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
     T u[m > 0 ? m : 1];
 #pragma unroll
     for (int b = 0; b < m; ++b) {
-        const double uv = (SC == SC_IRK && L.stagewise) ? base[n + j * m + b] : base[n + b];
+        const double uv = ((SC == SC_IRK && L.stagewise) || (SC == SC_MIDPOINT && S > 1)) ? base[n + j * m + b] : base[n + b];
 #pragma unroll
         for (int i = 0; i < K; ++i) sb[i] = unit(q[i], n + b);
         u[b] = hess_seed<K>(uv, unit(p, n + b), sb);
@@ -404,7 +411,18 @@ CTD_HD void hess_eval_stage(const HParams& hp, const HBlockCtx& cx, int k, int j
         T inner(0.0);
 #pragma unroll
         for (int r = 0; r < n; ++r) inner = inner + f[r] * (-y[r]);
-        if (P::HAS_LAGRANGE) inner = inner + P::template lagrange<T>(t, x, u, v) * hp.obj_weight;
+        if (P::HAS_LAGRANGE) {
+            if (SC == SC_MIDPOINT && S > 1) {
+                // the quadrature point of control j sits at t_i + (j - 1/2) h / S (midpoint.jl:110); the dynamics keep the step's midpoint (:57)
+                const double wj = ((double)j + 0.5) * hs;
+#pragma unroll
+                for (int i = 0; i < K; ++i) sb[i] = dt_of(q[i], tau0) + wj * hdb[i];
+                const T tl = hess_seed<K>(tA + wj * h, dt_of(p, tau0) + wj * hda, sb);
+                inner = inner + P::template lagrange<T>(tl, x, u, v) * hp.obj_weight;
+            } else {
+                inner = inner + P::template lagrange<T>(t, x, u, v) * hp.obj_weight;
+            }
+        }
         phi = hh * inner;
     } else {
         // node s is shared by step s-1 (length hm) and step s (length hh); the clamped tau makes the missing one 0
@@ -445,6 +463,12 @@ template <class P> struct SymStage {
     CTD_HD static void mid(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_mid(p, HD); }
     CTD_HD static void trap(const double* p, double* HD) { if constexpr (P::HAS_SYM) P::stage_sym_trap(p, HD); }
 };
+
+// Whether the stage-type points of (P, SC, S) run the symbolic functions.  Not with several controls per step AND a Lagrange
+// cost: that quadrature point has a time of its own (midpoint.jl:110) where the generated function has one evaluation time.
+template <class P, int SC, int S> constexpr bool hess_uses_sym() {
+    return SymStage<P>::value && !(SC == SC_MIDPOINT && S > 1 && P::HAS_LAGRANGE);
+}
 
 // The same stage-type point for an OCP that carries symbolically differentiated stage functions (run-time OCPs,
 // ctd_sym.hpp / ctd_jit.cpp): ONE lane fills the parameters of the point (SymPrm, ctd_hess.hpp) and the generated
@@ -520,6 +544,11 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
             SymStage<P>::trap(prm, HD);
         } else {
             const double wa = L.euler == 0 ? 0.5 : (L.euler == 1 ? 1.0 : 0.0), wb = 1.0 - wa;   // weights of (t_i, X_i) / (t_i+1, X_i+1)
+            if (S > 1) {       // several controls per step: point j integrates over h / S with the control U^j (midpoint.jl:134,146-153)
+                prm[Q.H0] = h / (double)S;
+#pragma unroll
+                for (int kk = 0; kk < nv; ++kk) prm[Q.HD + kk] = (d1[kk] - d0[kk]) / (double)S;
+            }
             prm[Q.T0] = wa * tA + wb * tB;
 #pragma unroll
             for (int kk = 0; kk < nv; ++kk) prm[Q.TD + kk] = wa * d0[kk] + wb * d1[kk];
@@ -530,7 +559,7 @@ CTD_HD void hess_eval_stage_sym(const HParams& hp, const HBlockCtx& cx, int k, i
                 prm[Q.W + r] = -y[r];
             }
 #pragma unroll
-            for (int b = 0; b < m; ++b) prm[Q.U0 + b] = base[n + b];
+            for (int b = 0; b < m; ++b) prm[Q.U0 + b] = S > 1 ? base[n + j * m + b] : base[n + b];
             prm[Q.CL] = P::HAS_LAGRANGE ? hp.obj_weight : 0.0;
             SymStage<P>::mid(prm, HD);
         }
@@ -677,7 +706,7 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
         const int k = (int)fast_div((uint32_t)w, hp.div_stage_tasks);
         const int r = w - k * R.S * hp.ntask;
         const int j = (int)fast_div((uint32_t)r, hp.div_ntask);
-        if constexpr (SymStage<P>::value) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
+        if constexpr (hess_uses_sym<P, SC, S>()) hess_eval_stage_sym<P, SC, S>(hp, cx, k, j);
         else hess_eval_stage<P, SC, S>(hp, cx, k, j, cx.tasks[r - j * hp.ntask]);
     }
     if (PATH_PT) {
@@ -844,6 +873,7 @@ CTD_HD void hess_phase_emit(const HParams& hp, const HBlockCtx& cx, int block, i
                 case 3: hess_emit_steps<3>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
                 case 4: hess_emit_steps<4>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
                 case 5: hess_emit_steps<5>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
+                case 6: hess_emit_steps<6>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
                 default: hess_emit_steps<kMaxTerms>(pa, pb, codes, nt, R.oZero, da, db, out, dout, nu, n_own, hp.wt_store); break;
             }
         }

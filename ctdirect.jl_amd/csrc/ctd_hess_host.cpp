@@ -335,7 +335,7 @@ Var decode_var(const Layout& L, int64_t idx) {
     const int q = (int)(idx - s * L.blk);
     if (q < L.n) return Var{VK_X, s, 0, q};
     if (q < L.n + L.cu) {
-        if (L.stagewise) return Var{VK_U, s, (q - L.n) / L.m, (q - L.n) % L.m};
+        if (L.stagewise || L.cs > 1) return Var{VK_U, s, (q - L.n) / L.m, (q - L.n) % L.m};      // (l: stage / control of the step)
         return Var{VK_U, s, -1, q - L.n};
     }
     return Var{VK_K, s, (q - L.n - L.cu) / L.n, (q - L.n - L.cu) % L.n};
@@ -356,7 +356,7 @@ Dir map_stage(const Layout& L, int64_t s, int j, const Var& v) {
         if (L.euler == 0 && v.kind == VK_X && (v.s == s || v.s == s + 1)) return Dir{true, v.c, HC_HALF};
         if (L.euler == 1 && v.kind == VK_X && v.s == s) return Dir{true, v.c, HC_ONE};          // f(t_i, X_i, U_i)
         if (L.euler == 2 && v.kind == VK_X && v.s == s + 1) return Dir{true, v.c, HC_ONE};      // f(t_{i+1}, X_{i+1}, U_i)
-        if (v.kind == VK_U && v.s == s) return Dir{true, n + v.c, HC_ONE};
+        if (v.kind == VK_U && v.s == s && (L.cs == 1 || v.l == j)) return Dir{true, n + v.c, HC_ONE};     // cs > 1: point j reads U_s^j
         return Dir{false, 0, 0};
     }
     if (v.s != s) return Dir{false, 0, 0};
@@ -368,6 +368,7 @@ Dir map_path(const Layout& L, int64_t xs, int64_t us, const Var& v) {
     const int n = L.n, m = L.m;
     if (v.kind == VK_V) return Dir{true, n + m + v.c, HC_ONE};
     if (v.kind == VK_X && v.s == xs) return Dir{true, v.c, HC_ONE};
+    if (v.kind == VK_U && v.s == us && L.cs > 1) return v.l == 0 ? Dir{true, n + v.c, HC_ONE} : Dir{false, 0, 0};   // first control of the step
     if (v.kind == VK_U && v.s == us) return Dir{true, n + v.c, L.stagewise ? HC_B + v.l : HC_ONE};
     return Dir{false, 0, 0};
 }
@@ -503,12 +504,13 @@ int build_hess_model(Model& mo, std::string& err) {
     const Layout& L = mo.L;
     HessModel& H = mo.H;
     const int64_t N = L.N;
-    H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, L.s, L.free_time != 0);
-    if (L.cs > 1) {
-        // control_steps > 1 (direct shooting layout): hess_structure! is served -- the blocks of DOCP_Hessian_pattern
-        // (midpoint.jl:240-300 are written in terms of the step block, whatever its size; with the optimized mode the same
-        // blocks: a superset of what a tracer would keep) -- hess_coord! is not: its evaluation points are not restated for
-        // several controls per step (ctd_hess_coord* return CTD_EPATTERN).
+    // (midpoint with control_steps > 1: one stage-type point per control of the step, midpoint.jl:61-69,108-112)
+    H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, (L.sc == SC_MIDPOINT && L.cs > 1) ? L.cs : L.s, L.free_time != 0);
+    if (2 * L.cs + 1 > kMaxTerms && L.cs > 1) {
+        // more than 3 controls per step (run-time OCPs; an X x X entry would sum 2 control_steps + 1 terms): hess_structure! is
+        // served -- the blocks of DOCP_Hessian_pattern (midpoint.jl:240-300 are written in terms of the step block, whatever its
+        // size; with the optimized mode the same blocks: a superset of what a tracer would keep) -- hess_coord! is refused
+        // (ctd_hess_coord* return CTD_EPATTERN).
         H.values = false;
         build_hess_tail(mo);
         H.reg_first = H.reg_last = N;
@@ -707,6 +709,7 @@ int build_hess_model(Model& mo, std::string& err) {
     {
         const RtOcp* ro = runtime_ocp(mo.problem);
         H.sym_stage = (ro && ro->has_sym) || registry_has_sym(mo.problem);
+        if (L.cs > 1 && mo.info.lagrange) H.sym_stage = false;      // hess_uses_sym (ctd_hess_body.hpp)
         if (H.sym_stage) H.tasks.assign(1, 0u);
     }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);

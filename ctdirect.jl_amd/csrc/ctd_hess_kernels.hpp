@@ -139,7 +139,12 @@ hipError_t launch_hess(const HParams& hp, const double* xu, const double* y, siz
                        hipEvent_t e1) {
     const int sc = hp.L.sc;
     if (sc == SC_TRAPEZE) return launch_hess_variant<P, SC_TRAPEZE, 1>(hp, xu, y, lds_bytes, st, e0, e1);
-    if (sc == SC_MIDPOINT) return launch_hess_variant<P, SC_MIDPOINT, 1>(hp, xu, y, lds_bytes, st, e0, e1);
+    if (sc == SC_MIDPOINT) {      // S: controls per step (registry problems 1 - 3, as the constraint / Jacobian kernels)
+        if (hp.L.cs == 2) return launch_hess_variant<P, SC_MIDPOINT, 2>(hp, xu, y, lds_bytes, st, e0, e1);
+        if (hp.L.cs == 3) return launch_hess_variant<P, SC_MIDPOINT, 3>(hp, xu, y, lds_bytes, st, e0, e1);
+        if (hp.L.cs > 3) return hipErrorInvalidValue;
+        return launch_hess_variant<P, SC_MIDPOINT, 1>(hp, xu, y, lds_bytes, st, e0, e1);
+    }
     if (hp.L.s == 1) return launch_hess_variant<P, SC_IRK, 1>(hp, xu, y, lds_bytes, st, e0, e1);
     if (hp.L.s == 2) return launch_hess_variant<P, SC_IRK, 2>(hp, xu, y, lds_bytes, st, e0, e1);
     return launch_hess_variant<P, SC_IRK, 3>(hp, xu, y, lds_bytes, st, e0, e1);

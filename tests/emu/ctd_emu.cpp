@@ -301,7 +301,11 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {
             case SC_TRAPEZE: run_hess_blocks<P, SC_TRAPEZE, 1>(hp, x, y, nthr); break;
-            case SC_MIDPOINT: run_hess_blocks<P, SC_MIDPOINT, 1>(hp, x, y, nthr); break;
+            case SC_MIDPOINT:
+                if (mo.L.cs == 2) run_hess_blocks<P, SC_MIDPOINT, 2>(hp, x, y, nthr);
+                else if (mo.L.cs == 3) run_hess_blocks<P, SC_MIDPOINT, 3>(hp, x, y, nthr);
+                else run_hess_blocks<P, SC_MIDPOINT, 1>(hp, x, y, nthr);
+                break;
             default:
                 if (mo.L.s == 1) run_hess_blocks<P, SC_IRK, 1>(hp, x, y, nthr);
                 else if (mo.L.s == 2) run_hess_blocks<P, SC_IRK, 2>(hp, x, y, nthr);

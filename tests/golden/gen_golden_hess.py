@@ -120,10 +120,10 @@ def multipliers(ncon):
 OBJ_WEIGHT = 0.75
 
 
-def run_case(tag, prob, scheme, N=None, time_grid=None):
+def run_case(tag, prob, scheme, N=None, time_grid=None, control_steps=1):
     # inputs: identical to the first-order fixture of the same tag (gen_golden.fill_inputs is deterministic)
     gg.Du, gg.dexp, gg.dsin, gg.dcos = gg_first_order
-    d = gg.Docp(prob, scheme, N=N, time_grid=time_grid)
+    d = gg.Docp(prob, scheme, N=N, time_grid=time_grid, control_steps=control_steps)
     xu = gg.fill_inputs(d)
     gg.Du, gg.dexp, gg.dsin, gg.dcos = Du2, dexp2, dsin2, dcos2
     z = [Du2(mpf(x), {j: mpf(1)}) for j, x in enumerate(xu)]
@@ -136,6 +136,7 @@ def run_case(tag, prob, scheme, N=None, time_grid=None):
         "tag": tag, "problem": prob.name, "scheme": scheme, "grid_size": d.N,
         "time_grid": [gg.hexf(t) for t in time_grid] if time_grid is not None else None,
         "xu": [gg.hexf(x) for x in xu], "y": [gg.hexf(v) for v in y], "obj_weight": OBJ_WEIGHT,
+        **({"control_steps": control_steps} if control_steps != 1 else {}),
         "hess_nonzeros": entries,
         "note": "lower triangle (row >= col, 0-based) of obj_weight*d2f + sum y_i d2c_i; correctly rounded doubles "
                 "(C99 hex) of a 50-digit mpmath evaluation",
@@ -149,7 +150,25 @@ def run_case(tag, prob, scheme, N=None, time_grid=None):
 gg_first_order = (gg.Du, gg.dexp, gg.dsin, gg.dcos)
 
 
+def main_control_steps():
+    """control_steps > 1 (direct shooting layout, midpoint scheme; same tags and inputs as gen_golden.main_control_steps):
+    `python gen_golden_hess.py cs` writes only these"""
+    try:
+        run_case("cs2_goddard_midpoint_N4", gg.Goddard(), "midpoint", N=4, control_steps=2)
+        run_case("cs3_goddard_midpoint_nonuniform", gg.Goddard(), "midpoint", time_grid=[0.0, 0.1, 0.45, 1.0], control_steps=3)
+        run_case("cs2_dip_midpoint_N4", gg.DoubleIntegratorPath(), "midpoint", N=4, control_steps=2)
+        run_case("cs3_dip_midpoint_nonuniform", gg.DoubleIntegratorPath(), "midpoint", time_grid=[0.0, 0.3, 0.5, 0.6, 1.0], control_steps=3)
+        run_case("cs2_goddard_all_midpoint_N3", gg.GoddardAll(), "midpoint", N=3, control_steps=2)
+        run_case("cs3_freet0tf_midpoint_N3", gg.DoubleIntegratorFreeT0Tf(), "midpoint", N=3, control_steps=3)
+        run_case("cs2_quadrotor_midpoint_N2", gg.Quadrotor8(), "midpoint", N=2, control_steps=2)
+        run_case("cs3_quadrotor_midpoint_N2", gg.Quadrotor8(), "midpoint", N=2, control_steps=3)
+    finally:
+        gg.Du, gg.dexp, gg.dsin, gg.dcos = gg_first_order
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cs":
+        return main_control_steps()
     try:
         run_case("goddard_midpoint_N4", gg.Goddard(), "midpoint", N=4)
         run_case("goddard_trapeze_N4", gg.Goddard(), "trapeze", N=4)
@@ -183,6 +202,7 @@ def main():
         run_case("freet0tf_euler_implicit_N3", gg.DoubleIntegratorFreeT0Tf(), "euler_implicit", N=3)
     finally:
         gg.Du, gg.dexp, gg.dsin, gg.dcos = gg_first_order
+    main_control_steps()
 
 
 if __name__ == "__main__":

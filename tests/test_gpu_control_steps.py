@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import ctdirect_jl_amd as ct
-from helpers import TOL, bench_inputs, describe, relerr
+from helpers import TOL, bench_inputs, describe, hess_err, relerr
 
 pytestmark = pytest.mark.gpu
 SENT = 777.125
@@ -56,11 +56,22 @@ def test_control_steps_parity(oracle_lib, prob, cs):
                 c3, v3, f3 = torch.full_like(c, SENT), torch.full_like(v, SENT), torch.full((1,), SENT, dtype=torch.float64, device="cuda")
                 d.eval_all(xd, None, 1.0, f3, g3, c3, v3, None, sync=True)
                 assert torch.equal(c3, c) and torch.equal(v3, v) and abs(float(f3[0]) - f) <= TOL * max(1.0, abs(f))
-                # hess_structure is served, hess_coord is refused (never a wrong value)
-                assert d.nnzh == len(o.hess_pattern()[1])
-                with pytest.raises(ct.CTDirectError) as e:
-                    d.hess_coord(xd, torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda"), 1.0)
-                assert e.value.status == ct._lib.CTD_EPATTERN
+            # hess_structure / hess_coord: one stage-type point per control of the step (all three patterns; the optimized one is
+            # the oracle's traced pattern), every entry written, 1e-10 on the backward-error scale of helpers.hess_err
+            hp, hr = o.hess_pattern()
+            hp2, hr2 = ct.DOCP_Hessian_pattern(d)
+            assert d.nnzh == len(hr) and np.array_equal(hp, hp2) and np.array_equal(hr, hr2), (N, name)
+            y = rng.standard_normal(d.dim_NLP_constraints)
+            hv = torch.full((d.nnzh,), SENT, dtype=torch.float64, device="cuda")
+            d.hess_coord(xd, torch.from_numpy(y).cuda(), 0.7, hv)
+            assert not bool((hv == SENT).any())
+            want, dropped = o.hess_coord(x, y, 0.7, return_dropped=True)
+            assert dropped == (0, 0)
+            assert hess_err(o, x, y, 0.7, hv.cpu().numpy(), ref=want) <= TOL, (N, name)
+            if mode == 1:       # the one-call iteration with the Hessian: same values
+                h3 = torch.full_like(hv, SENT)
+                d.eval_all(xd, torch.from_numpy(y).cuda(), 0.7, None, None, None, None, h3, sync=True)
+                assert torch.equal(h3, hv)
             d.close()
 
 
@@ -98,4 +109,27 @@ def test_control_steps_runtime_ocp_any_count(oracle_lib):
         assert relerr(c.cpu().numpy(), o.constraints(x)) <= TOL and relerr(v.cpu().numpy(), o.jac_coord(x)) <= TOL
         f = o.objective(x)
         assert abs(d.obj(xd) - f) <= TOL * max(1.0, abs(f)) and relerr(d.grad(xd).cpu().numpy(), o.gradient(x)) <= TOL
+        # hess_coord serves up to 3 controls per step (an X x X entry sums 2 control_steps + 1 terms); beyond: structure only,
+        # the values are refused -- never a wrong value
+        assert d.nnzh == len(o.hess_pattern()[1])
+        with pytest.raises(ct.CTDirectError) as e:
+            d.hess_coord(xd, torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda"), 1.0)
+        assert e.value.status == ct._lib.CTD_EPATTERN
         d.close()
+    # 2 and 3 controls per step: the Hessian kernel hiprtc builds for the run-time OCP (symbolic stage functions; the twin with a
+    # Lagrange cost takes the second-order numbers, its quadrature points have times of their own)
+    for name, cs in (("goddard", 2), ("goddard", 3), ("double_integrator_path", 3)):
+        rt = jit_defs.twin(name)
+        N = 40
+        o = oracle_lib.OracleDOCP(name, "midpoint", N, control_steps=cs)
+        x = _inputs(o, name, cs, cs)
+        y = np.random.default_rng(cs).standard_normal(o.dim_NLP_constraints)
+        for mode, pname in ((0, "manual"), (2, "optimized")):
+            o.set_pattern_mode(mode)
+            d = ct.DOCP(rt, N, "midpoint", pattern=pname, device=0, control_steps=cs)
+            hp, hr = o.hess_pattern()
+            hp2, hr2 = ct.DOCP_Hessian_pattern(d)
+            assert np.array_equal(hp, hp2) and np.array_equal(hr, hr2)
+            hv = d.hess_coord(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), 0.7)
+            assert hess_err(o, x, y, 0.7, hv.cpu().numpy()) <= TOL, (name, cs, pname)
+            d.close()

@@ -69,14 +69,16 @@ def test_structural_hessian_pattern_adds_final_state_x_variable():
 def test_emulated_hessian_kernel_matches_fixture(path):
     g = load_hess_golden(path)
     pid, sid = ct.PROBLEMS[g["problem"]], ct.SCHEMES[g["scheme"]]
-    cp, rv = emu.hess_csc(pid, sid, 0, g["grid_size"], g["time_grid"])
-    want, outside = hess_on_pattern(g["H"], cp, rv)
-    # (the Euler patterns of the reference, euler.jl:270-355, leave some true nonzeros out: test_oracle_goldens.py)
-    assert not outside or g["scheme"].startswith("euler")
-    for tile, nthr in ((0, 64), (1, 3), (3, 17)):
-        vals = emu.hess(pid, sid, 0, g["grid_size"], g["xu"], g["y"], g["obj_weight"], g["time_grid"], tile=tile, nthr=nthr)
-        assert not np.any(vals == 666.666)               # every entry of the pattern written
-        assert relerr(vals, want) <= TOL
+    with emu.control_steps(g.get("control_steps", 1)):
+        for mode in (0, 2) if "control_steps" in g else (0,):    # (several controls per step: also on the optimized pattern)
+            cp, rv = emu.hess_csc(pid, sid, mode, g["grid_size"], g["time_grid"])
+            want, outside = hess_on_pattern(g["H"], cp, rv)
+            # (the Euler patterns of the reference, euler.jl:270-355, leave some true nonzeros out: test_oracle_goldens.py)
+            assert not outside or g["scheme"].startswith("euler")
+            for tile, nthr in ((0, 64), (1, 3), (3, 17)):
+                vals = emu.hess(pid, sid, mode, g["grid_size"], g["xu"], g["y"], g["obj_weight"], g["time_grid"], tile=tile, nthr=nthr)
+                assert not np.any(vals == 666.666)               # every entry of the pattern written
+                assert relerr(vals, want) <= TOL
 
 
 @pytest.mark.parametrize("prob,sch", PAIRS, ids=[f"{p}-{s}" for p, s in PAIRS])

@@ -56,6 +56,14 @@ def test_kernels_compile_for_gfx950_without_a_gpu(sch):
     ct.jit_check(name, sch)
 
 
+def test_kernels_with_several_controls_per_step_compile_for_gfx950(monkeypatch):
+    """control_steps = 3: the midpoint kernels (first order and Hessian) of a run-time OCP with the symbolic stage functions
+    (Mayer cost) and of one with a Lagrange cost (second-order numbers, quadrature points with times of their own)"""
+    monkeypatch.setenv("CTD_JIT_CHECK_CS", "3")
+    ct.jit_check(jit_defs.twin("goddard"), "midpoint")
+    ct.jit_check(jit_defs.twin("double_integrator_path"), "midpoint")
+
+
 def test_compute_without_device_fails_loudly_for_runtime_ocps():
     d = ct.DOCP(jit_defs.twin("goddard"), 10, "midpoint", device=-1)
     with pytest.raises(ct.CTDirectError) as e:

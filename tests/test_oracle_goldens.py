@@ -1,5 +1,7 @@
 """CPU tests: the oracle (oracle/ctd_oracle.cpp) against every known-answer value the reference's own tests hold
 for this path and against the 50-digit mpmath fixtures in tests/golden/."""
+import os
+
 import numpy as np
 import pytest
 
@@ -177,9 +179,10 @@ def test_oracle_hessian_matches_mpmath_fixture(oracle_lib, path):
     """hess_coord! of the oracle (sparse second-order sweep in double) against the 50-digit Hessian of the Lagrangian,
     on the lower triangle of DOCP_Hessian_pattern; the reference's pattern holds every true nonzero of these cases."""
     g = load_hess_golden(path)
-    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"])
-    first = load_golden(path.replace("hess_", ""))
-    assert np.array_equal(first["xu"], g["xu"])           # same input vector as the first-order fixture of the tag
+    d = oracle_lib.OracleDOCP(g["problem"], g["scheme"], g["grid_size"], time_grid=g["time_grid"], control_steps=g.get("control_steps", 1))
+    if os.path.exists(path.replace("hess_", "")):
+        first = load_golden(path.replace("hess_", ""))
+        assert np.array_equal(first["xu"], g["xu"])       # same input vector as the first-order fixture of the tag
     colptr, rowval = d.hess_pattern()
     assert len(rowval) == d.hess_nnz()[1]
     for j in range(d.dim_NLP_variables):                  # lower triangle, rows sorted
