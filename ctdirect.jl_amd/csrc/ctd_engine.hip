@@ -1163,7 +1163,6 @@ static int32_t ensure_hess(ctd_handle* h) {
     if (h->hess_ready) return CTD_OK;
     const Model& mo = h->model;
     const HessModel& H = mo.H;
-    if (!H.values) return fail(h, CTD_EPATTERN, "hess_coord is not available with control_steps > 3 (hess_structure is); use a quasi-Newton solver or fewer controls per step");
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     h->hess_tile = env_int("CTD_HESS_TILE", 0);
     if (h->hess_tile <= 0) h->hess_tile = default_hess_tile(mo);

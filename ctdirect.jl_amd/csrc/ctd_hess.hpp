@@ -32,6 +32,11 @@ enum { HF_ONE = 0, HF_H = 1, HF_DH = 2 };
 
 constexpr int kMaxPairs = 64;          // distinct coefficient products C[c1] * C[c2] the term tables may use
 constexpr int kMaxTerms = 7;           // terms per output entry (S stage points of the step and of the one before + path point / state-equation row)
+// Midpoint scheme with more than 3 controls per step (run-time OCPs): an X x X entry would sum 2 control_steps + 1 terms.  The
+// second derivatives along directions that are not controls (X, V) are the same kind of term at every control's point, so a
+// pass between evaluation and emission adds the blocks of points 1 .. S-1 to the block of point 0 for those pairs
+// (hess_phase_stage_sum) and the term tables read point 0 only: at most 3 terms per entry whatever control_steps is.
+constexpr bool hess_sums_stages(int sc, int cs) { return sc == SC_MIDPOINT && 2 * cs + 1 > kMaxTerms; }
 constexpr int kMaxHessEdgeSlots = 6;   // step/node records of the edge block (3-bit record ids: + final path + boundary)
 
 // ---- per-slot LDS record (doubles) ---------------------------------------------------------------------

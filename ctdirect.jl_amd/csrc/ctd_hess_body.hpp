@@ -754,6 +754,28 @@ CTD_HD void hess_phase_eval(const HParams& hp, const HBlockCtx& cx, int tid, int
 }
 
 // ------------------------------------------------------------------------------------------------------
+// phase: sum of the stage-type points of a step (midpoint, more than 3 controls per step: hess_sums_stages, ctd_hess.hpp)
+// ------------------------------------------------------------------------------------------------------
+// For every record and every pair of directions without a control, the block of point 0 receives the sum over the points
+// (fixed order 0, 1, .. S-1: reproducible); the control pairs stay with their point.
+template <class P, int SC, int S>
+CTD_HD void hess_phase_stage_sum(const HParams& hp, const HBlockCtx& cx, int tid, int nthr) {
+    if constexpr (hess_sums_stages(SC, S)) {
+        constexpr int n = P::NX, m = P::NU, nd = P::NX + P::NV;
+        constexpr HessRecLayout R = HRL<P, SC, S>::R;
+        for (int w = tid; w < cx.nslots * nd * nd; w += nthr) {
+            const int k = w / (nd * nd), r = w - k * nd * nd, a = r / nd, b = r - a * nd;
+            if (a > b) continue;
+            double* HD = cx.rec + k * R.stride + R.oStage + hess_tri(R.md, a < n ? a : a + m, b < n ? b : b + m);
+            double sum = HD[0];
+#pragma unroll 1
+            for (int j = 1; j < S; ++j) sum = sum + HD[j * R.stage_sz];
+            HD[0] = sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // phase: emit
 // ------------------------------------------------------------------------------------------------------
 CTD_HD double hess_term(const double* rec, int stride, const double* cp, int npairs, uint32_t code, int slot) {

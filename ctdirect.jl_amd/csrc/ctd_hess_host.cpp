@@ -404,6 +404,9 @@ static void collect_terms(const Model& mo, int64_t row, int64_t col, std::vector
         for (int j = 0; j < S; ++j) {
             const Dir a = map_stage(L, s, j, vr), b = map_stage(L, s, j, vc);
             if (!a.ok || !b.ok) continue;
+            // (summed points: pairs without a control direction are read from point 0, which holds the sum over the points)
+            auto is_u = [&](int d) { return d >= L.n && d < L.n + L.m; };
+            if (j > 0 && hess_sums_stages(L.sc, L.cs) && !is_u(a.d) && !is_u(b.d)) continue;
             const int base = R.oStage + j * R.stage_sz;
             const Var* kv = (vr.kind == VK_K) ? &vr : (vc.kind == VK_K ? &vc : nullptr);
             const Var* vv = (vr.kind == VK_V) ? &vr : (vc.kind == VK_V ? &vc : nullptr);
@@ -506,31 +509,6 @@ int build_hess_model(Model& mo, std::string& err) {
     const int64_t N = L.N;
     // (midpoint with control_steps > 1: one stage-type point per control of the step, midpoint.jl:61-69,108-112)
     H.R = make_hess_layout(L.n, L.m, L.nv, L.p, L.sc, (L.sc == SC_MIDPOINT && L.cs > 1) ? L.cs : L.s, L.free_time != 0);
-    if (2 * L.cs + 1 > kMaxTerms && L.cs > 1) {
-        // more than 3 controls per step (run-time OCPs; an X x X entry would sum 2 control_steps + 1 terms): hess_structure! is
-        // served -- the blocks of DOCP_Hessian_pattern (midpoint.jl:240-300 are written in terms of the step block, whatever its
-        // size; with the optimized mode the same blocks: a superset of what a tracer would keep) -- hess_coord! is refused
-        // (ctd_hess_coord* return CTD_EPATTERN).
-        H.values = false;
-        build_hess_tail(mo);
-        H.reg_first = H.reg_last = N;
-        H.Lseg = 0;
-        H.tptr.assign(1, 0); H.terms.clear(); H.cp_tmpl.assign(L.blk + 1, 0);
-        std::vector<int64_t> rows;
-        const int64_t head_cols = N * (int64_t)L.blk, tail_cols = L.nvar - head_cols;
-        H.cp_head.assign(head_cols + 1, 0);
-        int64_t nz = 0;
-        for (int64_t j = 0; j < head_cols; ++j) { H.cp_head[j] = nz; mo.hess_gen_column(j, rows); nz += (int64_t)rows.size(); }
-        H.cp_head[head_cols] = nz;
-        H.seg_base = nz;
-        H.cp_tail.assign(tail_cols + 1, 0);
-        for (int64_t jj = 0; jj < tail_cols; ++jj) { H.cp_tail[jj] = nz; mo.hess_gen_column(head_cols + jj, rows); nz += (int64_t)rows.size(); }
-        H.cp_tail[tail_cols] = nz;
-        H.nnzh = nz;
-        H.nvv = 0;
-        H.head_ptr.assign(1, 0);
-        return ST_OK;
-    }
     if (H.R.stride >= 65536) { err = "per-step Hessian record too large for 16-bit data indices"; return ST_EPATTERN; }
     H.HL = (L.sc == SC_MIDPOINT) ? 1 : 0;
     H.HH = (L.euler == 2 && L.p > 0) ? 1 : 0;       // implicit Euler: the path point of node i+1 couples X_{i+1} with U_i
@@ -591,7 +569,7 @@ int build_hess_model(Model& mo, std::string& err) {
                 const auto it = std::find(rows.begin(), rows.end(), L.v_off + kr);
                 H.vv_idx[e] = it == rows.end() ? -1 : mo.hess_column_start(L.v_off + kc) + (int64_t)(it - rows.begin());
                 if (it == rows.end()) { H.vptr.push_back((uint32_t)H.vterms.size()); continue; }
-                for (int j = 0; j < H.R.S; ++j)
+                for (int j = 0; j < (hess_sums_stages(L.sc, L.cs) ? 1 : H.R.S); ++j)
                     if (H.need_stage[sym_index(md, vd + kc, vd + kr)])
                         H.vterms.push_back(pack_term(H.R.oStage + j * H.R.stage_sz + hess_tri(md, vd + kc, vd + kr), 0, 0));
                 if (L.p > 0 && L.sc != SC_TRAPEZE && H.need_path[sym_index(md, vd + kc, vd + kr)])

@@ -69,6 +69,10 @@ __device__ __forceinline__ void hess_body(const HParams& hp, const double* __res
     hess_stamp<DBG>(hp, 1);
     if (DBG && hp.debug_stop == 1) return;
     hess_phase_eval<P, SC, S>(hp, cx, tid, nthr);
+    if constexpr (hess_sums_stages(SC, S)) {
+        __syncthreads();
+        hess_phase_stage_sum<P, SC, S>(hp, cx, tid, nthr);
+    }
     __syncthreads();
     hess_stamp<DBG>(hp, 2);
     if (DBG && hp.debug_stop == 2) return;

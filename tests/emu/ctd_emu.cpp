@@ -86,6 +86,7 @@ static void run_hess_blocks(const HParams& hp, const double* xu, const double* y
         HBlockCtx cx = make_hctx(hp, b, lds.data());
         for (int t = 0; t < nthr; ++t) hess_phase_load<P>(hp, cx, xu, y, t, nthr);
         for (int t = 0; t < nthr; ++t) hess_phase_eval<P, SC, S>(hp, cx, t, nthr);
+        for (int t = 0; t < nthr; ++t) hess_phase_stage_sum<P, SC, S>(hp, cx, t, nthr);
         for (int t = 0; t < nthr; ++t) hess_phase_emit<P, SC, S>(hp, cx, b, t, nthr);
         for (int t = 0; t < nthr; ++t) hess_phase_vvsum(hp, cx, b, t, nthr);
     }
@@ -297,6 +298,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
     hp.vals = vals;
     std::vector<double> partials((size_t)(hp.ntiles + hp.n_edge_blocks) * (hp.nvv > 0 ? hp.nvv : 1), std::numeric_limits<double>::quiet_NaN());
     hp.partials = partials.data();
+    if (mo.L.cs > 3 && mo.L.cs != 5) { g_err = "emulator: Hessian kernels with 1, 2, 3 and 5 controls per step"; return 5; }
     bool ok = for_problem(problem, [&](auto tag) {
         using P = typename decltype(tag)::type;
         switch (mo.L.sc) {
@@ -304,6 +306,7 @@ int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double*
             case SC_MIDPOINT:
                 if (mo.L.cs == 2) run_hess_blocks<P, SC_MIDPOINT, 2>(hp, x, y, nthr);
                 else if (mo.L.cs == 3) run_hess_blocks<P, SC_MIDPOINT, 3>(hp, x, y, nthr);
+                else if (mo.L.cs == 5) run_hess_blocks<P, SC_MIDPOINT, 5>(hp, x, y, nthr);      // (summed points: hess_sums_stages)
                 else run_hess_blocks<P, SC_MIDPOINT, 1>(hp, x, y, nthr);
                 break;
             default:

@@ -162,6 +162,9 @@ def main_control_steps():
         run_case("cs3_freet0tf_midpoint_N3", gg.DoubleIntegratorFreeT0Tf(), "midpoint", N=3, control_steps=3)
         run_case("cs2_quadrotor_midpoint_N2", gg.Quadrotor8(), "midpoint", N=2, control_steps=2)
         run_case("cs3_quadrotor_midpoint_N2", gg.Quadrotor8(), "midpoint", N=2, control_steps=3)
+        # more than 3 controls per step: the kernels sum the points of a step before the emission (hess_sums_stages)
+        run_case("cs5_dip_midpoint_nonuniform", gg.DoubleIntegratorPath(), "midpoint", time_grid=[0.0, 0.3, 0.5, 0.6, 1.0], control_steps=5)
+        run_case("cs5_goddard_all_midpoint_N3", gg.GoddardAll(), "midpoint", N=3, control_steps=5)
     finally:
         gg.Du, gg.dexp, gg.dsin, gg.dcos = gg_first_order
 

@@ -302,12 +302,10 @@ def test_control_steps_host_logic_matches_oracle(oracle_lib, prob):
                 cp, rv = o.jac_pattern()
                 cp2, rv2 = ct.DOCP_Jacobian_pattern(d)
                 assert d.nnzj == o.jac_nnz() and np.array_equal(cp, cp2) and np.array_equal(rv, rv2), (cs, N, name)
-                # hess_structure: the blocks of midpoint.jl:240-300; optimized: the oracle's traced pattern up to 3 controls per
-                # step (the counts hess_coord serves), the manual blocks -- a superset -- beyond
-                if mode < 2 or cs <= 3:
-                    hp, hr = o.hess_pattern()
-                    hp2, hr2 = ct.DOCP_Hessian_pattern(d)
-                    assert np.array_equal(hp, hp2) and np.array_equal(hr, hr2), (cs, N, name)
+                # hess_structure: the blocks of midpoint.jl:240-300; optimized: the oracle's traced pattern
+                hp, hr = o.hess_pattern()
+                hp2, hr2 = ct.DOCP_Hessian_pattern(d)
+                assert np.array_equal(hp, hp2) and np.array_equal(hr, hr2), (cs, N, name)
                 d.close()
 
 

@@ -30,6 +30,28 @@ def test_hessian_on_host_only_handle_fails_loudly():
     assert e.value.status == ct._lib.CTD_ENODEVICE
 
 
+@pytest.mark.parametrize("prob,cs", [("goddard", 2), ("quadrotor", 3), ("quadrotor", 5), ("double_integrator_freet0tf", 5)])
+def test_emulated_hessian_kernel_with_several_controls_per_step(oracle_lib, prob, cs):
+    """control_steps > 1 (midpoint): one stage-type point per control of the step; 5 controls: the points of a step summed
+    before the emission (hess_sums_stages).  Edge-only sizes, one and several tiles, ragged grid, the three patterns."""
+    rng = np.random.default_rng(11)
+    pid, sid = ct.PROBLEMS[prob], ct.SCHEMES["midpoint"]
+    for N, tg, tile, nthr in ((1, None, 0, 64), (4, None, 2, 5), (7, None, 3, 64), (9, np.cumsum(rng.uniform(0.5, 1.5, 10)), 0, 96)):
+        o = oracle_lib.OracleDOCP(prob, "midpoint", N, time_grid=tg, control_steps=cs)
+        x = o.initial_guess() + 0.05 * rng.standard_normal(o.dim_NLP_variables)
+        y = rng.standard_normal(o.dim_NLP_constraints)
+        for mode in (0, 1, 2):
+            o.set_pattern_mode(mode)
+            want, dropped = o.hess_coord(x, y, 0.7, return_dropped=True)
+            assert dropped == (0, 0)
+            with emu.control_steps(cs):
+                cp, rv = emu.hess_csc(pid, sid, mode, N, tg)
+                vals = emu.hess(pid, sid, mode, N, x, y, 0.7, tg, tile=tile, nthr=nthr)
+            ocp, orv = o.hess_pattern()
+            assert np.array_equal(cp, ocp) and np.array_equal(rv, orv)
+            assert not np.any(vals == 666.666) and relerr(vals, want) <= TOL, (N, mode)
+
+
 @pytest.mark.parametrize("prob,sch", PAIRS, ids=[f"{p}-{s}" for p, s in PAIRS])
 def test_hessian_pattern_matches_oracle(oracle_lib, prob, sch):
     """lower triangle of DOCP_Hessian_pattern: library (periodic column starts + explicit edges) == oracle (literal
