@@ -113,7 +113,7 @@ typedef struct ctd_desc {
                                * every control (DOCP_variables.jl:44,138); path constraints see U_i^1 (common.jl:140-155).  CTD_SCHEME_MIDPOINT
                                * only (CTD_ESCHEME otherwise: no other scheme of the reference reads the extra controls).  Compiled problems:
                                * control_steps <= 3; problems registered at run time: any.  Constraints, Jacobian (all three patterns),
-                               * objective, gradient, hess_structure; ctd_hess_coord* return CTD_EPATTERN. */
+                               * objective, gradient, hess_structure and hess_coord (one second-order evaluation point per control). */
 } ctd_desc;
 
 enum { CTD_STREAM_OWN = 0, CTD_STREAM_GIVEN = 1 };
