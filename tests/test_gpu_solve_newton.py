@@ -68,6 +68,40 @@ def test_newton_kkt_step_solves_the_quadratic_program():
     assert np.max(np.abs(d.hess_coord(x1, y1, 1.0) - d.hess_coord(x, y1, 1.0))) <= 1e-12
 
 
+def test_newton_kkt_step_with_direct_shooting_layout():
+    """The same quadratic program on the direct-shooting layout (`control_steps = 3` controls per step, midpoint scheme,
+    src/direct_shooting.jl:55-71): ONE Newton-KKT step with the exact Hessian of that layout (one second-order point per
+    control of the step) is feasible, stationary and reproduces the analytic extremal to the scheme's order."""
+    N, cs = 40, 3
+    d = ct.DOCP("double_integrator_path", N, "midpoint", device=0, control_steps=cs)
+    nvar = d.dim_NLP_variables
+    lc, uc = ct.constraints_bounds(d)
+    eq = np.where(lc == uc)[0]
+    x = ct.initial_guess(d)
+    y = np.zeros(d.dim_NLP_constraints)
+    H = _sym(d, d.hess_coord(x, y, 1.0))
+    J = _jac(d, x)[eq]
+    K = sp.bmat([[H, J.T], [J, None]], format="csc")
+    sol = spla.spsolve(K, -np.concatenate([d.grad(x), (d.cons(x) - lc)[eq]]))
+    x1 = x + sol[:nvar]
+    y1 = np.zeros_like(y)
+    y1[eq] = sol[nvar:]
+    assert np.max(np.abs((d.cons(x1) - lc)[eq])) <= 1e-10
+    assert np.max(np.abs(d.grad(x1) + _jac(d, x1).T @ y1)) <= 1e-9
+    assert abs(d.obj(x1) - 1.5) <= 1e-3
+    assert np.all(d.cons(x1) <= uc + 1e-9)
+    out = ct.unpack_solution(d, x1, y1)
+    T, Tc = out["T"], out["T_control"]
+    assert Tc.shape == (N * cs + 1,) and np.allclose(Tc[:-1:cs], T[:-1])
+    assert np.allclose(out["X"], np.stack([0.75 * T ** 2 - 0.25 * T ** 3, 1.5 * T - 0.75 * T ** 2], axis=1), atol=1e-2)
+    # the controls of a step all see the step's midpoint state (midpoint.jl:57-69) and this cost is convex in them: they come out
+    # equal, at the extremal u = 1.5 - 1.5 t of the step's midpoint
+    U = x1[:N * (2 + cs)].reshape(N, 2 + cs)[:, 2:]
+    assert np.max(np.abs(U - U[:, :1])) <= 1e-9
+    assert np.allclose(U[:, 0], 1.5 - 1.5 * (T[:-1] + T[1:]) / 2, atol=2e-2)
+    d.close()
+
+
 def _trust_constr(prob, scheme, N, init=None, maxiter=500):
     d = ct.DOCP(prob, N, scheme, pattern="structural", device=0)
     ncon = d.dim_NLP_constraints
