@@ -14,7 +14,8 @@ import ctdirect_jl_amd as ct
 from oracle.oracle import OracleDOCP
 from helpers import relerr, TOL, bench_inputs, describe
 budget, seed = float(sys.argv[1]), int(sys.argv[2])
-JIT = len(sys.argv) > 3 and sys.argv[3] == "jit"      # also draw the expression twins of the registry problems (hiprtc)
+JIT = len(sys.argv) > 3 and sys.argv[3] in ("jit", "jitcs")      # also draw the expression twins of the registry problems (hiprtc)
+CS_ONLY = len(sys.argv) > 3 and sys.argv[3] in ("cs", "jitcs")    # midpoint scheme only, mostly with several controls per step
 if JIT:
     import jit_defs
 rng = np.random.default_rng(seed)
@@ -27,7 +28,7 @@ while time.time() < t_end:
     if time.time() >= t_note:          # progress line (long runs behind a quiet pipe look hung to gpurun)
         print(f"... {ncase} cases, {nfail} failures", flush=True)
         t_note += 60.0
-    prob, sch = probs[rng.integers(len(probs))], schemes[rng.integers(len(schemes))]
+    prob, sch = probs[rng.integers(len(probs))], ("midpoint" if CS_ONLY else schemes[rng.integers(len(schemes))])
     big = rng.random() < 0.25
     N = int(rng.integers(1, 2500 if big else 90))
     if prob in ("quadrotor", "quadrotor12") and big: N = int(rng.integers(1, 600))
@@ -50,13 +51,17 @@ while time.time() < t_end:
     # (operator-level dependence is a property of the expressions: Goddard's twin writes r' = x2 where the reference -- and the
     # registry functor and the oracle -- write F0 + u F1 with a zero component, so their optimized patterns differ by design)
     if use_twin and mode == "optimized": mode = "structural"
+    # round 3: the direct-shooting layout (midpoint scheme): 2 - 3 controls per step from the registry, up to 6 for the twins
+    cs = 1
+    if sch == "midpoint" and rng.random() < (0.9 if CS_ONLY else 0.5):
+        cs = int(rng.integers(2, 7 if use_twin else 4))
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
             f"twin={int(use_twin)} api={api} step={os.environ['CTD_HESS_STEP']} compact={os.environ['CTD_HESS_COMPACT']} "
-            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']}")
+            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']} cs={cs}")
     try:
-        d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps)
-        o = OracleDOCP(prob, sch, N, time_grid=tg) if tg is not None else OracleDOCP(prob, sch, N)
+        d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps, control_steps=cs)
+        o = OracleDOCP(prob, sch, N, time_grid=tg, control_steps=cs) if tg is not None else OracleDOCP(prob, sch, N, control_steps=cs)
         if mode == "structural": o.set_pattern_mode(1)
         if mode == "optimized": o.set_pattern_mode(2)
         nvar, ncon = d.dim_NLP_variables, d.dim_NLP_constraints
