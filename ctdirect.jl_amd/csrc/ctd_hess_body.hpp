@@ -465,9 +465,10 @@ template <class P> struct SymStage {
 };
 
 // Whether the stage-type points of (P, SC, S) run the symbolic functions.  Not with several controls per step AND a Lagrange
-// cost: that quadrature point has a time of its own (midpoint.jl:110) where the generated function has one evaluation time.
+// cost that reads the time: that quadrature point has a time of its own (midpoint.jl:110) where the generated function has
+// one evaluation time.
 template <class P, int SC, int S> constexpr bool hess_uses_sym() {
-    return SymStage<P>::value && !(SC == SC_MIDPOINT && S > 1 && P::HAS_LAGRANGE);
+    return SymStage<P>::value && !(SC == SC_MIDPOINT && S > 1 && P::HAS_LAGRANGE && P::LAG_T);
 }
 
 // The same stage-type point for an OCP that carries symbolically differentiated stage functions (run-time OCPs,

@@ -687,7 +687,9 @@ int build_hess_model(Model& mo, std::string& err) {
     {
         const RtOcp* ro = runtime_ocp(mo.problem);
         H.sym_stage = (ro && ro->has_sym) || registry_has_sym(mo.problem);
-        if (L.cs > 1 && mo.info.lagrange) H.sym_stage = false;      // hess_uses_sym (ctd_hess_body.hpp)
+        bool lag_t = ro ? ro->lag_t : true;
+        for_problem(mo.problem, [&](auto tag) { lag_t = decltype(tag)::type::LAG_T; });
+        if (L.cs > 1 && mo.info.lagrange && lag_t) H.sym_stage = false;      // hess_uses_sym (ctd_hess_body.hpp)
         if (H.sym_stage) H.tasks.assign(1, 0u);
     }
     make_tasks(H.R.md, H.need_path, false, H.ptasks);
@@ -790,6 +792,18 @@ int default_hess_tile(const Model& mo) {
         const int64_t budget = per_step >= 5000 ? 58 * 1024 : (per_step >= 2048 ? 48 * 1024 : 27 * 1024);
         int64_t Ts = std::max<int64_t>(1, std::min<int64_t>(128, budget / per_step - H.HL - H.HH - 1));
         if (Ts < 6) Ts = std::max<int64_t>(Ts, std::min<int64_t>(6, (78 * 1024) / per_step - H.HL - H.HH - 1));
+        // One-point schemes (midpoint, Euler, trapeze; any number of controls per step) with heavy steps: the kernel keeps TWO
+        // workgroups per CU resident (registers of the symbolic stage function), a round of 512 tiles, and its time follows
+        // rounds x steps per tile -- what counts is how full the last round is (8-state quadrotor, midpoint, N = 20 000: 40 steps =
+        // 502 tiles 14.4 us, 32 steps = 627 tiles 19.9, 24 steps = 836 tiles 18.9, 20 steps = 1002 tiles 14.5, 16 steps = 1252 tiles 17.6;
+        // 12-state: 15 steps 29.2 us, 20 steps = 1003 tiles 22.1; with 2 controls per step 7 steps 87.5 us, 16 steps 30.2, 20 steps =
+        // ONE resident workgroup 92.3: profiles/r03_control_steps.md).  The largest tile that lets two workgroups share the LDS
+        // fixes the number of rounds; the steps are then spread evenly over those rounds.
+        if (L.sc != SC_IRK && per_step >= 1400) {
+            const int64_t tmax = std::max<int64_t>(4, std::min<int64_t>(64 / L.cs, (70 * 1024) / per_step - H.HL - H.HH - 1));
+            const int64_t rounds = (L.N + tmax * 512 - 1) / (tmax * 512);
+            Ts = std::max<int64_t>(4, std::min<int64_t>(tmax, (L.N + rounds * 512 - 1) / (rounds * 512)));
+        }
         // small grids: at least ~1.5 workgroups per CU (Goddard, 2 stages, N = 10 000: 21 steps = 477 tiles 10.3 us, 11 steps 11.0 us)
         while (Ts > 4 && (L.N + Ts - 1) / Ts < 400) Ts = (Ts + 1) / 2;
         return (int)Ts;

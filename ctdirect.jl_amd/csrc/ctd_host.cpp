@@ -815,16 +815,26 @@ int default_tile(const Model& mo, int64_t nsteps) {
     // 16 steps 125; optimized pattern (3.7 KiB per step) 7 steps 36.3, 16 steps 25.8; 8-state quadrotor 11 KiB per step: 10 - 12
     // steps; one-point schemes flat from 16 steps on)
     const bool wide = mo.nch_dyn > 1;
+    const bool multi_u = wide && L.sc == SC_MIDPOINT && L.cs > 1;
     if (wide) {
         const int pts = L.sc == SC_IRK ? L.s : 1;
-        const int64_t lane_cap = L.sc == SC_IRK ? 64 / (pts + 1) : 24;
+        // (several controls per step: the evaluating lane runs the dynamics code once per control, a fixed cost per tile whatever
+        // its size, so the FEWEST tiles per CU win: up to 48 steps on two resident workgroups per CU, then the steps spread evenly
+        // over that many tiles per CU -- profiles/r03_control_steps.md: 12-state quadrotor, 2 controls, N = 20 000: 24 steps = 4 tiles
+        // per CU 26.0 us, 32 steps = 3 per CU 28.2, 40 steps = 2 per CU 19.3, 48 steps 19.8; 8-state: 17.1 / 12.2 / 11.4 / 11.9)
+        const int64_t lane_cap = L.sc == SC_IRK ? 64 / (pts + 1) : (multi_u ? 48 : 24);
         const double out_bytes = 8.0 * (double)(mo.Lseg + L.cb + (int64_t)L.nv * mo.vr);
         T = std::max<int64_t>(4, std::min<int64_t>(lane_cap, (int64_t)std::lround(131072.0 / std::max(out_bytes, 1.0))));
+        if (multi_u) T = lane_cap;
         // ... and the largest such tile that leaves three workgroups per CU (exact LDS accounting: 1280-byte granules)
         for (; T > 4; --T) {
             KParams kp;
             mo.fill_kparams(kp, 0, std::min<int64_t>(L.N, T * 4), (int)T);
-            if (wgs_per_cu(lds_doubles(kp) * 8) >= 3) break;
+            if (wgs_per_cu(lds_doubles(kp) * 8) >= (multi_u ? 2 : 3)) break;
+        }
+        if (multi_u) {
+            const int64_t ns = nsteps > 0 ? nsteps : L.N, per_cu = ((ns + T - 1) / T + 255) / 256;
+            T = std::max<int64_t>(4, std::min<int64_t>(T, (ns + per_cu * 256 - 1) / (per_cu * 256)));
         }
     }
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)

@@ -67,11 +67,11 @@ def test_runtime_twin_matches_registry_and_oracle(oracle_lib, torch_cuda, prob, 
         a.close(); b.close()
 
 
-def _mp_reference(P, scheme, N, xu, y, sigma):
+def _mp_reference(P, scheme, N, xu, y, sigma, control_steps=1):
     """c, dense Jacobian, objective, gradient (first-order dense dual) and the Hessian of the Lagrangian (sparse
     second-order number) of the mpmath restatement"""
     import gen_golden_hess as gh
-    d = gg.Docp(P, scheme, N=N)
+    d = gg.Docp(P, scheme, N=N, control_steps=control_steps)
     nvar = d.nvar
     gg.Du.NV = nvar
     z = []
@@ -126,6 +126,36 @@ def test_expression_only_problem_against_mpmath(torch_cuda, sch):
     hpat = set(zip(hr - 1, hc - 1))
     dropped = [k for k, v in Href.items() if v != 0.0 and k not in hpat]
     assert euler or not dropped, dropped
+    d.close()
+
+
+@pytest.mark.parametrize("cs", [2, 3, 5])
+def test_expression_only_problem_with_several_controls_per_step(torch_cuda, cs):
+    """The direct-shooting layout of a problem whose dynamics AND Lagrange cost read the time, with a free final time and a
+    parameter: the dynamics of every control's point at the step's midpoint, its quadrature point at t_i + (j - 1/2) h / cs
+    (midpoint.jl:57,110) -- all callbacks against the 50-digit restatement (cs = 5: the points of a step are summed before
+    the Hessian's emission)."""
+    torch = torch_cuda
+    name = "vdp_rt" if "vdp_rt" in ct.PROBLEMS else ct.register_ocp("vdp_rt", **jit_defs.VDP)
+    N = 6
+    d = ct.DOCP(name, N, "midpoint", pattern="structural", device=0, control_steps=cs)
+    rng = np.random.default_rng(40 + cs)
+    x = 0.4 + 0.3 * rng.standard_normal(d.dim_NLP_variables)
+    x[-2:] = [1.3, 2.1]                                            # v = (mu, tf)
+    y = rng.standard_normal(d.dim_NLP_constraints)
+    md, cref, Jref, fref, gref, Href = _mp_reference(jit_defs.VdpMp(), "midpoint", N, x, y, 0.6, control_steps=cs)
+    assert (md.nvar, md.ncon) == (d.dim_NLP_variables, d.dim_NLP_constraints)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    c, vals = d.cons_jac(xd)
+    rows, cols = d.jac_structure()
+    assert relerr(c.cpu().numpy(), cref) <= TOL and relerr(vals.cpu().numpy(), Jref[rows - 1, cols - 1]) <= TOL
+    assert abs(d.obj(xd) - fref) <= TOL * max(1.0, abs(fref)) and relerr(d.grad(xd).cpu().numpy(), gref) <= TOL
+    hr, hc = d.hess_structure()
+    hv = d.hess_coord(xd, yd, 0.6).cpu().numpy()
+    want = np.array([Href.get((int(r) - 1, int(cc) - 1), 0.0) for r, cc in zip(hr, hc)])
+    assert relerr(hv, want) <= TOL
+    hpat = set(zip(hr - 1, hc - 1))
+    assert not [k for k, v in Href.items() if v != 0.0 and k not in hpat]
     d.close()
 
 
