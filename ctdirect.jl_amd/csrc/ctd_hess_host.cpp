@@ -105,7 +105,7 @@ void Model::hess_gen_column(int64_t j, std::vector<int64_t>& rows) const {
     for (auto& p : iv) {
         int64_t r = std::max(p.first, next);
         for (; r < p.second; ++r)
-            if (pattern_mode != 2 || !H.values || hess_opt_keep(*this, r, j)) rows.push_back(r);
+            if (pattern_mode != 2 || hess_opt_keep(*this, r, j)) rows.push_back(r);
         next = std::max(next, p.second);
     }
 }

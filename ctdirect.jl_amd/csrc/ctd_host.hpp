@@ -28,7 +28,6 @@ struct HessModel {
     HessRecLayout R;
     int hk = 4;                       // inner directions per eval lane (ctd::HessK<P>)
     bool sym_stage = false;           // stage points use the OCP's symbolic second derivatives (run-time OCPs, ctd_sym.hpp)
-    bool values = true;               // false: pattern only (control_steps > 1: hess_coord is not implemented, hess_structure is)
     int64_t nnzh = 0;
     std::vector<Block> tail;          // blocks that do not belong to one step (already symmetrised)
     // regular part
