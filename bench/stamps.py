@@ -23,7 +23,7 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         "cfg5": ("quadrotor12", "gauss_legendre_3", 20000),
         # extra: OCPs whose kernels run the staged driver (path constraints in every scheme)
         "gall_trap": ("goddard_all", "trapeze", 20000), "gall_gl2": ("goddard_all", "gauss_legendre_2", 20000),
-        "quad_trap": ("quadrotor", "trapeze", 20000), "q12_mid": ("quadrotor12", "midpoint", 20000),
+        "quad_trap": ("quadrotor", "trapeze", 20000), "q12_mid": ("quadrotor12", "midpoint", 20000), "quad_mid": ("quadrotor", "midpoint", 20000),
         "q12_trap": ("quadrotor12", "trapeze", 20000),
         # one tile + the edge block: the kernel's serial latency chain without any contention
         "cfg2_tiny": ("goddard", "gauss_legendre_2", 21), "cfg2_small": ("goddard", "gauss_legendre_2", 2100)}
@@ -34,8 +34,9 @@ def main():
     for name in names:
         name, _, pattern = name.partition(":")          # "cfg5:optimized" -> CTD_PATTERN_OPTIMIZED
         prob, sch, N = CFGS[name]
-        d = ct.DOCP(prob, N, sch, device=0, pattern=pattern or "manual")
-        name = name + (":" + pattern if pattern else "")
+        cs = int(os.environ.get("CTD_STAMPS_CS", "1"))        # controls per step (midpoint workloads: the direct-shooting layout)
+        d = ct.DOCP(prob, N, sch, device=0, pattern=pattern or "manual", control_steps=cs)
+        name = name + (":" + pattern if pattern else "") + (f" cs={cs}" if cs > 1 else "")
         x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
         c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
         v = torch.zeros(d.nnzj, dtype=torch.float64, device="cuda")

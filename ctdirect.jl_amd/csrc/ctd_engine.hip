@@ -354,7 +354,9 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         // replica of the CSC period: 10 000-step Goddard / GL2, period 102: 3 x 102 = 306 of 320 lanes, 7.5 us vs 7.8 us
         h->block = 256;
         const int64_t ntl = (h->step_end - h->step_begin + h->tile - 1) / h->tile;
-        if (ntl <= 512 && mo.Lseg > 0 && 320 / mo.Lseg > 256 / mo.Lseg && mo.Lseg * (320 / mo.Lseg) * 10 >= 320 * 9) h->block = 320;
+        // (not for the wide OCPs: their kernels keep fewer workgroups resident with five waves each -- 8-state quadrotor, 2 controls per
+        // step, optimized pattern, 40-step tiles: 501 workgroups no longer start together, 14.4 us against 8.8)
+        if (ntl <= 512 && mo.nch_dyn <= 1 && mo.Lseg > 0 && 320 / mo.Lseg > 256 / mo.Lseg && mo.Lseg * (320 / mo.Lseg) * 10 >= 320 * 9) h->block = 320;
         // (a fifth wave for the symbolic path rows of the wide OCPs was measured slower -- quadrotor12 midpoint N = 20 000 30.1 us
         // against 24.4 -- and is gone: profiles/r03_experiments.md)
     }

@@ -819,8 +819,8 @@ int default_tile(const Model& mo, int64_t nsteps) {
     if (wide) {
         const int pts = L.sc == SC_IRK ? L.s : 1;
         // (several controls per step: the evaluating lane runs the dynamics code once per control, a fixed cost per tile whatever
-        // its size, so the FEWEST tiles per CU win: up to 48 steps on two resident workgroups per CU, then the steps spread evenly
-        // over that many tiles per CU -- profiles/r03_control_steps.md: 12-state quadrotor, 2 controls, N = 20 000: 24 steps = 4 tiles
+        // its size, so the FEWEST rounds of resident workgroups win: up to 48 steps on two resident workgroups per CU, then the steps
+        // spread evenly over that many rounds of 512 tiles -- profiles/r03_control_steps.md: 12-state quadrotor, 2 controls, N = 20 000: 24 steps = 4 tiles
         // per CU 26.0 us, 32 steps = 3 per CU 28.2, 40 steps = 2 per CU 19.3, 48 steps 19.8; 8-state: 17.1 / 12.2 / 11.4 / 11.9)
         const int64_t lane_cap = L.sc == SC_IRK ? 64 / (pts + 1) : (multi_u ? 48 : 24);
         const double out_bytes = 8.0 * (double)(mo.Lseg + L.cb + (int64_t)L.nv * mo.vr);
@@ -833,8 +833,8 @@ int default_tile(const Model& mo, int64_t nsteps) {
             if (wgs_per_cu(lds_doubles(kp) * 8) >= (multi_u ? 2 : 3)) break;
         }
         if (multi_u) {
-            const int64_t ns = nsteps > 0 ? nsteps : L.N, per_cu = ((ns + T - 1) / T + 255) / 256;
-            T = std::max<int64_t>(4, std::min<int64_t>(T, (ns + per_cu * 256 - 1) / (per_cu * 256)));
+            const int64_t ns = nsteps > 0 ? nsteps : L.N, rounds = (ns + T * 512 - 1) / (T * 512);     // (rounds of two workgroups per CU)
+            T = std::max<int64_t>(4, std::min<int64_t>(T, (ns + rounds * 512 - 1) / (rounds * 512)));
         }
     }
     if (nsteps <= 0) nsteps = L.N;               // steps this handle evaluates (a shard of the grid, or all of it)
