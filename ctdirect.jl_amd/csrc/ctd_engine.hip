@@ -371,6 +371,40 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
         mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
         h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
     }
+    // Gauss-Legendre schemes of the narrow OCPs on long grids: the kernel keeps R workgroups per CU resident (R from the runtime:
+    // registers and LDS of the instantiation), a round of 256 R tiles, and its time follows rounds x steps per tile -- Goddard GL3,
+    // N = 80 000 at the 32 steps of default_tile: 2501 tiles = 2.44 rounds of 1024, the workgroups start in three waves
+    // (profiles/r03_phase_stamps_final.log: start percentiles 0.1 / 10.1 / 19.3 us).  A tile of up to 48 steps with the same R fixes
+    // the number of rounds, the steps are spread evenly over them: 40 steps = 2001 tiles, 28.3 -> 26.9 us, optimized pattern
+    // 20.3 -> 17.9; N = 200 000: 79.9 -> 74.3 (profiles/r03_experiments.md).  Only ever a LARGER tile than the rule's.
+    if (desc->device >= 0 && !h->rt && env_int("CTD_TILE", 0) <= 0 && env_int("CTD_ROUND_TILES", 1) && mo.nch_dyn <= 1 && mo.L.sc == SC_IRK && h->tile >= 16) {
+        DeviceGuard dgq(desc->device);
+        if (dgq.err == hipSuccess) {
+            auto resident = [&](int tile, size_t& lds) {
+                KParams kq;
+                mo.fill_kparams(kq, h->step_begin, h->step_end, tile);
+                lds = (size_t)lds_doubles(kq) * sizeof(double);
+                int r = 0;
+                for_problem(mo.problem, [&](auto tag) { r = occupancy_cons_jac<typename decltype(tag)::type>(mo.L.sc, kq, h->block, lds); });
+                (void)hipGetLastError();
+                return r;
+            };
+            size_t l0 = 0;
+            const int r0 = resident(h->tile, l0);
+            const int64_t ns = h->step_end - h->step_begin, cap = 256 * (int64_t)r0;
+            if (r0 > 0 && (ns + h->tile - 1) / h->tile > cap) {
+                int tmax = 48;
+                for (; tmax > h->tile; --tmax) { size_t l = 0; if (resident(tmax, l) >= r0 && l <= lds_cap) break; }
+                const int64_t rounds = (ns + (int64_t)tmax * cap - 1) / ((int64_t)tmax * cap);
+                const int64_t tb = (ns + rounds * cap - 1) / (rounds * cap);
+                if (tb > h->tile && tb <= tmax) {
+                    h->tile = (int)tb;
+                    mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
+                    h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+                }
+            }
+        }
+    }
     h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
     h->kp.debug_stop = debug_stop;
     {   // write-through stores (emit_store) for launches whose outputs are small: what a kernel leaves dirty in the XCDs' L2s is written
