@@ -13,7 +13,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        # (one builder at a time: pytest-xdist workers would otherwise run make -- and load a half-written library -- concurrently)
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
         # CTD_EMU_LIB: an instrumented build of the same source (e.g. -fsanitize=address,undefined; run pytest with the
         # sanitizer runtime preloaded)
         L = C.CDLL(os.environ.get("CTD_EMU_LIB") or _LIB)
