@@ -21,12 +21,18 @@ iterate sent whole from rank 0) and `no_exchange` (x in place), and the per-rank
 `value`: weak scaling = shard evaluations all ranks completed per second; strong scaling = evaluations of the whole
 transcription per second; both over the max-over-ranks wall time of the K timed steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--x-mode peer|halo]
 
 N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank;
-started plainly (`python bench.py --gpus N`) it spawns the N rank processes itself -- before anything touches the GPU --
-and relays rank 0's line.  On a box with fewer than N GPUs the ranks share the devices (gloo carries the barrier: RCCL
-refuses two ranks on one device) and the line says `"rehearsal": true`.
+started plainly (`python bench.py --gpus N`) it spawns the N rank processes itself -- fresh interpreters, nothing in the
+launching process ever touches the GPU (it does not even import torch) -- watches ALL of them, and relays rank 0's line: when
+any rank exits non-zero the others are terminated and the launcher exits non-zero within seconds (no rank is left waiting
+in a collective for a peer that died).  On a box with fewer than N GPUs the ranks find that out themselves, share the
+devices (gloo carries the barrier: RCCL refuses two ranks on one device) and the line says `"rehearsal": true`.
+
+At N > 1 the default line (`--config cfg2_weak`) also carries a `strong` block: the strong-scaling workloads north_star names
+(cfg2_strong = the 10 000-step Goddard transcription sharded over the N GPUs, cfg4, cfg5), each with evals/s, per-rank kernel
+time and roofline fraction, and the `stitched_c` variant (+ the RCCL all-gather of the constraint vector).
 """
 import argparse
 import json
@@ -92,34 +98,56 @@ def cpu_baseline(problem, scheme, N, x, budget_s=10.0):
     return out
 
 
-def self_launch(argv, gpus):
-    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters; nothing in this
-    process has touched the GPU), relay rank 0's JSON line, exit with the worst return code."""
+def self_launch(argv, gpus, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (fresh interpreters; this process never touches
+    the GPU -- it does not import torch and counts no devices: a rank that finds fewer GPUs than ranks switches to the
+    rehearsal mode by itself), watch ALL of them, relay rank 0's JSON line.  The first rank that exits non-zero ends the run:
+    the others are terminated (then killed) and the launcher returns that code within seconds, instead of leaving rank 0 in a
+    collective until some outer timeout.  CTD_BENCH_DEADLINE_S (default 1500) bounds the whole run the same way."""
     import socket
     import subprocess
-    import torch
-    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    out0 = tempfile.TemporaryFile()
     procs = []
     for r in range(gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if ndev < gpus:                       # rehearsal: the ranks share the box's device(s)
-            env["CTD_BENCH_DEVICE"] = str(r % max(ndev, 1))
-            env.setdefault("CTD_BENCH_BACKEND", "gloo")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + float(os.environ.get("CTD_BENCH_DEADLINE_S", "1500"))
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = bad[0][1], f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            rc, why = 124, "deadline (CTD_BENCH_DEADLINE_S) reached"
+            break
+        time.sleep(0.2)
+    if why is not None:          # end exactly the processes started here, by pid
+        sys.stderr.write(f"bench.py launcher: {why}; terminating the other ranks\n")
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return rc
+    return rc if rc >= 0 else 128 - rc       # (a rank killed by a signal: 128 + signal number, like a shell)
 
 
 def main():
@@ -129,6 +157,8 @@ def main():
         gpus = ap.parse_known_args()[0].gpus
         if gpus > 1:
             sys.exit(self_launch(sys.argv[1:], gpus))
+    # dmabuf IPC (the only mode the host driver supports): needed by hipIpcGetMemHandle / RCCL, whoever launched this rank
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # exactly ONE line on stdout: libraries that print banners there (RCCL prints its version block on communicator creation)
     # write to stderr for the duration of the run; the JSON line goes to the saved descriptor at the end
     sys.stdout.flush()
@@ -148,15 +178,23 @@ def _main(real_stdout):
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2_weak")
+    ap.add_argument("--x-mode", choices=("peer", "halo"), default="peer",
+                    help="N > 1: how a rank obtains the few entries of x its neighbours own: 'peer' = read in place by the kernel from "
+                         "the owner's HBM (IPC-mapped buffers over xGMI; falls back to 'halo' when the mapping is refused), 'halo' = "
+                         "one all-gather before the evaluation.  The line records the other one as a secondary figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernel-only figures of the other configs")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the `strong` block (cfg2_strong / cfg4 / cfg5) of the default line")
     ap.add_argument("--two-streams", action="store_true",
                     help="also time independent evaluations on two streams (overlapping kernels: keeps it out of the default run, whose rocprofv3 "
                          "kernel statistics are the timed region's)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     PROBLEM, SCHEME = cfg["problem"], cfg["scheme"]
+    t_start = time.monotonic()
+    budget_s = float(os.environ.get("CTD_BENCH_BUDGET_S", "420"))      # optional blocks are skipped once this much wall time is gone
 
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -177,8 +215,8 @@ def _main(real_stdout):
     if rehearsal:
         local_rank = int(os.environ["CTD_BENCH_DEVICE"])
     elif world > 1 and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
-        # launched by torch.distributed.run on a box with fewer GPUs than ranks: the ranks share the devices (a rehearsal of the
-        # code path, not a scaling measurement; RCCL refuses two ranks on one device, gloo carries the barrier)
+        # a box with fewer GPUs than ranks (whoever launched them): the ranks share the devices (a rehearsal of the code path,
+        # not a scaling measurement; RCCL refuses two ranks on one device, gloo carries the barrier)
         rehearsal = True
         local_rank = local_rank % max(1, torch.cuda.device_count())
         os.environ.setdefault("CTD_BENCH_BACKEND", "gloo")
@@ -190,38 +228,29 @@ def _main(real_stdout):
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # a collective whose peer never arrives (a rank that died, a mapping that hangs) ends this rank after the timeout instead
+        # of holding the line until an outer limit; the launcher / torch.distributed.run then ends the others
+        tmo = datetime.timedelta(seconds=float(os.environ.get("CTD_BENCH_COLLECTIVE_TIMEOUT_S", "180")))
         if backend == "nccl":     # bind the communicator to this rank's GPU up front (barriers need no device guess)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    N = cfg["steps"] * world if cfg["per_gpu"] else cfg["steps"]
-
-    def make(steps=None):      # the handle launches on torch's current stream: ordered with the RCCL collectives
-        return ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, steps=steps, stream="torch")
-
-    sh = ctdist.ShardedDOCP(make, N, world=world, rank=rank)
-    docp = sh.docp
-    x_host = bench_inputs(describe(docp, PROBLEM, SCHEME), perturb=1e-3)
-    x_full = torch.from_numpy(x_host).to(dev)
-    if dist_on:           # sharded iterate: own variables + the replicated v, NaN everywhere else
-        xs = np.full_like(x_host, np.nan)
-        a_, b_ = sh.owned_variables()
-        xs[a_:b_] = x_host[a_:b_]
-        nv_ = docp.dims.NLP_v
-        if nv_:
-            xs[-nv_:] = x_host[-nv_:]
-        x = torch.from_numpy(xs).to(dev)
-    else:
-        x = x_full
-    c = torch.zeros(docp.dim_NLP_constraints, dtype=torch.float64, device=dev)
-    vals = torch.zeros(docp.nnzj, dtype=torch.float64, device=dev)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    if os.environ.get("CTD_BENCH_TEST_EXIT_RANK") == str(rank):      # test hook: this rank dies before the first collective of the run
+        os._exit(17)
 
     def sync_all():
         torch.cuda.synchronize(dev)
         if dist_on:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    def within_budget():
+        """rank 0 decides whether an optional block still runs; every rank follows (one tiny collective)"""
+        ok = torch.tensor([1.0 if time.monotonic() - t_start < budget_s else 0.0], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
+        if dist_on:
+            dist.broadcast(ok, src=0)
+        return bool(ok.item() == 1.0)
 
     region = {}
     # the timing machinery itself is warmed before the timed region (first creation / recording of HIP events costs tens of
@@ -256,68 +285,157 @@ def _main(real_stdout):
             el = float(t[0])
         return el
 
-    # The timed step.  N = 1: one fused evaluation, pointers pre-bound.  N > 1: the rank's evaluation on the SHARDED iterate,
-    # the neighbours' entries read in place by the kernel (x_mode "peer"); outputs stay row-sharded: no
-    # collective before or after the kernel.
-    x_mode = "peer" if dist_on else None
-    peer_error = None
-    if dist_on and world > 1:
-        try:        # (raises on every rank together or on none: the ranks agree inside)
-            sh.enable_peer_x(x)
-        except RuntimeError as e:      # IPC mapping refused on this node: fall back to fetching the entries with one all-gather
-            peer_error = repr(e)[:300]
-            x_mode = "halo"
-    el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), args.warmup, args.steps)
-    region_ms = region["ms_per_launch"]
-    per_step_value = (world if cfg["scaling"] == "weak" else 1)
-    secondary = {}
-    if dist_on:
-        # the rank's outputs from the sharded iterate (NaN outside what it owns) equal those from the whole iterate, bit for bit
-        c_chk, v_chk = torch.zeros_like(c), torch.zeros_like(vals)
-        sh.bind_cons_jac(x_full, c_chk, v_chk, stitch=False, x_mode=None)()
-        sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode)()
-        torch.cuda.synchronize(dev)
-        r0, r1 = docp.shard.c_row_begin, docp.shard.c_row_end
-        lo_, hi_ = docp.shard.vals_main_begin, docp.shard.vals_main_end
-        same = torch.tensor([float(torch.equal(c[r0:r1], c_chk[r0:r1]) and torch.equal(vals[lo_:hi_], v_chk[lo_:hi_])
-                                   and (world == 1 or bool(torch.isnan(x).any())))], dtype=torch.float64, device=dev)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        secondary["sharded_iterate_check"] = {"bit_identical_to_whole_iterate_on_every_rank": bool(same.item() == 1.0),
-                                              "what": "each rank's c rows and CSC range from its NaN-padded shard of x vs from the whole x"}
-        ks = max(1, min(args.steps, 500))
-        if peer_error:
-            secondary["peer_error"] = peer_error
-        for key, kw, what in (
-                ("halo_allgather", dict(stitch=False, x_mode="halo"), "the neighbours' entries fetched with one all-gather (pack / all-gather / unpack) before the evaluation instead of read in place"),
-                ("stitched_c", dict(stitch=True, x_mode=x_mode), "the timed step + all-gather of the row blocks of c (every rank ends with the whole c)"),
-                ("broadcast_x", dict(stitch=False, x_mode="broadcast"), "replicated iterate: rank 0 broadcasts all of x before the evaluation"),
-                ("no_exchange", dict(stitch=False, x_mode=None), "evaluation only, the whole x in place on every rank: what reading the neighbours' entries in place costs is the difference to the timed step")):
-            try:      # a secondary figure must never cost the line
-                xin = x if kw["x_mode"] in ("peer", "halo") else x_full
-                els = timed(sh.bind_cons_jac(xin, c, vals, **kw), min(args.warmup, 50), ks)
-                secondary[key] = {"value": ks * per_step_value / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3,
-                                  "steps": ks, "what": what}
-            except Exception as e:
-                secondary[key] = {"error": repr(e)[:300]}
+    def measure(name, steps, warmup, ksec):
+        """One workload of CONFIGS on this job's ranks: the timed step + its secondary figures + per-rank kernel times.
+        N = 1: one fused evaluation, pointers pre-bound.  N > 1: the rank's evaluation on the SHARDED iterate -- x_mode "peer":
+        the neighbours' entries read in place by the kernel, outputs row-sharded, no collective before or
+        after the kernel; x_mode "halo": one all-gather of the few entries first."""
+        from types import SimpleNamespace
+        cf = CONFIGS[name]
+        prob, sch = cf["problem"], cf["scheme"]
+        N = cf["steps"] * world if cf["per_gpu"] else cf["steps"]
+
+        def make(steps=None):      # the handle launches on torch's current stream: ordered with the RCCL collectives
+            return ct.DOCP(prob, N, sch, device=local_rank, steps=steps, stream="torch")
+
+        sh = ctdist.ShardedDOCP(make, N, world=world, rank=rank)
+        docp = sh.docp
+        x_host = bench_inputs(describe(docp, prob, sch), perturb=1e-3)
+        x_full = torch.from_numpy(x_host).to(dev)
+        if dist_on:           # sharded iterate: own variables + the replicated v, NaN everywhere else
+            xs = np.full_like(x_host, np.nan)
+            a_, b_ = sh.owned_variables()
+            xs[a_:b_] = x_host[a_:b_]
+            nv_ = docp.dims.NLP_v
+            if nv_:
+                xs[-nv_:] = x_host[-nv_:]
+            x = torch.from_numpy(xs).to(dev)
+        else:
+            x = x_full
+        c = torch.zeros(docp.dim_NLP_constraints, dtype=torch.float64, device=dev)
+        vals = torch.zeros(docp.nnzj, dtype=torch.float64, device=dev)
+        x_mode = args.x_mode if dist_on else None
+        peer_error = None
+        if dist_on and world > 1 and x_mode == "peer":
+            try:        # (raises on every rank together or on none: the ranks agree inside)
+                sh.enable_peer_x(x)
+            except RuntimeError as e:      # IPC mapping refused on this node: fall back to fetching the entries with one all-gather
+                peer_error = repr(e)[:300]
+                x_mode = "halo"
+        el = timed(sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode), warmup, steps)
+        out = SimpleNamespace(name=name, cfg=cf, N=N, sh=sh, docp=docp, x_host=x_host, x_full=x_full, x=x, c=c, vals=vals, el=el,
+                              steps=steps, x_mode=x_mode, peer_error=peer_error, region_ms=region["ms_per_launch"],
+                              per_step_value=(world if cf["scaling"] == "weak" else 1), secondary={})
+        secondary = out.secondary
+        if dist_on:
+            # the rank's outputs from the sharded iterate (NaN outside what it owns) equal those from the whole iterate, bit for bit
+            c_chk, v_chk = torch.zeros_like(c), torch.zeros_like(vals)
+            sh.bind_cons_jac(x_full, c_chk, v_chk, stitch=False, x_mode=None)()
+            sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode)()
+            torch.cuda.synchronize(dev)
+            r0, r1 = docp.shard.c_row_begin, docp.shard.c_row_end
+            lo_, hi_ = docp.shard.vals_main_begin, docp.shard.vals_main_end
+            same = torch.tensor([float(torch.equal(c[r0:r1], c_chk[r0:r1]) and torch.equal(vals[lo_:hi_], v_chk[lo_:hi_])
+                                       and (world == 1 or bool(torch.isnan(x).any())))], dtype=torch.float64, device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            del c_chk, v_chk
+            secondary["sharded_iterate_check"] = {"bit_identical_to_whole_iterate_on_every_rank": bool(same.item() == 1.0),
+                                                  "what": "each rank's c rows and CSC range from its NaN-padded shard of x vs from the whole x"}
+            ks = max(1, min(steps, ksec))
+            if peer_error:
+                secondary["peer_error"] = peer_error
+            other = "halo" if x_mode == "peer" else "peer"
+            a_, b_ = sh.owned_variables()
+            flag = torch.zeros(1, dtype=torch.float64, device=dev)
+
+            def ordered(launch):
+                # what a solver iteration adds around the evaluation: the rank updates ITS entries of x (here: multiplied by one),
+                # then a collective every rank takes part in (the step-acceptance all-reduce; gloo moves host memory: a barrier
+                # stands in) orders all updates before any rank's next evaluation reads its neighbours' entries in place
+                def call():
+                    x[a_:b_].mul_(1.0)
+                    if backend == "nccl":
+                        dist.all_reduce(flag)
+                    else:
+                        torch.cuda.synchronize(dev)
+                        dist.barrier()
+                    launch()
+                return call
+            figures = [
+                ("other_x_mode", dict(stitch=False, x_mode=other), None,
+                 "the timed step with the other way of obtaining the neighbours' entries: 'halo' = one all-gather (pack / all-gather / unpack) "
+                 "before the evaluation, 'peer' = read in place"),
+                ("stitched_c", dict(stitch=True, x_mode=x_mode), None, "the timed step + all-gather of the row blocks of c (every rank ends with the whole c)"),
+                ("ordered_step", dict(stitch=False, x_mode=x_mode), ordered,
+                 "own-shard update of x + one all-reduce of one double (a solver's step acceptance, which orders every rank's update before "
+                 "its neighbours' reads) + the timed step: what the ordering contract of the in-place reads costs per iteration"),
+                ("broadcast_x", dict(stitch=False, x_mode="broadcast"), None, "replicated iterate: rank 0 broadcasts all of x before the evaluation"),
+                ("no_exchange", dict(stitch=False, x_mode=None), None, "evaluation only, the whole x in place on every rank: what reading the neighbours' entries in place costs is the difference to the timed step")]
+            for key, kw, wrap, what in figures:
+                if key == "other_x_mode" and (peer_error or world == 1):
+                    continue
+                try:      # a secondary figure must never cost the line
+                    xin = x if kw["x_mode"] in ("peer", "halo") else x_full
+                    call = sh.bind_cons_jac(xin, c, vals, **kw)
+                    els = timed(wrap(call) if wrap else call, min(warmup, 50), ks)
+                    secondary[key] = {"value": ks * out.per_step_value / els, "unit": "evals/s", "ms_per_step": els / ks * 1e3,
+                                      "steps": ks, "what": what}
+                    if key == "other_x_mode":
+                        secondary[key]["x_mode"] = other
+                except Exception as e:
+                    secondary[key] = {"error": repr(e)[:300]}
+            if "other_x_mode" in secondary and "x_mode" in secondary["other_x_mode"]:      # (the key earlier lines used)
+                secondary["halo_allgather" if other == "halo" else "peer_in_place"] = secondary["other_x_mode"]
+        # kernel time per rank: per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
+        out.per_dispatch = sorted(docp.time_cons_jac(x_full, c, vals, iters=200) for _ in range(5))[2]
+        # algorithmic bytes of one launch (SURVEY.md section 8d): read the shard's x, write its c rows and Jacobian values:
+        # B = 8 (nvar + ncon + nnzj) of the per-rank sub-problem
+        b, e = sh.steps
+        out.one = ct.DOCP(prob, e - b, sch, device=-1)
+        out.alg_bytes = 8 * (out.one.dim_NLP_variables + out.one.dim_NLP_constraints + out.one.nnzj)
+        out.per_rank = None
+        if dist_on:
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = out.per_dispatch
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out.per_rank = [{"rank": r, "kernel_ms": float(t[r]), "frac": out.alg_bytes / (float(t[r]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            for r in range(world)]
+        return out
+
+    m = measure(args.config, args.steps, args.warmup, 500)
+    sh, docp, x_host, x_full, x, c, vals = m.sh, m.docp, m.x_host, m.x_full, m.x, m.c, m.vals
+    N, el, x_mode, one, alg_bytes = m.N, m.el, m.x_mode, m.one, m.alg_bytes
+    region_ms, per_step_value, secondary, per_dispatch, per_rank = m.region_ms, m.per_step_value, m.secondary, m.per_dispatch, m.per_rank
+    b, e = sh.steps
+
+    # N > 1, default line: the strong-scaling workloads north_star names ("a 10k-step Goddard transcription at 1/2/4/8" =
+    # cfg2_strong; BASELINE configs[3] / [4] sharded), each with its stitched-c variant -- `value` stays the weak-scaling figure
+    strong = {}
+    if world > 1 and args.config == "cfg2_weak" and not args.no_strong:
+        for name in ("cfg2_strong", "cfg4", "cfg5"):
+            if not within_budget():
+                strong[name] = {"skipped": f"wall-time budget of {budget_s:.0f} s (CTD_BENCH_BUDGET_S) used up"}
+                continue
+            try:
+                ks = max(20, min(args.steps, 500 if name == "cfg2_strong" else 200))
+                ms_ = measure(name, ks, min(args.warmup, 50), 200)
+                blk = {"value": ks / ms_.el, "unit": "evals/s", "scaling": "strong", "steps": ks, "ms_per_step": ms_.el / ks * 1e3,
+                       "workload": f"{ms_.cfg['problem']} / {ms_.cfg['scheme']}, {ms_.N} time steps sharded over {world} GPUs: "
+                                   f"{ms_.cfg['what']}; value = evaluations of the whole transcription per second",
+                       "x_mode": ms_.x_mode, "per_rank": ms_.per_rank, "algorithmic_bytes_per_rank_launch": ms_.alg_bytes}
+                blk.update(ms_.secondary)
+                strong[name] = blk
+                ms_.sh.close()
+                del ms_
+                torch.cuda.empty_cache()
+            except Exception as ex:      # (a failure on one rank only leaves the others in a collective: its timeout ends the run)
+                strong[name] = {"error": repr(ex)[:300]}
 
     # roofline of the dominant (only) kernel, per rank.  kernel_ms: N = 1: HIP events on the launch stream around the K
     # timed launches / K (back-to-back launches: the kernel's average duration including the dispatch gap); N > 1 (the
     # region also holds collectives): per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
-    per_dispatch = sorted(docp.time_cons_jac(x_full, c, vals, iters=200) for _ in range(5))[2]
     kernel_ms = region_ms if not dist_on else per_dispatch
-    # algorithmic bytes of one launch: read the shard's x, write its c rows and Jacobian values:
-    # B = 8 (nvar + ncon + nnzj) of the per-rank sub-problem
-    b, e = sh.steps
-    one = ct.DOCP(PROBLEM, e - b, SCHEME, device=-1)
-    alg_bytes = 8 * (one.dim_NLP_variables + one.dim_NLP_constraints + one.nnzj)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    per_rank = None
-    if dist_on:
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
-        t[rank] = per_dispatch
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        per_rank = [{"rank": r, "kernel_ms": float(t[r]), "frac": alg_bytes / (float(t[r]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                    for r in range(world)]
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if world == 1 and args.config == "cfg2_weak" and os.path.exists(pmc):
@@ -499,6 +617,10 @@ def _main(real_stdout):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(PROBLEM, SCHEME, N, x_host)
         out.update(secondary)
+        if strong:
+            out["strong"] = strong
+        if dist_on:
+            out["config"]["x_mode"] = x_mode
         out.update(separately)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

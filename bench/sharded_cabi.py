@@ -3,7 +3,7 @@
 Julia host owning a whole node would use) for every iterate mode.  On a one-GPU box the device is listed G times (the
 shards' kernels then run one after the other on that device, so a step costs G shard kernels): what the figures show is what
 each mode ADDS to the plain shard kernels -- peer copies + events (CTD_X_SHARDED_COPY, CTD_X_FROM_DEVICE0, stitch) or
-nothing (CTD_X_SHARDED: neighbours' entries read in place by the kernels).
+nothing but two event operations per neighbour (CTD_X_SHARDED_IN_PLACE: neighbours' entries read in place by the kernels).
 
     python bench/sharded_cabi.py [G] [cfg ...]        -> one JSON line per (cfg, stream mode)"""
 import json
@@ -61,10 +61,10 @@ def main():
             out = {"workload": f"{prob}/{sch} N={N}", "shards": G, "devices": devices, "stream": stream,
                    "us_per_step": {
                        "in_place": rate(xs_whole, md.X_IN_PLACE, False),
-                       "sharded_read_in_place": rate([t.clone() for t in xs_shard], md.X_SHARDED, False),
+                       "sharded_read_in_place": rate([t.clone() for t in xs_shard], md.X_SHARDED_IN_PLACE, False),
                        "sharded_peer_copies": rate([t.clone() for t in xs_shard], md.X_SHARDED_COPY, False),
                        "from_device0": rate(xs_whole, md.X_FROM_DEVICE0, False),
-                       "sharded_read_in_place+stitch": rate([t.clone() for t in xs_shard], md.X_SHARDED, True)}}
+                       "sharded_read_in_place+stitch": rate([t.clone() for t in xs_shard], md.X_SHARDED_IN_PLACE, True)}}
             print(json.dumps(out), flush=True)
             md.close()
             full.close()

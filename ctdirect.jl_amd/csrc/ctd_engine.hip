@@ -1519,6 +1519,7 @@ struct ctd_sharded {
     std::vector<hipEvent_t> done;        // recorded on shard k's stream after its kernel (its rows of c are final)
     std::vector<hipEvent_t> pulled;      // recorded on shard k's stream after it has pulled the others' row blocks (stitching)
     bool pulls_pending = false;          // the last call stitched: the next kernels must not overwrite rows still being pulled
+    std::vector<char> peer_ok;           // [a * G + b]: device of shard a can load from device of shard b (same device, or peer access enabled)
     int64_t N = 0;
     std::string err;
     ~ctd_sharded() {
@@ -1575,10 +1576,13 @@ int32_t ctd_create_sharded(const ctd_desc* desc, const int32_t* devices, int32_t
             hipEventCreateWithFlags(&s->pulled[k], hipEventDisableTiming) != hipSuccess)
             return sfail(nullptr, CTD_EHIP, "ctd_create_sharded: event creation failed");
     }
-    // peer access between every pair of distinct devices (xGMI); hipMemcpyPeerAsync works without it, through the host
+    // peer access between every pair of distinct devices (xGMI); hipMemcpyPeerAsync works without it, through the host.  Which
+    // pairs can load from each other is RECORDED: CTD_X_SHARDED_IN_PLACE dereferences the other shards' buffers inside the kernels
+    // and falls back to the copying protocol when a pair it needs is not peer-capable (a fault inside a kernel otherwise)
+    s->peer_ok.assign((size_t)n_devices * n_devices, 0);
     for (int a = 0; a < n_devices; ++a)
         for (int b = 0; b < n_devices; ++b) {
-            if (devices[a] == devices[b]) continue;
+            if (devices[a] == devices[b]) { s->peer_ok[(size_t)a * n_devices + b] = (a == b || !env_int("CTD_TEST_NO_PEER", 0)) ? 1 : 0; continue; }      // (test knob: pretend distinct shards cannot reach each other)
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
                 DeviceGuard dg(devices[a]);
@@ -1586,6 +1590,7 @@ int32_t ctd_create_sharded(const ctd_desc* desc, const int32_t* devices, int32_t
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
                     return sfail(nullptr, CTD_ERCCL, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
                 (void)hipGetLastError();
+                s->peer_ok[(size_t)a * n_devices + b] = 1;
             }
         }
     *out = s.release();
@@ -1651,17 +1656,32 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
     const int G = (int)s->h.size();
     for (int k = 0; k < G; ++k)
         if (!x_dev[k] || (stitch && (!c_dev || !c_dev[k]))) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: null buffer");
-    if (x_mode != CTD_X_IN_PLACE && x_mode != CTD_X_SHARDED && x_mode != CTD_X_FROM_DEVICE0 && x_mode != CTD_X_SHARDED_COPY)
+    if (x_mode != CTD_X_IN_PLACE && x_mode != CTD_X_SHARDED && x_mode != CTD_X_FROM_DEVICE0 && x_mode != CTD_X_SHARDED_COPY &&
+        x_mode != CTD_X_SHARDED_IN_PLACE)
         return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: unknown x_mode");
     const Layout& L = s->h[0]->model.L;
     const int64_t N = L.N;
-    // (0) CTD_X_SHARDED: the kernels read the neighbours' entries in place through the peer mappings -- nothing is copied and
-    // nothing is ordered here; the table of buffers is rewritten only when the caller passes other pointers than last time
+    // shards whose buffers shard k reads besides its own: its neighbours, the first (X_1) and the last (X_{N+1})
+    auto reads = [&](int k, int j) { return j != k && (j == k - 1 || j == k + 1 || j == 0 || j == G - 1); };
+    // (0) CTD_X_SHARDED_IN_PLACE: the kernels read the neighbours' entries in place through the peer mappings -- nothing is copied;
+    // the table of buffers is rewritten only when the caller passes other pointers than last time.  A pair of devices that cannot
+    // load from each other (no peer access: hipDeviceCanAccessPeer said no at creation) would fault inside the kernel: the call then
+    // takes the copying protocol of CTD_X_SHARDED instead (same results; ctd_sharded_last_error says so)
+    if (x_mode == CTD_X_SHARDED_IN_PLACE && G > 1) {
+        if (G > kMaxShards) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: CTD_X_SHARDED_IN_PLACE supports at most 16 shards");
+        for (int k = 0; k < G && x_mode == CTD_X_SHARDED_IN_PLACE; ++k)
+            for (int j = 0; j < G; ++j)
+                if (reads(k, j) && !s->peer_ok[(size_t)k * G + j]) {
+                    s->err = "CTD_X_SHARDED_IN_PLACE: device " + std::to_string(s->dev[k]) + " has no peer access to device " + std::to_string(s->dev[j]) +
+                             "; the halo entries are copied instead (CTD_X_SHARDED)";
+                    x_mode = CTD_X_SHARDED;
+                    break;
+                }
+    }
     {
         int64_t sb[kMaxShards + 1];
-        const bool peer = x_mode == CTD_X_SHARDED && G > 1;
+        const bool peer = x_mode == CTD_X_SHARDED_IN_PLACE && G > 1;
         if (peer) {
-            if (G > kMaxShards) return sfail(s, CTD_EINVAL, "ctd_cons_jac_sharded_dev_async: CTD_X_SHARDED supports at most 16 shards");
             for (int k = 0; k < G; ++k) sb[k] = s->h[k]->step_begin;
             sb[G] = N;
         }
@@ -1669,10 +1689,24 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
             const int32_t st = peer ? ctd_set_x_shards(s->h[k], G, sb, x_dev, k) : (s->h[k]->kp.halo ? ctd_set_x_shards(s->h[k], 0, nullptr, nullptr, 0) : CTD_OK);
             if (st) return sfail(s, st, ctd_last_error(s->h[k]));
         }
+        // ... and the cheap half of the copying protocol stays: every shard marks the point of ITS stream behind which its buffer holds
+        // this iterate (work the caller queued there -- e.g. its update of x on that device's stream -- included), and a shard's kernel
+        // waits for the marks of the shards it reads.  No copy; two event operations per neighbour
+        if (peer) {
+            for (int k = 0; k < G; ++k) {
+                DeviceGuard dg(s->dev[k]);
+                SH_TRY(s, hipEventRecord(s->x_ready[k], s->h[k]->stream));
+            }
+            for (int k = 0; k < G; ++k) {
+                DeviceGuard dg(s->dev[k]);
+                for (int j = 0; j < G; ++j)
+                    if (reads(k, j)) SH_TRY(s, hipStreamWaitEvent(s->h[k]->stream, s->x_ready[j], 0));
+            }
+        }
     }
     // (1) iterate distribution.  Every shard first marks the point of its stream behind which its x buffer may be read by
     // the others (its own previous kernel has finished with it; the caller's writes are complete by contract).
-    if ((x_mode == CTD_X_SHARDED_COPY || x_mode == CTD_X_FROM_DEVICE0) && G > 1) {
+    if ((x_mode == CTD_X_SHARDED || x_mode == CTD_X_SHARDED_COPY || x_mode == CTD_X_FROM_DEVICE0) && G > 1) {
         for (int k = 0; k < G; ++k) {
             DeviceGuard dg(s->dev[k]);
             SH_TRY(s, hipEventRecord(s->x_ready[k], s->h[k]->stream));

@@ -169,9 +169,12 @@ class ShardedDOCP:
         self._halo = None
         self._vv = None
         self._f = None
-        self._peer = None                   # data_ptr of the x buffer the peer table was built for (enable_peer_x)
-        self._peer_tables = {}              # x data_ptr -> mapped pointers of the other ranks' buffers
+        self._peer = None                   # data_ptr of the x buffer the peer table is ACTIVE for (enable_peer_x), None: off
+        self._peer_tables = {}              # x data_ptr -> (the tensor itself, mapped pointers of the other ranks' buffers): the
+                                            # tensor is kept alive so the allocator cannot hand its address to another buffer
+                                            # while the other ranks still hold a mapping of it
         self._ipc_bases = []                # (device, base) of every IPC mapping this object opened
+        self._bind_gen = 0                  # bumped whenever the handle's iterate mode changes: bound callables re-assert theirs
 
     def _rebind(self):
         """The engine's kernels and the collectives issued here must share a stream: follow torch's current stream (a cheap
@@ -235,8 +238,10 @@ class ShardedDOCP:
         block, X_1, X_{N+1}) straight from their HBM over xGMI.  The evaluation of a step then contains NO collective, no
         pack / unpack kernel and no copy.  `x` must stay the iterate buffer (same storage) for the life of this object; the
         solver's update of x on every rank has to be complete before the evaluations that follow it are enqueued (its step
-        acceptance is a collective anyway).  Objective / gradient / Hessian callbacks read the x they are given: run
-        `exchange_halo` before those."""
+        acceptance is a collective anyway).  The shard table is state of the HANDLE: while it is active, `cons_jac`, `obj` and
+        `hess_coord` read the neighbours' entries in place too and must be given this same x (anything else raises); the
+        gradient (`docp.grad`) is the whole objective's and ignores the table -- it needs an all-gathered x.  `disable_peer_x`
+        (or binding another x_mode) switches back."""
         from . import _lib
         import ctypes as C
         if self.world == 1:
@@ -245,8 +250,9 @@ class ShardedDOCP:
         if self._peer == x.data_ptr():
             return x
         if x.data_ptr() in self._peer_tables:            # mapped before (the caller alternates between modes)
-            self.docp.set_x_shards(begins, self._peer_tables[x.data_ptr()], self.rank)
+            self.docp.set_x_shards(begins, self._peer_tables[x.data_ptr()][1], self.rank)
             self._peer = x.data_ptr()
+            self._bind_gen += 1
             return x
         L = _lib.lib()
         dev = x.device.index
@@ -292,9 +298,24 @@ class ShardedDOCP:
             raise RuntimeError("enable_peer_x: " + (err or "another rank could not map the buffers"))
         self._ipc_bases += opened
         self.docp.set_x_shards(begins, ptrs, self.rank)
-        self._peer_tables[x.data_ptr()] = ptrs
+        self._peer_tables[x.data_ptr()] = (x, ptrs)
         self._peer = x.data_ptr()
+        self._bind_gen += 1
         return x
+
+    def disable_peer_x(self):
+        """Back to "the x passed to a call holds everything the rank reads" (the mappings stay open for a later enable_peer_x)."""
+        if self._peer is not None:
+            self.docp.set_x_shards(None, None, 0)
+            self._peer = None
+            self._bind_gen += 1
+
+    def _check_peer(self, x, what):
+        """While the shard table is active the kernels take a rank's own entries from the x of the call and its neighbours'
+        entries from the buffers registered with enable_peer_x: any other x would silently mix two iterates."""
+        if self._peer is not None and torch.is_tensor(x) and x.data_ptr() != self._peer:
+            raise ValueError(f"ShardedDOCP.{what}: the sharded iterate is read in place from the buffers registered with "
+                             "enable_peer_x; pass that same x, or call disable_peer_x() first")
 
     def broadcast_iterate(self, x, src=0):
         """Replicated iterate: the rank that holds the new x sends all of it (nvar doubles) to every other rank."""
@@ -312,6 +333,7 @@ class ShardedDOCP:
         """Evaluate this rank's rows into the full-length c / vals buffers; `stitch`: all-gather the row blocks of c so that
         every rank holds the whole residual (the Jacobian values always stay sharded)."""
         self._rebind()
+        self._check_peer(x, "cons_jac")
         self.docp.cons_jac(x, c, vals, sync=False)
         if stitch:
             self._stitcher(c)(c)
@@ -326,15 +348,19 @@ class ShardedDOCP:
         launch = self.docp.bind_cons_jac(x, c, vals, sync=False)
         if self.world == 1 and not _FORCE:
             return launch
-        if x_mode == "peer":                 # neighbours' entries are read in place by the kernel: nothing precedes the launch
-            self.enable_peer_x(x)
-        elif self._peer is not None:
-            self.docp.set_x_shards(None, None, 0)
-            self._peer = None
+        def assert_mode():                   # (the shard table is per-handle state: the callable bound LAST owns it ...)
+            if x_mode == "peer":             # neighbours' entries are read in place by the kernel: nothing precedes the launch
+                self.enable_peer_x(x)        # (first time: collective set-up; afterwards a table lookup)
+            else:
+                self.disable_peer_x()
+            return self._bind_gen
+        gen = [assert_mode()]
         pre = {None: None, "peer": None, "halo": self.exchange_halo, "broadcast": self.broadcast_iterate}[x_mode]
         post = self._stitcher(c) if stitch else None
 
         def call():
+            if gen[0] != self._bind_gen:     # (... and an older callable that runs again puts its own mode back first)
+                gen[0] = assert_mode()
             if pre is not None:
                 pre(x)
             launch()
@@ -347,6 +373,7 @@ class ShardedDOCP:
         the Jacobian values), plus the all-reduced variable x variable entries on every rank.  No host synchronisation: the
         kernel and the all-reduce are ordered on torch's current stream."""
         self._rebind()
+        self._check_peer(x, "hess_coord")
         self.docp.hess_coord(x, y, obj_weight, vals, sync=False)
         if self.world > 1 or _FORCE:
             if self._vv is None:
@@ -362,6 +389,7 @@ class ShardedDOCP:
         if self._f is None:
             self._f = torch.zeros(1, dtype=torch.float64, device=x.device)
         self._rebind()
+        self._check_peer(x, "obj")
         self.docp.obj_async(x, self._f)
         if self.world > 1 or _FORCE:
             dist.all_reduce(self._f, op=dist.ReduceOp.SUM, group=self.group)
@@ -375,4 +403,5 @@ class ShardedDOCP:
                 _lib.lib().ctd_ipc_close(dev, b)
             self._ipc_bases = []
         self._peer = None
+        self._peer_tables = {}
         self.docp.close()

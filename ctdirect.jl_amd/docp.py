@@ -744,7 +744,9 @@ class MultiDeviceDOCP:
     counterpart of `dist.ShardedDOCP`.  Buffers are full-length on every device (global indexing); shard k writes its rows
     of c and its CSC ranges of the Jacobian values.  `devices` may repeat an ordinal (tests on a one-GPU box)."""
 
-    X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0, X_SHARDED_COPY = 0, 1, 2, 3
+    # include/ctdirect_hip.h: X_SHARDED copies the halo entries (peer copies ordered by events, any topology); X_SHARDED_IN_PLACE lets
+    # the kernels load them from the owner's buffer (needs peer access; falls back to the copies when a pair of devices has none)
+    X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0, X_SHARDED_COPY, X_SHARDED_IN_PLACE = 0, 1, 2, 3, 4
 
     def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual", stream="torch"):
         L = _lib.lib()
@@ -822,6 +824,11 @@ class MultiDeviceDOCP:
 
     def sync(self):
         self._ck(_lib.lib().ctd_sharded_sync(self._s))
+
+    def last_error(self):
+        """`ctd_sharded_last_error`: the message of the last failed call -- or of the last fallback (X_SHARDED_IN_PLACE on devices
+        without peer access takes the copying protocol and says so here)."""
+        return _lib.lib().ctd_sharded_last_error(self._s).decode()
 
     def close(self):
         if getattr(self, "_s", None):

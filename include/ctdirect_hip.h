@@ -336,15 +336,25 @@ typedef struct ctd_sharded ctd_sharded;
 
 enum {
     CTD_X_IN_PLACE = 0,      /* every x_dev[k] already holds what shard k reads (e.g. the solver replicates x)               */
-    CTD_X_SHARDED = 1,       /* x_dev[k] holds shard k's own variables (+ the replicated v).  The kernels load the few entries */
-                             /*   a shard needs from its neighbours -- next shard's first node, previous shard's last block     */
-                             /*   (midpoint / Euler), X_1, X_{N+1} -- IN PLACE from the owner's buffer through the peer         */
-                             /*   mappings (xGMI): no copy, no event, no collective in the step (ctd_set_x_shards).  The       */
-                             /*   caller's writes to EVERY x_dev[k] must be complete, or ordered before every shard's stream    */
+    CTD_X_SHARDED = 1,       /* x_dev[k] holds shard k's own variables (+ the replicated v).  The few entries a shard needs    */
+                             /*   from its neighbours -- next shard's first node, previous shard's last block (midpoint /      */
+                             /*   Euler), X_1, X_{N+1} -- are COPIED into x_dev[k] (hipMemcpyPeerAsync on the shards' streams, */
+                             /*   ordered by events: a shard's buffer is read behind the work already queued on ITS stream);   */
+                             /*   afterwards every callback of shard k's handle can run on x_dev[k].  Works on any topology    */
+                             /*   (without peer access the copies go through the host).  The meaning this value has had since  */
+                             /*   round 2; round 3 had given it to the in-place mode below                                      */
     CTD_X_FROM_DEVICE0 = 2,  /* x_dev[0] holds the whole iterate: the engine copies all of it to the other devices          */
-    CTD_X_SHARDED_COPY = 3   /* as CTD_X_SHARDED, but the halo entries are COPIED into x_dev[k] (hipMemcpyPeerAsync on the   */
-                             /*   shards' streams, ordered by events: a shard's buffer is read behind the work already queued  */
-                             /*   on ITS stream); afterwards every callback of shard k's handle can run on x_dev[k]          */
+    CTD_X_SHARDED_COPY = 3,  /* = CTD_X_SHARDED (kept for callers of round 3)                                                 */
+    CTD_X_SHARDED_IN_PLACE = 4 /* as CTD_X_SHARDED, but nothing is copied: the kernels LOAD those entries in place from the   */
+                             /*   owner's buffer through the peer mappings (xGMI; ctd_set_x_shards).  Ordering: every shard's  */
+                             /*   stream records an event, the shards that read its buffer wait for it -- so work the caller   */
+                             /*   queued on x_dev[k]'s device stream (ctd_set_stream) before this call is ordered before the   */
+                             /*   neighbours' reads; writes from anywhere else must be complete.  The other callbacks of a     */
+                             /*   shard handle then read the neighbours' entries through the same table (objective, Hessian)   */
+                             /*   -- except ctd_grad*, which needs a whole iterate.  Needs peer access between the devices of  */
+                             /*   neighbouring shards, of the first and of the last shard (recorded by ctd_create_sharded): a  */
+                             /*   pair without it makes the call take the CTD_X_SHARDED protocol instead of faulting inside    */
+                             /*   the kernel, and ctd_sharded_last_error names the pair                                         */
 };
 
 /* desc->device, step_begin / step_end and stream are ignored (must be 0 / NULL); devices[k] are HIP ordinals */

@@ -163,14 +163,14 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
     assert (md.dim_NLP_variables, md.dim_NLP_constraints, md.nnzj) == (full.dim_NLP_variables, full.dim_NLP_constraints, full.nnzj)
     assert [s.step_begin for s in md.shards] == [0, md.shards[0].step_end, md.shards[1].step_end] and md.shards[2].step_end == N
     blk, nv = full.discretization._step_variables_block, full.dims.NLP_v
-    for mode in (md.X_SHARDED, md.X_SHARDED_COPY, md.X_FROM_DEVICE0, md.X_IN_PLACE):
+    for mode in (md.X_SHARDED_IN_PLACE, md.X_SHARDED, md.X_SHARDED_COPY, md.X_FROM_DEVICE0, md.X_IN_PLACE):
         xs = []
         for k, s in enumerate(md.shards):
             if mode == md.X_IN_PLACE or (mode == md.X_FROM_DEVICE0 and k == 0):
                 xs.append(xd.clone())
                 continue
             t = np.full_like(x, np.nan)
-            if mode in (md.X_SHARDED, md.X_SHARDED_COPY):
+            if mode in (md.X_SHARDED_IN_PLACE, md.X_SHARDED, md.X_SHARDED_COPY):
                 end = s.step_end * blk if k < 2 else x.size - nv
                 t[s.step_begin * blk:end] = x[s.step_begin * blk:end]
                 if nv:
@@ -181,7 +181,7 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
         for _ in range(2):            # twice: the second call must not overwrite rows another shard is still pulling
             md.cons_jac(xs, cs, vs, x_mode=mode, stitch=True, sync=False)
         md.sync()
-        if mode == md.X_SHARDED:          # read in place: nothing was copied into the shards' buffers
+        if mode == md.X_SHARDED_IN_PLACE:          # read in place: nothing was copied into the shards' buffers
             for k in range(3):
                 assert torch.isnan(xs[k]).any()
                 assert torch.isnan(xs[k][:md.shards[k].step_begin * blk]).all()
@@ -190,6 +190,39 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
             assert torch.equal(cs[k], cf), (mode, k)                 # whole residual on every shard, bit for bit
             v = torch.where(vs[k] != 777.0, vs[k], v)
         assert torch.equal(v, vf), mode
+    md.close()
+    full.close()
+
+
+def test_in_place_mode_without_peer_access_falls_back_to_copies(monkeypatch):
+    """CTD_X_SHARDED_IN_PLACE dereferences the other shards' buffers inside the kernels; on a topology without peer
+    access (simulated: CTD_TEST_NO_PEER makes ctd_create_sharded record every pair of distinct shards as unreachable) the call
+    must take the copying protocol instead of faulting, say so, and give the same bits."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import ctdirect_jl_amd as ct
+    from helpers import bench_inputs, describe
+    prob, sch, N = "double_integrator_path", "midpoint", 999
+    full = ct.DOCP(prob, N, sch, device=0)
+    x = bench_inputs(describe(full, prob, sch), perturb=1e-3)
+    cf, vf = full.cons_jac(torch.from_numpy(x).cuda())
+    monkeypatch.setenv("CTD_TEST_NO_PEER", "1")
+    md = ct.MultiDeviceDOCP(prob, N, sch, [0, 0])
+    monkeypatch.delenv("CTD_TEST_NO_PEER")
+    blk = full.discretization._step_variables_block
+    xs = []
+    for k, s in enumerate(md.shards):
+        t = np.full_like(x, np.nan)
+        end = s.step_end * blk if k == 0 else x.size
+        t[s.step_begin * blk:end] = x[s.step_begin * blk:end]
+        xs.append(torch.from_numpy(t).cuda())
+    cs = [torch.full_like(cf, 777.0) for _ in range(2)]
+    vs = [torch.full_like(vf, 777.0) for _ in range(2)]
+    md.cons_jac(xs, cs, vs, x_mode=md.X_SHARDED_IN_PLACE, stitch=True, sync=True)
+    assert "no peer access" in md.last_error()
+    assert not torch.isnan(xs[0][md.shards[0].step_end * blk:md.shards[0].step_end * blk + 2]).any()     # the halo was COPIED
+    v = torch.where(vs[0] != 777.0, vs[0], vs[1])
+    assert torch.equal(cs[0], cf) and torch.equal(cs[1], cf) and torch.equal(v, vf)
     md.close()
     full.close()
 
