@@ -6,14 +6,14 @@ cd "$(dirname "$0")/.."
 O=gpurun_out
 mkdir -p $O
 set -o pipefail
-t0=$(date +%s.%N)
-timeout -k 10 420 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_selflaunch.json 2> $O/r04_2rank_selflaunch.err; echo "selflaunch rc=$? $(echo "$(date +%s.%N) - $t0" | bc) s"
-t0=$(date +%s.%N)
+t0=$SECONDS
+timeout -k 10 420 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_selflaunch.json 2> $O/r04_2rank_selflaunch.err; echo "selflaunch rc=$? $((SECONDS - t0)) s"
+t0=$SECONDS
 timeout -k 10 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_torchrun.json 2> $O/r04_2rank_torchrun.err; echo "torchrun rc=$? $(echo "$(date +%s.%N) - $t0" | bc) s"
+    bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_torchrun.json 2> $O/r04_2rank_torchrun.err; echo "torchrun rc=$? $((SECONDS - t0)) s"
 timeout -k 10 300 python bench.py --gpus 2 --steps 200 --warmup 20 --x-mode halo --no-strong > $O/r04_2rank_halo.json 2> $O/r04_2rank_halo.err; echo "halo rc=$?"
-t0=$(date +%s.%N)
-CTD_BENCH_TEST_EXIT_RANK=1 timeout -k 10 300 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_kill.json 2> $O/r04_2rank_kill.err; echo "kill-hook rc=$? (expected 17) $(echo "$(date +%s.%N) - $t0" | bc) s total (includes the ranks' start-up)"
+t0=$SECONDS
+CTD_BENCH_TEST_EXIT_RANK=1 timeout -k 10 300 python bench.py --gpus 2 --steps 200 --warmup 20 > $O/r04_2rank_kill.json 2> $O/r04_2rank_kill.err; echo "kill-hook rc=$? (expected 17) $((SECONDS - t0)) s total (includes the ranks' start-up)"
 grep "launcher:" $O/r04_2rank_kill.err
 python - <<'PY'
 import json
