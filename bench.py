@@ -447,7 +447,7 @@ def _main(real_stdout):
             traffic = None
 
     # the other single-GPU BASELINE configs (parity-test cases, not the bench line): kernel time and roofline fraction
-    others, hessian, optimized = [], [], []
+    others, hessian, optimized, csr_rows = [], [], [], []
     if world == 1 and not args.no_extras:
         for prob, sch, n in (("double_integrator_path", "midpoint", 100000), ("goddard", "gauss_legendre_3", 80000),
                              ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000),
@@ -477,6 +477,29 @@ def _main(real_stdout):
                               "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
             d2.close()
             del x2, c2, v2
+        # CTD_ORDER_CSR (north_star: "assembled ... in CSR on device"): the same kernel with a row-order emit template; the same bytes
+        # are written, so the time should stay within a few per cent of the CSC order's (never `value`: the metric's order is the
+        # reference's CSC)
+        for prob, sch, n, pat in (("goddard", "gauss_legendre_2", 10000, "manual"), ("goddard", "gauss_legendre_3", 80000, "manual"),
+                                  ("quadrotor12", "gauss_legendre_3", 20000, "manual"), ("quadrotor12", "gauss_legendre_3", 20000, "optimized"),
+                                  ("double_integrator_path", "midpoint", 100000, "manual")):
+            try:
+                row = {"workload": f"{prob}/{sch} N={n}, pattern={pat}"}
+                for order in ("csc", "csr"):
+                    d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch", pattern=pat, value_order=order)
+                    x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
+                    c2 = torch.zeros(d2.dim_NLP_constraints, dtype=torch.float64, device=dev)
+                    v2 = torch.zeros(d2.nnzj, dtype=torch.float64, device=dev)
+                    ms2 = sorted(d2.time_cons_jac(x2, c2, v2, iters=50) for _ in range(3))[1]
+                    b2 = 8 * (d2.dim_NLP_variables + d2.dim_NLP_constraints + d2.nnzj)
+                    row[order] = {"kernel_ms": ms2, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "launch": d2.launch_info()}
+                    row["algorithmic_bytes"] = b2
+                    d2.close()
+                    del x2, c2, v2
+                row["csr_over_csc"] = row["csr"]["kernel_ms"] / row["csc"]["kernel_ms"]
+                csr_rows.append(row)
+            except Exception as ex:
+                csr_rows.append({"workload": f"{prob}/{sch} N={n}, pattern={pat}", "error": repr(ex)[:300]})
         # the Hessian-of-the-Lagrangian row (hess_coord!): kernel-only figures, not part of `value`.
         # Algorithmic bytes: read x and y, write the lower-triangular values: 8 (nvar + ncon + nnzh).
         for prob, sch, n in (("goddard", "gauss_legendre_2", 10000), ("goddard", "gauss_legendre_3", 80000),
@@ -612,6 +635,8 @@ def _main(real_stdout):
             out["other_configs_kernel_only"] = others
         if optimized:
             out["optimized_pattern_kernel_only"] = optimized
+        if csr_rows:
+            out["csr_order_kernel_only"] = csr_rows
         if hessian:
             out["hessian_kernel_only"] = hessian
         if world == 1 and not args.no_cpu_baseline:

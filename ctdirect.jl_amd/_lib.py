@@ -19,7 +19,7 @@ class ctd_desc(C.Structure):
     _fields_ = [("problem", C.c_int32), ("scheme", C.c_int32), ("pattern_mode", C.c_int32), ("device", C.c_int32),
                 ("grid_size", C.c_int64), ("time_grid", C.POINTER(C.c_double)), ("time_grid_len", C.c_int64),
                 ("step_begin", C.c_int64), ("step_end", C.c_int64), ("stream", C.c_void_p),
-                ("stream_mode", C.c_int32), ("control_steps", C.c_int32)]
+                ("stream_mode", C.c_int32), ("control_steps", C.c_int32), ("value_order", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class ctd_init(C.Structure):
@@ -59,6 +59,8 @@ SYMBOLS = {
     "ctd_initial_guess": (C.c_int32, [_vp, _dp, C.POINTER(ctd_init)]),
     "ctd_jac_structure": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_jac_csc": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_jac_csr": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_value_order": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "ctd_dropped_nonzeros": (C.c_int32, [_vp, _ip]),
     "ctd_obj": (C.c_int32, [_vp, _dp, _dp]),
     "ctd_grad": (C.c_int32, [_vp, _dp, _dp]),
@@ -82,6 +84,7 @@ SYMBOLS = {
     "ctd_jit_check": (C.c_int32, [C.c_int32, C.c_int32]),
     "ctd_hess_structure": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_hess_csc": (C.c_int32, [_vp, _ip, _ip]),
+    "ctd_hess_csr": (C.c_int32, [_vp, _ip, _ip]),
     "ctd_hess_coord": (C.c_int32, [_vp, _dp, _dp, C.c_double, _dp]),
     "ctd_hess_coord_dev": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp]),
     "ctd_hess_coord_dev_async": (C.c_int32, [_vp, _vp, _vp, C.c_double, _vp]),

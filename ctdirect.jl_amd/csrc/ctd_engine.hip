@@ -325,7 +325,8 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     std::unique_ptr<ctd_handle, Del> h(new (std::nothrow) ctd_handle());
     if (!h) return fail(nullptr, CTD_ENOMEM, "ctd_create: out of memory");
     HostDesc hd{desc->problem, desc->scheme, desc->pattern_mode, desc->grid_size, desc->time_grid, desc->time_grid_len,
-                desc->control_steps > 1 ? desc->control_steps : 1};
+                desc->control_steps > 1 ? desc->control_steps : 1, desc->value_order};
+    if (desc->reserved0 != 0) return fail(nullptr, CTD_EINVAL, "ctd_create: ctd_desc.reserved0 must be 0 (zero-initialise the descriptor: memset / ctd_desc d = {0})");
     std::string err;
     int st;
     try {
@@ -625,6 +626,13 @@ int32_t ctd_jac_structure(const ctd_handle* h, int64_t* rows, int64_t* cols) {
     const Model& mo = h->model;
     std::vector<int64_t> r;
     int64_t nz = 0;
+    if (mo.order == 1) {                 // CTD_ORDER_CSR: the k-th value belongs to the k-th entry read by rows
+        for (int64_t i = 0; i < mo.L.ncon; ++i) {
+            mo.gen_row(i, r);
+            for (int64_t col : r) { rows[nz] = i + 1; cols[nz] = col + 1; ++nz; }
+        }
+        return nz == mo.nnzj ? CTD_OK : CTD_EPATTERN;
+    }
     for (int64_t j = 0; j < mo.L.nvar; ++j) {
         mo.gen_column(j, r);
         for (int64_t row : r) { rows[nz] = row + 1; cols[nz] = j + 1; ++nz; }
@@ -646,6 +654,27 @@ int32_t ctd_jac_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval) {
     return nz == mo.nnzj ? CTD_OK : CTD_EPATTERN;
 }
 
+int32_t ctd_jac_csr(const ctd_handle* h, int64_t* rowptr, int64_t* colind) {
+    if (!h || !rowptr || !colind) return CTD_EINVAL;
+    const Model& mo = h->model;
+    std::vector<int64_t> c;
+    int64_t nz = 0;
+    for (int64_t i = 0; i < mo.L.ncon; ++i) {
+        rowptr[i] = nz;
+        if (mo.order == 1 && mo.row_start(i) != nz) return fail(const_cast<ctd_handle*>(h), CTD_EPATTERN, "internal: row_start disagrees with the generated rows");
+        mo.gen_row(i, c);
+        for (int64_t col : c) colind[nz++] = col;
+    }
+    rowptr[mo.L.ncon] = nz;
+    return nz == mo.nnzj ? CTD_OK : CTD_EPATTERN;
+}
+
+int32_t ctd_value_order(const ctd_handle* h, int32_t* order) {
+    if (!h || !order) return CTD_EINVAL;
+    *order = h->model.order;
+    return CTD_OK;
+}
+
 int32_t ctd_dropped_nonzeros(const ctd_handle* h, int64_t* count) {
     if (!h || !count) return CTD_EINVAL;
     *count = h->model.dropped;
@@ -660,8 +689,8 @@ int32_t ctd_shard_info(const ctd_handle* h, int64_t* o) {
     o[0] = h->step_begin; o[1] = h->step_end;
     o[2] = h->step_begin * L.cb;
     o[3] = h->step_end * L.cb;      // (+ the p + bc tail rows [N*cb, ncon), which every shard writes)
-    o[4] = mo.column_start(h->step_begin * L.blk);
-    o[5] = mo.column_start(h->step_end * L.blk);
+    o[4] = mo.shard_vals_begin(h->step_begin);
+    o[5] = mo.shard_vals_end(h->step_end);
     o[6] = first; o[7] = last;
     return CTD_OK;
 }
@@ -1180,6 +1209,10 @@ int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols) {
     }
     return CTD_OK;
 }
+
+int32_t ctd_hess_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval);
+// upper triangle by rows = lower triangle by columns (symmetric matrix): the same arrays, the same value order
+int32_t ctd_hess_csr(const ctd_handle* h, int64_t* rowptr, int64_t* colind) { return ctd_hess_csc(h, rowptr, colind); }
 
 int32_t ctd_hess_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval) {
     if (!h || !colptr || !rowval) return CTD_EINVAL;

@@ -578,6 +578,48 @@ int64_t Model::column_start(int64_t j) const {
     return cp_tail[j - t];
 }
 
+// Columns of row r, sorted: the same union of add_nonzero_block! rectangles, read along a row (CSR order of the value array).
+// A step row only meets the blocks of its own step (step_blocks(i) lists the U_{i-1} columns of implicit Euler's path rows too),
+// the p + bc tail rows only the tail blocks.
+void Model::gen_row(int64_t r, std::vector<int64_t>& cols) const {
+    cols.clear();
+    std::vector<Block> cand;
+    if (r < L.N * (int64_t)L.cb) step_blocks(r / L.cb, cand);
+    else cand = tail;
+    std::vector<std::pair<int64_t, int64_t>> iv;
+    for (const Block& b : cand)
+        if (r >= b.r0 && r < b.r1) iv.emplace_back(b.c0, b.c1);
+    std::sort(iv.begin(), iv.end());
+    int64_t next = -1;
+    for (auto& p : iv) {
+        int64_t c = std::max(p.first, next);
+        for (; c < p.second; ++c)
+            if (pattern_mode != 2 || opt_dep(r, c)) cols.push_back(c);
+        next = std::max(next, p.second);
+    }
+}
+
+int64_t Model::row_start(int64_t r) const {
+    const int64_t h = reg_first * L.cb, t = reg_last * L.cb;
+    if (r < h) return cp_head[r];
+    if (r < t) {
+        const int64_t i = r / L.cb;
+        return seg_base + (i - reg_first) * (int64_t)Lseg + cp_tmpl[r - i * L.cb];
+    }
+    return cp_tail[r - t];
+}
+
+// CSC: the contiguous range of the shard's step columns (its slices of the V columns and, for the neighbours of a one-point
+// scheme, nothing else).  CSR: the shard's ONE range -- its step rows; the last shard's range runs to the end of the array (the
+// p + bc tail rows follow the step rows)
+int64_t Model::shard_vals_begin(int64_t step_begin) const {
+    return order == 1 ? row_start(step_begin * L.cb) : column_start(step_begin * L.blk);
+}
+int64_t Model::shard_vals_end(int64_t step_end) const {
+    if (order == 1) return step_end == L.N ? nnzj : row_start(step_end * L.cb);
+    return column_start(step_end * L.blk);
+}
+
 // relative template codes of the step-periodic segment of step i
 static bool segment_codes(const Model& mo, int64_t i, std::vector<uint32_t>& codes, std::vector<int64_t>& cp,
                           std::vector<int64_t>& relrows, int& need_prev) {
@@ -778,19 +820,165 @@ static int build_tables(Model& mo, std::string& err) {
         }
     }
 
-    // structural nonzeros the selected pattern leaves out (hazard H1)
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// CSR value order (ctd_desc.value_order = CTD_ORDER_CSR).  The reference assembles (Is, Js) and lets SparseArrays.sparse sort them
+// by column (midpoint.jl:229-232, irk_stagewise.jl:555-558); a GPU KKT consumer (rocSPARSE / hipSOLVER) takes rows.  Read by rows
+// the pattern is simpler than by columns: row r of step i only meets columns of its own block, of X_{i+1} (U_{i+1} for trapeze,
+// U_{i-1} for implicit Euler's path rows) and V, so step i owns ONE contiguous range of Lseg values -- V entries inline -- for
+// EVERY step (no irregular first / last step columns, no V streams), and only the p + bc tail rows are explicit edge entries.
+// The emit phase is unchanged: the same 32-bit codes, one template of Lseg codes per step, kp.vr = 0.
+// ------------------------------------------------------------------------------------------------------
+static bool row_segment_codes(const Model& mo, int64_t i, std::vector<uint32_t>& codes, std::vector<int64_t>& rp,
+                              std::vector<int64_t>& relcols, int& need) {
+    const Layout& L = mo.L;
+    codes.clear(); relcols.clear();
+    rp.assign(L.cb + 1, 0);
+    std::vector<int64_t> cols;
+    for (int lr = 0; lr < L.cb; ++lr) {
+        const int64_t row = i * L.cb + lr;
+        mo.gen_row(row, cols);
+        for (int64_t col : cols) {
+            Model::Entry e = mo.classify(row, col);
+            if (e.kind != 0) return false;
+            int64_t crel = i - e.cstep, drel = i - e.dstep;
+            if (e.cconst) crel = 0;
+            if (e.di == 0) drel = 0;
+            if (crel != 0 || drel < -1 || drel > 0) return false;      // a row reads its own step's record (trapeze: + the next node's)
+            if (drel == -1) need |= 2;
+            codes.push_back(pack_code(e.di, e.ci, e.beta, drel == -1 ? kRecNext : 0, 0));
+            relcols.push_back(col >= L.v_off ? ((int64_t)1 << 40) + (col - L.v_off) : col - i * L.blk);
+        }
+        rp[lr + 1] = (int64_t)codes.size();
+    }
+    return true;
+}
+
+static int build_tables_csr(Model& mo, std::string& err) {
+    const Layout& L = mo.L;
+    const int64_t N = L.N;
+    if (L.nv > kMaxNV) { err = "more than 4 optimisation variables are not supported by the emit tables"; return ST_EPATTERN; }
+    if (mo.R.stride >= 65536 || mo.R.bsize >= 65536) { err = "per-step record too large for 16-bit data indices"; return ST_EPATTERN; }
+    // halo records of a tile: rows never read the previous step's record; implicit Euler's path rows are EVALUATED with U_{i-1}, which
+    // the staged tiles find in the previous slot (path_control); trapeze reads the next node's record
+    mo.HL = (L.euler == 2) ? 1 : 0;
+    mo.HH = (L.sc == SC_TRAPEZE) ? 1 : 0;
+    std::vector<uint32_t> c1, c2;
+    std::vector<int64_t> rp1, rp2, rc1, rc2;
+    int need = 0;
+    mo.vr = 0; mo.vtmpl.clear();
+    for (int k = 0; k < kMaxNV; ++k) mo.vcol_base[k] = 0;
+    // By rows every step has the same segment -- also the first and the last one, for any N >= 1 (no all-edge mode for tiny grids) --
+    // except implicit Euler's step 0 on the structural / optimized patterns (its path rows have no U_{-1} columns): the template is
+    // step 1's (step 0's when N = 1), steps that differ from it become explicit edge entries
+    {
+        const int64_t ref = N >= 2 ? 1 : 0;
+        if (!row_segment_codes(mo, ref, c1, rp1, rc1, need)) { err = "Jacobian pattern is not step-local by rows"; return ST_EPATTERN; }
+        auto same = [&](int64_t i) { int n2 = 0; return row_segment_codes(mo, i, c2, rp2, rc2, n2) && c2 == c1 && rp2 == rp1 && rc2 == rc1; };
+        mo.reg_first = same(0) ? 0 : 1;
+        mo.reg_last = same(N - 1) ? N : N - 1;
+        if (mo.reg_last < mo.reg_first) mo.reg_last = mo.reg_first;
+        for (int64_t chk : {(int64_t)2, N / 2, N - 2})
+            if (chk > mo.reg_first && chk < mo.reg_last - 1 && !same(chk)) { err = "Jacobian pattern is not step-periodic by rows"; return ST_EPATTERN; }
+        if ((need & 2) && mo.HH == 0) { err = "internal: row template needs the next step's record but the tile has no halo"; return ST_EPATTERN; }
+        mo.tmpl = c1;
+        mo.cp_tmpl = rp1;
+        mo.Lseg = (int)c1.size();
+    }
+    // ---- row starts ------------------------------------------------------------------------------------------
+    std::vector<int64_t> cols;
+    const int64_t head_rows = mo.reg_first * L.cb;
+    mo.cp_head.assign(head_rows + 1, 0);
+    int64_t nz = 0;
+    for (int64_t r = 0; r < head_rows; ++r) { mo.cp_head[r] = nz; mo.gen_row(r, cols); nz += (int64_t)cols.size(); }
+    mo.cp_head[head_rows] = nz;
+    mo.seg_base = nz;
+    nz += (mo.reg_last - mo.reg_first) * (int64_t)mo.Lseg;
+    const int64_t tail0 = mo.reg_last * L.cb, tail_rows = L.ncon - tail0;
+    mo.cp_tail.assign(tail_rows + 1, 0);
+    for (int64_t rr = 0; rr < tail_rows; ++rr) { mo.cp_tail[rr] = nz; mo.gen_row(tail0 + rr, cols); nz += (int64_t)cols.size(); }
+    mo.cp_tail[tail_rows] = nz;
+    mo.nnzj = nz;
+    // ---- edge entries: the rows of irregular leading / trailing steps (all steps when N < 5) and the p + bc tail rows ----------
+    struct Raw { int64_t idx; Model::Entry e; };
+    std::vector<Raw> first, last;
+    std::set<int64_t> needrec;
+    needrec.insert(0);
+    needrec.insert(N - 1);
+    auto scan_row = [&](int64_t r, std::vector<Raw>& dst) {
+        mo.gen_row(r, cols);
+        const int64_t base = mo.row_start(r);
+        for (size_t t = 0; t < cols.size(); ++t) {
+            Model::Entry e = mo.classify(r, cols[t]);
+            if (e.kind == 0) {
+                if (!e.cconst) needrec.insert(e.cstep);
+                if (e.di != 0) needrec.insert(e.dstep);
+            }
+            dst.push_back(Raw{base + (int64_t)t, e});
+        }
+    };
+    mo.head_ptr.assign(mo.reg_first + 1, 0);       // head entries grouped by step: a shard emits the groups of its own steps
+    for (int64_t r = 0; r < head_rows; ++r) {
+        if (r % L.cb == 0) mo.head_ptr[r / L.cb] = (int)first.size();
+        scan_row(r, first);
+    }
+    mo.head_ptr[mo.reg_first] = (int)first.size();
+    for (int64_t r = tail0; r < L.ncon; ++r) scan_row(r, last);
+    if ((int)needrec.size() > kMaxEdgeSlots) { err = "internal: too many edge records"; return ST_EPATTERN; }
+    std::map<int64_t, int> slot_of;
+    mo.n_edge_slots = 0;
+    for (int64_t s : needrec) { slot_of[s] = mo.n_edge_slots; mo.edge_steps[mo.n_edge_slots++] = s; }
+    mo.edge_fp = mo.n_edge_slots;
+    mo.edge_b = mo.n_edge_slots + 1;
+    mo.edge_slot_first = slot_of[0];
+    mo.edge_slot_last = slot_of[N - 1];
+    mo.edge_idx.clear(); mo.edge_code.clear();
+    auto emit = [&](const std::vector<Raw>& src) {
+        for (const Raw& r : src) {
+            const Model::Entry& e = r.e;
+            int crec, drec;
+            if (e.kind == 0) {
+                drec = (e.di != 0) ? slot_of[e.dstep] : slot_of[0];
+                crec = (!e.cconst) ? slot_of[e.cstep] : drec;
+            } else {
+                crec = drec = (e.kind == 1) ? mo.edge_fp : mo.edge_b;
+            }
+            mo.edge_idx.push_back(r.idx);
+            mo.edge_code.push_back(pack_code(e.di, e.ci, e.beta, drec, crec));
+        }
+    };
+    emit(first);
+    mo.edge_split = (int)mo.edge_idx.size();
+    for (int q = 0; q < L.p; ++q) {                // tail of c: final path values and boundary values (computed by every shard)
+        mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + q));
+        mo.edge_code.push_back(pack_code(mo.R.oR + q, C_ONE, 0, mo.edge_fp, mo.edge_fp));
+    }
+    for (int r = 0; r < L.bc; ++r) {
+        mo.edge_idx.push_back(kEdgeCBit | (N * L.cb + L.p + r));
+        mo.edge_code.push_back(pack_code(mo.R.oBval + r, C_ONE, 0, mo.edge_b, mo.edge_b));
+    }
+    mo.edge_split2 = (int)mo.edge_idx.size();
+    emit(last);
+    mo.pos_order.clear();                          // (early emission is a CSC-order experiment)
+    mo.n_late = mo.Lseg; mo.n_early = mo.c_early = mo.vr_early = 0;
+    return ST_OK;
+}
+
+// structural nonzeros the selected pattern leaves out (hazard H1; implicit Euler's (path_i, U_{i-1}) entries)
+static void count_dropped(Model& mo) {
+    const Layout& L = mo.L;
+    const int64_t N = L.N;
     mo.dropped = 0;
     if (mo.pattern_mode == 0 && L.sc == SC_TRAPEZE && L.nv > 0 && (L.free_time || mo.dyn_v))
         mo.dropped = N * (int64_t)L.n * L.nv;
-    // implicit Euler: the path rows of nodes 2..N depend on U_{i-1}, the pattern lists U_i (euler.jl:59-72 vs :231), in
-    // either pattern mode (the periodic emit tables cannot reference the next step's record)
     if (L.euler == 2 && L.p > 0 && L.m > 0 && mo.pattern_mode == 0) {
         int64_t pairs = 0;                                  // (path row, control) pairs the path functions really couple
         for (int q = 0; q < L.p; ++q)
             for (int c = 0; c < L.m; ++c) pairs += (mo.dep_g.size() > (size_t)q && (mo.dep_g[q] >> (L.n + c) & 1u)) ? 1 : 0;
         mo.dropped += (N - 1) * pairs;
     }
-    return ST_OK;
 }
 
 int default_tile(const Model& mo, int64_t nsteps) {
@@ -941,8 +1129,11 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
     build_bounds(mo);
     build_tail_blocks(mo);
     compute_dep_masks(mo);          // operator-level dependence masks: the OPTIMIZED pattern, and the count of dropped nonzeros
-    st = build_tables(mo, err);
+    if (d.value_order != 0 && d.value_order != 1) { err = "unknown value order (CTD_ORDER_CSC = 0, CTD_ORDER_CSR = 1)"; return ST_EINVAL; }
+    mo.order = d.value_order;
+    st = mo.order == 1 ? build_tables_csr(mo, err) : build_tables(mo, err);
     if (st) return st;
+    count_dropped(mo);
     return build_hess_model(mo, err);
 }
 

@@ -18,6 +18,7 @@ struct HostDesc {
     const double* time_grid;
     int64_t time_grid_len;
     int control_steps = 1;            // DOCP(ocp, grid_size, control_steps, scheme, time_grid), src/DOCP_data.jl:293
+    int value_order = 0;              // ctd_desc.value_order: 0 = CSC (the reference's SparseArrays.sparse order), 1 = CSR
 };
 
 struct Block { int64_t r0, r1, c0, c1; };   // rows [r0,r1) x cols [c0,c1), 0-based
@@ -65,6 +66,12 @@ struct HessModel {
 
 struct Model {
     int problem = 0, pattern_mode = 0;
+    // Order of the Jacobian VALUE array (ctd_desc.value_order).  0: CSC, the order of SparseArrays.sparse(Is, Js, ...) the reference
+    // hands to ADNLPModels (midpoint.jl:229-232, irk_stagewise.jl:555-558).  1: CSR (north_star: "assembled ... in CSR on device"):
+    // the rows of step i -- with their entries in the V columns inline -- are ONE contiguous range of Lseg values, so every field
+    // below that speaks of "columns" then speaks of rows: tmpl / Lseg / seg_base / cp_* describe the row-periodic segment, vr = 0
+    // (no separate V streams), and a shard of the grid owns one contiguous range of the value array
+    int order = 0;
     ProblemInfo info;
     Layout L;
     RecLayout R;
@@ -117,7 +124,11 @@ struct Model {
     Entry classify(int64_t row, int64_t col) const;
     void step_blocks(int64_t i, std::vector<Block>& out) const;
     void gen_column(int64_t j, std::vector<int64_t>& rows) const;
-    int64_t column_start(int64_t j) const;    // CSC colptr[j] without materialising the pattern
+    int64_t column_start(int64_t j) const;    // CSC colptr[j] without materialising the pattern (order == 0)
+    void gen_row(int64_t r, std::vector<int64_t>& cols) const;      // sorted columns of row r of the same pattern
+    int64_t row_start(int64_t r) const;       // CSR rowptr[r] without materialising the pattern (order == 1)
+    int64_t shard_vals_begin(int64_t step_begin) const;             // value range a shard [step_begin, step_end) of the grid owns
+    int64_t shard_vals_end(int64_t step_end) const;
     void fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int tile) const;
 
     // ---- Hessian (ctd_hess_host.cpp)

@@ -50,6 +50,7 @@ PROBLEMS = {
     "double_integrator_freet0tf": 9,
 }
 PATTERN_MODES = {"manual": 0, "reference_manual": 0, "structural": 1, "optimized": 2}
+VALUE_ORDERS = {"csc": 0, "csr": 1}
 
 
 class CTDirectError(RuntimeError):
@@ -171,10 +172,12 @@ class DOCP:
     hipStream_t.
     `control_steps` > 1: the direct-shooting layout (src/direct_shooting.jl:55-71; :midpoint only): `control_steps` controls per
     time step, dynamics summed over the control sub-steps (midpoint.jl:137-155).
+    `value_order`: "csc" (default: the reference's SparseArrays.sparse order, what jac_coord! fills) or "csr" (the same entries by
+    rows: `jac_structure`, `jac_coord`, `cons_jac` follow it; `DOCP_Jacobian_csr` gives rowptr / colind).
     """
 
     def __init__(self, ocp, grid_size=250, scheme="midpoint", time_grid=None, *, pattern="manual", device=0,
-                 steps=None, stream="torch", control_steps=1):
+                 steps=None, stream="torch", control_steps=1, value_order="csc"):
         L = _lib.lib()
         self.problem_name = ocp if isinstance(ocp, str) else {v: k for k, v in PROBLEMS.items()}.get(int(ocp), str(ocp))
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
@@ -204,6 +207,9 @@ class DOCP:
             d.step_begin, d.step_end = int(steps[0]), int(steps[1])
         d.stream, d.stream_mode = None, 0
         d.control_steps = int(control_steps)
+        d.value_order = VALUE_ORDERS[value_order] if isinstance(value_order, str) else int(value_order)
+        d.reserved0 = 0
+        self.value_order = {0: "csc", 1: "csr"}.get(d.value_order, str(d.value_order))
         self.control_steps = max(1, int(control_steps))
         if int(device) >= 0 and stream != "own":
             if stream == "torch":
@@ -659,6 +665,23 @@ def DOCP_Jacobian_pattern(docp):
     return colptr, rowval
 
 
+def DOCP_Jacobian_csr(docp):
+    """The same pattern as 0-based CSR arrays (rowptr, colind): the order of the values of a DOCP built with value_order="csr"."""
+    rowptr = np.zeros(docp.dim_NLP_constraints + 1, dtype=np.int64)
+    colind = np.zeros(docp.nnzj, dtype=np.int64)
+    docp._ck(_lib.lib().ctd_jac_csr(docp._h, _ip(rowptr), _ip(colind)))
+    return rowptr, colind
+
+
+def DOCP_Hessian_csr(docp):
+    """(rowptr, colind) of the UPPER triangle by rows -- the CSR reading of the value array hess_coord fills (the lower triangle by
+    columns of a symmetric matrix is its upper triangle by rows)."""
+    rowptr = np.zeros(docp.dim_NLP_variables + 1, dtype=np.int64)
+    colind = np.zeros(docp.nnzh, dtype=np.int64)
+    docp._ck(_lib.lib().ctd_hess_csr(docp._h, _ip(rowptr), _ip(colind)))
+    return rowptr, colind
+
+
 def DOCP_Hessian_pattern(docp):
     """Lower triangle of `CTDirect.DOCP_Hessian_pattern(docp)` as 0-based CSC arrays (colptr, rowval) -- the part of the
     symmetric Bool pattern ADNLPModels keeps for hess_structure!."""
@@ -748,7 +771,7 @@ class MultiDeviceDOCP:
     # the kernels load them from the owner's buffer (needs peer access; falls back to the copies when a pair of devices has none)
     X_IN_PLACE, X_SHARDED, X_FROM_DEVICE0, X_SHARDED_COPY, X_SHARDED_IN_PLACE = 0, 1, 2, 3, 4
 
-    def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual", stream="torch"):
+    def __init__(self, ocp, grid_size, scheme, devices, time_grid=None, pattern="manual", stream="torch", value_order="csc"):
         L = _lib.lib()
         pid = PROBLEMS[ocp] if isinstance(ocp, str) else int(ocp)
         scheme = SCHEME_ALIASES.get(scheme, scheme) if isinstance(scheme, str) else scheme
@@ -756,6 +779,7 @@ class MultiDeviceDOCP:
         d.problem, d.scheme = pid, SCHEMES[scheme] if isinstance(scheme, str) else int(scheme)
         d.pattern_mode = PATTERN_MODES[pattern] if isinstance(pattern, str) else int(pattern)
         d.device = -1
+        d.value_order = VALUE_ORDERS[value_order] if isinstance(value_order, str) else int(value_order)
         self._tg = None
         if time_grid is not None:
             self._tg = np.ascontiguousarray(time_grid, dtype=np.float64)

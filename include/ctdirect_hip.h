@@ -20,7 +20,8 @@
  *   - external layouts are the reference's: variables step-major [X_i, U_i.., K_i..]..., X_{N+1}, [U_{N+1}], V
  *     (src/ode/trapeze.jl:1-4, midpoint.jl:1-7, irk.jl:1-9, irk_stagewise.jl:6-11); constraints
  *     [C_i^x, C_i^{k,1..s}, G_i]..., G_{N+1}, B (src/ode/irk_stagewise.jl:13-30, src/DOCP_functions.jl:92-111);
- *     Jacobian values in the CSC order of SparseArrays.sparse(Is, Js, ...) as DOCP_Jacobian_pattern returns it;
+ *     Jacobian values in the CSC order of SparseArrays.sparse(Is, Js, ...) as DOCP_Jacobian_pattern returns it (default), or by rows
+ *     (ctd_desc.value_order = CTD_ORDER_CSR);
  *   - all arithmetic is FP64; there is NO CPU fallback: compute entry points on a handle without a device fail
  *     with CTD_ENODEVICE.
  *   - a handle is not thread-safe; distinct handles are independent (one HIP stream each).
@@ -114,7 +115,18 @@ typedef struct ctd_desc {
                                * only (CTD_ESCHEME otherwise: no other scheme of the reference reads the extra controls).  Compiled problems:
                                * control_steps <= 3; problems registered at run time: any.  Constraints, Jacobian (all three patterns),
                                * objective, gradient, hess_structure and hess_coord (one second-order evaluation point per control). */
+    int32_t value_order;      /* CTD_ORDER_CSC (0): Jacobian values in the order of SparseArrays.sparse(Is, Js, ...) as DOCP_Jacobian_pattern
+                               * returns it (src/ode/midpoint.jl:229-232, irk_stagewise.jl:555-558) -- what ADNLPModels' jac_coord! fills.
+                               * CTD_ORDER_CSR (1): the same entries by ROWS -- what GPU KKT consumers (rocSPARSE / hipSOLVER) take, and what
+                               * BASELINE north_star names ("assembled ... in CSR on device").  Same kernel, same bytes; the rows of a time step,
+                               * V entries inline, are one contiguous run of the value array, so a shard of the grid owns ONE range
+                               * (ctd_shard_info).  ctd_jac_structure / ctd_jac_coord / ctd_cons_jac* follow the order chosen here. */
+    int32_t reserved0;        /* must be 0.  ZERO-INITIALISE the whole struct (memset / `ctd_desc d = {0}` / Ref{ctd_desc}(zeros)): fields that were
+                               * reserved in an earlier version of this header get a meaning later (control_steps was one), and a nonzero
+                               * reserved field is refused with CTD_EINVAL */
 } ctd_desc;
+
+enum { CTD_ORDER_CSC = 0, CTD_ORDER_CSR = 1 };
 
 enum { CTD_STREAM_OWN = 0, CTD_STREAM_GIVEN = 1 };
 
@@ -208,8 +220,13 @@ int32_t ctd_initial_guess(const ctd_handle* h, double* x0, const ctd_init* init)
 /* jac_structure!(nlp, rows, cols): 1-based (row, col) of every entry of DOCP_Jacobian_pattern(docp) in CSC order
  * (src/ode/trapeze.jl:149-233, midpoint.jl:163-233, irk.jl:315-416, irk_stagewise.jl:468-558) */
 int32_t ctd_jac_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
-/* same pattern as 0-based CSC (colptr[nvar+1], rowval[nnzj]) */
+/* same pattern as 0-based CSC (colptr[nvar+1], rowval[nnzj]) -- the order of the values of a CTD_ORDER_CSC handle */
 int32_t ctd_jac_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval);
+/* same pattern as 0-based CSR (rowptr[ncon+1], colind[nnzj]) -- the order of the values of a CTD_ORDER_CSR handle: pass rowptr / colind and the
+ * device array ctd_cons_jac_dev fills straight to rocsparse_create_csr_descr.  Available on every handle (the pattern is the same set). */
+int32_t ctd_jac_csr(const ctd_handle* h, int64_t* rowptr, int64_t* colind);
+/* ctd_desc.value_order of the handle */
+int32_t ctd_value_order(const ctd_handle* h, int32_t* order);
 /* number of structurally nonzero Jacobian entries that the selected pattern does not hold (0 except
  * REFERENCE_MANUAL + trapeze + a free time / v-dependent dynamics: hazard H1) */
 int32_t ctd_dropped_nonzeros(const ctd_handle* h, int64_t* count);
@@ -250,8 +267,12 @@ int32_t ctd_sync(ctd_handle* h);
 /* ---- multi-GPU shards (time-step partition) ------------------------------------------ */
 /* out[0..7]: step_begin, step_end, c_row_begin, c_row_end (step rows this shard writes; in addition EVERY shard writes
  * the p + bc tail rows [N*cb, ncon) -- final-time path and boundary constraints, x being replicated -- so stitching c
- * is a single all-gather), vals_main_begin, vals_main_end (contiguous CSC range of the shard's step columns), owns_first,
- * owns_last */
+ * is a single all-gather), vals_main_begin, vals_main_end, owns_first, owns_last.
+ * CTD_ORDER_CSC: [vals_main_begin, vals_main_end) is the contiguous CSC range of the shard's step columns; the shard ALSO writes its
+ * slice of every V column, the first shard the irregular first-step columns and the last shard the final-state columns (SURVEY 8e
+ * "CSC caveat").  CTD_ORDER_CSR: [vals_main_begin, vals_main_end) is EVERYTHING the shard writes: its step rows, V entries inline
+ * (the last shard's range runs to nnzj: the p + bc tail rows follow the step rows) -- one range per rank, the ranges of the ranks
+ * partition the value array. */
 int32_t ctd_shard_info(const ctd_handle* h, int64_t* out8);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
@@ -296,6 +317,11 @@ int32_t ctd_eval_all_dev_async(ctd_handle* h, const double* x_dev, const double*
 int32_t ctd_hess_structure(const ctd_handle* h, int64_t* rows, int64_t* cols);
 /* same pattern as 0-based CSC (colptr[nvar + 1], rowval[nnzh]) */
 int32_t ctd_hess_csc(const ctd_handle* h, int64_t* colptr, int64_t* rowval);
+/* The Hessian values in CSR: the Hessian is symmetric, so the value array of ctd_hess_coord* (lower triangle by columns) IS the CSR value
+ * array of the UPPER triangle (row j of the upper triangle = column j of the lower one).  rowptr[nvar + 1], colind[nnzh], 0-based,
+ * colind >= row: hand them with the values to a CSR consumer as a symmetric matrix stored by its upper triangle
+ * (rocsparse_fill_mode_upper).  No second value order is needed for the Hessian -- nothing is permuted, no extra bytes move. */
+int32_t ctd_hess_csr(const ctd_handle* h, int64_t* rowptr, int64_t* colind);
 /* host pointers: x[nvar], y[ncon] (constraint multipliers), vals[nnzh]; includes the PCIe copies */
 int32_t ctd_hess_coord(ctd_handle* h, const double* x, const double* y, double obj_weight, double* vals);
 /* device pointers on the handle's device; the first returns after the handle's stream has drained, the second only

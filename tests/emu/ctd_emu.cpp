@@ -102,17 +102,19 @@ static void run_hess_blocks(const HParams& hp, const double* xu, const double* y
 
 static std::string g_err;
 static int g_control_steps = 1;          // DOCP(..., control_steps, ...) of the models built below (tests set it around a call)
+static int g_value_order = 0;            // ctd_desc.value_order of the models built below (0 CSC, 1 CSR)
 
 extern "C" {
 
 void emu_set_control_steps(int cs) { g_control_steps = cs < 1 ? 1 : cs; }
+void emu_set_value_order(int o) { g_value_order = o; }
 
 const char* emu_last_error() { return g_err.c_str(); }
 
 // out[0..3] = nvar, ncon, nnzj, dropped
 int emu_sizes(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* out) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     out[0] = mo.L.nvar; out[1] = mo.L.ncon; out[2] = mo.nnzj; out[3] = mo.dropped;
@@ -121,7 +123,7 @@ int emu_sizes(int problem, int scheme, int pattern_mode, int64_t N, const double
 
 int emu_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* colptr, int64_t* rowval) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     std::vector<int64_t> rows;
@@ -137,10 +139,42 @@ int emu_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* 
     return 0;
 }
 
+// rowptr / colind of the pattern by rows (+ consistency of Model::row_start with the generated rows for CSR-order models), and
+// info[0..5] = reg_first, reg_last, Lseg, vr, HL, HH of the model
+int emu_csr(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* rowptr, int64_t* colind, int64_t* info) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    std::vector<int64_t> cols;
+    int64_t nz = 0;
+    for (int64_t r = 0; r < mo.L.ncon; ++r) {
+        rowptr[r] = nz;
+        if (mo.order == 1 && mo.row_start(r) != nz) { g_err = "row_start mismatch"; return 99; }
+        mo.gen_row(r, cols);
+        for (int64_t c : cols) colind[nz++] = c;
+    }
+    rowptr[mo.L.ncon] = nz;
+    if (nz != mo.nnzj) { g_err = "nnz mismatch"; return 98; }
+    if (info) { info[0] = mo.reg_first; info[1] = mo.reg_last; info[2] = mo.Lseg; info[3] = mo.vr; info[4] = mo.HL; info[5] = mo.HH; }
+    return 0;
+}
+
+// value range [begin, end) a shard [step_begin, step_end) of the grid owns (Model::shard_vals_begin / _end)
+int emu_shard_range(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t step_begin, int64_t step_end, int64_t* out2) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    out2[0] = mo.shard_vals_begin(step_begin);
+    out2[1] = mo.shard_vals_end(step_end);
+    return 0;
+}
+
 int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
                  int64_t step_begin, int64_t step_end, const double* x, double* c, double* vals) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     if (step_end <= 0) { step_begin = 0; step_end = mo.L.N; }
@@ -192,7 +226,7 @@ int emu_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, const dou
 int emu_cons_jac_sharded(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
                          int G, const double* x, double* c, double* vals) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     const Layout& L = mo.L;
@@ -253,7 +287,7 @@ void emu_stitch_src(int64_t N, int cb, int G, int64_t smax, int64_t ncon, int64_
 
 int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     if (build_model(d, mo, g_err)) return -1;
     return mo.H.nnzh;
 }
@@ -261,7 +295,7 @@ int64_t emu_hess_nnz(int problem, int scheme, int pattern_mode, int64_t N, const
 // lower triangle of DOCP_Hessian_pattern, 0-based CSC
 int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int64_t* colptr, int64_t* rowval) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     std::vector<int64_t> rows;
@@ -280,7 +314,7 @@ int emu_hess_csc(int problem, int scheme, int pattern_mode, int64_t N, const dou
 int emu_hess(int problem, int scheme, int pattern_mode, int64_t N, const double* tg, int64_t tglen, int tile, int nthr,
              const double* x, const double* y, double obj_weight, double* vals, int64_t step_begin, int64_t step_end) {
     Model mo;
-    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps};
+    HostDesc d{problem, scheme, pattern_mode, N, tg, tglen, g_control_steps, g_value_order};
     int st = build_model(d, mo, g_err);
     if (st) return st;
     if (tile <= 0) tile = default_hess_tile(mo);

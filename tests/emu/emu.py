@@ -55,6 +55,31 @@ def csc(problem, scheme, mode, N, time_grid=None):
     return colptr, rowval
 
 
+def csr(problem, scheme, mode, N, time_grid=None):
+    """(rowptr, colind, info) of the pattern by rows; info = dict(reg_first, reg_last, Lseg, vr, HL, HH) of the model built with
+    the current value order (`with emu.value_order(1)`)"""
+    nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
+    tg, n = _tg(time_grid)
+    rowptr = np.zeros(ncon + 1, dtype=np.int64)
+    colind = np.zeros(nnz, dtype=np.int64)
+    info = np.zeros(6, dtype=np.int64)
+    st = lib().emu_csr(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                       C.c_int64(n), rowptr.ctypes.data_as(C.c_void_p), colind.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return rowptr, colind, dict(zip(("reg_first", "reg_last", "Lseg", "vr", "HL", "HH"), (int(v) for v in info)))
+
+
+def shard_range(problem, scheme, mode, N, step_begin, step_end, time_grid=None):
+    tg, n = _tg(time_grid)
+    out = np.zeros(2, dtype=np.int64)
+    st = lib().emu_shard_range(problem, scheme, mode, C.c_int64(N or 0), tg.ctypes.data_as(C.c_void_p) if tg is not None else None,
+                               C.c_int64(n), C.c_int64(step_begin), C.c_int64(step_end), out.ctypes.data_as(C.c_void_p))
+    if st:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return int(out[0]), int(out[1])
+
+
 def cons_jac(problem, scheme, mode, N, x, time_grid=None, tile=0, nthr=64, step_begin=0, step_end=0, c=None, vals=None):
     nvar, ncon, nnz, _ = sizes(problem, scheme, mode, N, time_grid)
     tg, n = _tg(time_grid)
@@ -150,3 +175,16 @@ class control_steps:
 
     def __exit__(self, *a):
         lib().emu_set_control_steps(1)
+
+
+class value_order:
+    """`with emu.value_order(1): ...` -- the models the emulator builds inside use ctd_desc.value_order = CTD_ORDER_CSR"""
+
+    def __init__(self, order):
+        self.order = int(order)
+
+    def __enter__(self):
+        lib().emu_set_value_order(self.order)
+
+    def __exit__(self, *a):
+        lib().emu_set_value_order(0)
