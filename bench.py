@@ -556,21 +556,47 @@ def _main(real_stdout):
               t_two = rate(lambda: (l_a(), l_b()), 500) / 2.0
               same2 = bool(torch.equal(c_b, c) and torch.equal(v_b, vals))
               d_b.close()
-            separately = {"same_workload_other_callbacks": {
+            # the SAME workload with the values in CSR order (north_star: "in CSR on device"; NLPModels' jac_structure! / jac_coord! are
+            # coordinate lists in any order, so a shim may serve either): same kernel, row-order emit template.  Never `value`, which
+            # stays on the reference's own order (SparseArrays.sparse = CSC)
+            d_r = ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, stream="torch", value_order="csr")
+            c_r, v_r = torch.zeros_like(c), torch.zeros_like(vals)
+            l_r = d_r.bind_cons_jac(x_full, c_r, v_r, sync=False)
+            t_csr = rate(l_r, min(args.steps, 2000))
+            t_csc = rate(docp.bind_cons_jac(x_full, c, vals, sync=False), min(args.steps, 2000))
+            d_r.close()
+            separately = {"csr_order_same_workload": {
+                "evals_per_s": 1.0 / t_csr, "ms_per_step": t_csr * 1e3, "csc_order_same_loop_ms_per_step": t_csc * 1e3,
+                "what": "ctd_desc.value_order = CTD_ORDER_CSR: K back-to-back fused evaluations of the bench workload, wall clock around the loop "
+                        "(the CSC figure of the same loop beside it)"}}
+            separately.update({"same_workload_other_callbacks": {
                 "objective_device": {"ms_per_call": t_obj * 1e3, "calls_per_s": 1.0 / t_obj},
                 "gradient_device": {"ms_per_call": t_grad * 1e3, "calls_per_s": 1.0 / t_grad},
                 "whole_iteration_device": {"ms_per_call": t_iter * 1e3, "calls_per_s": 1.0 / t_iter,
                                            "what": "ctd_eval_all_dev_async: objective + gradient + constraints + Jacobian values + Hessian values at one (x, y), two launches"},
                 "fused_cons_jac_host_pointers_pinned": {"ms_per_call": t_host * 1e3, "calls_per_s": 1.0 / t_host,
                                                          "bytes_over_pcie": 8 * (docp.dim_NLP_variables + docp.dim_NLP_constraints + docp.nnzj),
-                                                         "what": "ctd_cons_jac on page-locked host arrays: H2D x + kernel + D2H c, values (PCIe inclusive; never `value`)"}}}
+                                                         "what": "ctd_cons_jac on page-locked host arrays: H2D x + kernel + D2H c, values (PCIe inclusive; never `value`)"}}})
             if s2 is not None:
                 separately["two_streams_alternating"] = {
                     "ms_per_eval": t_two * 1e3, "evals_per_s": 1.0 / t_two, "outputs_identical": same2,
                     "what": "independent evaluations of the same workload on two handles / two streams, launched alternately (never `value`; --two-streams)"}
             del g_, f_, y_, h_
         except Exception as e:      # a secondary figure must never cost the line
-            separately = {"same_workload_other_callbacks": {"error": repr(e)[:300]}}
+            # the SAME workload with the values in CSR order (north_star: "in CSR on device"; NLPModels' jac_structure! / jac_coord! are
+            # coordinate lists in any order, so a shim may serve either): same kernel, row-order emit template.  Never `value`, which
+            # stays on the reference's own order (SparseArrays.sparse = CSC)
+            d_r = ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, stream="torch", value_order="csr")
+            c_r, v_r = torch.zeros_like(c), torch.zeros_like(vals)
+            l_r = d_r.bind_cons_jac(x_full, c_r, v_r, sync=False)
+            t_csr = rate(l_r, min(args.steps, 2000))
+            t_csc = rate(docp.bind_cons_jac(x_full, c, vals, sync=False), min(args.steps, 2000))
+            d_r.close()
+            separately = {"csr_order_same_workload": {
+                "evals_per_s": 1.0 / t_csr, "ms_per_step": t_csr * 1e3, "csc_order_same_loop_ms_per_step": t_csc * 1e3,
+                "what": "ctd_desc.value_order = CTD_ORDER_CSR: K back-to-back fused evaluations of the bench workload, wall clock around the loop "
+                        "(the CSC figure of the same loop beside it)"}}
+            separately.update({"same_workload_other_callbacks": {"error": repr(e)[:300]}}
 
     # per-workload rocprofv3 rows (profiles/collect_workloads.sh: one process per workload, so a row is ONE workload): IMPORTED
     # from the committed summary, not measured in this run
