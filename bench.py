@@ -583,20 +583,7 @@ def _main(real_stdout):
                     "what": "independent evaluations of the same workload on two handles / two streams, launched alternately (never `value`; --two-streams)"}
             del g_, f_, y_, h_
         except Exception as e:      # a secondary figure must never cost the line
-            # the SAME workload with the values in CSR order (north_star: "in CSR on device"; NLPModels' jac_structure! / jac_coord! are
-            # coordinate lists in any order, so a shim may serve either): same kernel, row-order emit template.  Never `value`, which
-            # stays on the reference's own order (SparseArrays.sparse = CSC)
-            d_r = ct.DOCP(PROBLEM, N, SCHEME, device=local_rank, stream="torch", value_order="csr")
-            c_r, v_r = torch.zeros_like(c), torch.zeros_like(vals)
-            l_r = d_r.bind_cons_jac(x_full, c_r, v_r, sync=False)
-            t_csr = rate(l_r, min(args.steps, 2000))
-            t_csc = rate(docp.bind_cons_jac(x_full, c, vals, sync=False), min(args.steps, 2000))
-            d_r.close()
-            separately = {"csr_order_same_workload": {
-                "evals_per_s": 1.0 / t_csr, "ms_per_step": t_csr * 1e3, "csc_order_same_loop_ms_per_step": t_csc * 1e3,
-                "what": "ctd_desc.value_order = CTD_ORDER_CSR: K back-to-back fused evaluations of the bench workload, wall clock around the loop "
-                        "(the CSC figure of the same loop beside it)"}}
-            separately.update({"same_workload_other_callbacks": {"error": repr(e)[:300]}}
+            separately = {"same_workload_other_callbacks": {"error": repr(e)[:300]}}
 
     # per-workload rocprofv3 rows (profiles/collect_workloads.sh: one process per workload, so a row is ONE workload): IMPORTED
     # from the committed summary, not measured in this run
