@@ -184,7 +184,31 @@ CTD_HD double d_atan(double x) { return ::atan(x); }
 CTD_HD double d_tanh(double x) { return ::tanh(x); }
 CTD_HD double d_abs(double x) { return ::fabs(x); }
 CTD_HD double d_sgn(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+// asin acos sinh cosh floor, real powers and max / min: the rest of what the reference's problem folder uses (test/problems/bioreactor.jl:19
+// max(0, sin)^2 and floor, parametric.jl:4; swimmer / action use sqrt and trigonometry only)
+CTD_HD double d_asin(double x) { return ::asin(x); }
+CTD_HD double d_acos(double x) { return ::acos(x); }
+CTD_HD double d_sinh(double x) { return ::sinh(x); }
+CTD_HD double d_cosh(double x) { return ::cosh(x); }
+CTD_HD double d_floor(double x) { return ::floor(x); }
+CTD_HD double d_powr(double x, double p) { return ::pow(x, p); }
+// 1.0 where a > b, else 0.0: the selector of max / min.  ForwardDiff's rules (DiffRules: max -> (x > y ? 1 : 0, x > y ? 0 : 1),
+// min -> (x > y ? 0 : 1, x > y ? 1 : 0)): at a tie max follows its SECOND argument and min its FIRST
+CTD_HD double d_gt(double a, double b) { return a > b ? 1.0 : 0.0; }
+CTD_HD double d_max(double a, double b) { return a > b ? a : b; }
+CTD_HD double d_min(double a, double b) { return a > b ? b : a; }
 template <int K> CTD_HD Dual<K> d_log(const Dual<K>& a) { return d1_chain(a, ::log(a.v), 1.0 / a.v); }
+template <int K> CTD_HD Dual<K> d_asin(const Dual<K>& a) { return d1_chain(a, ::asin(a.v), 1.0 / ::sqrt(1.0 - a.v * a.v)); }
+template <int K> CTD_HD Dual<K> d_acos(const Dual<K>& a) { return d1_chain(a, ::acos(a.v), -1.0 / ::sqrt(1.0 - a.v * a.v)); }
+template <int K> CTD_HD Dual<K> d_sinh(const Dual<K>& a) { return d1_chain(a, ::sinh(a.v), ::cosh(a.v)); }
+template <int K> CTD_HD Dual<K> d_cosh(const Dual<K>& a) { return d1_chain(a, ::cosh(a.v), ::sinh(a.v)); }
+template <int K> CTD_HD Dual<K> d_floor(const Dual<K>& a) { return d1_chain(a, ::floor(a.v), 0.0); }
+template <int K> CTD_HD Dual<K> d_powr(const Dual<K>& a, double p) { return d1_chain(a, ::pow(a.v, p), p * ::pow(a.v, p - 1.0)); }
+template <int K> CTD_HD Dual<K> d_max(const Dual<K>& a, const Dual<K>& b) { return a.v > b.v ? a : b; }
+template <int K> CTD_HD Dual<K> d_min(const Dual<K>& a, const Dual<K>& b) { return a.v > b.v ? b : a; }
+// (generated functors call these with the scalar type named: d_max2<T>(0.0, e) converts a constant operand)
+template <class T> CTD_HD T d_max2(const T& a, const T& b) { return d_max(a, b); }
+template <class T> CTD_HD T d_min2(const T& a, const T& b) { return d_min(a, b); }
 template <int K> CTD_HD Dual<K> d_tan(const Dual<K>& a) { const double t = ::tan(a.v); return d1_chain(a, t, 1.0 + t * t); }
 template <int K> CTD_HD Dual<K> d_atan(const Dual<K>& a) { return d1_chain(a, ::atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
 template <int K> CTD_HD Dual<K> d_tanh(const Dual<K>& a) { const double t = ::tanh(a.v); return d1_chain(a, t, 1.0 - t * t); }
@@ -277,6 +301,16 @@ template <int K> CTD_HD Dual2<K> d_tan(const Dual2<K>& x) { const double t = ::t
 template <int K> CTD_HD Dual2<K> d_atan(const Dual2<K>& x) { const double q = 1.0 / (1.0 + x.v * x.v); return d2_chain(x, ::atan(x.v), q, -2.0 * x.v * (q * q)); }
 template <int K> CTD_HD Dual2<K> d_tanh(const Dual2<K>& x) { const double t = ::tanh(x.v), s = 1.0 - t * t; return d2_chain(x, t, s, -2.0 * t * s); }
 template <int K> CTD_HD Dual2<K> d_abs(const Dual2<K>& x) { return d2_chain(x, ::fabs(x.v), d_sgn(x.v), 0.0); }
+template <int K> CTD_HD Dual2<K> d_asin(const Dual2<K>& x) { const double q = 1.0 / (1.0 - x.v * x.v), r = ::sqrt(q); return d2_chain(x, ::asin(x.v), r, x.v * q * r); }
+template <int K> CTD_HD Dual2<K> d_acos(const Dual2<K>& x) { const double q = 1.0 / (1.0 - x.v * x.v), r = ::sqrt(q); return d2_chain(x, ::acos(x.v), -r, -(x.v * q * r)); }
+template <int K> CTD_HD Dual2<K> d_sinh(const Dual2<K>& x) { const double s = ::sinh(x.v), c = ::cosh(x.v); return d2_chain(x, s, c, s); }
+template <int K> CTD_HD Dual2<K> d_cosh(const Dual2<K>& x) { const double s = ::sinh(x.v), c = ::cosh(x.v); return d2_chain(x, c, s, c); }
+template <int K> CTD_HD Dual2<K> d_floor(const Dual2<K>& x) { return d2_chain(x, ::floor(x.v), 0.0, 0.0); }
+template <int K> CTD_HD Dual2<K> d_powr(const Dual2<K>& x, double p) {
+    return d2_chain(x, ::pow(x.v, p), p * ::pow(x.v, p - 1.0), p * (p - 1.0) * ::pow(x.v, p - 2.0));
+}
+template <int K> CTD_HD Dual2<K> d_max(const Dual2<K>& a, const Dual2<K>& b) { return a.v > b.v ? a : b; }
+template <int K> CTD_HD Dual2<K> d_min(const Dual2<K>& a, const Dual2<K>& b) { return a.v > b.v ? b : a; }
 template <int K> CTD_HD double d_val(const Dual2<K>& x) { return x.v; }
 
 }  // namespace ctd

@@ -216,6 +216,16 @@ int32_t jit_compile(const RtOcp& ro, const char* header, const std::vector<std::
                     std::string& code, std::vector<std::string>& lowered, std::string& err) {
     std::string key = ro.name + "|" + std::to_string((size_t)&ro) + "|" + header;
     for (const std::string& e : exprs) key += "|" + e;
+    // diagnostics: extra compiler options for the run-time kernels (e.g. CTD_JIT_EXTRA="-DCTD_NO_FOLD -DCTD_NO_SPLIT"), split at blanks
+    std::vector<std::string> extra;
+    if (const char* ex = std::getenv("CTD_JIT_EXTRA")) {
+        std::string cur;
+        for (const char* c = ex;; ++c) {
+            if (*c == ' ' || *c == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (*c == 0) break; }
+            else cur += *c;
+        }
+        key += std::string("|") + ex;
+    }
     {
         std::lock_guard<std::mutex> lk(g_jit_mu);
         auto it = g_jit_cache.find(key);
@@ -230,8 +240,9 @@ int32_t jit_compile(const RtOcp& ro, const char* header, const std::vector<std::
     for (const std::string& e : exprs) (void)hiprtcAddNameExpression(prog, e.c_str());
     const std::string inc = "-I" + jit_include_dir();
     const std::string fpc = std::string("-ffp-contract=") + fp_contract;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", fpc.c_str(), inc.c_str()};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
+    std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", fpc.c_str(), inc.c_str()};
+    for (const std::string& e : extra) opts.push_back(e.c_str());
+    const hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (rc != HIPRTC_SUCCESS) {
         size_t ls = 0;
         (void)hiprtcGetProgramLogSize(prog, &ls);

@@ -185,11 +185,12 @@ struct RuntimeFns {
                 case RT_XF: st.push_back(xf[o.k]); break;
                 case RT_NEG: break;
                 case RT_NONLIN: st.back() = sp_nonlin(st.back()); break;
+                case RT_ZERO: st.back() = SP(); break;
                 case RT_POW: if (o.k == 0) st.back() = SP(); else if (o.k >= 2) st.back() = sp_nonlin(st.back()); break;
                 default: {
                     const SP b = st.back(); st.pop_back();
                     const SP a = st.back(); st.pop_back();
-                    st.push_back(o.kind == RT_MUL ? a * b : (o.kind == RT_DIV ? a / b : sp_lin(a, b)));
+                    st.push_back(o.kind == RT_MUL ? a * b : (o.kind == RT_DIV ? a / b : sp_lin(a, b)));      // (RT_ADD, RT_SUB, RT_MAX)
                 }
             }
         }

@@ -17,8 +17,11 @@ namespace ctd {
 
 // ------------------------------------------------------------------------------------------------------
 // expressions:  expr := term (('+'|'-') term)* ; term := unary (('*'|'/') unary)* ; unary := '-' unary | power ;
-//               power := atom ('^' integer)? ; atom := number | name | func '(' expr ')' | '(' expr ')'
-// names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants; functions exp log sin cos tan atan tanh sqrt abs
+//               power := atom ('^' exponent)? ; exponent := ['-'] number | constant name | '(' constant expression ')'
+//               atom := number | name | func '(' expr ')' | func2 '(' expr ',' expr ')' | '(' expr ')'
+// names: t, x<k>, u<k>, v<k> (kind 0) or x0_<k>, xf_<k>, v<k> (kind 1), declared constants and aliases ("name = expression" entries
+// of the constants string); functions exp log sin cos tan atan tanh sqrt abs asin acos sinh cosh floor, max(a, b) min(a, b)
+// (derivatives of max / min: ForwardDiff's convention, d_gt in ctd_common.hpp; floor: zero)
 // ------------------------------------------------------------------------------------------------------
 namespace {
 // common sub-expression pool of one generated function: every distinct non-constant function call (exp, sin, ...) is
@@ -49,6 +52,7 @@ struct Parser {
     sym::Graph* g = nullptr;
     int g_t = -1;
     const int *g_x = nullptr, *g_u = nullptr, *g_v = nullptr;
+    int depth = 0;                       // alias nesting
 
     Parser(const std::string& s_, const ExprCtx& cx_) : s(s_), cx(cx_) {}
     void skip() { while (pos < s.size() && std::isspace((unsigned char)s[pos])) ++pos; }
@@ -111,21 +115,55 @@ struct Parser {
         if (pos < s.size() && s[pos] == '+') { ++pos; return unary(out); }
         return power(out);
     }
+    // the exponent of '^': a constant -- a (signed) number, a declared constant, or a parenthesised constant expression.  Small
+    // non-negative integers multiply out (d_powi, exact for every scalar type), anything else is a real power pow(x, p)
+    bool exponent(double& p) {
+        skip();
+        double sign = 1.0;
+        if (pos < s.size() && (s[pos] == '-' || s[pos] == '+')) { if (s[pos] == '-') sign = -1.0; ++pos; skip(); }
+        if (pos >= s.size()) return fail("exponent expected after '^'");
+        if (std::isdigit((unsigned char)s[pos]) || s[pos] == '.') {
+            char* end = nullptr;
+            p = sign * std::strtod(s.c_str() + pos, &end);
+            if (end == s.c_str() + pos) return fail("malformed exponent");
+            pos = (size_t)(end - s.c_str());
+            return true;
+        }
+        // a constant name or a parenthesised constant expression: evaluated with a throw-away symbolic graph
+        sym::Graph gc;
+        Parser sub(s, cx);
+        sub.pos = pos; sub.g = &gc; sub.depth = depth;
+        static const int none[32] = {0};
+        sub.g_t = gc.var(31); sub.g_x = sub.g_u = sub.g_v = none;
+        Val v;
+        if (!sub.atom(v)) { err = sub.err; return false; }
+        if (!v.is_const || v.node < 0 || !gc.is_const(v.node)) return fail("the exponent of '^' must be a constant (write exp(b*log(a)) for a variable exponent)");
+        p = sign * gc.cval(v.node);
+        pos = sub.pos;
+        return true;
+    }
     bool power(Val& out) {
         if (!atom(out)) return false;
         skip();
         if (pos < s.size() && s[pos] == '^') {
-            ++pos; skip();
-            size_t b = pos;
-            while (pos < s.size() && std::isdigit((unsigned char)s[pos])) ++pos;
-            if (b == pos) return fail("'^' needs a non-negative integer exponent (write 1/x^k for negative powers)");
-            const int k = std::atoi(s.substr(b, pos - b).c_str());
-            if (k > 64) return fail("exponent too large");
-            if (k == 0) { out.code = "1.0"; out.is_const = true; }
-            else if (k == 2) out.code = "d_sqr(" + out.code + ")";
-            else if (k > 2) out.code = "d_powi(" + out.code + ", " + std::to_string(k) + ")";
-            if (g) out.node = g->powi(out.node, k);
-            op(RT_POW, k);
+            ++pos;
+            double p = 0.0;
+            if (!exponent(p)) return false;
+            if (p == std::floor(p) && p >= 0.0 && p <= 64.0) {
+                const int k = (int)p;
+                if (k == 0) { out.code = "1.0"; out.is_const = true; }
+                else if (k == 2) out.code = "d_sqr(" + out.code + ")";
+                else if (k > 2) out.code = "d_powi(" + out.code + ", " + std::to_string(k) + ")";
+                if (g) out.node = g->powi(out.node, k);
+                op(RT_POW, k);
+            } else {
+                if (!(p == p) || std::fabs(p) > 1.0e6) return fail("exponent out of range");
+                if (out.is_const) out.code = "::pow(" + out.code + ", " + num(p) + ")";
+                else out.code = "d_powr(" + out.code + ", " + num(p) + ")";
+                if (g) out.node = g->powr(out.node, p);
+                if (cse && !out.is_const) out.code = cse->intern(out.code);
+                op(RT_NONLIN);
+            }
         }
         return true;
     }
@@ -158,12 +196,33 @@ struct Parser {
             skip();
             if (pos < s.size() && s[pos] == '(') {          // function call
                 static const char* fn[][2] = {{"exp", "d_exp"}, {"sin", "d_sin"}, {"cos", "d_cos"}, {"sqrt", "d_sqrt"}, {"log", "d_log"},
-                                              {"tan", "d_tan"}, {"atan", "d_atan"}, {"tanh", "d_tanh"}, {"abs", "d_abs"}};
-                static const sym::Fn fid[] = {sym::F_EXP, sym::F_SIN, sym::F_COS, sym::F_SQRT, sym::F_LOG, sym::F_TAN, sym::F_ATAN, sym::F_TANH, sym::F_ABS};
+                                              {"tan", "d_tan"}, {"atan", "d_atan"}, {"tanh", "d_tanh"}, {"abs", "d_abs"},
+                                              {"asin", "d_asin"}, {"acos", "d_acos"}, {"sinh", "d_sinh"}, {"cosh", "d_cosh"}, {"floor", "d_floor"}};
+                static const sym::Fn fid[] = {sym::F_EXP, sym::F_SIN, sym::F_COS, sym::F_SQRT, sym::F_LOG, sym::F_TAN, sym::F_ATAN, sym::F_TANH, sym::F_ABS,
+                                              sym::F_ASIN, sym::F_ACOS, sym::F_SINH, sym::F_COSH, sym::F_FLOOR};
+                if (name == "max" || name == "min") {        // two arguments; derivative = that of the selected operand (d_gt)
+                    const bool mx = name == "max";
+                    ++pos;
+                    Val a, b;
+                    if (!expr(a)) return false;
+                    skip();
+                    if (pos >= s.size() || s[pos] != ',') return fail("',' expected: " + name + " takes two arguments");
+                    ++pos;
+                    if (!expr(b)) return false;
+                    skip();
+                    if (pos >= s.size() || s[pos] != ')') return fail("')' expected");
+                    ++pos;
+                    out.is_const = a.is_const && b.is_const;
+                    out.code = std::string(mx ? "d_max2<" : "d_min2<") + (out.is_const ? "double" : "T") + ">(" + a.code + ", " + b.code + ")";
+                    if (g) out.node = mx ? g->max2(a.node, b.node) : g->min2(a.node, b.node);
+                    if (cse && !out.is_const) out.code = cse->intern(out.code);
+                    op(RT_MAX);
+                    return true;
+                }
                 const char* target = nullptr;
                 int fidx = -1;
                 for (int i = 0; i < (int)(sizeof(fn) / sizeof(fn[0])); ++i) if (name == fn[i][0]) { target = fn[i][1]; fidx = i; }
-                if (!target) return fail("unknown function '" + name + "' (available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs)");
+                if (!target) return fail("unknown function '" + name + "' (available: exp, log, sin, cos, tan, atan, tanh, sqrt, abs, asin, acos, sinh, cosh, floor, max, min)");
                 ++pos;
                 Val a;
                 if (!expr(a)) return false;
@@ -174,7 +233,7 @@ struct Parser {
                 out.is_const = a.is_const;
                 if (g) out.node = g->fn(fid[fidx], a.node);
                 if (cse && !a.is_const) out.code = cse->intern(out.code);
-                op(RT_NONLIN);
+                op(fid[fidx] == sym::F_FLOOR ? RT_ZERO : RT_NONLIN);
                 return true;
             }
             int k = 0;
@@ -190,14 +249,29 @@ struct Parser {
             if (name[0] == 'v' && index_of(name, 1, cx.nv, k)) { uses_v = true; out.code = "v[" + std::to_string(k - 1) + "]"; if (g) out.node = g_v[k - 1]; op(RT_V, k - 1); return true; }
             auto it = cx.constants.find(name);
             if (it != cx.constants.end()) { out.code = num(it->second); out.is_const = true; if (g) out.node = g->constant(it->second); op(RT_CONST); return true; }
+            auto al = cx.aliases.find(name);
+            if (al != cx.aliases.end()) {          // a named sub-expression: parsed in place (same graph, same temporaries, same postfix program)
+                if (depth >= 24) return fail("aliases nested too deeply (or defined in terms of themselves): '" + name + "'");
+                Parser sub(al->second, cx);
+                sub.cse = cse; sub.g = g; sub.g_t = g_t; sub.g_x = g_x; sub.g_u = g_u; sub.g_v = g_v; sub.depth = depth + 1;
+                Val v;
+                if (!sub.expr(v)) { err = "in alias '" + name + "': " + sub.err; return false; }
+                sub.skip();
+                if (sub.pos != al->second.size()) { sub.fail("unexpected trailing input"); err = "in alias '" + name + "': " + sub.err; return false; }
+                uses_t = uses_t || sub.uses_t; uses_v = uses_v || sub.uses_v;
+                rpn.insert(rpn.end(), sub.rpn.begin(), sub.rpn.end());
+                out = v;
+                out.code = "(" + v.code + ")";
+                return true;
+            }
             return fail("unknown name '" + name + "'");
         }
         return fail(std::string("unexpected character '") + c + "'");
     }
 };
 
-bool parse_constants(const char* text, std::map<std::string, double>& out, std::string& err) {
-    out.clear();
+bool parse_constants(const char* text, std::map<std::string, double>& out, std::map<std::string, std::string>& aliases, std::string& err) {
+    out.clear(); aliases.clear();
     if (!text) return true;
     std::string s(text);
     size_t pos = 0;
@@ -218,7 +292,13 @@ bool parse_constants(const char* text, std::map<std::string, double>& out, std::
         for (char ch : name) if (!(std::isalnum((unsigned char)ch) || ch == '_')) { err = "bad constant name '" + name + "'"; return false; }
         char* e = nullptr;
         const double v = std::strtod(val.c_str(), &e);
-        if (val.empty() || *e != 0) { err = "constant '" + name + "' has no numeric value"; return false; }
+        if (val.empty()) { err = "constant '" + name + "' has no value"; return false; }
+        if (out.count(name) || aliases.count(name)) { err = "'" + name + "' is defined twice"; return false; }
+        if (*e != 0) {                    // not a plain number: a named sub-expression (checked where it is used)
+            if (val.size() > 20000) { err = "alias '" + name + "' is too long"; return false; }
+            aliases[name] = val;
+            continue;
+        }
         out[name] = v;
     }
     return true;
@@ -371,7 +451,7 @@ static bool gen_sym_pathh(const ctd_ocp_def* d, const ExprCtx& c0, std::string& 
 // The code stores the nonzeros only, at the offsets of the SPARSE eval block (make_rec_layout with nF, nG; DynNZ in
 // ctd_kernel_body.hpp); CTD_DENSE_EVAL=1 at generation time keeps the dense n x ldx / n x ldu blocks (every zero stored).
 static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bool& dyn_v, std::string& body, std::string& err, int nparts = 1,
-                        DynNZMap* nz = nullptr) {
+                        DynNZMap* nz = nullptr, size_t* code_lines = nullptr) {
     const int n = d->n, m = d->m, nv = d->nv;
     sym::Graph g;
     // parameters: p[0] = t, then x[n], u[m], v[nv]; variables: the same positions
@@ -424,6 +504,7 @@ static bool gen_sym_dyn(const ctd_ocp_def* d, const ExprCtx& c0, bool& dyn_t, bo
         if (nparts == 1) body = g.codegen(outs, "p", "        ");
         else body += "            case " + std::to_string(part) + ": {\n" + g.codegen(outs, "p", "                ") + "            } break;\n";
     }
+    if (code_lines) { *code_lines = 0; for (char ch : body) if (ch == '\n') ++*code_lines; }
     return true;
 }
 
@@ -520,9 +601,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
             err = "problem name may only hold the characters A-Z a-z 0-9 _ . -";
             return CTD_EINVAL;
         }
-    ExprCtx c0{d->n, d->m, d->nv, 0, {}}, c1{d->n, d->m, d->nv, 1, {}};
-    if (!parse_constants(d->constants, c0.constants, err)) return CTD_EINVAL;
-    c1.constants = c0.constants;
+    ExprCtx c0{d->n, d->m, d->nv, 0, {}, {}}, c1{d->n, d->m, d->nv, 1, {}, {}};
+    if (!parse_constants(d->constants, c0.constants, c0.aliases, err)) return CTD_EINVAL;
+    c1.constants = c0.constants; c1.aliases = c0.aliases;
+    for (const auto& al : c0.aliases)         // names the grammar reserves cannot be aliased (x1, u2, t, ... would shadow the variables)
+        if (al.first == "t" || ((al.first[0] == 'x' || al.first[0] == 'u' || al.first[0] == 'v') && al.first.size() > 1 && std::isdigit((unsigned char)al.first[1]))) {
+            err = "alias name '" + al.first + "' collides with a variable name";
+            return CTD_EINVAL;
+        }
     o->dyn_t = o->dyn_v = o->path_t = o->path_v = o->lag_t = o->lag_v = false;
     std::string body_dyn, body_lag, body_may, body_path, body_bnd;
     CsePool pool_dyn, pool_lag, pool_may, pool_path, pool_bnd;
@@ -585,8 +671,14 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         std::string b_dyn, e2;
         bool dt = false, dv = false;
         DynNZMap nz;
-        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2, 1, &nz);
+        size_t dyn_lines = 0;
+        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2, 1, &nz, &dyn_lines);
         if (ok) o->dyn_nz = nz;
+        // LONG generated code (the reference's swimmer: 213 statements, ~250 trigonometric terms per evaluation point; the 12-state quadrotor has 68): compiled for the default four waves
+        // per SIMD (128 registers) it spills hundreds of registers -- and the spilled kernel computed garbage on the lanes of a
+        // divergent wave (MI355X, ROCm 7.2).  Such an OCP asks for one wave per SIMD (no spills, ctd_kernels.hpp MinWaves) and keeps the
+        // separate fin phase (LongCode, ctd_kernel_body.hpp: what was measured correct)
+        if (ok && dyn_lines > 120 && !std::getenv("CTD_JIT_KEEP_WAVES")) s += "    static constexpr int MIN_WAVES = 1;\n    static constexpr bool LONG_CODE = true;\n";
         s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
         // wide OCPs (four direction chunks and more, Dirs<P>::NCH_DYN): the same code split by rows, one part per wave (SymDyn::parts)

@@ -23,7 +23,8 @@ constexpr int kRuntimeIdBase = 1000;
 
 // postfix form of one expression, kept for analyses that need the functions on the HOST (the structural-sparsity probe
 // of the Hessian tables, ctd_hess_host.cpp); the numbers themselves are only ever computed by the compiled kernels
-enum RtOpKind : uint8_t { RT_CONST, RT_T, RT_X, RT_U, RT_V, RT_X0, RT_XF, RT_ADD, RT_SUB, RT_MUL, RT_DIV, RT_NEG, RT_NONLIN, RT_POW };
+// RT_ZERO: a function whose derivative vanishes identically (floor): no dependence; RT_MAX: max / min, first order in both operands
+enum RtOpKind : uint8_t { RT_CONST, RT_T, RT_X, RT_U, RT_V, RT_X0, RT_XF, RT_ADD, RT_SUB, RT_MUL, RT_DIV, RT_NEG, RT_NONLIN, RT_POW, RT_ZERO, RT_MAX };
 struct RtOp { uint8_t kind; int16_t k; };
 using RtProgram = std::vector<RtOp>;
 
@@ -59,6 +60,9 @@ struct ExprCtx {
     int n, m, nv;
     int kind;
     std::map<std::string, double> constants;
+    // "name = expression" entries of ctd_ocp_def.constants: sub-expressions with a name (the `aux = ...` lines of a CTParser @def
+    // block, e.g. test/problems/swimmer.jl:39-53), substituted where they are used; an alias may use the aliases declared before it
+    std::map<std::string, std::string> aliases;
 };
 bool expr_to_cpp(const std::string& expr, const ExprCtx& cx, std::string& out, bool& is_const, bool& uses_t, bool& uses_v,
                  std::string& err, RtProgram* prog = nullptr);

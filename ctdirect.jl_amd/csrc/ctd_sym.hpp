@@ -21,10 +21,12 @@
 namespace ctd {
 namespace sym {
 
-enum Op : uint8_t { CONST, PARAM, VAR, ADD, SUB, MUL, DIV, NEG, POWI, FN };
-enum Fn : uint8_t { F_EXP, F_LOG, F_SIN, F_COS, F_TAN, F_ATAN, F_TANH, F_SQRT, F_ABS, F_SGN };
+// POWR: a ^ (constant real exponent; b = the exponent's CONST node).  MAX / MIN / GT (1.0 where a > b, else 0.0): binary; the
+// derivative of max / min selects with GT (ForwardDiff's convention, d_gt in ctd_common.hpp)
+enum Op : uint8_t { CONST, PARAM, VAR, ADD, SUB, MUL, DIV, NEG, POWI, FN, POWR, MAX, MIN, GT };
+enum Fn : uint8_t { F_EXP, F_LOG, F_SIN, F_COS, F_TAN, F_ATAN, F_TANH, F_SQRT, F_ABS, F_SGN, F_ASIN, F_ACOS, F_SINH, F_COSH, F_FLOOR };
 
-struct Node { Op op; int a, b; double c; };   // PARAM / VAR: a = index; POWI: b = exponent; FN: b = Fn id
+struct Node { Op op; int a, b; double c; };   // PARAM / VAR: a = index; POWI: b = exponent; FN: b = Fn id; POWR: b = exponent node
 
 class Graph {
 public:
@@ -94,10 +96,34 @@ public:
         if (is_const(a)) { double r = 1.0; for (int i = 0; i < k; ++i) r *= cval(a); return constant(r); }
         return intern(POWI, a, k);
     }
+    int powr(int a, double p) {
+        if (p == 0.0) return constant(1.0);
+        if (p == 1.0) return a;
+        if (p == std::floor(p) && p >= 2.0 && p <= 64.0) return powi(a, (int)p);
+        if (is_const(a)) return constant(std::pow(cval(a), p));
+        return intern(POWR, a, constant(p));
+    }
+    int gt(int a, int b) {
+        if (is_const(a) && is_const(b)) return constant(cval(a) > cval(b) ? 1.0 : 0.0);
+        return intern(GT, a, b);
+    }
+    int max2(int a, int b) {
+        if (is_const(a) && is_const(b)) return constant(cval(a) > cval(b) ? cval(a) : cval(b));
+        return intern(MAX, a, b);
+    }
+    int min2(int a, int b) {
+        if (is_const(a) && is_const(b)) return constant(cval(a) > cval(b) ? cval(b) : cval(a));
+        return intern(MIN, a, b);
+    }
     int fn(Fn f, int a) {
         if (is_const(a)) {
             const double x = cval(a);
             switch (f) {
+                case F_ASIN: return constant(std::asin(x));
+                case F_ACOS: return constant(std::acos(x));
+                case F_SINH: return constant(std::sinh(x));
+                case F_COSH: return constant(std::cosh(x));
+                case F_FLOOR: return constant(std::floor(x));
                 case F_EXP: return constant(std::exp(x));
                 case F_LOG: return constant(std::log(x));
                 case F_SIN: return constant(std::sin(x));
@@ -133,6 +159,15 @@ public:
                 break;
             }
             case POWI: r = mul(mul(constant((double)nd.b), powi(nd.a, nd.b - 1)), diff(nd.a, v)); break;
+            case POWR: { const double p = cval(nd.b); r = mul(mul(constant(p), powr(nd.a, p - 1.0)), diff(nd.a, v)); break; }
+            case GT: break;
+            case MAX: case MIN: {            // max: a > b ? a' : b';  min: a > b ? b' : a'
+                const int da = diff(nd.a, v), db = diff(nd.b, v);
+                if (is_zero(da) && is_zero(db)) break;
+                const int g1 = gt(nd.a, nd.b), g0 = sub(constant(1.0), g1);
+                r = nd.op == MAX ? add(mul(g1, da), mul(g0, db)) : add(mul(g0, da), mul(g1, db));
+                break;
+            }
             case FN: {
                 const int da = diff(nd.a, v);
                 if (is_zero(da)) break;
@@ -147,7 +182,11 @@ public:
                     case F_TANH: f1 = sub(constant(1.0), mul(n, n)); break;
                     case F_SQRT: f1 = div(constant(0.5), n); break;
                     case F_ABS: f1 = fn(F_SGN, nd.a); break;
-                    case F_SGN: break;
+                    case F_SGN: case F_FLOOR: break;
+                    case F_ASIN: f1 = div(constant(1.0), fn(F_SQRT, sub(constant(1.0), mul(nd.a, nd.a)))); break;
+                    case F_ACOS: f1 = neg(div(constant(1.0), fn(F_SQRT, sub(constant(1.0), mul(nd.a, nd.a))))); break;
+                    case F_SINH: f1 = fn(F_COSH, nd.a); break;
+                    case F_COSH: f1 = fn(F_SINH, nd.a); break;
                 }
                 r = mul(f1, da);
                 break;
@@ -172,6 +211,10 @@ public:
             case MUL: r = mul(at_zero(nd.a), at_zero(nd.b)); break;
             case DIV: r = div(at_zero(nd.a), at_zero(nd.b)); break;
             case POWI: r = powi(at_zero(nd.a), nd.b); break;
+            case POWR: r = powr(at_zero(nd.a), cval(nd.b)); break;
+            case MAX: r = max2(at_zero(nd.a), at_zero(nd.b)); break;
+            case MIN: r = min2(at_zero(nd.a), at_zero(nd.b)); break;
+            case GT: r = gt(at_zero(nd.a), at_zero(nd.b)); break;
             case FN: r = fn((Fn)nd.b, at_zero(nd.a)); break;
         }
         zmemo_[n] = r;
@@ -204,9 +247,18 @@ private:
             case MUL: return eval(nd.a, prm, vars) * eval(nd.b, prm, vars);
             case DIV: return eval(nd.a, prm, vars) / eval(nd.b, prm, vars);
             case POWI: { const double x = eval(nd.a, prm, vars); double r = 1.0; for (int i = 0; i < nd.b; ++i) r *= x; return r; }
+            case POWR: return std::pow(eval(nd.a, prm, vars), nodes[nd.b].c);
+            case MAX: { const double x = eval(nd.a, prm, vars), y = eval(nd.b, prm, vars); return x > y ? x : y; }
+            case MIN: { const double x = eval(nd.a, prm, vars), y = eval(nd.b, prm, vars); return x > y ? y : x; }
+            case GT: return eval(nd.a, prm, vars) > eval(nd.b, prm, vars) ? 1.0 : 0.0;
             case FN: {
                 const double x = eval(nd.a, prm, vars);
                 switch ((Fn)nd.b) {
+                    case F_ASIN: return std::asin(x);
+                    case F_ACOS: return std::acos(x);
+                    case F_SINH: return std::sinh(x);
+                    case F_COSH: return std::cosh(x);
+                    case F_FLOOR: return std::floor(x);
                     case F_EXP: return std::exp(x);
                     case F_LOG: return std::log(x);
                     case F_SIN: return std::sin(x);
@@ -266,14 +318,19 @@ public:
                 case DIV: e = name[nd.a] + " / " + name[nd.b]; break;
                 case NEG: e = "-" + name[nd.a]; break;
                 case POWI: e = "d_powi(" + name[nd.a] + ", " + std::to_string(nd.b) + ")"; break;
+                case POWR: e = "d_powr(" + name[nd.a] + ", " + name[nd.b] + ")"; break;
+                case MAX: e = "d_max(" + name[nd.a] + ", " + name[nd.b] + ")"; break;
+                case MIN: e = "d_min(" + name[nd.a] + ", " + name[nd.b] + ")"; break;
+                case GT: e = "d_gt(" + name[nd.a] + ", " + name[nd.b] + ")"; break;
                 case FN: {
-                    static const char* fnn[] = {"d_exp", "d_log", "d_sin", "d_cos", "d_tan", "d_atan", "d_tanh", "d_sqrt", "d_abs", "d_sgn"};
+                    static const char* fnn[] = {"d_exp", "d_log", "d_sin", "d_cos", "d_tan", "d_atan", "d_tanh", "d_sqrt", "d_abs", "d_sgn",
+                                                "d_asin", "d_acos", "d_sinh", "d_cosh", "d_floor"};
                     e = std::string(fnn[nd.b]) + "(" + name[nd.a] + ")";
                     break;
                 }
                 default: e = "0.0"; break;
             }
-            if (uses[n] > 1 || nd.op == FN || nd.op == DIV || nd.op == POWI) {
+            if (uses[n] > 1 || nd.op == FN || nd.op == DIV || nd.op == POWI || nd.op == POWR || nd.op == MAX || nd.op == MIN || nd.op == GT) {
                 name[n] = "s" + std::to_string(ntmp++);
                 s += indent + "const double " + name[n] + " = " + e + ";\n";
             } else {
@@ -313,7 +370,7 @@ private:
         const Node& nd = nodes[n];
         if (nd.op >= ADD) {
             visit(nd.a, uses, seen, order); ++uses[nd.a];
-            if (nd.op == ADD || nd.op == SUB || nd.op == MUL || nd.op == DIV) { visit(nd.b, uses, seen, order); ++uses[nd.b]; }
+            if (nd.op == ADD || nd.op == SUB || nd.op == MUL || nd.op == DIV || nd.op == POWR || nd.op == MAX || nd.op == MIN || nd.op == GT) { visit(nd.b, uses, seen, order); ++uses[nd.b]; }
         }
         order.push_back(n);
     }

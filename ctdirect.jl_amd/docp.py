@@ -92,7 +92,9 @@ def register_ocp(name, *, dynamics, n=None, m=0, nv=0, lagrange=None, mayer=None
     """Defines an OCP at run time from arithmetic expressions (the stand-in for the Julia closures of a CTModels.Model,
     include/ctdirect_hip.h `ctd_ocp_def`) and returns `name`, usable as the `ocp` argument of DOCP.
 
-    dynamics / path: expressions in t, x1..xn, u1..um, v1..vnv; mayer / boundary: in x0_k, xf_k, vk; `constants` a dict.
+    dynamics / path: expressions in t, x1..xn, u1..um, v1..vnv; mayer / boundary: in x0_k, xf_k, vk; `constants` a dict of
+    numbers (constants) and strings (aliases: named sub-expressions, e.g. the `aux = ...` lines of a CTParser @def block).
+    Functions: exp log sin cos tan atan tanh sqrt abs asin acos sinh cosh floor, max(a, b), min(a, b); `^` takes a constant exponent.
     Boxes and bounds are (lb, ub) pairs of sequences (None = free boxes / equality-with-zero rows); it0 / itf are the
     0-based positions of a free initial / final time inside v.  The kernels are compiled with hiprtc when a DOCP is built."""
     L = _lib.lib()
@@ -120,7 +122,8 @@ def register_ocp(name, *, dynamics, n=None, m=0, nv=0, lagrange=None, mayer=None
     d.dynamics, d.path, d.boundary = strs(dynamics), strs(path), strs(boundary)
     d.lagrange = lagrange.encode() if lagrange else None
     d.mayer = mayer.encode() if mayer else None
-    d.constants = "; ".join(f"{k}={float(v)!r}" for k, v in constants.items()).encode() if constants else None
+    # numbers are constants; strings are aliases: named sub-expressions ("aux = 543 + 186*cos(x4) + ...") substituted where used
+    d.constants = "; ".join(f"{k}={v if isinstance(v, str) else repr(float(v))}" for k, v in constants.items()).encode() if constants else None
     inf = float("inf")
     for key, box, dim in (("state", state_box, n), ("control", control_box, int(m)), ("variable", variable_box, int(nv))):
         setattr(d, key + "_lb", dbl(None if box is None else box[0], dim, -inf))

@@ -153,9 +153,14 @@ typedef struct ctd_init {
  * The reference obtains the OCP functions as Julia closures from CTModels (CTModels.dynamics(ocp)(dx, t, x, u, v) called
  * at src/ode/trapeze.jl:66, midpoint.jl:64, irk.jl:291, irk_stagewise.jl:441; lagrange / mayer src/DOCP_functions.jl:35-48;
  * path / boundary constraints :108-110,136-138).  A closure cannot cross a C ABI, so an OCP that is not in the compiled
- * registry is handed over as TEXT: one arithmetic expression per output.  Grammar: + - * / ^(integer) parentheses, numbers,
- * exp log sin cos tan atan tanh sqrt abs, the names t, x1..xn, u1..um, v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer,
- * boundary), and the constants declared in `constants` ("Cd=310; beta=500").  No C++ is accepted.  ctd_register_ocp parses
+ * registry is handed over as TEXT: one arithmetic expression per output.  Grammar: + - * / parentheses, numbers, ^ with a CONSTANT
+ * exponent (small non-negative integers multiply out; any other real exponent is pow), exp log sin cos tan atan tanh sqrt abs asin acos
+ * sinh cosh floor, max(a, b) min(a, b) (derivative of the selected operand: ForwardDiff's rule, at a tie max follows b and min a;
+ * floor has derivative 0) -- everything the reference's problem folder test/problems/*.jl uses --, the names t, x1..xn, u1..um,
+ * v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer, boundary), and what `constants` declares: "Cd=310; beta=500"
+ * (numbers) and "aux = 543 + 186*cos(x4); g13 = -(105 + 2*cos(2*x4)) / (2*aux)" (ALIASES: named sub-expressions, the `aux = ...`
+ * lines of a CTParser @def block such as test/problems/swimmer.jl:39-53; substituted where they are used, may use each other).
+ * No C++ is accepted.  ctd_register_ocp parses
  * the expressions, generates a functor of the registry's shape and returns a problem id (>= 1000) for ctd_desc.problem;
  * ctd_create then compiles the SAME kernel templates for it with hiprtc (gfx950) -- same code path as a built-in problem.
  * dims, flags and bounds restate DOCPdims / DOCPFlags (src/DOCP_data.jl:24-30,88-94) and the boxes of CTModels

@@ -1236,6 +1236,8 @@ template <class F> static void dispatch(int pid, F&& f) {
         case 7: f(Tag<EstimateRotationRate>{}); break;
         case 8: f(Tag<LeastSquaresConstraint>{}); break;
         case 9: f(Tag<DoubleIntegratorFreeT0Tf>{}); break;
+        case 10: f(Tag<GoddardAllF0F1>{}); break;
+        case 11: f(Tag<AlgalBacterial>{}); break;
         default: throw std::runtime_error("unknown problem id");
     }
 }

@@ -37,6 +37,9 @@ PROBLEMS = {
     "estimate_rotation_rate": 7,
     "least_squares_with_constraint": 8,
     "double_integrator_freet0tf": 9,
+    # oracle-only restatements (the engine takes these as run-time OCPs, tests/problem_folder_defs.py)
+    "goddard_all_f0f1": 10,           # goddard_all with xdot = F0 + u F1 (test/problems/goddard.jl:7-15,44): the archived 28011 pattern
+    "algal_bacterial": 11,            # test/problems/algal_bacterial.jl
 }
 
 

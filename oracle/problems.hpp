@@ -399,4 +399,63 @@ struct DoubleIntegratorFreeT0Tf {
     static bool init_variable(double*) { return false; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// id 10 (oracle only; the engine takes it as a run-time OCP): goddard_all with the dynamics of the abstract form,
+//   xdot = F0(x) + u F1(x)  (test/problems/goddard.jl:7-15,44) instead of the f! of goddard.jl:127-132.  The two forms
+//   compute the same numbers; their TRACED patterns differ: `u * 0` in the r-row makes that row depend on the control at the
+//   operator level, so a trapeze step has 28 Jacobian entries instead of 26 -- the count of the archived table
+//   test/archives/AD_backend.md:63 (28011 at N = 1000, 280011 at N = 10000), which predates the current f!.
+// ---------------------------------------------------------------------------------------------
+struct GoddardAllF0F1 : GoddardAll {
+    template <class T> static void dynamics(T* r, const T&, const T* x, const T* u, const T*) {
+        const T& rr = x[0]; const T& vv = x[1]; const T& mm = x[2];
+        T D = Cd * sq(vv) * exp(-beta * (rr - 1.0));
+        T f0[3] = {vv, -D / mm - 1.0 / sq(rr), T(0.0)};
+        T f1[3] = {T(0.0), Tmax / mm, T(-b * Tmax)};
+        for (int i = 0; i < 3; ++i) r[i] = f0[i] + u[0] * f1[i];
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// id 11 (oracle only; the engine takes it as a run-time OCP): algal-bacterial consortium.
+//   test/problems/algal_bacterial.jl:3-52: parameters :6-15, phi / rho / mu :17-19, f :26-33, x(t0) == x0 :40,
+//   x >= [0,0,0,qmin,0,0] :41, 0 <= u <= [1, dmax] :42, maximise x6(tf) :46; t in [0, 20].
+//   The only problem the reference publishes per-configuration tables for (test/archives/jump_ctdirect.md:41-67).
+// ---------------------------------------------------------------------------------------------
+struct AlgalBacterial {
+    static constexpr int n = 6, m = 2, nv = 0, p = 0, bc = 6;
+    static constexpr bool freet0 = false, freetf = false, has_lagrange = false, has_mayer = true, maximize = true;
+    static constexpr double s_in = 0.5, beta = 23e-3, gamma = 0.44, dmax = 1.5, phimax = 6.48, ks = 0.09, rhomax = 27.3e-3,
+                            kv = 0.57e-3, mumax = 1.0211, qmin = 2.7628e-3;
+    template <class T> static T t0(const T*) { return T(0.0); }
+    template <class T> static T tf(const T*) { return T(20.0); }
+    template <class T> static T phi(const T& s) { return phimax * s / (ks + s); }
+    template <class T> static T rho(const T& v) { return rhomax * v / (kv + v); }
+    template <class T> static T mu(const T& q) { return mumax * (1.0 - qmin / q); }
+    template <class T> static void dynamics(T* r, const T&, const T* x, const T* u, const T*) {
+        const T& al = u[0]; const T& d = u[1];
+        r[0] = d * (s_in - x[0]) - phi(x[0]) * x[1] / gamma;
+        r[1] = ((1.0 - al) * phi(x[0]) - d) * x[1];
+        r[2] = al * beta * phi(x[0]) * x[1] - rho(x[2]) * x[4] - d * x[2];
+        r[3] = rho(x[2]) - mu(x[3]) * x[3];
+        r[4] = (mu(x[3]) - d) * x[4];
+        r[5] = d * x[4];
+    }
+    template <class T> static T lagrange(const T&, const T*, const T*, const T*) { return T(0.0); }
+    template <class T> static T mayer(const T*, const T* xf, const T*) { return xf[5]; }
+    template <class T> static void path(T*, const T&, const T*, const T*, const T*) {}
+    template <class T> static void boundary(T* r, const T* x0, const T*, const T*) { for (int i = 0; i < 6; ++i) r[i] = x0[i]; }
+    static void path_bounds(double*, double*) {}
+    static void boundary_bounds(double* lb, double* ub) {
+        const double b_[6] = {0.1629, 0.0487, 0.0003, 0.0177, 0.035, 0.0};
+        for (int i = 0; i < 6; ++i) lb[i] = ub[i] = b_[i];
+    }
+    static std::vector<BoxEntry> state_box() { return {{0, 0.0, INF}, {1, 0.0, INF}, {2, 0.0, INF}, {3, qmin, INF}, {4, 0.0, INF}, {5, 0.0, INF}}; }
+    static std::vector<BoxEntry> control_box() { return {{0, 0.0, 1.0}, {1, 0.0, dmax}}; }
+    static std::vector<BoxEntry> variable_box() { return {}; }
+    static bool init_state(double, double*) { return false; }
+    static bool init_control(double, double*) { return false; }
+    static bool init_variable(double*) { return false; }
+};
+
 }  // namespace orc

@@ -364,7 +364,7 @@ int emu_sym_check(const char* expr, int n, int m, int nv, const double* point, d
     for (int r = 0; r < n; ++r) X[r] = g.var(1 + r);
     for (int b = 0; b < m; ++b) U[b] = g.var(1 + n + b);
     for (int k = 0; k < nv; ++k) V[k] = g.var(1 + n + m + k);
-    ExprCtx cx{n, m, nv, 0, {}};
+    ExprCtx cx{n, m, nv, 0, {}, {}};
     const std::string text(expr);
     Parser ps(text, cx);
     ps.g = &g; ps.g_t = g.var(0); ps.g_x = X.data(); ps.g_u = U.data(); ps.g_v = V.data();

@@ -10,7 +10,7 @@ import jit_defs
 
 def test_expression_errors_are_reported():
     for bad, frag in ((["x2 + foo(x1)", "x1"], "unknown function"), (["x3", "x1"], "unknown name 'x3'"), (["x1 +", "x1"], "unexpected end"),
-                      (["x1^-1", "x1"], "integer exponent"), (["(x1", "x1"], "')' expected"), (["x1 x2", "x1"], "trailing"),
+                      (["x1^x2", "x1"], "must be a constant"), (["x1^(1+x1)", "x1"], "must be a constant"), (["max(x1)", "x1"], "two arguments"), (["(x1", "x1"], "')' expected"), (["x1 x2", "x1"], "trailing"),
                       (["u1", "x1"], "unknown name 'u1'"), (["xf_1", "x1"], "unknown name")):
         with pytest.raises(ct.CTDirectError) as e:
             ct.register_ocp("bad", dynamics=bad)
@@ -89,6 +89,9 @@ def test_all_grammar_functions_parse_and_compile():
     "log(1 + x1^2 + u1^2)*tanh(x2 - v1) + atan(x1*x2) + tan(0.3*u1)", "sqrt(1 + x1^2 + x2^2)*abs(u1 - 0.3) + (x1 - x2)^4/(1 + t)",
     "-Cd*x2^2*exp(-beta*(x1 - 1))/x3 - 1/x1^2 + u1*Tmax/x3".replace("Cd", "310").replace("beta", "5").replace("Tmax", "3.5"),
     "((x1 + 2*x2)*(3 - u1))/((1 + v1)*(2 + t)) - -x1", "2^3 + x1*0 + 0*u1 + x2^1 + x1^0",
+    # round 4: asin acos sinh cosh floor, real powers, max / min (away from their kinks)
+    "asin(0.5*x1*x2) + acos(0.3*u1 - 0.2*x3) + sinh(x1 - v1)*cosh(0.5*x2*t)", "x1^2.5*x2^(-1.5) + (1 + u1^2)^0.5 + x3^-2 + (x1*x2)^(1/3)",
+    "max(x1*x2, 0.1*u1)^2 + min(x3 + t, 5 - x1*x1) * x2 + max(0, sin(3*x1))^2", "(x1*8 - floor(x1*8))*x2^2 + floor(x3)*x1*u1",
 ])
 def test_symbolic_second_derivatives_match_finite_differences(expr):
     """the symbolic engine behind the stage functions of run-time OCPs (ctd_sym.hpp): every operator and function of the
@@ -149,3 +152,45 @@ def test_committed_assembly_registry_is_what_the_generator_writes(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-I", csrc, "-o", exe, os.path.join(csrc, "ctd_gen_asm.cpp")])
     out = subprocess.check_output([exe]).decode()
     assert out == open(os.path.join(csrc, "ctd_asm_registry.hpp")).read()
+
+
+def test_round4_grammar_parses_compiles_and_reports_errors():
+    """max / min (two arguments), asin acos sinh cosh floor, `^` with any constant exponent, and ALIASES: named sub-expressions in the
+    constants string (what the rest of the reference's problem folder needs: bioreactor.jl:15-20, swimmer.jl:39-143)"""
+    name = ct.register_ocp("g4_rt", dynamics=["aux*x2 + max(0, sin(w*t))^2", "-x1^1.5 + min(u1, 0.5*x2) + floor(2*t)*0.1 + asin(0.3*x1)"], m=1,
+                           lagrange="sinh(0.1*u1)^2 + cosh(x1 - x2) + acos(0.2*aux) + x1^(-0.5) + x2^p", mayer="max(xf_1, xf_2) + xf_1^(1/3)",
+                           constants=dict(w=3.0, p=2.5, aux="0.5 + 0.1*inner", inner="cos(x1)*x2"))
+    src = ct.ocp_source(name)
+    for frag in ("d_max2<T>(", "d_min2<T>(", "d_floor(", "d_asin(", "d_acos(", "d_sinh(", "d_cosh(", "d_powr(", "1.5)", "2.5)", "d_gt("):
+        assert frag in src, frag
+    assert "DYN_T = true" in src            # (an alias's use of t counts)
+    for sch in ("gauss_legendre_2", "midpoint"):
+        ct.jit_check(name, sch)
+    d = ct.DOCP(name, 7, "trapeze", device=-1, pattern="optimized")
+    assert d.nnzj > 0 and d.nnzh > 0
+    for kw, frag in ((dict(dynamics=["a*x1"], constants=dict(a="b + 1", b="a*2")), "nested too deeply"),
+                     (dict(dynamics=["x1"], constants=dict(x1="2*t")), "collides"),
+                     (dict(dynamics=["a"], constants=dict(a="x1 +")), "in alias 'a'"),
+                     (dict(dynamics=["x1"], mayer="a", constants=dict(a="x1*2")), "unknown name 'x1'")):
+        with pytest.raises(ct.CTDirectError) as e:
+            ct.register_ocp("bad", **kw)
+        assert frag in str(e.value), str(e.value)
+
+
+def test_reference_problem_folder_registers_and_builds():
+    """every problem of /root/reference/test/problems the registry and round 3's catalogue did not hold: registered from text,
+    host model on all schemes and patterns, kernels compile for gfx950 (the large swimmer expressions included)"""
+    import problem_folder_defs as pf
+    for name in pf.FOLDER:
+        rt, _, _ = pf.folder(name)
+        for sch in ("trapeze", "midpoint", "gauss_legendre_2", "gauss_legendre_3_constant_control", "euler_implicit"):
+            for pattern in ("manual", "structural", "optimized"):
+                try:
+                    d = ct.DOCP(rt, 9, sch, device=-1, pattern=pattern)
+                except ct.CTDirectError:
+                    assert pattern == "optimized" and sch == "euler_implicit"
+                    continue
+                assert d.nnzj > 0 and d.nnzh > 0
+    for name, sch in (("swimmer", "gauss_legendre_2"), ("bioreactor_1day", "midpoint"), ("algal_bacterial", "trapeze"), ("action", "gauss_legendre_3"),
+                      ("parametric", "midpoint"), ("schlogl", "trapeze")):
+        ct.jit_check(pf.folder(name)[0], sch)
