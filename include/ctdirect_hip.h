@@ -112,9 +112,18 @@ typedef struct ctd_desc {
                                * src/direct_shooting.jl:55-71 -- step block [X_i, U_i^1 .. U_i^cs] (midpoint.jl:20), dynamics summed over
                                * the control sub-steps (midpoint.jl:47-72,137-155), cost midpoint.jl:99-116, bounds / initial guess for
                                * every control (DOCP_variables.jl:44,138); path constraints see U_i^1 (common.jl:140-155).  CTD_SCHEME_MIDPOINT
-                               * only (CTD_ESCHEME otherwise: no other scheme of the reference reads the extra controls).  Compiled problems:
-                               * control_steps <= 3; problems registered at run time: any.  Constraints, Jacobian (all three patterns),
-                               * objective, gradient, hess_structure and hess_coord (one second-order evaluation point per control). */
+                               * only.  KNOWN DEVIATION (decided, not an omission): the reference accepts control_steps > 1 with every scheme --
+                               * it sizes the step block with it (trapeze.jl:20, euler.jl:22, irk.jl:141) and bounds / initialises the extra
+                               * controls (DOCP_variables.jl:44-47,138-140) -- but only midpoint.jl integrates over them, and elsewhere its own
+                               * layout is incoherent: the stage-variable getter of the IRK schemes keeps the offset n + m (common.jl:166-170),
+                               * so K_i^j ALIASES the controls U_i^2.. it has just bounded; the trapeze `:manual` pattern addresses X_{i+1} at
+                               * n + m behind X_i (trapeze.jl:180-186), i.e. inside the extra controls, and misses the real X_{i+1} columns;
+                               * the stagewise schemes ignore control_steps altogether (irk_stagewise.jl:138-146); Euler is coherent (extra
+                               * controls that nothing reads).  The engine returns CTD_ESCHEME for all of them instead of reproducing aliased or
+                               * dead variables (direct shooting, the only caller that sets
+                               * control_steps, advertises :midpoint and :trapeze, src/direct_shooting.jl:33-37; its default is :midpoint).
+                               * Compiled problems: control_steps <= 3; problems registered at run time: any.  Constraints, Jacobian (all three
+                               * patterns), objective, gradient, hess_structure and hess_coord (one second-order evaluation point per control). */
     int32_t value_order;      /* CTD_ORDER_CSC (0): Jacobian values in the order of SparseArrays.sparse(Is, Js, ...) as DOCP_Jacobian_pattern
                                * returns it (src/ode/midpoint.jl:229-232, irk_stagewise.jl:555-558) -- what ADNLPModels' jac_coord! fills.
                                * CTD_ORDER_CSR (1): the same entries by ROWS -- what GPU KKT consumers (rocSPARSE / hipSOLVER) take, and what
@@ -156,7 +165,7 @@ typedef struct ctd_init {
  * registry is handed over as TEXT: one arithmetic expression per output.  Grammar: + - * / parentheses, numbers, ^ with a CONSTANT
  * exponent (small non-negative integers multiply out; any other real exponent is pow), exp log sin cos tan atan tanh sqrt abs asin acos
  * sinh cosh floor, max(a, b) min(a, b) (derivative of the selected operand: ForwardDiff's rule, at a tie max follows b and min a;
- * floor has derivative 0) -- everything the reference's problem folder test/problems/*.jl uses --, the names t, x1..xn, u1..um,
+ * floor has derivative 0) -- everything the reference's problem folder (test/problems, every .jl file) uses --, the names t, x1..xn, u1..um,
  * v1..vnv (dynamics, lagrange, path) or x0_1.., xf_1.., v1.. (mayer, boundary), and what `constants` declares: "Cd=310; beta=500"
  * (numbers) and "aux = 543 + 186*cos(x4); g13 = -(105 + 2*cos(2*x4)) / (2*aux)" (ALIASES: named sub-expressions, the `aux = ...`
  * lines of a CTParser @def block such as test/problems/swimmer.jl:39-53; substituted where they are used, may use each other).
