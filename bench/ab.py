@@ -23,11 +23,11 @@ def child(names):
     from stamps import CFGS
     out = {}
     for name in names:
-        base, _, tail = name.partition(":")
-        kind = "hess" if tail == "hess" else "cj"
-        pattern = tail if tail in ("optimized", "structural") else "manual"
+        base, *tail = name.split(":")                     # "cfg5:optimized:hess", "cfg2:csr"
+        kind = "hess" if "hess" in tail else "cj"
+        pattern = "optimized" if "optimized" in tail else ("structural" if "structural" in tail else "manual")
         prob, sch, N = CFGS[base]
-        d = ct.DOCP(prob, N, sch, device=0, pattern=pattern)
+        d = ct.DOCP(prob, N, sch, device=0, pattern=pattern, value_order="csr" if "csr" in tail else "csc")
         x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
         if kind == "cj":
             c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")

@@ -25,8 +25,9 @@ def main():
     base, tail = parts[0], parts[1:]
     kind = "hess" if "hess" in tail else "cons_jac"
     pattern = "optimized" if "optimized" in tail else "manual"
+    order = "csr" if "csr" in tail else "csc"              # (ctd_desc.value_order: the constraint / Jacobian kernel's value order)
     prob, sch, N = CFGS[base]
-    d = ct.DOCP(prob, N, sch, device=0, pattern=pattern)
+    d = ct.DOCP(prob, N, sch, device=0, pattern=pattern, value_order=order)
     x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
     if kind == "cons_jac":
         c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
@@ -43,7 +44,7 @@ def main():
         alg = 8 * (d.dim_NLP_variables + d.dim_NLP_constraints + d.nnzh)
     d.sync()
     torch.cuda.synchronize()
-    print(json.dumps({"workload": spec, "problem": prob, "scheme": sch, "N": N, "pattern": pattern, "kernel": kind, "launches": iters,
+    print(json.dumps({"workload": spec, "problem": prob, "scheme": sch, "N": N, "pattern": pattern, "value_order": order, "kernel": kind, "launches": iters,
                       "nvar": d.dim_NLP_variables, "ncon": d.dim_NLP_constraints, "nnzj": d.nnzj, "nnzh": d.nnzh,
                       "algorithmic_bytes_per_launch": alg}))
     d.close()

@@ -417,7 +417,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             }
         }
     }
-    h->grid = h->kp.ntiles + (h->kp.has_edge ? 1 : 0);
+    h->grid = h->kp.ntiles + h->kp.has_edge;
     h->kp.debug_stop = debug_stop;
     {   // write-through stores (emit_store) for launches whose outputs are small: what a kernel leaves dirty in the XCDs' L2s is written
         // back at its end, serial with the next launch.  CTD_WT_STORE: 0 never, 1 always, unset: outputs of this handle up to
@@ -501,10 +501,10 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
                         });
                     }
                 }
-                const int64_t cap = (int64_t)per_cu * cus - (hp->kp.has_edge ? 1 : 0);      // (the edge block holds a slot of its own)
+                const int64_t cap = (int64_t)per_cu * cus - hp->kp.has_edge;      // (the edge blocks hold slots of their own)
                 if (cap > 0 && hp->kp.ntiles > cap) {
                     hp->kp.wg_stride = (int)cap;
-                    hp->grid = hp->kp.wg_stride + (hp->kp.has_edge ? 1 : 0);
+                    hp->grid = hp->kp.wg_stride + hp->kp.has_edge;
                 }
             }
         }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -1060,7 +1061,14 @@ void Model::fill_kparams(KParams& kp, int64_t step_begin, int64_t step_end, int 
     kp.edge_end = head_ptr[std::min<int64_t>(step_end, reg_first)];
     kp.edge2_begin = edge_split;                       // tail rows of c (every shard), then the trailing columns (last shard)
     kp.edge2_end = owns_last ? (int)edge_idx.size() : edge_split2;
-    kp.has_edge = (kp.edge_end > kp.edge_begin || kp.edge2_end > kp.edge2_begin) ? 1 : 0;
+    {   // edge workgroups: one, or -- long explicit lists (wide OCPs: 6432 entries for the 12-state quadrotor on Gauss-Legendre 3) --
+        // one per ~512 entries up to 16, each evaluating the edge records and emitting its share (edge_share_begin, ctd_kernel_body.hpp)
+        const int nedge = (kp.edge_end - kp.edge_begin) + (kp.edge2_end - kp.edge2_begin);
+        int E = nedge > 0 ? 1 : 0;
+        if (nedge > 1024) E = std::min(16, (nedge + 511) / 512);
+        if (const char* e = std::getenv("CTD_EDGE_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && nedge > 0) E = std::min(v, 64); }
+        kp.has_edge = E;
+    }
     kp.n_edge_slots = n_edge_slots;
     kp.edge_fp = edge_fp; kp.edge_b = edge_b;
     kp.edge_slot_first = edge_slot_first; kp.edge_slot_last = edge_slot_last;

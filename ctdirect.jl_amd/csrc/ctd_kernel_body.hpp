@@ -65,6 +65,8 @@ namespace ctd {
 
 struct BlockCtx {
     int is_edge;
+    int edge_part;     // edge blocks only: which of the kp.has_edge edge workgroups this is (each evaluates the edge records and emits its
+                       // share of the explicit (index, code) list)
     int direct;        // 1: in / v point into xu (global memory), tau is null (make_direct_ctx)
     int nslots;        // records held by this block (step / node records)
     int in_stride;     // doubles between the inputs of consecutive slots
@@ -110,8 +112,10 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
     cx.codes = codes_staged(kp) ? reinterpret_cast<const uint32_t*>(lds) : kp.tmpl;
     cx.vcodes = codes_staged(kp) ? cx.codes + kp.Lseg : kp.vtmpl;
     lds += code_doubles(kp);
-    if (kp.has_edge && block == 0) {
+    cx.edge_part = 0;
+    if (block < kp.has_edge) {
         cx.is_edge = 1;
+        cx.edge_part = block;
         cx.nslots = kp.n_edge_slots;
         cx.in_stride = edge_in_stride(L);
         cx.a = cx.b = cx.lo = 0;
@@ -120,7 +124,7 @@ CTD_HD BlockCtx make_ctx(const KParams& kp, int block, double* lds) {
         cx.tau = cx.v + kMaxNV;
         cx.rec = cx.tau + 2 * kMaxEdgeSlots + 2;
     } else {
-        const int tb = block - (kp.has_edge ? 1 : 0);
+        const int tb = block - kp.has_edge;
         const int tile = kp.xcd_remap ? xcd_tile(tb, kp.ntiles) : tb;
         const int cap = kp.T + kp.HL + kp.HH;
         cx.is_edge = 0;
@@ -157,17 +161,19 @@ CTD_HD BlockCtx make_direct_ctx(const KParams& kp, int block, double* lds, const
     cx.rec = lds + code_doubles(kp);
     cx.xu = xu;
     cx.halo = nullptr;
-    if (kp.has_edge && block == 0) {
+    cx.edge_part = 0;
+    if (block < kp.has_edge) {
         // edge block: slot k holds step kp.edge_steps[k] (slot_base); X_{i+1} (and U_{i-1} for implicit Euler) are where
         // the global layout has them
         cx.is_edge = 1;
+        cx.edge_part = block;
         cx.nslots = kp.n_edge_slots;
         cx.a = cx.b = cx.lo = 0;
         cx.in = const_cast<double*>(xu);
         cx.halo = kp.halo;
         return cx;
     }
-    const int tile = block - (kp.has_edge ? 1 : 0);      // (the XCD-aware tile order of the staged driver measured neutral: not offered here)
+    const int tile = block - kp.has_edge;      // (the XCD-aware tile order of the staged driver measured neutral: not offered here)
     cx.is_edge = 0;
     cx.a = kp.step_begin + (int64_t)tile * kp.T;
     cx.b = cx.a + kp.T < kp.step_end ? cx.a + kp.T : kp.step_end;
@@ -1520,6 +1526,22 @@ CTD_HD double eval_code(int oC, const double* rec_c, const double* rec_d, uint32
     return coef * data + beta;
 }
 
+// The explicit edge entries [0, ntot) are dealt over the kp.has_edge edge workgroups in contiguous shares: a 12-state quadrotor on
+// Gauss-Legendre 3 has 6432 of them (boundary rows x (x0, xf, v), final-time path rows, first / last step columns), each a dependent
+// chain global load -> LDS reads -> scattered store queued behind the whole chip's stores: ONE workgroup needed ~80 us for them
+// (the Hessian kernel has shared its edge list over up to 16 workgroups since round 2, ctd_hess_host.cpp).
+// Every edge workgroup evaluates the edge records itself (a few points; they run side by side on different CUs).
+CTD_HD int edge_share_begin(const KParams& kp, const BlockCtx& cx, int ntot) {
+    const int E = kp.has_edge > 1 ? kp.has_edge : 1, per = (ntot + E - 1) / E;
+    const int lo = cx.edge_part * per;
+    return lo < ntot ? lo : ntot;
+}
+CTD_HD int edge_share_end(const KParams& kp, const BlockCtx& cx, int ntot) {
+    const int E = kp.has_edge > 1 ? kp.has_edge : 1, per = (ntot + E - 1) / E;
+    const int hi = (cx.edge_part + 1) * per;
+    return hi < ntot ? hi : ntot;
+}
+
 // The codes a lane needs in phase_emit when it owns ONE position of each period (period <= workgroup size): read from the
 // global tables before the evaluation starts, so their latency hides behind it and the emission starts from registers.
 // upper bound of the CSC period of (OCP, scheme class, stages) -- the reference's dense-block patterns (Appendix A.4 of SURVEY.md)
@@ -1546,8 +1568,9 @@ CTD_HD EmitPreT<NB> emit_prefetch(const KParams& kp, const BlockCtx& cx, int tid
     for (int kk = 0; kk < kMaxNV; ++kk) pre.v[kk] = 0u;
     if (cx.is_edge) {
         const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
-        if (tid < ntot) {
-            const int e = tid < n1 ? kp.edge_begin + tid : kp.edge2_begin + (tid - n1);
+        const int w = edge_share_begin(kp, cx, ntot) + tid;          // first entry of this edge workgroup's share that the lane owns
+        if (w < edge_share_end(kp, cx, ntot)) {
+            const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
             pre.b = kp.edge_code[e];
             pre.eidx = kp.edge_idx[e];
         }
@@ -1596,17 +1619,18 @@ CTD_HD void phase_emit_impl(const KParams& kp, const BlockCtx& cx, int tid, int 
     constexpr RecLayout R = RL<P, SC, S>::R;
     const EmitPreT<NB>* pre_ = &pre_v;                     // hp: the lane's codes were prefetched (pre_v holds them)
     if (cx.is_edge) {
-        const int n1 = kp.edge_end - kp.edge_begin, ntot = n1 + (kp.edge2_end - kp.edge2_begin);
+        const int n1 = kp.edge_end - kp.edge_begin, nall = n1 + (kp.edge2_end - kp.edge2_begin);
+        const int wlo = edge_share_begin(kp, cx, nall), ntot = edge_share_end(kp, cx, nall);      // this edge workgroup's share
         // four entries per round: their (code, index) loads are in flight together -- one dependent global load per entry, queued
         // behind the whole chip's stores, made the 6432 edge entries of the 12-state quadrotor (Gauss-Legendre 3) a 48 us phase
-        for (int w0 = tid; w0 < ntot; w0 += 4 * nthr) {
+        for (int w0 = wlo + tid; w0 < ntot; w0 += 4 * nthr) {
             uint32_t code[4];
             int64_t idx[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int w = w0 + u * nthr;
                 const int e = w < n1 ? kp.edge_begin + w : kp.edge2_begin + (w - n1);
-                const bool have = hp && w == tid;          // first entry: prefetched before the evaluation
+                const bool have = hp && w == wlo + tid;          // first entry: prefetched before the evaluation
                 code[u] = have ? pre_->b : (w < ntot ? kp.edge_code[e] : 0u);
                 idx[u] = have ? pre_->eidx : (w < ntot ? kp.edge_idx[e] : 0);
             }

@@ -107,7 +107,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
     // 106, optimized pattern 55.5 against 42.4.  A resident round of workgroups that all start together stays in lock-step (every
     // workgroup evaluates, then every workgroup stores: the memory system idles, then saturates), while the hardware dispatcher
     // starts the next tile whenever a slot frees and so spreads the phases; the loop also costs 30 - 55 registers.
-    const int nblk = kp.ntiles + (kp.has_edge ? 1 : 0);
+    const int nblk = kp.ntiles + kp.has_edge;
     for (;;) {
         __syncthreads();
         ctd_stamp<DBG>(kp, 1);

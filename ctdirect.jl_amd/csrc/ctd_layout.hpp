@@ -236,7 +236,7 @@ struct KParams {
     int32_t T;                  // steps per tile
     int32_t HL, HH;             // extra records a tile needs below / above its steps (midpoint: 1,0; trapeze: 0,1)
     int32_t ntiles;
-    int32_t has_edge;           // block 0 is the edge block
+    int32_t has_edge;           // E = number of edge workgroups: blocks [0, E) are edge blocks (0: none), tiles follow
     int32_t xcd_remap;          // tiles follow xcd_tile(block) instead of the block id
     int64_t step_begin, step_end;
     // regular CSC segments: step i in [reg_first, reg_last) owns vals[seg_base + (i - reg_first) * Lseg, +Lseg)

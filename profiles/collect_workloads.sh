@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")/.."
 TAG=${1:-r03}
 shift || true
-WL=${@:-cfg2 cfg3 cfg4 cfg4:optimized cfg5 cfg5:optimized cfg5p cfg5p:optimized q12_mid cfg2:hess cfg4:hess cfg5p:hess cfg5:hess}
+WL=${@:-cfg2 cfg3 cfg4 cfg4:optimized cfg5 cfg5:optimized cfg5p cfg5p:optimized q12_mid cfg2:hess cfg4:hess cfg5p:hess cfg5:hess q12_mid:hess cfg4:optimized:hess cfg5p:optimized:hess cfg5:optimized:hess q12_mid:optimized:hess cfg2:csr cfg4:csr cfg5:csr cfg5:optimized:csr}
 OUT=gpurun_out/wl_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

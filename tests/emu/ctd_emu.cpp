@@ -27,11 +27,11 @@ using namespace ctd;
 
 template <class P, int SC, int S>
 static void run_blocks(const KParams& kp, const double* xu, int nthr) {
-    const int nblocks = kp.ntiles + (kp.has_edge ? 1 : 0);
+    const int nblocks = kp.ntiles + kp.has_edge;
     const int64_t nlds = lds_doubles(kp);
     // multi-tile workgroups (KParams::wg_stride, staged driver): workgroup w walks the blocks w, w + wg_stride, ... on ONE LDS image
     const int stride = DirectTile<P, SC>::value ? 0 : kp.wg_stride;
-    const int nwg = stride > 0 ? std::min(nblocks, stride + (kp.has_edge ? 1 : 0)) : nblocks;
+    const int nwg = stride > 0 ? std::min(nblocks, stride + kp.has_edge) : nblocks;
     for (int w = 0; w < nwg; ++w) {
         int b = w;
         std::vector<double> lds(nlds, std::numeric_limits<double>::quiet_NaN());
