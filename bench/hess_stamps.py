@@ -15,9 +15,10 @@ from stamps import CFGS  # noqa: E402
 
 
 def main():
-    for name in sys.argv[1:] or ["cfg2", "cfg4", "cfg5p", "cfg5"]:
+    for spec in sys.argv[1:] or ["cfg2", "cfg4", "cfg5p", "cfg5"]:
+        name, _, pattern = spec.partition(":")            # "cfg5:optimized"
         prob, sch, N = CFGS[name]
-        d = ct.DOCP(prob, N, sch, device=0)
+        d = ct.DOCP(prob, N, sch, device=0, pattern=pattern or "manual")
         x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
         y = torch.from_numpy(0.6 + 0.4 * np.sin(0.7 * np.arange(d.dim_NLP_constraints) + 0.3)).cuda()
         v = torch.zeros(d.nnzh, dtype=torch.float64, device="cuda")
@@ -27,7 +28,7 @@ def main():
         cy = st[:, :, 1]
         t0 = rt[:, 0].min()
         b = 8 * (d.dim_NLP_variables + d.dim_NLP_constraints + d.nnzh)
-        print(f"== {name} {prob} {sch} N={N} {d.hess_launch_info()} kernel {ms * 1e3:.2f} us = {b / ms / 1e6 / 8000:.3f} of 8 TB/s; "
+        print(f"== {spec} {prob} {sch} N={N} nnzh {d.nnzh} {d.hess_launch_info()} kernel {ms * 1e3:.2f} us = {b / ms / 1e6 / 8000:.3f} of 8 TB/s; "
               f"last block start {rt[:, 0].max() - t0:.2f}, end {rt[:, 4].max() - t0:.2f}")
         for i, nm in enumerate(["load", "eval", "emit-issue", "drain"]):
             dt = rt[1:, i + 1] - rt[1:, i]

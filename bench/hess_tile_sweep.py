@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of the Hessian kernel over the steps per tile (CTD_HESS_TILE): python bench/hess_tile_sweep.py cfg4 [...]"""
+"""Kernel time of the Hessian kernel over the steps per tile (CTD_HESS_TILE): python bench/hess_tile_sweep.py cfg4 cfg5:optimized [...]"""
 import os
 import sys
 
@@ -14,24 +14,26 @@ from helpers import bench_inputs, describe  # noqa: E402
 from stamps import CFGS  # noqa: E402
 
 TILES = {"cfg2": (6, 8, 10, 12, 14, 17, 20, 24, 32, 40), "cfg3": (32, 64, 128, 196, 256), "cfg4": (8, 10, 12, 16, 20, 24, 26, 28, 32, 40, 48),
-         "cfg5p": (3, 4, 5, 6, 8, 10, 12, 14), "cfg5": (4, 5, 6, 7, 8, 9, 10, 12)}
+         "cfg5p": (3, 4, 5, 6, 8, 10, 12, 14, 16, 20), "cfg5": (4, 5, 6, 7, 8, 9, 10, 12, 14, 16), "q12_mid": (8, 12, 16, 20, 24, 32, 40, 48),
+         "quad_mid": (8, 12, 16, 24, 32, 40, 48)}
 
 
 def main():
-    for name in sys.argv[1:] or ["cfg4"]:
+    for spec in sys.argv[1:] or ["cfg4"]:
+        name, _, pattern = spec.partition(":")
         prob, sch, N = CFGS[name]
         row = []
-        for T in TILES[name]:
+        for T in (0,) + TILES[name]:                       # 0: the engine's own choice (default_hess_tile)
             os.environ["CTD_HESS_TILE"] = str(T)
-            d = ct.DOCP(prob, N, sch, device=0)
+            d = ct.DOCP(prob, N, sch, device=0, pattern=pattern or "manual")
             x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
             y = torch.from_numpy(0.6 + 0.4 * np.sin(0.7 * np.arange(d.dim_NLP_constraints) + 0.3)).cuda()
             v = torch.zeros(d.nnzh, dtype=torch.float64, device="cuda")
             ms = sorted(d.time_hess(x, y, v, 1.0, iters=50) for _ in range(3))[1]
             li = d.hess_launch_info()
-            row.append(f"T={li['steps_per_tile']}(lds {li['lds_bytes'] // 1024}K):{ms * 1e3:.1f}")
+            row.append(f"{'default ' if T == 0 else ''}T={li['steps_per_tile']}(lds {li['lds_bytes'] // 1024}K, {d.hess_kernel_info()['kernel']}):{ms * 1e3:.1f}")
             d.close()
-        print(f"{name}  " + "  ".join(row), flush=True)
+        print(f"{spec}  " + "  ".join(row), flush=True)
     os.environ.pop("CTD_HESS_TILE", None)
 
 

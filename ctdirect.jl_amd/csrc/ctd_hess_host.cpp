@@ -790,7 +790,10 @@ int default_hess_tile(const Model& mo) {
         // workgroups per CU), ~48 KiB for steps of 2 KiB and more (the CSC period is then several wave passes per step)
         // (records hold packed triangles since round 2: sweeps in profiles/r02_hessian_tiles.log -- the 12-state quadrotor,
         // 6.3 KiB per step: 8 steps = 57 KiB 90 us, 6 steps 101 us, 10 steps 95 us, 12 steps = one workgroup per CU 133 us)
-        const int64_t budget = per_step >= 5000 ? 58 * 1024 : (per_step >= 2048 ? 48 * 1024 : 27 * 1024);
+        // (optimized pattern, round 4: no compact segment to zero-fill, a fifth of the manual pattern's entries per step -- the emission
+        // is short and the largest tile that still leaves two workgroups per CU wins: 12-state quadrotor GL3, N = 20 000: 8 steps 60.5 us,
+        // 10 steps = 69 KiB 55.3, 12 steps = one workgroup per CU 90.5: profiles/r04_hess_tiles_optimized.log)
+        const int64_t budget = per_step >= 5000 ? (mo.pattern_mode == 2 ? 70 * 1024 : 58 * 1024) : (per_step >= 2048 ? 48 * 1024 : 27 * 1024);
         int64_t Ts = std::max<int64_t>(1, std::min<int64_t>(128, budget / per_step - H.HL - H.HH - 1));
         if (Ts < 6) Ts = std::max<int64_t>(Ts, std::min<int64_t>(6, (78 * 1024) / per_step - H.HL - H.HH - 1));
         // One-point schemes (midpoint, Euler, trapeze; any number of controls per step) with heavy steps: the kernel keeps TWO

@@ -734,6 +734,12 @@ CTD_HD void eval_point(const KParams& kp, const double* vv, int q, double t, con
         for (int c = 0; c < m; ++c) prm[1 + n + c] = uv[c];
 #pragma unroll
         for (int c = 0; c < nv; ++c) prm[1 + n + m + c] = cx.v[c];
+#ifdef CTD_ABL_NOEVAL      /* EXPERIMENT build only (profiles/r04_experiments.md): no arithmetic in the evaluation -- the bound of anything a
+                              restructured evaluation (row split, ...) could gain.  Outputs are garbage. */
+#pragma unroll
+        for (int e = 0; e < R.eval_sz; ++e) ev[e] = prm[e % (1 + n + m + nv)];
+        return;
+#endif
         if constexpr (split) SymDyn<P>::eval_part(q, prm, ev);
         else SymDyn<P>::eval(prm, ev);
         return;

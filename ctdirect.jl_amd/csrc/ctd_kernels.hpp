@@ -3,6 +3,9 @@
 // so the registry compiles in parallel.
 #pragma once
 #if !defined(__HIPCC_RTC__)
+#include <cstring>
+#endif
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #endif
@@ -165,6 +168,18 @@ __global__ void __launch_bounds__(P::MAXB, (MinWaves<P, SC, S>::value)) cons_jac
     extern __shared__ double ctd_lds[];
     cons_jac_body<P, SC, S, DBG>(kp, xu, (int)blockIdx.x, ctd_lds);
 }
+
+// EXPERIMENT build only (make EXTRA=-DCTD_KP_INDIRECT; VERDICT r03 item 7 ii): the 640-byte parameter block lives in device memory
+// and the kernel takes a 16-byte argument list (pointer to it, xu).  Measured on MI355X (profiles/r04_experiments.md): no gain --
+// back-to-back launches of this kernel are GPU-bound (5.9 us per kernel against 3.3 us of host time per launch), and the scalar
+// loads of the parameters now hang off one more dependent load.
+#ifdef CTD_KP_INDIRECT
+template <class P, int SC, int S, bool DBG>
+__global__ void __launch_bounds__(P::MAXB, (MinWaves<P, SC, S>::value)) cons_jac_kernel_ind(const KParams* __restrict__ kpp, const double* __restrict__ xu) {
+    extern __shared__ double ctd_lds[];
+    cons_jac_body<P, SC, S, DBG>(*kpp, xu, (int)blockIdx.x, ctd_lds);
+}
+#endif
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
 // One lane per quadrature unit (trapeze: node, otherwise: step) of the shard; per-workgroup partial sums are
@@ -648,6 +663,23 @@ hipError_t launch_variant_dbg(const KParams& kp, const double* xu, int grid, int
                                            (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
+#ifdef CTD_KP_INDIRECT
+    {
+        static KParams* d_kp = nullptr;          // (one block per kernel instantiation: an experiment, one handle at a time)
+        static KParams last;
+        static bool have = false;
+        if (!d_kp && hipMalloc((void**)&d_kp, sizeof(KParams)) != hipSuccess) return hipGetLastError();
+        if (!have || std::memcmp(&last, &kp, sizeof(KParams)) != 0) {
+            hipError_t e = hipMemcpyAsync(d_kp, &kp, sizeof(KParams), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+            (void)hipStreamSynchronize(st);
+            last = kp; have = true;
+        }
+        if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel_ind<P, SC, S, DBG>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, (const KParams*)d_kp, xu);
+        else cons_jac_kernel_ind<P, SC, S, DBG><<<grid, block, lds_bytes, st>>>((const KParams*)d_kp, xu);
+        return hipGetLastError();
+    }
+#endif
     // e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel, so
     // hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
     if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S, DBG>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);

@@ -12,14 +12,14 @@ TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extras"      # (--no-extras: the trace then holds ONLY the timed kernel -- the extras launch the same template on the CSR order and other sizes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- $BENCH > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections, shutil
 out = sys.argv[1]
-res = {"command": "python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline", "kernels": {}}
+res = {"command": "python3 bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-extras", "kernels": {}}
 for f in glob.glob(out + "/bench_stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, out + "/kernel_stats.csv")
     for r in csv.DictReader(open(f)):
