@@ -41,6 +41,10 @@ while time.time() < t_end:
     os.environ["CTD_HESS_STEP"] = str(rng.choice(["0", "1", "2", "2"]))
     os.environ["CTD_HESS_COMPACT"] = str(rng.choice(["", "", "0", "1", "2"]))
     os.environ["CTD_HESS_EDGE_BLOCKS"] = str(rng.choice(["", "", "1", "3", "7"]))
+    # round 4: the value order of the Jacobian (CSR: row-order emit template; checked against the oracle's CSC values under the host
+    # permutation) and the number of edge workgroups of the constraint / Jacobian kernel
+    order = "csr" if rng.random() < 0.4 else "csc"
+    os.environ["CTD_EDGE_BLOCKS"] = str(rng.choice(["", "", "1", "2", "5", "16"]))
     tile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     htile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     steps = None
@@ -58,9 +62,9 @@ while time.time() < t_end:
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
             f"twin={int(use_twin)} api={api} step={os.environ['CTD_HESS_STEP']} compact={os.environ['CTD_HESS_COMPACT']} "
-            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']} cs={cs}")
+            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']} cs={cs} order={order} ceb={os.environ['CTD_EDGE_BLOCKS']}")
     try:
-        d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps, control_steps=cs)
+        d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps, control_steps=cs, value_order=order)
         o = OracleDOCP(prob, sch, N, time_grid=tg, control_steps=cs) if tg is not None else OracleDOCP(prob, sch, N, control_steps=cs)
         if mode == "structural": o.set_pattern_mode(1)
         if mode == "optimized": o.set_pattern_mode(2)
@@ -86,6 +90,10 @@ while time.time() < t_end:
         else:
             c, v = d.cons_jac(x)
         cref, vref = o.constraints(x), o.jac_coord(x)
+        if order == "csr":                                      # the oracle's values are in the reference's CSC order
+            cp_, rv_ = o.jac_pattern()
+            cols_ = np.repeat(np.arange(len(cp_) - 1), np.diff(cp_))
+            vref = vref[np.lexsort((cols_, rv_))]
         errs = {}
         if steps is None:
             errs["c"], errs["jac"] = relerr(c, cref), relerr(v, vref)
