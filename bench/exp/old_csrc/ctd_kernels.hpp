@@ -3,9 +3,6 @@
 // so the registry compiles in parallel.
 #pragma once
 #if !defined(__HIPCC_RTC__)
-#include <cstring>
-#endif
-#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #endif
@@ -110,7 +107,7 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
     // 106, optimized pattern 55.5 against 42.4.  A resident round of workgroups that all start together stays in lock-step (every
     // workgroup evaluates, then every workgroup stores: the memory system idles, then saturates), while the hardware dispatcher
     // starts the next tile whenever a slot frees and so spreads the phases; the loop also costs 30 - 55 registers.
-    const int nblk = kp.ntiles + kp.has_edge;
+    const int nblk = kp.ntiles + (kp.has_edge ? 1 : 0);
     for (;;) {
         __syncthreads();
         ctd_stamp<DBG>(kp, 1);
@@ -168,18 +165,6 @@ __global__ void __launch_bounds__(P::MAXB, (MinWaves<P, SC, S>::value)) cons_jac
     extern __shared__ double ctd_lds[];
     cons_jac_body<P, SC, S, DBG>(kp, xu, (int)blockIdx.x, ctd_lds);
 }
-
-// EXPERIMENT build only (make EXTRA=-DCTD_KP_INDIRECT; VERDICT r03 item 7 ii): the 640-byte parameter block lives in device memory
-// and the kernel takes a 16-byte argument list (pointer to it, xu).  Measured on MI355X (profiles/r04_experiments.md): no gain --
-// back-to-back launches of this kernel are GPU-bound (5.9 us per kernel against 3.3 us of host time per launch), and the scalar
-// loads of the parameters now hang off one more dependent load.
-#ifdef CTD_KP_INDIRECT
-template <class P, int SC, int S, bool DBG>
-__global__ void __launch_bounds__(P::MAXB, (MinWaves<P, SC, S>::value)) cons_jac_kernel_ind(const KParams* __restrict__ kpp, const double* __restrict__ xu) {
-    extern __shared__ double ctd_lds[];
-    cons_jac_body<P, SC, S, DBG>(*kpp, xu, (int)blockIdx.x, ctd_lds);
-}
-#endif
 
 // ---- objective: Mayer + Lagrange quadrature (src/DOCP_functions.jl:23-54) ------------------------------------
 // One lane per quadrature unit (trapeze: node, otherwise: step) of the shard; per-workgroup partial sums are
@@ -331,19 +316,7 @@ struct GradParams {
     double* g;          // nvar, zero-filled before the launch
     double* partial;    // nblocks * kMaxNV
     int32_t nblocks;
-    // quadrature units [unit_begin, unit_end) this launch evaluates: all of them (ctd_grad*: the whole objective's gradient), or the
-    // units of a shard of the grid (ctd_grad_shard_dev_async: the shard's own entries of g + its partial sums of d/dv)
-    int64_t unit_begin, unit_end;
-    int32_t owns_first, owns_last;      // the Mayer term's d/dx0 goes to the shard that owns X_1, d/dxf and d/dv to the one that owns X_{N+1}
-    // sharded iterate read in place (ctd_set_x_shards): blocks of other shards come from their owners' buffers; null: xu holds everything
-    const XHalo* halo;
-    XNear near;
 };
-// start of the variable block of step / node `st` in the buffer that owns it
-CTD_HD const double* grad_block(const GradParams& gp, const double* xu, int64_t st) {
-    const int64_t g = st * (int64_t)gp.L.blk;
-    return (gp.halo ? xnear(gp.near, xu, g) : xu) + g;
-}
 
 template <class P> struct LagDirs {
     static constexpr int N = P::NX + P::NU + (P::LAG_T ? 1 : 0) + (P::LAG_V ? P::NV : 0);
@@ -463,11 +436,11 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
     const Layout& L = gp.L;
     double v[nv > 0 ? nv : 1], gv[nv > 0 ? nv : 1];
     for (int k = 0; k < nv; ++k) { v[k] = xu[L.v_off + k]; gv[k] = 0.0; }
-    const int64_t i = gp.unit_begin + (int64_t)block * blockDim.x + threadIdx.x;      // step, or node for trapeze / midpoint
-    if (P::HAS_LAGRANGE && i < gp.unit_end) {
+    const int64_t i = (int64_t)block * blockDim.x + threadIdx.x;
+    const int64_t units = (SC == SC_IRK) ? L.N : L.N + 1;      // steps, or nodes for trapeze / midpoint
+    if (P::HAS_LAGRANGE && i < units) {
         double* g = gp.g;
-        const double* base = grad_block(gp, xu, i);
-        const double* nextb = (SC == SC_MIDPOINT && i < L.N) ? grad_block(gp, xu, i + 1) : base;      // X_{i+1}: the next shard's for a shard's last node
+        const double* base = xu + i * (int64_t)L.blk;
         double x[n > 0 ? n : 1], u[m > 0 ? m : 1], lx[n > 0 ? n : 1], lu[m > 0 ? m : 1], lv[nv > 0 ? nv : 1];
         double lt = 0.0, val = 0.0;
         for (int k = 0; k < nv; ++k) lv[k] = 0.0;
@@ -499,11 +472,10 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
                 for (int side = 0; side < 2; ++side) {           // 0: own step i, 1: previous step i - 1
                     const int64_t st = side == 0 ? i : i - 1;
                     if (st < 0 || st >= L.N) continue;
-                    const double* sb = grad_block(gp, xu, st);
-                    const double* sn = grad_block(gp, xu, st + 1);
+                    const double* sb = xu + st * (int64_t)L.blk;
                     const double t0 = grad_tau<P>(gp, st), t1 = grad_tau<P>(gp, st + 1);
                     const double ta = grad_time<P>(gp, v, t0), hi = (grad_time<P>(gp, v, t1) - ta) / cs;
-                    for (int c = 0; c < n; ++c) x[c] = 0.5 * (sb[c] + sn[c]);
+                    for (int c = 0; c < n; ++c) x[c] = 0.5 * (sb[c] + sb[L.blk + c]);
                     for (int j = 1; j <= L.cs; ++j) {
                         for (int c = 0; c < m; ++c) u[c] = sb[n + (j - 1) * m + c];
                         const double w = (double)j - 0.5;
@@ -523,7 +495,7 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
             if (i < L.N) {
                 const double t0 = grad_tau<P>(gp, i), t1 = grad_tau<P>(gp, i + 1);
                 const double ta = grad_time<P>(gp, v, t0), tb = grad_time<P>(gp, v, t1), h = tb - ta;
-                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (base[c] + nextb[c]) : (L.euler == 1 ? base[c] : nextb[c]);
+                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (base[c] + base[L.blk + c]) : (L.euler == 1 ? base[c] : base[L.blk + c]);
                 for (int c = 0; c < m; ++c) u[c] = base[n + c];
                 lagrange_partials<P, 0>(L.euler == 0 ? 0.5 * (ta + tb) : (L.euler == 1 ? ta : tb), x, u, v, val, lx, lu, lt, lv);
                 if (wa != 0.0) for (int c = 0; c < n; ++c) gx[c] = h * (wa * lx[c]);
@@ -535,10 +507,10 @@ __device__ __forceinline__ void grad_units_body(const GradParams& gp, const doub
                 }
             }
             if (i >= 1 && wb != 0.0) {
-                const double* pb = grad_block(gp, xu, i - 1);      // (the previous shard's last block for a shard's first node)
+                const double* pb = base - L.blk;
                 const double ta = grad_time<P>(gp, v, grad_tau<P>(gp, i - 1)), tb = grad_time<P>(gp, v, grad_tau<P>(gp, i));
                 const double h = tb - ta;
-                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (pb[c] + base[c]) : base[c];
+                for (int c = 0; c < n; ++c) x[c] = L.euler == 0 ? 0.5 * (pb[c] + pb[L.blk + c]) : pb[L.blk + c];
                 for (int c = 0; c < m; ++c) u[c] = pb[n + c];
                 double val2 = 0.0, lt2 = 0.0, lu2[m > 0 ? m : 1], lv2[nv > 0 ? nv : 1];
                 lagrange_partials<P, 0>(L.euler == 0 ? 0.5 * (ta + tb) : tb, x, u, v, val2, lx, lu2, lt2, lv2);
@@ -631,18 +603,13 @@ __device__ __forceinline__ void grad_finish_body(const GradParams& gp, const dou
         gvs[k] = sacc;
     }
     if (threadIdx.x != 0) return;
-    if (P::HAS_MAYER && (gp.owns_first || gp.owns_last)) {
+    if (P::HAS_MAYER) {
         double x0[n > 0 ? n : 1], xf[n > 0 ? n : 1], v[nv > 0 ? nv : 1], g0x[n > 0 ? n : 1], gfx[n > 0 ? n : 1], gmv[nv > 0 ? nv : 1];
-        const double* b0 = grad_block(gp, xu, 0);
-        const double* bf = grad_block(gp, xu, L.N);
-        for (int c = 0; c < n; ++c) { x0[c] = b0[c]; xf[c] = bf[c]; g0x[c] = 0.0; gfx[c] = 0.0; }
+        for (int c = 0; c < n; ++c) { x0[c] = xu[c]; xf[c] = xu[L.N * (int64_t)L.blk + c]; g0x[c] = 0.0; gfx[c] = 0.0; }
         for (int k = 0; k < nv; ++k) { v[k] = xu[L.v_off + k]; gmv[k] = 0.0; }
         mayer_partials<P, 0>(x0, xf, v, g0x, gfx, gmv);
-        for (int c = 0; c < n; ++c) {
-            if (gp.owns_first) gp.g[c] += g0x[c];
-            if (gp.owns_last) gp.g[L.N * (int64_t)L.blk + c] += gfx[c];
-        }
-        if (gp.owns_last) for (int k = 0; k < nv; ++k) gvs[k] += gmv[k];
+        for (int c = 0; c < n; ++c) { gp.g[c] += g0x[c]; gp.g[L.N * (int64_t)L.blk + c] += gfx[c]; }
+        for (int k = 0; k < nv; ++k) gvs[k] += gmv[k];
     }
     for (int k = 0; k < nv; ++k) gp.g[L.v_off + k] = gvs[k];
 }
@@ -681,23 +648,6 @@ hipError_t launch_variant_dbg(const KParams& kp, const double* xu, int grid, int
                                            (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-#ifdef CTD_KP_INDIRECT
-    {
-        static KParams* d_kp = nullptr;          // (one block per kernel instantiation: an experiment, one handle at a time)
-        static KParams last;
-        static bool have = false;
-        if (!d_kp && hipMalloc((void**)&d_kp, sizeof(KParams)) != hipSuccess) return hipGetLastError();
-        if (!have || std::memcmp(&last, &kp, sizeof(KParams)) != 0) {
-            hipError_t e = hipMemcpyAsync(d_kp, &kp, sizeof(KParams), hipMemcpyHostToDevice, st);
-            if (e != hipSuccess) return e;
-            (void)hipStreamSynchronize(st);
-            last = kp; have = true;
-        }
-        if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel_ind<P, SC, S, DBG>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, (const KParams*)d_kp, xu);
-        else cons_jac_kernel_ind<P, SC, S, DBG><<<grid, block, lds_bytes, st>>>((const KParams*)d_kp, xu);
-        return hipGetLastError();
-    }
-#endif
     // e0/e1 (optional): events recorded by the dispatch itself right before / after THIS kernel, so
     // hipEventElapsedTime(e0, e1) is the kernel's own duration on the stream it was launched on
     if (e0 || e1) hipExtLaunchKernelGGL((cons_jac_kernel<P, SC, S, DBG>), dim3(grid), dim3(block), lds_bytes, st, e0, e1, 0, kp, xu);

@@ -73,6 +73,7 @@ SYMBOLS = {
     "ctd_obj_dev": (C.c_int32, [_vp, _vp, _dp]),
     "ctd_obj_dev_async": (C.c_int32, [_vp, _vp, _vp]),
     "ctd_grad_dev_async": (C.c_int32, [_vp, _vp, _vp]),
+    "ctd_grad_shard_dev_async": (C.c_int32, [_vp, _vp, _vp]),
     "ctd_sync": (C.c_int32, [_vp]),
     "ctd_set_stream": (C.c_int32, [_vp, _vp]),
     "ctd_shard_info": (C.c_int32, [_vp, _ip]),

@@ -1063,8 +1063,10 @@ int32_t ctd_obj_dev(ctd_handle* h, const double* x_dev, double* f_host) {
     return CTD_OK;
 }
 
-static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params = nullptr);
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params = nullptr, bool shard = false);
 int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev) { return enqueue_grad(h, x_dev, g_dev); }
+// the shard's own entries of the gradient from a sharded iterate read in place (see include/ctdirect_hip.h)
+int32_t ctd_grad_shard_dev_async(ctd_handle* h, const double* x_dev, double* g_dev) { return enqueue_grad(h, x_dev, g_dev, nullptr, true); }
 int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
     int32_t st = enqueue_grad(h, x_dev, g_dev);
     if (st) return st;
@@ -1072,15 +1074,19 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev) {
     return CTD_OK;
 }
 
-static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params) {
+static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, GradParams* only_params, bool shard) {
     if (!h) return CTD_EINVAL;
     if (h->device < 0) return fail(h, CTD_ENODEVICE, "compute call on a host-only handle (device = -1); there is no CPU fallback");
     if (!x_dev || !g_dev) return fail(h, CTD_EINVAL, "null argument");
-    // (constraints / Jacobian, objective and Hessian read a sharded iterate in place; the gradient is always that of the WHOLE
-    // objective -- O(nvar) work on every rank -- and reads only the x it is given, shard table or not: it needs a whole iterate)
+    // ctd_grad*: the gradient of the WHOLE objective (O(nvar) work on every rank), from the x it is given -- a whole iterate.
+    // ctd_grad_shard_dev_async (shard = true): the quadrature units of this handle's steps only (the last shard also the final node),
+    // neighbours' blocks through the shard table like the other callbacks: the shard's own entries of g + its partial d/dv
     DeviceGuard dg_(h->device); HIP_TRY(h, dg_.err);
     const Layout& L = h->model.L;
-    const int64_t units = (L.sc == SC_IRK) ? L.N : L.N + 1;
+    const bool last = h->step_end == L.N, first = h->step_begin == 0;
+    const int64_t all_units = (L.sc == SC_IRK) ? L.N : L.N + 1;
+    const int64_t ub = shard ? h->step_begin : 0, ue = shard ? ((L.sc != SC_IRK && last) ? L.N + 1 : h->step_end) : all_units;
+    const int64_t units = ue - ub;
     const int blocks = (int)((units + 255) / 256);
     if (!h->d_gpartial || h->gblocks < blocks) {
         if (h->d_gpartial) (void)hipFree(h->d_gpartial);
@@ -1095,12 +1101,23 @@ static int32_t enqueue_grad(ctd_handle* h, const double* x_dev, double* g_dev, G
     gp.g = g_dev;
     gp.partial = h->d_gpartial;
     gp.nblocks = blocks;
+    gp.unit_begin = ub; gp.unit_end = ue;
+    gp.owns_first = (!shard || first) ? 1 : 0;
+    gp.owns_last = (!shard || last) ? 1 : 0;
+    if (shard) { gp.halo = h->kp.halo; gp.near = h->kp.near; }
     if (only_params) { gp.nblocks = h->model.info.lagrange ? blocks : 0; *only_params = gp; return CTD_OK; }
     // With a Lagrange cost the per-step kernel writes every entry of the step blocks (owner computes), only the tail
     // (final state, variables) needs zeroing before the finish kernel adds the Mayer part; a Mayer-only gradient is zero
     // except at x_0, x_f, v: one memset and the finish kernel
     const bool lagrange = h->model.info.lagrange;
-    if (lagrange) HIP_TRY(h, hipMemsetAsync(g_dev + L.N * (int64_t)L.blk, 0, sizeof(double) * (L.nvar - L.N * (int64_t)L.blk), h->stream));
+    if (shard) {
+        // a shard touches its own entries only: zero what the unit kernel does not write (everything, for a Mayer-only cost), the
+        // final-state entries on the last shard, and the nv variable entries (the finish kernel assigns them)
+        const int64_t lo = h->step_begin * (int64_t)L.blk, hi = h->step_end * (int64_t)L.blk;
+        if (!lagrange) HIP_TRY(h, hipMemsetAsync(g_dev + lo, 0, sizeof(double) * (hi - lo), h->stream));
+        if (last && (!lagrange || L.sc == SC_IRK))
+            HIP_TRY(h, hipMemsetAsync(g_dev + L.N * (int64_t)L.blk, 0, sizeof(double) * (L.v_off - L.N * (int64_t)L.blk), h->stream));
+    } else if (lagrange) HIP_TRY(h, hipMemsetAsync(g_dev + L.N * (int64_t)L.blk, 0, sizeof(double) * (L.nvar - L.N * (int64_t)L.blk), h->stream));
     else HIP_TRY(h, hipMemsetAsync(g_dev, 0, sizeof(double) * L.nvar, h->stream));
     gp.nblocks = lagrange ? blocks : 0;
     hipError_t e = hipErrorInvalidValue;

@@ -672,13 +672,16 @@ int register_runtime_ocp(const ctd_ocp_def* d, int* id, std::string& err) {
         bool dt = false, dv = false;
         DynNZMap nz;
         size_t dyn_lines = 0;
-        const bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2, 1, &nz, &dyn_lines);
+        bool ok = !(env && std::string(env) == "0") && gen_sym_dyn(d, c0, dt, dv, b_dyn, e2, 1, &nz, &dyn_lines);
+        // LONG generated code (the reference's swimmer: 213 statements with ~250 trigonometric terms per evaluation point; the 12-state
+        // quadrotor has 68) stays on forward duals in the constraint / Jacobian kernel.  Measured on MI355X, ROCm 7.2
+        // (profiles/r04_experiments.md section 5): the kernel with that code inlined was FRAGILE -- compiled for four waves per SIMD it
+        // spilled 540 registers and computed garbage on every lane but the first of a divergent wave; for one wave per SIMD it was right,
+        // wrong or faulting (memory aperture violation) depending on unrelated small changes elsewhere in the kernel source -- while the
+        // same phase functions with the same functor run clean under AddressSanitizer / UBSan in emulation (tests/emu, emu_user_cons_jac)
+        // and the dual-number kernel was exact in every build.  CTD_JIT_LONG_SYM=1 keeps the generated code (experiments).
+        if (ok && dyn_lines > 120 && !std::getenv("CTD_JIT_LONG_SYM")) ok = false;
         if (ok) o->dyn_nz = nz;
-        // LONG generated code (the reference's swimmer: 213 statements, ~250 trigonometric terms per evaluation point; the 12-state quadrotor has 68): compiled for the default four waves
-        // per SIMD (128 registers) it spills hundreds of registers -- and the spilled kernel computed garbage on the lanes of a
-        // divergent wave (MI355X, ROCm 7.2).  Such an OCP asks for one wave per SIMD (no spills, ctd_kernels.hpp MinWaves) and keeps the
-        // separate fin phase (LongCode, ctd_kernel_body.hpp: what was measured correct)
-        if (ok && dyn_lines > 120 && !std::getenv("CTD_JIT_KEEP_WAVES")) s += "    static constexpr int MIN_WAVES = 1;\n    static constexpr bool LONG_CODE = true;\n";
         s += std::string("    static constexpr bool HAS_SYM_DYN = ") + B(ok) + ";\n";
         if (ok) s += "    CTD_HD static void dyn_sym(const double* p, double* ev) {\n" + b_dyn + "    }\n";
         // wide OCPs (four direction chunks and more, Dirs<P>::NCH_DYN): the same code split by rows, one part per wave (SymDyn::parts)

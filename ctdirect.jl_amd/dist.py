@@ -239,8 +239,8 @@ class ShardedDOCP:
         pack / unpack kernel and no copy.  `x` must stay the iterate buffer (same storage) for the life of this object; the
         solver's update of x on every rank has to be complete before the evaluations that follow it are enqueued (its step
         acceptance is a collective anyway).  The shard table is state of the HANDLE: while it is active, `cons_jac`, `obj` and
-        `hess_coord` read the neighbours' entries in place too and must be given this same x (anything else raises); the
-        gradient (`docp.grad`) is the whole objective's and ignores the table -- it needs an all-gathered x.  `disable_peer_x`
+        `hess_coord` and `grad` read the neighbours' entries in place too and must be given this same x (anything else raises);
+        `docp.grad` (the C ABI's ctd_grad*) stays the whole objective's gradient and needs an all-gathered x.  `disable_peer_x`
         (or binding another x_mode) switches back."""
         from . import _lib
         import ctypes as C
@@ -380,6 +380,19 @@ class ShardedDOCP:
                 self._vv = torch.as_tensor(self.docp.hess_shard_info()[2], dtype=torch.long, device=vals.device)
             reduce_hessian_vv(vals, self._vv, self.group)
         return vals
+
+    def grad(self, x, g):
+        """grad!(nlp, x, g) of the sharded transcription: this rank's own entries of g (its step blocks; the last rank also the
+        final state) into the full-length g, from the sharded iterate read in place (or with copied halos) -- no all-gathered x --
+        plus ONE all-reduce of the nv entries of d/dv, which sum over every step.  Entries other ranks own are left untouched."""
+        self._rebind()
+        self._check_peer(x, "grad")
+        self.docp.grad_shard(x, g)
+        nv = self.docp.dims.NLP_v
+        if nv and (self.world > 1 or _FORCE):
+            tail = g[g.numel() - nv:]
+            dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+        return g
 
     def obj(self, x, as_tensor=False):
         """Objective of the whole transcription: the shards' partial sums added with one all-reduce of one double that never

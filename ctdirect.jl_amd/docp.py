@@ -449,6 +449,16 @@ class DOCP:
         self._ck(L.ctd_grad(self._h, _dp(x), _dp(g)))
         return g
 
+    def grad_shard(self, x, g, sync=False):
+        """`ctd_grad_shard_dev_async`: the gradient entries of THIS shard's own variables into the full-length device tensor g
+        (+ the shard's partial sums of d/dv in the nv tail entries), from a sharded iterate read in place -- no all-gathered x."""
+        self._check_x(x)
+        self._ck(_lib.lib().ctd_grad_shard_dev_async(self._h, self._dev_ptr(x, self.dim_NLP_variables, "x"),
+                                                     self._dev_ptr(g, self.dim_NLP_variables, "g")))
+        if sync:
+            self.sync()
+        return g
+
     def eval_all(self, x, y=None, obj_weight=1.0, f=None, g=None, c=None, vals=None, hvals=None, sync=False):
         """One solver iteration in one call (`ctd_eval_all_dev_async`): objective -> f[0], gradient -> g, constraints -> c,
         Jacobian values -> vals, Hessian values of the Lagrangian -> hvals, for device tensors; outputs left None are skipped.

@@ -276,6 +276,16 @@ int32_t ctd_grad_dev(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_set_stream(ctd_handle* h, void* stream);
 int32_t ctd_obj_dev_async(ctd_handle* h, const double* x_dev, double* f_dev);
 int32_t ctd_grad_dev_async(ctd_handle* h, const double* x_dev, double* g_dev);
+/* The gradient of a SHARDED transcription without an all-gathered iterate (round 4): on a handle restricted to the steps
+ * [step_begin, step_end) this writes ONLY the gradient entries of the shard's own variables -- its step blocks; the last shard also
+ * the final state (and final control) -- into the full-length g_dev, and leaves the shard's PARTIAL sums of d/dv in the nv variable
+ * entries (the caller adds them over the shards: one all-reduce of nv doubles, as for the V x V entries of the Hessian).  The Mayer
+ * term's d/dx0 goes to the shard that owns X_1, its d/dxf and d/dv to the one that owns X_{N+1}.  Neighbours' entries (the next
+ * shard's first node and the previous shard's last block for the midpoint / Euler quadrature, X_1 / X_{N+1} for the Mayer term) are read
+ * through the table of ctd_set_x_shards like the other callbacks do, or from x_dev itself when no table is set (halos copied).  The
+ * quadrature being differentiated: src/DOCP_functions.jl:23-54 with trapeze.jl:78-110, midpoint.jl:79-116, irk_stagewise.jl:344-384.
+ * On an unsharded handle it equals ctd_grad_dev_async. */
+int32_t ctd_grad_shard_dev_async(ctd_handle* h, const double* x_dev, double* g_dev);
 int32_t ctd_sync(ctd_handle* h);
 
 /* ---- multi-GPU shards (time-step partition) ------------------------------------------ */
@@ -426,7 +436,8 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
  * The objective (src/DOCP_functions.jl:23-54: its quadrature over the shard's steps, the Mayer term on the last shard) and the
  * Hessian callbacks (ctd_hess_coord*, ctd_eval_all_dev_async; the multipliers y are replicated) follow the same table since
  * round 3.  ctd_grad* is the gradient of the WHOLE objective on every rank (see there) and ignores the table: it reads only the
- * x it is given, which must then hold every variable (an all-gathered copy). */
+ * x it is given, which must then hold every variable (an all-gathered copy); ctd_grad_shard_dev_async (round 4) is the sharded
+ * form that follows the table. */
 int32_t ctd_set_x_shards(ctd_handle* h, int32_t n_shards, const int64_t* step_begin, const double* const* x_bufs, int32_t self);
 /* One process per GPU (e.g. a Julia host under MPI): the "RCCL all-gather over xGMI for the stitched constraint vector" of the
  * north star, inside the library.  comm is an ncclComm_t of n_ranks ranks created by the host with ITS copy of librccl (found

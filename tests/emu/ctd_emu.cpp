@@ -390,3 +390,48 @@ int emu_sym_check(const char* expr, int n, int m, int nv, const double* point, d
 }
 
 }  // extern "C"
+
+// ---- a run-time OCP in emulation (TEST INFRASTRUCTURE ONLY) --------------------------------------------------------------------
+// Build with -DCTD_EMU_USER_OCP_HEADER='"file.hpp"' where file.hpp holds the functor text ctd_ocp_source returns for an OCP
+// (namespace ctd { struct UserOCP ... }): the SAME phase templates then run with that functor, serially, with the LDS on the heap
+// -- AddressSanitizer / UBSan can look at the tiles of a hiprtc-compiled kernel's logic (tests/test_jit_cpu.py).  The OCP is
+// registered again inside this library (its own registry) from the same ctd_ocp_def, so host model and functor match.
+#ifdef CTD_EMU_USER_OCP_HEADER
+#include CTD_EMU_USER_OCP_HEADER
+extern "C" {
+int emu_user_register(const ctd_ocp_def* def, int* id) {
+    const int st = register_runtime_ocp(def, id, g_err);
+    return st;
+}
+int emu_user_cons_jac(int problem, int scheme, int pattern_mode, int64_t N, int tile, int nthr, const double* x, double* c, double* vals, int64_t* sizes) {
+    Model mo;
+    HostDesc d{problem, scheme, pattern_mode, N, nullptr, 0, g_control_steps, g_value_order};
+    int st = build_model(d, mo, g_err);
+    if (st) return st;
+    if (sizes) { sizes[0] = mo.L.nvar; sizes[1] = mo.L.ncon; sizes[2] = mo.nnzj; }
+    if (!x) return 0;
+    if (tile <= 0) tile = default_tile(mo);
+    KParams kp;
+    mo.fill_kparams(kp, 0, mo.L.N, tile);
+    kp.tau = mo.uniform ? nullptr : mo.tau.data();
+    kp.tmpl = mo.tmpl.data();
+    kp.vtmpl = mo.vtmpl.data();
+    kp.edge_idx = mo.edge_idx.data();
+    kp.edge_code = mo.edge_code.data();
+    kp.c = c;
+    kp.vals = vals;
+    using P = UserOCP;
+    switch (mo.L.sc) {
+        case SC_TRAPEZE: run_blocks<P, SC_TRAPEZE, 1>(kp, x, nthr); break;
+        case SC_MIDPOINT: run_blocks<P, SC_MIDPOINT, 1>(kp, x, nthr); break;
+        default:
+            if (mo.L.s == 1) run_blocks<P, SC_IRK, 1>(kp, x, nthr);
+            else if (mo.L.s == 2) run_blocks<P, SC_IRK, 2>(kp, x, nthr);
+            else run_blocks<P, SC_IRK, 3>(kp, x, nthr);
+            break;
+    }
+    return 0;
+}
+}  // extern "C"
+#endif
+

@@ -114,7 +114,27 @@ def _worker(rank, world, port, N, prob, sch, q):
         chk['peer H'] = bool(np.array_equal(hv3.cpu().numpy(), hh))
         # the gradient is the whole objective's on every rank and reads only the x it is given: a whole iterate, shard table or not
         gw = d.grad(torch.from_numpy(x).cuda()).cpu().numpy()
-        chk['grad on the whole x'] = relerr(gw, o.gradient(x)) <= TOL
+        gref = o.gradient(x)
+        chk['grad on the whole x'] = relerr(gw, gref) <= TOL
+        # ... and the SHARDED gradient (round 4): own entries from the NaN-padded iterate read in place, d/dv all-reduced; the entries
+        # other ranks own stay untouched, the ranks' pieces compose the whole gradient
+        gs = torch.full((d.dim_NLP_variables,), 777.0, dtype=torch.float64, device="cuda")
+        sh.grad(xp, gs)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gh = gs.cpu().numpy()
+        own = np.zeros(len(gh), dtype=bool)
+        own[a:b] = True
+        if nv:
+            own[-nv:] = True
+        chk['sharded grad own'] = bool(np.all(np.isfinite(gh[own]))) and relerr(gh[own], gref[own]) <= TOL
+        chk['sharded grad elsewhere untouched'] = bool(np.all(gh[~own] == 777.0))
+        # with copied halos instead of the shard table (x_mode "halo" left them in xd)
+        sh.disable_peer_x()
+        gs2 = torch.full_like(gs, 777.0)
+        sh.grad(xd, gs2)
+        torch.cuda.synchronize()
+        chk['sharded grad (halo copies)'] = bool(np.array_equal(gs2.cpu().numpy(), gh))
         sh.close()
         bad = [k for k, v_ in chk.items() if not v_]
         q.put((rank, True if not bad else bad))
@@ -191,6 +211,53 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
             v = torch.where(vs[k] != 777.0, vs[k], v)
         assert torch.equal(v, vf), mode
     md.close()
+    full.close()
+
+
+@pytest.mark.parametrize("prob,sch,N", [("double_integrator_path", "midpoint", 999), ("goddard_all", "trapeze", 500), ("quadrotor", "gauss_legendre_2", 301),
+                                        ("double_integrator_path", "euler_implicit", 77), ("goddard", "gauss_legendre_3", 1000),
+                                        ("double_integrator_freet0tf", "euler", 300), ("least_squares_with_constraint", "midpoint", 200)])
+def test_sharded_gradient_three_shards_through_the_c_abi(prob, sch, N):
+    """ctd_grad_shard_dev_async on three shard handles of one process: each buffer holds its shard's variables + v, NaN elsewhere,
+    the neighbours' entries come through ctd_set_x_shards; the shards' pieces compose the whole gradient bit for bit (the d/dv
+    entries are the sum of the three partials, the one all-reduce a distributed caller makes) -- Lagrange, Mayer and Bolza costs,
+    free times, every scheme class."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    import ctdirect_jl_amd as ct
+    from helpers import TOL, bench_inputs, describe, relerr
+    full = ct.DOCP(prob, N, sch, device=0)
+    x = bench_inputs(describe(full, prob, sch), perturb=1e-3)
+    gref = full.grad(torch.from_numpy(x).cuda())
+    blk, nv = full.discretization._step_variables_block, full.dims.NLP_v
+    cuts = [0, N // 3, (2 * N) // 3 + 1, N]
+    hs = [ct.DOCP(prob, N, sch, device=0, steps=(cuts[k], cuts[k + 1])) for k in range(3)]
+    xs = []
+    for k in range(3):
+        t = np.full_like(x, np.nan)
+        end = cuts[k + 1] * blk if k < 2 else x.size - nv
+        t[cuts[k] * blk:end] = x[cuts[k] * blk:end]
+        if nv:
+            t[-nv:] = x[-nv:]
+        xs.append(torch.from_numpy(t).cuda())
+    g = torch.full_like(gref, 777.0)
+    tail = torch.zeros(nv, dtype=torch.float64, device="cuda")
+    for k in range(3):
+        hs[k].set_x_shards(cuts, [t.data_ptr() for t in xs], k)
+        gk = torch.full_like(gref, 777.0)
+        hs[k].grad_shard(xs[k], gk, sync=True)
+        end = cuts[k + 1] * blk if k < 2 else x.size - nv
+        assert bool((gk[:cuts[k] * blk] == 777.0).all()) and bool((gk[end:x.size - nv] == 777.0).all()), k      # own entries only
+        g[cuts[k] * blk:end] = gk[cuts[k] * blk:end]
+        if nv:
+            tail += gk[-nv:]
+    if nv:
+        g[-nv:] = tail
+    assert not bool((g == 777.0).any())
+    assert torch.equal(g[:x.size - nv], gref[:x.size - nv])                                  # bit for bit
+    assert relerr(g.cpu().numpy(), gref.cpu().numpy()) <= TOL                               # (d/dv: three partial sums instead of one)
+    for h in hs:
+        h.close()
     full.close()
 
 

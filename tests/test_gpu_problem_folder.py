@@ -75,6 +75,49 @@ def test_folder_problem_against_mpmath(torch_cuda, name, sch, N):
     d.close()
 
 
+@pytest.mark.parametrize("sch", ["midpoint", "gauss_legendre_2"])
+@pytest.mark.parametrize("name", ["swimmer", "algal_bacterial", "bioreactor_1day", "schlogl", "action", "goddard_all_f0f1"])
+def test_folder_problem_midsize(torch_cuda, name, sch):
+    """N = 100 / 250: many tiles, more than one resident round, the solver's grid sizes (the swimmer's kernels once FAULTED at N >= 100
+    while every N <= 6 case passed: profiles/r04_experiments.md section 5).  c against the 50-digit restatement of the text (values only: no
+    derivative bookkeeping, so it is quick), J d and grad . d against central differences of the same handle's c and objective, both
+    value orders bit-identical under the host permutation."""
+    import gen_golden as gg
+    from mpmath import mpf
+    torch = torch_cuda
+    rt, _, _ = pf.folder(name)
+    for N in (100, 250):
+        d = ct.DOCP(rt, N, sch, pattern="structural", device=0)
+        rng = np.random.default_rng(7)
+        x = _point(name, d, rng)
+        xd = torch.from_numpy(x).cuda()
+        c = torch.full((d.dim_NLP_constraints,), 777.0, dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), 777.0, dtype=torch.float64, device="cuda")
+        d.cons_jac(xd, c, v)
+        assert not bool((c == 777.0).any()) and not bool((v == 777.0).any())
+        if N == 100:
+            gg.Du.NV = 0
+            md = gg.Docp(pf.mp_problem(name), sch, N=N)
+            cref = np.array([float(gg.Du.lift(e).v) for e in md.constraints([gg.Du(mpf(float(t)), []) for t in x])])
+            assert relerr(c.cpu().numpy(), cref) <= TOL
+        dirv = torch.from_numpy(np.cos(0.37 * np.arange(d.dim_NLP_variables))).cuda()
+        rp, ci = ct.DOCP_Jacobian_csr(d)
+        dc = ct.DOCP(rt, N, sch, pattern="structural", device=0, value_order="csr")
+        vc = dc.jac_coord(xd)
+        J = torch.sparse_csr_tensor(torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), vc, size=(d.dim_NLP_constraints, d.dim_NLP_variables))
+        jd = (J @ dirv.unsqueeze(1)).squeeze(1)
+        h = 1e-6
+        fd = (d.cons(xd + h * dirv) - d.cons(xd - h * dirv)) / (2 * h)
+        assert float((jd - fd).abs().max()) <= 2e-6 * max(1.0, float(fd.abs().max()))
+        r0, c0 = d.jac_structure()
+        perm = torch.argsort(torch.from_numpy((r0 - 1) * d.dim_NLP_variables + (c0 - 1)).cuda())
+        assert torch.equal(vc, v[perm])
+        gd = float(d.grad(xd) @ dirv)
+        fdo = (d.obj(xd + h * dirv) - d.obj(xd - h * dirv)) / (2 * h)
+        assert abs(gd - fdo) <= 2e-6 * max(1.0, abs(fdo))
+        d.close(); dc.close()
+
+
 def _solve(name, scheme, N, maxiter=600, x0=None):
     from test_gpu_solve_catalogue import _solve as solve_named      # (same driver: scipy trust-constr on the engine's exact callbacks)
     import jit_defs
@@ -88,6 +131,7 @@ def _solve(name, scheme, N, maxiter=600, x0=None):
     ("bioreactor_1day", "midpoint", 100, 1500),                               # 0.614134
     ("parametric", "midpoint", 60, 800),                                      # -0.336
     ("goddard_all_f0f1", "midpoint", 60, 2000),                               # 1.01257 (the same optimum as goddard_all)
+    ("swimmer", "midpoint", 250, 1500),                                       # 0.984273 (the reference's default grid: 250 steps)
 ])
 def test_folder_catalogued_objective(name, scheme, N, maxiter):
     obj, want, viol, res = _solve(name, scheme, N, maxiter=maxiter)
