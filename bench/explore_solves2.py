@@ -28,12 +28,6 @@ def solve_tc(prob, scheme, N, init, maxiter):
     return sign * res.fun, viol, res, d
 
 
-t0 = time.time()
-rt, want, init = pf.folder("swimmer")
-for N in (250,):
-    obj, viol, res, d = solve_tc(rt, "midpoint", N, None, 2000)
-    print(f"swimmer/midpoint N={N}: {obj:.6f} (cat {want}) viol {viol:.1e} status {res.status} nit {res.nit} {time.time()-t0:.0f}s", flush=True)
-    d.close()
 # truck_trailer: N = 50 from the problem file's guess, then warm starts on finer grids (the reference's default grid is 250)
 prob, want, init = jit_defs.catalogue("truck_trailer")
 prev = init

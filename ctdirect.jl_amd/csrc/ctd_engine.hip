@@ -1773,7 +1773,8 @@ int32_t ctd_cons_jac_sharded_dev_async(ctd_sharded* s, double* const* x_dev, dou
             SH_TRY(s, hipEventRecord(s->x_ready[k], s->h[k]->stream));
         }
         const int64_t w = L.n + (L.final_control ? L.m : 0);
-        const int64_t lo = s->h[0]->model.HL > 0 ? L.blk : 0;
+        // (whatever the Jacobian's value order needs: the gradient and the Hessian of a one-point scheme read the previous block too)
+        const int64_t lo = (L.sc == SC_IRK) ? 0 : L.blk;
         for (int k = 0; k < G; ++k) {
             DeviceGuard dg(s->dev[k]);
             ctd_handle* hk = s->h[k];

@@ -167,6 +167,7 @@ class ShardedDOCP:
             self._rebind()                  # launch on torch's current stream: ordered with the collectives issued here
         self._stitch = None
         self._halo = None
+        self._yhalo = None
         self._vv = None
         self._f = None
         self._peer = None                   # data_ptr of the x buffer the peer table is ACTIVE for (enable_peer_x), None: off
@@ -230,6 +231,46 @@ class ShardedDOCP:
         if dst.numel():
             x.index_copy_(0, dst, recv.index_select(0, src))
         return x
+
+    def owned_constraints(self):
+        """[begin, end) of the rows of c -- and of the multipliers y -- this rank owns: the rows of its own steps; the last rank also
+        the tail (final path rows + boundary rows), as in `stitch_constraints`."""
+        b, e = self.steps
+        return b * self.cb, (self.docp.dim_NLP_constraints if self.rank == self.world - 1 else e * self.cb)
+
+    def exchange_multipliers(self, y):
+        """Sharded multipliers for `hess_coord`: fills, inside this rank's full-length y, the rows other ranks own that its Hessian
+        entries read -- the PREVIOUS rank's last step (the second-order terms of that step's defect in this rank's first node:
+        trapeze, midpoint, implicit Euler; the Gauss-Legendre schemes read none) and the tail rows (final path + boundary
+        multipliers, owned by the last rank) -- with ONE all-gather of (cb + tail) doubles per rank, instead of a replicated y
+        (an all-gather of all ncon rows).  Entries: /root/reference/src/DOCP_functions.jl:80-140 rows, multiplied into the
+        Lagrangian by hess_coord!(nlp, x, y, vals; obj_weight)."""
+        if self.world == 1 and not _FORCE:
+            return y
+        if self._yhalo is None:
+            cb, N = self.cb, self.N
+            tail = self.docp.dim_NLP_constraints - N * cb
+            b, e = self.steps
+            r, G = self.rank, self.world
+            ar = torch.arange
+            Ly = cb + tail
+            pack = torch.cat([(e - 1) * cb + ar(cb), N * cb + ar(tail)])            # my last step | the tail (meaningful on the last rank)
+            dst, src = [], []
+            if r > 0:
+                dst.append((b - 1) * cb + ar(cb))
+                src.append((r - 1) * Ly + ar(cb))
+            if r + 1 < G and tail:
+                dst.append(N * cb + ar(tail))
+                src.append((G - 1) * Ly + cb + ar(tail))
+            empty = torch.zeros(0, dtype=torch.long)
+            self._yhalo = (pack.to(y.device), (torch.cat(dst) if dst else empty).to(y.device), (torch.cat(src) if src else empty).to(y.device),
+                           torch.zeros(Ly, dtype=torch.float64, device=y.device), torch.zeros(G * Ly, dtype=torch.float64, device=y.device))
+        pack, dst, src, send, recv = self._yhalo
+        torch.index_select(y, 0, pack, out=send)
+        _all_gather_into(recv, send, self.group)
+        if dst.numel():
+            y.index_copy_(0, dst, recv.index_select(0, src))
+        return y
 
     def enable_peer_x(self, x):
         """Sharded iterate read IN PLACE (`ctd_set_x_shards`): every rank exports its full-length x buffer once (IPC handle,
@@ -371,7 +412,8 @@ class ShardedDOCP:
     def hess_coord(self, x, y, obj_weight, vals):
         """This rank's entries of hess_coord!(nlp, x, y, vals; obj_weight) into the full-length `vals` (they stay sharded like
         the Jacobian values), plus the all-reduced variable x variable entries on every rank.  No host synchronisation: the
-        kernel and the all-reduce are ordered on torch's current stream."""
+        kernel and the all-reduce are ordered on torch's current stream.  `y` is full-length; only this rank's own rows, the
+        previous rank's last step and the tail rows are read (`exchange_multipliers` fills the latter two of a sharded y)."""
         self._rebind()
         self._check_peer(x, "hess_coord")
         self.docp.hess_coord(x, y, obj_weight, vals, sync=False)

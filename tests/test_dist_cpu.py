@@ -96,13 +96,25 @@ def _worker(rank, world, port, N, prob, sch, q):
         for lo_, hi_ in need:
             untouched[lo_:hi_] = False
         ok = ok and bool(np.isnan(xt.numpy()[untouched]).all())
+        # sharded multipliers: own rows + what exchange_multipliers fetches is everything this rank's Hessian entries read
+        ys = np.full_like(y, np.nan)
+        ca, cz = sh.owned_constraints()
+        ys[ca:cz] = y[ca:cz]
+        yt = torch.from_numpy(ys)
+        sh.exchange_multipliers(yt)
+        ok = ok and (cz == (o.dim_NLP_constraints if rank == world - 1 else se * cb)) and ca == sb * cb
+        ok = ok and bool(np.array_equal(yt.numpy()[N * cb:], y[N * cb:]))                     # tail rows everywhere
+        part_s = emu.hess(ct.PROBLEMS[prob], ct.SCHEMES[sch], 0, N, xt.numpy(), yt.numpy(), 0.5, step_begin=sb, step_end=se)
+        wr = part != 666.666
+        ok = ok and bool(np.array_equal(part_s != 666.666, wr)) and bool(np.array_equal(part_s[wr], part[wr]))     # bit for bit, no NaN
         q.put((rank, ok, tot))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("N,prob,sch", [(10, "goddard_all", "gauss_legendre_2"), (7, "goddard", "trapeze"),
-                                        (64, "double_integrator_path", "midpoint"), (9, "double_integrator_path", "midpoint")])
+                                        (64, "double_integrator_path", "midpoint"), (9, "double_integrator_path", "midpoint"),
+                                        (11, "goddard_all", "midpoint"), (8, "quadrotor", "trapeze"), (6, "goddard_all", "euler_implicit")])
 def test_stitch_constraints_world2_gloo(N, prob, sch):
     world = 2
     ctx = mp.get_context("spawn")

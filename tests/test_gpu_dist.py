@@ -131,6 +131,16 @@ def _worker(rank, world, port, N, prob, sch, q):
         chk['sharded grad elsewhere untouched'] = bool(np.all(gh[~own] == 777.0))
         # with copied halos instead of the shard table (x_mode "halo" left them in xd)
         sh.disable_peer_x()
+        # sharded MULTIPLIERS (round 4): own rows of y + what exchange_multipliers fetches (previous rank's last step, tail rows), NaN elsewhere
+        ys = np.full_like(y, np.nan)
+        ca, cz = sh.owned_constraints()
+        ys[ca:cz] = y[ca:cz]
+        yd = torch.from_numpy(ys).cuda()
+        sh.exchange_multipliers(yd)
+        hv4 = torch.full((d.nnzh,), 777.0, dtype=torch.float64, device="cuda")
+        sh.hess_coord(xd, yd, 0.5, hv4)
+        torch.cuda.synchronize()
+        chk['H from sharded multipliers'] = bool(np.array_equal(hv4.cpu().numpy(), hh))
         gs2 = torch.full_like(gs, 777.0)
         sh.grad(xd, gs2)
         torch.cuda.synchronize()
@@ -167,7 +177,8 @@ def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
 @pytest.mark.parametrize("N,prob,sch", [(1000, "goddard", "gauss_legendre_2"), (1000, "goddard_all", "trapeze"),
                                         (999, "double_integrator_path", "midpoint"), (400, "quadrotor12", "gauss_legendre_3"),
                                         (500, "goddard_all", "euler_implicit")])
-def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
+@pytest.mark.parametrize("order", ["csc", "csr"])
+def test_multi_device_handle_three_shards_one_gpu(N, prob, sch, order):
     """ctd_create_sharded / ctd_cons_jac_sharded_dev_async (the single-process multi-GPU entry point of the C ABI) with the
     one GPU of this box named three times: sharded iterate (NaN outside what a shard owns until the engine's peer copies
     fetch the halos, or the kernels read them in place through ctd_set_x_shards), stitched c on every shard, Jacobian pieces composed -- bit-identical to the unsharded handle."""
@@ -175,11 +186,11 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
     sys.path.insert(0, os.path.dirname(here))
     import ctdirect_jl_amd as ct
     from helpers import bench_inputs, describe
-    full = ct.DOCP(prob, N, sch, device=0, pattern="structural")
+    full = ct.DOCP(prob, N, sch, device=0, pattern="structural", value_order=order)
     x = bench_inputs(describe(full, prob, sch), perturb=1e-3)
     xd = torch.from_numpy(x).cuda()
     cf, vf = full.cons_jac(xd)
-    md = ct.MultiDeviceDOCP(prob, N, sch, [0, 0, 0], pattern="structural")
+    md = ct.MultiDeviceDOCP(prob, N, sch, [0, 0, 0], pattern="structural", value_order=order)
     assert (md.dim_NLP_variables, md.dim_NLP_constraints, md.nnzj) == (full.dim_NLP_variables, full.dim_NLP_constraints, full.nnzj)
     assert [s.step_begin for s in md.shards] == [0, md.shards[0].step_end, md.shards[1].step_end] and md.shards[2].step_end == N
     blk, nv = full.discretization._step_variables_block, full.dims.NLP_v
@@ -205,6 +216,12 @@ def test_multi_device_handle_three_shards_one_gpu(N, prob, sch):
             for k in range(3):
                 assert torch.isnan(xs[k]).any()
                 assert torch.isnan(xs[k][:md.shards[k].step_begin * blk]).all()
+        if mode in (md.X_SHARDED, md.X_SHARDED_COPY) and not sch.startswith("gauss"):
+            # the copying protocol leaves in every shard's buffer what ANY callback of that shard reads (the gradient and the Hessian of a
+            # one-point scheme read the previous block whatever the Jacobian's value order needs)
+            for k in (1, 2):
+                b = md.shards[k].step_begin
+                assert not torch.isnan(xs[k][(b - 1) * blk:b * blk]).any(), (mode, k)
         v = torch.full_like(vf, 777.0)
         for k in range(3):
             assert torch.equal(cs[k], cf), (mode, k)                 # whole residual on every shard, bit for bit
