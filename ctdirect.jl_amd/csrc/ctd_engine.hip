@@ -579,7 +579,7 @@ int32_t ctd_time_grid(const ctd_handle* h, double* normalized, double* fixed) {
     if (!h) return CTD_EINVAL;
     const Model& mo = h->model;
     if (normalized) std::memcpy(normalized, mo.tau.data(), sizeof(double) * (mo.L.N + 1));
-    if (fixed) std::memcpy(fixed, mo.fixed_grid.data(), sizeof(double) * (mo.L.N + 1));
+    if (fixed) for (int64_t i = 0; i <= mo.L.N; ++i) fixed[i] = mo.fixed_time(i);
     return CTD_OK;
 }
 
@@ -590,7 +590,7 @@ int32_t ctd_time_grid_at(const ctd_handle* h, const double* x, double* grid) {
     const Layout& L = mo.L;
     const double t0 = L.it0 >= 0 ? x[L.v_off + L.it0] : L.t0;
     const double tf = L.itf >= 0 ? x[L.v_off + L.itf] : L.tf;
-    for (int64_t i = 0; i <= L.N; ++i) grid[i] = L.free_time ? t0 + mo.tau[i] * (tf - t0) : mo.fixed_grid[i];
+    for (int64_t i = 0; i <= L.N; ++i) grid[i] = L.free_time ? t0 + mo.tau[i] * (tf - t0) : mo.fixed_time(i);
     return CTD_OK;
 }
 
@@ -608,10 +608,7 @@ int32_t ctd_butcher(const ctd_handle* h, double* a, double* b, double* c) {
 int32_t ctd_bounds(const ctd_handle* h, double* lvar, double* uvar, double* lcon, double* ucon) {
     if (!h) return CTD_EINVAL;
     const Model& mo = h->model;
-    if (lvar) std::memcpy(lvar, mo.var_l.data(), sizeof(double) * mo.L.nvar);
-    if (uvar) std::memcpy(uvar, mo.var_u.data(), sizeof(double) * mo.L.nvar);
-    if (lcon) std::memcpy(lcon, mo.con_l.data(), sizeof(double) * mo.L.ncon);
-    if (ucon) std::memcpy(ucon, mo.con_u.data(), sizeof(double) * mo.L.ncon);
+    mo.fill_bounds(lvar, uvar, lcon, ucon);
     return CTD_OK;
 }
 

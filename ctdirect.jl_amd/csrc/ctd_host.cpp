@@ -133,47 +133,47 @@ static void bounds_block(int dim, const std::vector<BoxItem>& box, std::vector<d
     for (const BoxItem& e : box) { lb[e.index] = e.lb; ub[e.index] = e.ub; }
 }
 
-static void build_bounds(Model& mo) {
-    const Layout& L = mo.L;
-    const ProblemInfo& pi = mo.info;
-    mo.var_l.assign(L.nvar, -kInf);
-    mo.var_u.assign(L.nvar, kInf);
+// written straight into the caller's arrays (any of them may be null): nothing of size nvar / ncon is kept on the handle
+void Model::fill_bounds(double* var_l, double* var_u, double* con_l, double* con_u) const {
+    const ProblemInfo& pi = info;
     std::vector<double> xl, xu, ul, uu, vl, vu;
     bounds_block(L.n, pi.state_box, xl, xu);
     bounds_block(L.m, pi.control_box, ul, uu);
-    for (int64_t i = 0; i <= L.N; ++i)
-        for (int k = 0; k < L.n; ++k) { mo.var_l[i * L.blk + k] = xl[k]; mo.var_u[i * L.blk + k] = xu[k]; }
-    if (L.m > 0) {
-        if (L.stagewise) {
-            for (int64_t i = 0; i < L.N; ++i)
-                for (int j = 0; j < L.s; ++j)
-                    for (int k = 0; k < L.m; ++k) {
-                        mo.var_l[i * L.blk + L.n + j * L.m + k] = ul[k];
-                        mo.var_u[i * L.blk + L.n + j * L.m + k] = uu[k];
-                    }
-        } else {
-            const int64_t last = L.final_control ? L.N : L.N - 1;     // set_control_at_time_step!, common.jl:209-223
-            for (int64_t i = 0; i <= last; ++i)
-                for (int j = 0; j < L.cs; ++j)                        // DOCP_variables.jl:44-47: every control of the step
-                    for (int k = 0; k < L.m; ++k) {
-                        mo.var_l[i * L.blk + L.n + j * L.m + k] = ul[k];
-                        mo.var_u[i * L.blk + L.n + j * L.m + k] = uu[k];
-                    }
+    if (L.nv > 0) bounds_block(L.nv, pi.variable_box, vl, vu);
+    auto fill_var = [&](double* dst, const std::vector<double>& xb, const std::vector<double>& ub, const std::vector<double>& vb, double dflt) {
+        if (!dst) return;
+        for (int64_t k = 0; k < L.nvar; ++k) dst[k] = dflt;
+        for (int64_t i = 0; i <= L.N; ++i)
+            for (int k = 0; k < L.n; ++k) dst[i * L.blk + k] = xb[k];
+        if (L.m > 0) {
+            if (L.stagewise) {
+                for (int64_t i = 0; i < L.N; ++i)
+                    for (int j = 0; j < L.s; ++j)
+                        for (int k = 0; k < L.m; ++k) dst[i * L.blk + L.n + j * L.m + k] = ub[k];
+            } else {
+                const int64_t last = L.final_control ? L.N : L.N - 1;     // set_control_at_time_step!, common.jl:209-223
+                for (int64_t i = 0; i <= last; ++i)
+                    for (int j = 0; j < L.cs; ++j)                        // DOCP_variables.jl:44-47: every control of the step
+                        for (int k = 0; k < L.m; ++k) dst[i * L.blk + L.n + j * L.m + k] = ub[k];
+            }
         }
-    }
-    if (L.nv > 0) {
-        bounds_block(L.nv, pi.variable_box, vl, vu);
-        for (int k = 0; k < L.nv; ++k) { mo.var_l[L.v_off + k] = vl[k]; mo.var_u[L.v_off + k] = vu[k]; }
-    }
-    mo.con_l.assign(L.ncon, 0.0);
-    mo.con_u.assign(L.ncon, 0.0);
-    int64_t off = 0;
-    for (int64_t i = 0; i <= L.N; ++i) {
-        if (i < L.N) off += L.eqs;
-        for (int k = 0; k < L.p; ++k) { mo.con_l[off + k] = pi.path_lb[k]; mo.con_u[off + k] = pi.path_ub[k]; }
-        off += L.p;
-    }
-    for (int k = 0; k < L.bc; ++k) { mo.con_l[off + k] = pi.bc_lb[k]; mo.con_u[off + k] = pi.bc_ub[k]; }
+        for (int k = 0; k < L.nv; ++k) dst[L.v_off + k] = vb[k];
+    };
+    fill_var(var_l, xl, ul, vl, -kInf);
+    fill_var(var_u, xu, uu, vu, kInf);
+    auto fill_con = [&](double* dst, const std::vector<double>& pb, const std::vector<double>& bb) {
+        if (!dst) return;
+        for (int64_t k = 0; k < L.ncon; ++k) dst[k] = 0.0;
+        int64_t off = 0;
+        for (int64_t i = 0; i <= L.N; ++i) {
+            if (i < L.N) off += L.eqs;
+            for (int k = 0; k < L.p; ++k) dst[off + k] = pb[k];
+            off += L.p;
+        }
+        for (int k = 0; k < L.bc; ++k) dst[off + k] = bb[k];
+    };
+    fill_con(con_l, pi.path_lb, pi.bc_lb);
+    fill_con(con_u, pi.path_ub, pi.bc_ub);
 }
 
 // __initial_guess: DOCP_variables.jl:122-145, irk_stagewise.jl:302-335
@@ -293,18 +293,9 @@ static void build_tail_blocks(Model& mo) {
     if ((L.stagewise || L.euler) && mo.info.lagrange && n > 0) push_block(out, L.ncon - 1, L.ncon, n - 1, n);
 }
 
-void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
+// rows of column j among the candidate blocks, sorted, each once
+void Model::rows_from_blocks(int64_t j, const std::vector<Block>& cand, std::vector<int64_t>& rows) const {
     rows.clear();
-    std::vector<Block> cand;
-    if (j >= L.v_off) {
-        for (int64_t i = 0; i < L.N; ++i) step_blocks(i, cand);
-    } else {
-        const int64_t sj = j / L.blk;
-        if (sj - 1 >= 0 && sj - 1 < L.N) step_blocks(sj - 1, cand);
-        if (sj < L.N) step_blocks(sj, cand);
-        if (L.euler == 2 && pattern_mode >= 1 && sj + 1 < L.N) step_blocks(sj + 1, cand);      // path rows of the next node read U_sj
-    }
-    for (const Block& b : tail) cand.push_back(b);
     std::vector<std::pair<int64_t, int64_t>> iv;
     for (const Block& b : cand)
         if (j >= b.c0 && j < b.c1) iv.emplace_back(b.r0, b.r1);
@@ -316,6 +307,29 @@ void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
             if (pattern_mode != 2 || opt_dep(r, j)) rows.push_back(r);      // OPTIMIZED: the traced subset of the structural blocks
         next = std::max(next, p.second);
     }
+}
+
+void Model::gen_column(int64_t j, std::vector<int64_t>& rows) const {
+    std::vector<Block> cand;
+    if (j >= L.v_off) {
+        for (int64_t i = 0; i < L.N; ++i) step_blocks(i, cand);
+    } else {
+        const int64_t sj = j / L.blk;
+        if (sj - 1 >= 0 && sj - 1 < L.N) step_blocks(sj - 1, cand);
+        if (sj < L.N) step_blocks(sj, cand);
+        if (L.euler == 2 && pattern_mode >= 1 && sj + 1 < L.N) step_blocks(sj + 1, cand);      // path rows of the next node read U_sj
+    }
+    for (const Block& b : tail) cand.push_back(b);
+    rows_from_blocks(j, cand, rows);
+}
+
+// the piece of V column k (an optimisation variable: a row in every step) that the steps [i0, i1) contribute, and / or its tail rows
+// (final path + boundary): the table builder looks at a few steps and the tail instead of generating all N of them
+void Model::gen_vcolumn_piece(int k, int64_t i0, int64_t i1, bool with_tail, std::vector<int64_t>& rows) const {
+    std::vector<Block> cand;
+    for (int64_t i = i0; i < i1; ++i) step_blocks(i, cand);
+    if (with_tail) for (const Block& b : tail) cand.push_back(b);
+    rows_from_blocks(L.v_off + k, cand, rows);
 }
 
 // CTD_PATTERN_OPTIMIZED: does constraint `row` depend on variable `col` at the operator level?  The rules restate what a
@@ -696,38 +710,45 @@ static int build_tables(Model& mo, std::string& err) {
     const int64_t tail0 = mo.reg_last * L.blk;
     const int64_t tail_cols = L.nvar - tail0;
     mo.cp_tail.assign(tail_cols + 1, 0);
-    std::vector<std::vector<int64_t>> vrows(L.nv);
+    // V columns (one row set per step + tail rows): the local rows of a step come from step 0, the periodicity the tiles rely on is
+    // checked on sample steps (the step blocks are the same function of the step offset for every step), the tail rows apart --
+    // nothing of size N is generated here (N = 10^6 .. 10^7 steps: seconds and gigabytes otherwise)
+    std::vector<std::vector<int64_t>> vtail(L.nv);
+    std::vector<int> lrows;
+    mo.vr = 0;
+    if (L.nv > 0) {
+        mo.gen_vcolumn_piece(0, 0, 1, false, rows);
+        for (int64_t r : rows) lrows.push_back((int)r);
+        mo.vr = (int)lrows.size();
+        const int64_t samples[] = {0, 1, 2, N / 2, N - 2, N - 1};
+        for (int k = 0; k < L.nv; ++k) {
+            for (int64_t i : samples) {
+                if (i < 0 || i >= N) continue;
+                mo.gen_vcolumn_piece(k, i, i + 1, false, rows);
+                bool same = (int)rows.size() == mo.vr;
+                for (int e = 0; same && e < mo.vr; ++e) same = rows[e] == i * L.cb + lrows[e];
+                if (!same) { err = "V column is not step-periodic"; return ST_EPATTERN; }
+            }
+            mo.gen_vcolumn_piece(k, 0, 0, true, vtail[k]);
+        }
+    }
     for (int64_t jj = 0; jj < tail_cols; ++jj) {
         const int64_t j = tail0 + jj;
         mo.cp_tail[jj] = nz;
+        if (j >= L.v_off) { nz += N * (int64_t)mo.vr + (int64_t)vtail[j - L.v_off].size(); continue; }
         mo.gen_column(j, rows);
         nz += (int64_t)rows.size();
-        if (j >= L.v_off) vrows[j - L.v_off] = rows;
     }
     mo.cp_tail[tail_cols] = nz;
     mo.nnzj = nz;
 
     // ---- V columns: per-step periodic part ----------------------------------------------------------------
-    mo.vr = 0;
     mo.vtmpl.clear();
-    if (L.nv > 0) {
-        // local rows of step 0 present in V column 0
-        std::vector<int> lrows;
-        for (int64_t r : vrows[0]) { if (r < L.cb) lrows.push_back((int)r); else break; }
-        mo.vr = (int)lrows.size();
-        for (int k = 0; k < L.nv; ++k) {
-            const std::vector<int64_t>& vr_ = vrows[k];
-            int64_t cnt = 0;
-            for (int64_t r : vr_) if (r < N * L.cb) ++cnt;
-            if (cnt != N * (int64_t)mo.vr) { err = "V column is not step-periodic"; return ST_EPATTERN; }
-            for (int64_t i = 0; i < N; ++i)
-                for (int e = 0; e < mo.vr; ++e)
-                    if (vr_[i * mo.vr + e] != i * L.cb + lrows[e]) { err = "V column is not step-periodic"; return ST_EPATTERN; }
-            mo.vcol_base[k] = mo.column_start(L.v_off + k);
-            for (int e = 0; e < mo.vr; ++e) {
-                Loc lc = local_entry_v(mo, lrows[e], k);
-                mo.vtmpl.push_back(pack_code(lc.di, lc.ci, lc.beta, 0, 0));
-            }
+    for (int k = 0; k < L.nv; ++k) {
+        mo.vcol_base[k] = mo.column_start(L.v_off + k);
+        for (int e = 0; e < mo.vr; ++e) {
+            Loc lc = local_entry_v(mo, lrows[e], k);
+            mo.vtmpl.push_back(pack_code(lc.di, lc.ci, lc.beta, 0, 0));
         }
     }
 
@@ -738,11 +759,12 @@ static int build_tables(Model& mo, std::string& err) {
     need.insert(0);
     need.insert(N - 1);
     auto scan_col = [&](int64_t j, std::vector<Raw>& dst) {
-        mo.gen_column(j, rows);
-        const int64_t base = mo.column_start(j);
-        for (size_t t = 0; t < rows.size(); ++t) {
-            const int64_t row = rows[t];
-            if (j >= L.v_off && row < N * L.cb) continue;       // V-column step rows are emitted by the tiles
+        const bool vcol = j >= L.v_off;                          // V-column step rows are emitted by the tiles: only its tail rows here
+        if (!vcol) mo.gen_column(j, rows);
+        const std::vector<int64_t>& rws = vcol ? vtail[j - L.v_off] : rows;
+        const int64_t base = mo.column_start(j) + (vcol ? N * (int64_t)mo.vr : 0);
+        for (size_t t = 0; t < rws.size(); ++t) {
+            const int64_t row = rws[t];
             Model::Entry e = mo.classify(row, j);
             if (e.kind == 0) {
                 if (!e.cconst) need.insert(e.cstep);
@@ -812,7 +834,7 @@ static int build_tables(Model& mo, std::string& err) {
         }
         int vre = 0;
         if (L.nv > 0 && mo.vr > 0)
-            for (int64_t r : vrows[0]) { if (r < L.n) ++vre; else break; }       // (rows of a V column are sorted: the state rows lead)
+            for (int r : lrows) { if (r < L.n) ++vre; else break; }       // (rows of a V column are sorted: the state rows lead)
         if (!early.empty()) {
             mo.n_late = (int)late.size(); mo.n_early = (int)early.size();
             mo.c_early = L.n; mo.vr_early = vre;
@@ -1130,11 +1152,6 @@ int build_model(const HostDesc& d, Model& mo, std::string& err) {
     if (st) return st;
     st = build_layout(mo, d.scheme, N, d.control_steps, err);
     if (st) return st;
-    // fixed grid (DOCP_data.jl:201-211): only meaningful when no time is free
-    mo.fixed_grid.assign(N + 1, 0.0);
-    if (!mo.L.free_time)
-        for (int64_t i = 0; i <= N; ++i) mo.fixed_grid[i] = mo.L.t0 + (mo.tau[i] * (mo.L.tf - mo.L.t0));
-    build_bounds(mo);
     build_tail_blocks(mo);
     compute_dep_masks(mo);          // operator-level dependence masks: the OPTIMIZED pattern, and the count of dropped nonzeros
     if (d.value_order != 0 && d.value_order != 1) { err = "unknown value order (CTD_ORDER_CSC = 0, CTD_ORDER_CSR = 1)"; return ST_EINVAL; }

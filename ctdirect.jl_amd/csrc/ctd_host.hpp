@@ -85,9 +85,11 @@ struct Model {
     bool fused = true;
     // DOCPtime (src/DOCP_data.jl:147-152)
     bool uniform = true;
-    std::vector<double> tau, fixed_grid;
+    std::vector<double> tau;
+    // fixed grid (DOCP_data.jl:201-211): only meaningful when no time is free (zeros otherwise)
+    double fixed_time(int64_t i) const { return L.free_time ? 0.0 : L.t0 + (tau[i] * (L.tf - L.t0)); }
     // DOCPbounds (src/DOCP_data.jl:235-240)
-    std::vector<double> var_l, var_u, con_l, con_u;
+    void fill_bounds(double* var_l, double* var_u, double* con_l, double* con_u) const;     // ctd_bounds
     // pattern
     std::vector<Block> tail;
     int64_t nnzj = 0;
@@ -124,6 +126,8 @@ struct Model {
     Entry classify(int64_t row, int64_t col) const;
     void step_blocks(int64_t i, std::vector<Block>& out) const;
     void gen_column(int64_t j, std::vector<int64_t>& rows) const;
+    void rows_from_blocks(int64_t j, const std::vector<Block>& cand, std::vector<int64_t>& rows) const;
+    void gen_vcolumn_piece(int k, int64_t i0, int64_t i1, bool with_tail, std::vector<int64_t>& rows) const;
     int64_t column_start(int64_t j) const;    // CSC colptr[j] without materialising the pattern (order == 0)
     void gen_row(int64_t r, std::vector<int64_t>& cols) const;      // sorted columns of row r of the same pattern
     int64_t row_start(int64_t r) const;       // CSR rowptr[r] without materialising the pattern (order == 1)
