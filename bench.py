@@ -447,7 +447,7 @@ def _main(real_stdout):
             traffic = None
 
     # the other single-GPU BASELINE configs (parity-test cases, not the bench line): kernel time and roofline fraction
-    others, hessian, optimized, csr_rows = [], [], [], []
+    others, hessian, optimized, csr_rows, large = [], [], [], [], []
     if world == 1 and not args.no_extras:
         for prob, sch, n in (("double_integrator_path", "midpoint", 100000), ("goddard", "gauss_legendre_3", 80000),
                              ("quadrotor", "gauss_legendre_3", 20000), ("quadrotor12", "gauss_legendre_3", 20000),
@@ -500,6 +500,25 @@ def _main(real_stdout):
                 csr_rows.append(row)
             except Exception as ex:
                 csr_rows.append({"workload": f"{prob}/{sch} N={n}, pattern={pat}", "error": repr(ex)[:300]})
+        # the SAME kernels on grids large enough to be bandwidth-bound (the bench workload's 10 000 steps are one round of workgroups:
+        # launch + one dependent chain; at 4 million steps the launch is 0.1 % of the kernel): what fraction of the 8 TB/s the
+        # emission sustains.  (tests/test_gpu_max_sizes.py checks 2^24 steps -- 3.2e9 values -- bit for bit.)
+        for prob, sch, n, order in (("goddard", "gauss_legendre_2", 1 << 22, "csc"), ("goddard", "gauss_legendre_2", 1 << 22, "csr"),
+                                    ("goddard", "gauss_legendre_3", 1 << 22, "csc")):
+            try:
+                d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch", value_order=order)
+                x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
+                c2 = torch.zeros(d2.dim_NLP_constraints, dtype=torch.float64, device=dev)
+                v2 = torch.zeros(d2.nnzj, dtype=torch.float64, device=dev)
+                ms2 = d2.time_cons_jac(x2, c2, v2, iters=10)
+                b2 = 8 * (d2.dim_NLP_variables + d2.dim_NLP_constraints + d2.nnzj)
+                large.append({"workload": f"{prob}/{sch} N={n}, order={order}", "kernel_ms": ms2, "algorithmic_bytes": b2,
+                              "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                d2.close()
+                del x2, c2, v2
+                torch.cuda.empty_cache()
+            except Exception as ex:
+                large.append({"workload": f"{prob}/{sch} N={n}, order={order}", "error": repr(ex)[:300]})
         # the Hessian-of-the-Lagrangian row (hess_coord!): kernel-only figures, not part of `value`.
         # Algorithmic bytes: read x and y, write the lower-triangular values: 8 (nvar + ncon + nnzh).
         for prob, sch, n, pat in (("goddard", "gauss_legendre_2", 10000, "manual"), ("goddard", "gauss_legendre_3", 80000, "manual"),
@@ -657,6 +676,8 @@ def _main(real_stdout):
             out["optimized_pattern_kernel_only"] = optimized
         if csr_rows:
             out["csr_order_kernel_only"] = csr_rows
+        if large:
+            out["large_grid_kernel_only"] = large
         if hessian:
             out["hessian_kernel_only"] = hessian
         if world == 1 and not args.no_cpu_baseline:

@@ -26,7 +26,9 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         "quad_trap": ("quadrotor", "trapeze", 20000), "q12_mid": ("quadrotor12", "midpoint", 20000), "quad_mid": ("quadrotor", "midpoint", 20000),
         "q12_trap": ("quadrotor12", "trapeze", 20000),
         # one tile + the edge block: the kernel's serial latency chain without any contention
-        "cfg2_tiny": ("goddard", "gauss_legendre_2", 21), "cfg2_small": ("goddard", "gauss_legendre_2", 2100)}
+        "cfg2_tiny": ("goddard", "gauss_legendre_2", 21), "cfg2_small": ("goddard", "gauss_legendre_2", 2100),
+        # grids large enough to be bandwidth-bound (round 4): 4 194 304 steps
+        "cfg2_4M": ("goddard", "gauss_legendre_2", 1 << 22), "cfg4_4M": ("goddard", "gauss_legendre_3", 1 << 22)}
 
 
 def main():

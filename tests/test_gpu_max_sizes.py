@@ -2,7 +2,8 @@
 N = 2^24 = 16 777 216 time steps: nvar 251 658 244, ncon 201 326 596, nnzj 3 221 225 500 (25.8 GB of values), nnzh 2 264 924 185
 (18.1 GB) -- evaluated on one MI355X in both value orders.  No oracle finishes at this size, so the check is size-independent
 and EXACT: with a power-of-two number of steps, the same step block in every step and an autonomous OCP every regular step
-computes the same numbers, and a 16-step transcription with t_f scaled by 2^-20 has the same step length h bit for bit, so
+computes the same numbers (t_f = 1/4: the node times t_i = tau_i t_f and their differences h are exact), and a 16-step
+transcription with t_f scaled by 2^-20 has the same step length h bit for bit, so
 
   * every value of the big Jacobian equals, bit for bit, the value of the 16-step Jacobian at the corresponding position (first
     step, a regular step, last step, tail rows; the d/dt_f entries after an exact scaling by 2^-20), which in turn is checked
@@ -58,7 +59,7 @@ def test_more_than_2_to_31_jacobian_values(order):
     L = mid.discretization
     blk, cb, n = L._step_variables_block, L._state_stage_eqs_block + L._step_pathcons_block, mid.dims.NLP_x
     xb = bench_inputs(describe(mid, PROB, SCH), perturb=1e-3)
-    B, F, tf = xb[3 * blk:4 * blk].copy(), xb[3 * blk:3 * blk + n].copy(), 0.2
+    B, F, tf = xb[3 * blk:4 * blk].copy(), xb[3 * blk:3 * blk + n].copy(), 0.25           # t_f a power of two: every t_i = tau_i t_f, hence every h, is exact
     x_mid, x_big = _x(B, NM, F, tf * scale), _x(B, N, F, tf)
     # --- the 16-step twin: engine against the oracle (CSC order on the oracle's side)
     c_mid, v_mid = mid.cons_jac(x_mid)
@@ -86,6 +87,15 @@ def test_more_than_2_to_31_jacobian_values(order):
     v = torch.full((nnz_b,), float("nan"), dtype=torch.float64, device="cuda")
     big.cons_jac(xd, c, v)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        big.cons_jac(xd, c, v, sync=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print(f"\n{PROB}/{SCH} N=2^{LOG2N} ({order}): nnzj {nnz_b}, {8e-9 * (nvar_b + ncon_b + nnz_b):.2f} GB per evaluation in {ms:.3f} ms = "
+          f"{8e-9 * (nvar_b + ncon_b + nnz_b) / ms:.2f} TB/s")
     # c: rows of steps periodic, equal to the twin's; tail rows equal
     c_m = torch.from_numpy(np.asarray(c_mid)).cuda()
     assert bool((c[:cb] == c_m[:cb]).all()) and _chunks_equal_first(c, cb, cb, N - 2, c_m[cb:2 * cb]) == -1
@@ -143,13 +153,22 @@ def test_more_than_2_to_31_hessian_values():
     nnzh = big.nnzh
     assert nnzh > 2 ** 31 or LOG2N < 24
     assert nnzh_m + seg * (N - NM) == nnzh
-    xd = torch.from_numpy(_x(B, N, F, 0.2)).cuda()
+    xd = torch.from_numpy(_x(B, N, F, 0.25)).cuda()
     ystep = 0.5 + 0.3 * np.cos(np.arange(cb))
     tail = big.dim_NLP_constraints - N * cb
     yd = torch.cat([torch.from_numpy(ystep).cuda().repeat(N), torch.full((tail,), 0.7, dtype=torch.float64, device="cuda")])
     h = torch.full((nnzh,), float("nan"), dtype=torch.float64, device="cuda")
     big.hess_coord(xd, yd, 0.9, h)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        big.hess_coord(xd, yd, 0.9, h, sync=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    gb = 8e-9 * (big.dim_NLP_variables + big.dim_NLP_constraints + nnzh)
+    print(f"\n{PROB}/{SCH} N=2^{LOG2N} Hessian: nnzh {nnzh}, {gb:.2f} GB per evaluation in {ms:.3f} ms = {gb / ms:.2f} TB/s")
     assert not bool(torch.isnan(h[:s1]).any()) and not bool(torch.isnan(h[s1 + (N - 2) * seg:]).any())
     bad = _chunks_equal_first(h, s1, seg, N - 2, h[s1:s2].clone())
     assert bad == -1, f"regular step {bad + 1} differs from step 1"
