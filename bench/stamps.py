@@ -28,7 +28,9 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         # one tile + the edge block: the kernel's serial latency chain without any contention
         "cfg2_tiny": ("goddard", "gauss_legendre_2", 21), "cfg2_small": ("goddard", "gauss_legendre_2", 2100),
         # grids large enough to be bandwidth-bound (round 4): 4 194 304 steps
-        "cfg2_4M": ("goddard", "gauss_legendre_2", 1 << 22), "cfg4_4M": ("goddard", "gauss_legendre_3", 1 << 22)}
+        "cfg2_4M": ("goddard", "gauss_legendre_2", 1 << 22), "cfg4_4M": ("goddard", "gauss_legendre_3", 1 << 22),
+        "di_gl2_4M": ("double_integrator_path", "gauss_legendre_2", 1 << 22), "gall_gl2_2M": ("goddard_all", "gauss_legendre_2", 1 << 21),
+        "di_gl3_4M": ("double_integrator_freet0tf", "gauss_legendre_3", 1 << 22)}
 
 
 def main():

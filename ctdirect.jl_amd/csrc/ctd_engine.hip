@@ -404,7 +404,28 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             size_t l0 = 0;
             const int r0 = resident(h->tile, l0);
             const int64_t ns = h->step_end - h->step_begin, cap = 256 * (int64_t)r0;
-            if (r0 > 0 && (ns + h->tile - 1) / h->tile > cap) {
+            // VERY long grids (16 rounds of resident workgroups and more: millions of steps) are bandwidth-bound, the rounds no
+            // longer quantise anything, and what is left per tile is its fixed cost -- launch slot, argument pinning, time table,
+            // prologue latency.  Eight waves per workgroup and the largest tile whose records fit 64 KiB of LDS (two workgroups
+            // per CU) amortise it: Goddard GL2, 4 194 304 steps 930 -> 795 us (0.59 -> 0.69 of 8 TB/s), GL3 1333 -> 1297,
+            // double integrator + path GL2 508 -> 460, double integrator free t0 / tf GL3 915 -> 800, goddard_all GL2 (2 M steps,
+            // staged driver) 598 -> 556 (profiles/r04_tiles_long_grids.log; CTD_LONG_GRID=0: off; CTD_LONG_GRID_ROUNDS: the threshold, for tests)
+            if (r0 > 0 && (ns + h->tile - 1) / h->tile >= env_int("CTD_LONG_GRID_ROUNDS", 16) * cap && maxb >= 512 && env_int("CTD_BLOCK", 0) <= 0 &&
+                env_int("CTD_LONG_GRID", 1)) {
+                int tbest = h->tile;
+                for (int tt = h->tile + 1; tt <= 256; ++tt) {
+                    KParams kq;
+                    mo.fill_kparams(kq, h->step_begin, h->step_end, tt);
+                    if ((size_t)lds_doubles(kq) * sizeof(double) > 64 * 1024) break;
+                    tbest = tt;
+                }
+                if (tbest > h->tile) {
+                    h->tile = tbest;
+                    h->block = 512;
+                    mo.fill_kparams(h->kp, h->step_begin, h->step_end, h->tile);
+                    h->lds_bytes = (size_t)lds_doubles(h->kp) * sizeof(double);
+                }
+            } else if (r0 > 0 && (ns + h->tile - 1) / h->tile > cap) {
                 int tmax = 48;
                 for (; tmax > h->tile; --tmax) { size_t l = 0; if (resident(tmax, l) >= r0 && l <= lds_cap) break; }
                 const int64_t rounds = (ns + (int64_t)tmax * cap - 1) / ((int64_t)tmax * cap);

@@ -174,3 +174,49 @@ def test_more_than_2_to_31_hessian_values():
     assert bad == -1, f"regular step {bad + 1} differs from step 1"
     assert not bool(torch.isnan(h[s1:s2]).any())
     big.close()
+
+
+def _long_grid_case(prob, sch, N, orders):
+    import ctdirect_jl_amd as ct
+    from helpers import TOL, bench_inputs, describe, relerr
+    from oracle.oracle import OracleDOCP
+    o = OracleDOCP(prob, sch, N)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+    ref = o.cons_jac_block(x, min(16, os.cpu_count() or 1))
+    assert ref is not None
+    for order in orders:
+        d = ct.DOCP(prob, N, sch, device=0, value_order=order)
+        li = d.launch_info()
+        assert li["block"] == 512 and li["steps_per_tile"] >= 64 and li["lds_bytes"] <= 64 * 1024, li
+        c = torch.full((d.dim_NLP_constraints,), float("nan"), dtype=torch.float64, device="cuda")
+        v = torch.full((d.nnzj,), float("nan"), dtype=torch.float64, device="cuda")
+        d.cons_jac(torch.from_numpy(x).cuda(), c, v)
+        vref = ref[1]
+        if order == "csr":                 # the same entries by rows
+            rows, cols = d.jac_structure()
+            cp, rv = o.jac_pattern()
+            oc = np.repeat(np.arange(len(cp) - 1), np.diff(cp))
+            perm = np.lexsort((oc, rv))
+            assert np.array_equal(rows - 1, rv[perm]) and np.array_equal(cols - 1, oc[perm])
+            vref = vref[perm]
+        assert relerr(c.cpu().numpy(), ref[0]) <= TOL, (prob, sch, order)
+        assert relerr(v.cpu().numpy(), vref) <= TOL, (prob, sch, order)
+        d.close()
+
+
+def test_long_grid_geometry_against_the_oracle():
+    """Grids of 16 rounds of resident workgroups and more take another launch geometry (eight waves per workgroup, the largest tile
+    whose records fit 64 KiB: `ctd_create`, CTD_LONG_GRID).  2^20 steps of the bench OCP: EVERY value of c and of the Jacobian, both
+    value orders, against the oracle's block mode (the reference's `constraints` template differentiated one step at a time on dense
+    local duals, OpenMP over the steps)."""
+    _long_grid_case("goddard", "gauss_legendre_2", 1 << 20, ("csc", "csr"))
+
+
+@pytest.mark.parametrize("prob,sch", [("goddard", "gauss_legendre_3"), ("double_integrator_freet0tf", "gauss_legendre_3"),
+                                      ("goddard_all", "gauss_legendre_2"), ("double_integrator_path", "gauss_legendre_2"),
+                                      ("goddard_all", "gauss_legendre_1"), ("double_integrator_path", "gauss_legendre_3")])
+def test_long_grid_geometry_other_ocps(prob, sch, monkeypatch):
+    """the same geometry forced on 2^17 steps (CTD_LONG_GRID_ROUNDS = 1: every grid of more than one round) for the other narrow OCPs and
+    both drivers (direct: Goddard, double integrators; staged: goddard_all)"""
+    monkeypatch.setenv("CTD_LONG_GRID_ROUNDS", "1")
+    _long_grid_case(prob, sch, 1 << 17, ("csc", "csr"))
