@@ -30,6 +30,7 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         # grids large enough to be bandwidth-bound (round 4): 4 194 304 steps
         "cfg2_4M": ("goddard", "gauss_legendre_2", 1 << 22), "cfg4_4M": ("goddard", "gauss_legendre_3", 1 << 22),
         "di_gl2_4M": ("double_integrator_path", "gauss_legendre_2", 1 << 22), "gall_gl2_2M": ("goddard_all", "gauss_legendre_2", 1 << 21),
+        "cfg3_8M": ("double_integrator_path", "midpoint", 1 << 23), "g_trap_4M": ("goddard", "trapeze", 1 << 22), "g_mid_4M": ("goddard", "midpoint", 1 << 22),
         "di_gl3_4M": ("double_integrator_freet0tf", "gauss_legendre_3", 1 << 22)}
 
 

@@ -1075,24 +1075,14 @@ template <class P, int SC, int S = 1> struct RegEval {
 // the path rows' d/dv behind the path pass, the lead role on a lane of its own -- so a tile has no fin phase and one barrier
 // less (12-state quadrotor, Gauss-Legendre 3: the fin phase was 1.8 of the tile's 10.9 us; midpoint 1.5 of 11.5).  Edge blocks
 // keep the fin phase (final-time path record, one lane per kind of task).
-// Traits a generated functor may carry (run-time OCPs with LONG generated dynamics code, ctd_jit.cpp): MIN_WAVES = the second launch
-// bound of its kernels, LONG_CODE = keep the separate fin phase.  Measured on MI355X with the swimmer of the reference's problem
-// folder (213 statements / ~250 trigonometric terms per evaluation point; profiles/r04_experiments.md): compiled for four waves per
-// SIMD it spills 540 vector registers and the tiles computed garbage on every lane but the first; with one wave per SIMD (no spill)
-// the folded fin still left the tiles' rows of c unwritten on the midpoint and Gauss-Legendre schemes; one wave per SIMD + the
-// separate fin phase: every callback within 1e-15 of the 50-digit restatement on every scheme.
-template <class...> struct ctd_void { typedef void type; };
-template <class P, class = void> struct OwnMinWaves { static constexpr int value = 0; };
-template <class P> struct OwnMinWaves<P, typename ctd_void<decltype(P::MIN_WAVES)>::type> { static constexpr int value = P::MIN_WAVES; };
-template <class P, class = void> struct LongCode { static constexpr bool value = false; };
-template <class P> struct LongCode<P, typename ctd_void<decltype(P::LONG_CODE)>::type> { static constexpr bool value = P::LONG_CODE; };
-
+// (Run-time OCPs whose generated dynamics code is LONG -- the swimmer of the reference's problem folder: 213 statements -- do not
+// come here with generated code at all: inlined into this kernel it compiled into spills and, on some trees, wrong or faulting code
+// whatever launch bound and fin variant was chosen; ctd_jit.cpp routes them to the forward-dual path, profiles/r04_experiments.md.)
 template <class P, int SC, int S>
 CTD_HD bool fin_folded(const BlockCtx& cx) {
 #ifdef CTD_NO_FOLD
     return false;
 #else
-    if (LongCode<P>::value) return false;
     constexpr bool path_ok = P::NPATH == 0 || SymPath<P>::value || Dirs<P>::NCH_PATH == 1;
     return !Dirs<P>::FUSED && SymDyn<P>::value && path_ok && !cx.is_edge;
 #endif

@@ -155,12 +155,8 @@ __device__ __forceinline__ void cons_jac_body(const KParams& kp, const double* _
 // 12-state quadrotor's Gauss-Legendre 3 instantiation needed 129 registers -- ONE more than four waves per SIMD allow -- and ran
 // three workgroups per CU where its 15 KiB of LDS would let ten in.  The midpoint kernels with several controls per step
 // (195 - 245 registers) and OCPs wider than the registry's keep the compiler's own choice.
-// Run-time OCPs with LONG generated code name their own bound (UserOCP::MIN_WAVES, ctd_jit.cpp): the swimmer of the reference's
-// problem folder (test/problems/swimmer.jl: ~250 trigonometric terms per evaluation point) compiled for four waves per SIMD spills
-// 540 vector and 40 scalar registers, and the spilled code computed garbage on every lane but the first of a divergent wave.
-// (OwnMinWaves: ctd_kernel_body.hpp)
 template <class P, int SC, int S> struct MinWaves {
-    static constexpr int value = OwnMinWaves<P>::value > 0 ? OwnMinWaves<P>::value : ((P::NX <= 12 && !(SC == SC_MIDPOINT && S > 1)) ? 4 : 1);
+    static constexpr int value = (P::NX <= 12 && !(SC == SC_MIDPOINT && S > 1)) ? 4 : 1;
 };
 
 template <class P, int SC, int S, bool DBG>
