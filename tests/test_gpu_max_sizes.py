@@ -212,11 +212,12 @@ def test_long_grid_geometry_against_the_oracle():
     _long_grid_case("goddard", "gauss_legendre_2", 1 << 20, ("csc", "csr"))
 
 
-@pytest.mark.parametrize("prob,sch", [("goddard", "gauss_legendre_3"), ("double_integrator_freet0tf", "gauss_legendre_3"),
-                                      ("goddard_all", "gauss_legendre_2"), ("double_integrator_path", "gauss_legendre_2"),
-                                      ("goddard_all", "gauss_legendre_1"), ("double_integrator_path", "gauss_legendre_3")])
-def test_long_grid_geometry_other_ocps(prob, sch, monkeypatch):
-    """the same geometry forced on 2^17 steps (CTD_LONG_GRID_ROUNDS = 1: every grid of more than one round) for the other narrow OCPs and
-    both drivers (direct: Goddard, double integrators; staged: goddard_all)"""
+@pytest.mark.parametrize("prob,sch,log2n", [("goddard", "gauss_legendre_3", 17), ("double_integrator_freet0tf", "gauss_legendre_3", 17),
+                                            ("goddard_all", "gauss_legendre_2", 17), ("double_integrator_path", "gauss_legendre_2", 17),
+                                            ("goddard_all", "gauss_legendre_1", 17), ("double_integrator_path", "gauss_legendre_3", 17),
+                                            ("double_integrator_path", "midpoint", 19), ("goddard", "midpoint", 19), ("goddard_all", "midpoint", 19)])
+def test_long_grid_geometry_other_ocps(prob, sch, log2n, monkeypatch):
+    """the same geometry forced on 2^17 / 2^19 steps (CTD_LONG_GRID_ROUNDS = 1: every grid of more than one round) for the other narrow
+    OCPs, both drivers (direct: Goddard, double integrators; staged: goddard_all) and the midpoint scheme"""
     monkeypatch.setenv("CTD_LONG_GRID_ROUNDS", "1")
-    _long_grid_case(prob, sch, 1 << 17, ("csc", "csr"))
+    _long_grid_case(prob, sch, 1 << log2n, ("csc", "csr"))
