@@ -4,7 +4,9 @@
  *   ./cabi_demo            host-only part: sizes, bounds, default initial guess, Jacobian structure   (no GPU needed)
  *   ./cabi_demo gpu        + one fused evaluation of constraints and Jacobian values on device 0, and the same evaluation
  *                          through the multi-device entry points (two shards; both on device 0 here, devices {0, 1, ..} on a
- *                          multi-GPU node): iterate sent from shard 0, residual stitched on every shard
+ *                          multi-GPU node): iterate sent from shard 0, residual stitched on every shard; and the Jacobian in CSR order
+ *                          (ctd_desc.value_order = CTD_ORDER_CSR: rowptr / colind for a GPU KKT consumer), checked entry by entry
+ *                          against the CSC values
  *
  * Goddard problem, Gauss-Legendre 2 (stagewise controls), 100 steps: CTDirect.DOCP(goddard().ocp, 100, 1,
  * :gauss_legendre_2, nothing) in the reference (src/DOCP_data.jl:293). */
@@ -85,6 +87,29 @@ int main(int argc, char** argv) {
             ctd_sharded_destroy(s);
             free(c2);
             if (bad) return 4;
+        }
+        {   /* the same Jacobian assembled in CSR order: rowptr / colind (0-based) + values by rows */
+            ctd_handle* hr = NULL;
+            int64_t* rowptr = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ncon + 1));
+            int64_t* colind = (int64_t*)malloc(sizeof(int64_t) * (size_t)nnzj);
+            double* cr = (double*)malloc(sizeof(double) * (size_t)ncon);
+            double* vr = (double*)malloc(sizeof(double) * (size_t)nnzj);
+            int64_t k, q, bad = 0;
+            d.device = 0;
+            d.value_order = CTD_ORDER_CSR;
+            if (ctd_create(&d, &hr) != CTD_OK) { fprintf(stderr, "%s\n", ctd_last_error(NULL)); return 5; }
+            if (ctd_jac_csr(hr, rowptr, colind) || ctd_cons_jac(hr, x, cr, vr)) { fprintf(stderr, "%s\n", ctd_last_error(hr)); return 5; }
+            for (k = 0; k < nnzj; ++k) {           /* CSC entry k = (rows[k], cols[k]) 1-based: find it in its CSR row */
+                const int64_t r = rows[k] - 1, cc = cols[k] - 1;
+                for (q = rowptr[r]; q < rowptr[r + 1] && colind[q] != cc; ++q) {}
+                bad += (q == rowptr[r + 1] || vr[q] != vals[k]);
+            }
+            printf("CSR order: rowptr[ncon] %lld, values differ from the CSC values in %lld of %lld entries\n", (long long)rowptr[ncon], (long long)bad,
+                   (long long)nnzj);
+            ctd_destroy(hr);
+            free(rowptr); free(colind); free(cr); free(vr);
+            d.value_order = CTD_ORDER_CSC;
+            if (bad) return 6;
         }
         free(c); free(vals);
     } else {

@@ -407,6 +407,8 @@ def test_c_program_evaluates_on_the_gpu(torch_cuda, tmp_path):
     assert f"objective {d.obj(x0):.6f}  c[0] {c[0]:.6e}  vals[0] {v[0]:.6e}" in out.stdout, out.stdout
     # the multi-device entry points from plain C: two shards, iterate sent from shard 0, residual stitched on every shard
     assert "differs from the single-device c in 0 of 904 rows" in out.stdout, out.stdout
+    # the Jacobian in CSR order from plain C (ctd_jac_csr + a handle with value_order = CTD_ORDER_CSR): every entry found in its row, same value
+    assert "CSR order: rowptr[ncon] 11128, values differ from the CSC values in 0 of 11128 entries" in out.stdout, out.stdout
     d.close()
 
 
