@@ -405,14 +405,15 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             size_t l0 = 0;
             const int r0 = resident(h->tile, l0);
             const int64_t ns = h->step_end - h->step_begin, cap = 256 * (int64_t)r0;
-            // VERY long grids (16 rounds of resident workgroups and more: millions of steps) are bandwidth-bound, the rounds no
+            // VERY long grids (8 rounds of resident workgroups and more: from ~half a million steps; crossover measured in
+            // profiles/r04_long_grid_crossover.log: 2^18 steps +-5 % either way, 2^19 +3 .. +15 %, 2^20 +5 .. +18 %) are bandwidth-bound, the rounds no
             // longer quantise anything, and what is left per tile is its fixed cost -- launch slot, argument pinning, time table,
             // prologue latency.  Eight waves per workgroup and the largest tile whose records fit 64 KiB of LDS (two workgroups
             // per CU) amortise it: Goddard GL2, 4 194 304 steps 930 -> 795 us (0.59 -> 0.69 of 8 TB/s), GL3 1333 -> 1297,
             // double integrator + path GL2 508 -> 460, double integrator free t0 / tf GL3 915 -> 800, goddard_all GL2 (2 M steps,
             // staged driver) 598 -> 556; the midpoint scheme (records up to 74 KiB): double integrator + path, 8 M steps 506 -> 421, Goddard 4 M 350 -> 283;
             // trapeze: flat, left alone (profiles/r04_tiles_long_grids.log; CTD_LONG_GRID=0: off; CTD_LONG_GRID_ROUNDS: the threshold, for tests)
-            if (r0 > 0 && (ns + h->tile - 1) / h->tile >= env_int("CTD_LONG_GRID_ROUNDS", 16) * cap && maxb >= 512 && env_int("CTD_BLOCK", 0) <= 0 &&
+            if (r0 > 0 && (ns + h->tile - 1) / h->tile >= env_int("CTD_LONG_GRID_ROUNDS", 8) * cap && maxb >= 512 && env_int("CTD_BLOCK", 0) <= 0 &&
                 env_int("CTD_LONG_GRID", 1)) {
                 int tbest = h->tile;
                 for (int tt = h->tile + 1; tt <= 256; ++tt) {

@@ -205,7 +205,7 @@ def _long_grid_case(prob, sch, N, orders):
 
 
 def test_long_grid_geometry_against_the_oracle():
-    """Grids of 16 rounds of resident workgroups and more take another launch geometry (eight waves per workgroup, the largest tile
+    """Grids of 8 rounds of resident workgroups and more take another launch geometry (eight waves per workgroup, the largest tile
     whose records fit 64 KiB: `ctd_create`, CTD_LONG_GRID).  2^20 steps of the bench OCP: EVERY value of c and of the Jacobian, both
     value orders, against the oracle's block mode (the reference's `constraints` template differentiated one step at a time on dense
     local duals, OpenMP over the steps)."""
