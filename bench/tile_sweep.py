@@ -28,7 +28,7 @@ def main():
             row = []
             for T in TILES.get(name, (16, 32)):
                 os.environ["CTD_TILE"], os.environ["CTD_BLOCK"] = (str(T) if T else ""), (str(blk) if T else "")       # T = 0: the defaults
-                d = ct.DOCP(prob, N, sch, device=0)
+                d = ct.DOCP(prob, N, sch, device=0, value_order=os.environ.get("SWEEP_ORDER", "csc"))
                 x = torch.from_numpy(bench_inputs(describe(d, prob, sch), perturb=1e-3)).cuda()
                 c = torch.zeros(d.dim_NLP_constraints, dtype=torch.float64, device="cuda")
                 v = torch.zeros(d.nnzj, dtype=torch.float64, device="cuda")
