@@ -510,10 +510,11 @@ def _main(real_stdout):
                 x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
                 c2 = torch.zeros(d2.dim_NLP_constraints, dtype=torch.float64, device=dev)
                 v2 = torch.zeros(d2.nnzj, dtype=torch.float64, device=dev)
-                ms2 = d2.time_cons_jac(x2, c2, v2, iters=10)
+                ms2 = sorted(d2.time_cons_jac(x2, c2, v2, iters=12) for _ in range(3))[1]      # (the first pass over fresh gigabytes is a cold one)
                 b2 = 8 * (d2.dim_NLP_variables + d2.dim_NLP_constraints + d2.nnzj)
                 large.append({"workload": f"{prob}/{sch} N={n}, order={order}", "kernel_ms": ms2, "algorithmic_bytes": b2,
-                              "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                              "achieved_GBs": b2 / (ms2 * 1e-3) / 1e9, "frac_of_8TBs": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "launch": d2.launch_info()})
                 d2.close()
                 del x2, c2, v2
                 torch.cuda.empty_cache()
