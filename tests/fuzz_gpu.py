@@ -45,6 +45,8 @@ while time.time() < t_end:
     # permutation) and the number of edge workgroups of the constraint / Jacobian kernel
     order = "csr" if rng.random() < 0.4 else "csc"
     os.environ["CTD_EDGE_BLOCKS"] = str(rng.choice(["", "", "1", "2", "5", "16"]))
+    # the long-grid launch geometry (eight waves per workgroup, the largest tile whose records fit 64 / 74 KiB) forced on every grid
+    os.environ["CTD_LONG_GRID_ROUNDS"] = str(rng.choice(["", "", "0"]))
     tile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     htile = int(rng.integers(1, 70)) if rng.random() < 0.5 else 0
     steps = None
@@ -62,7 +64,7 @@ while time.time() < t_end:
     api = int(rng.integers(0, 3))          # 0: fused device call, 1: cons + jac_coord separately, 2: host-pointer (numpy) call
     desc = (f"{prob} {sch} N={N} grid={'user' if tg is not None else 'uniform'} mode={mode} tile={tile} htile={htile} steps={steps} "
             f"twin={int(use_twin)} api={api} step={os.environ['CTD_HESS_STEP']} compact={os.environ['CTD_HESS_COMPACT']} "
-            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']} cs={cs} order={order} ceb={os.environ['CTD_EDGE_BLOCKS']}")
+            f"eb={os.environ['CTD_HESS_EDGE_BLOCKS']} cs={cs} order={order} ceb={os.environ['CTD_EDGE_BLOCKS']} lg={os.environ['CTD_LONG_GRID_ROUNDS']}")
     try:
         d = ct.DOCP(jit_defs.twin(prob) if use_twin else prob, N, sch, time_grid=tg, pattern=mode, device=0, steps=steps, control_steps=cs, value_order=order)
         o = OracleDOCP(prob, sch, N, time_grid=tg, control_steps=cs) if tg is not None else OracleDOCP(prob, sch, N, control_steps=cs)

@@ -132,8 +132,8 @@ def _solve(name, scheme, N, maxiter=600, x0=None):
     ("parametric", "midpoint", 60, 800),                                      # -0.336
     ("goddard_all_f0f1", "midpoint", 60, 2000),                               # 1.01257 (the same optimum as goddard_all)
 ])
-# (swimmer, catalogued 0.984273: scipy's trust-constr ends 1.0 % off on the 100-step midpoint grid (0.99418) and does not converge on the
-#  250-step grid within 1500 iterations (0.9105, still improving); bioreactor_Ndays (T = 300) does not converge either: recorded in
+# (swimmer, catalogued 0.984273: scipy's trust-constr ends 1.0 % off on the 100-step midpoint grid (0.99418) and CONVERGES to other KKT points
+#  on finer grids (N = 150: 0.9168, N = 200: 0.9098, N = 250 warm-started: 0.9383 -- several local solutions); bioreactor_Ndays (T = 300) does not converge either: recorded in
 #  profiles/r04_experiments.md section 7, not asserted.  action / schlogl have no catalogued objective.)
 def test_folder_catalogued_objective(name, scheme, N, maxiter):
     obj, want, viol, res = _solve(name, scheme, N, maxiter=maxiter)
