@@ -386,6 +386,35 @@ def _main(real_stdout):
                     secondary[key] = {"error": repr(e)[:300]}
             if "other_x_mode" in secondary and "x_mode" in secondary["other_x_mode"]:      # (the key earlier lines used)
                 secondary["halo_allgather" if other == "halo" else "peer_in_place"] = secondary["other_x_mode"]
+            # one whole solver iteration on the SHARDED iterate and SHARDED multipliers (round 4): objective (all-reduce of one double),
+            # gradient (own entries; all-reduce of the nv entries of d/dv), constraints + Jacobian (the timed step), multipliers of the
+            # previous rank's last step + tail rows (one small all-gather), Hessian values (all-reduce of the V x V entries) -- nothing
+            # replicated, nothing of length nvar or ncon moved
+            try:
+                ys = np.full(docp.dim_NLP_constraints, np.nan)
+                ca_, cz_ = sh.owned_constraints()
+                ys[ca_:cz_] = 0.6 + 0.4 * np.sin(0.7 * np.arange(ca_, cz_) + 0.3)
+                y_sh = torch.from_numpy(ys).to(dev)
+                g_sh = torch.zeros(docp.dim_NLP_variables, dtype=torch.float64, device=dev)
+                h_sh = torch.zeros(docp.nnzh, dtype=torch.float64, device=dev)
+                cj = sh.bind_cons_jac(x, c, vals, stitch=False, x_mode=x_mode)
+
+                def iteration():
+                    sh.obj(x, as_tensor=True)
+                    cj()                                  # (x_mode "halo": its all-gather also serves the gradient and the Hessian below)
+                    sh.grad(x, g_sh)
+                    sh.exchange_multipliers(y_sh)
+                    sh.hess_coord(x, y_sh, 1.0, h_sh)
+                ki = max(20, min(ks, 200))
+                els = timed(iteration, min(warmup, 20), ki)
+                secondary["sharded_iteration"] = {
+                    "ms_per_iteration": els / ki * 1e3, "iterations": ki,
+                    "finite_own_outputs": bool(torch.isfinite(g_sh[a_:b_]).all()) and bool(torch.isfinite(h_sh[docp.hess_shard_info()[0]:docp.hess_shard_info()[1]]).all()),
+                    "what": "objective + gradient + constraints + Jacobian values + Hessian values of the rank's shard on the sharded x and sharded y "
+                            "(collectives: 1 double, nv doubles, cb + tail doubles, the V x V entries); never `value`"}
+                del y_sh, g_sh, h_sh
+            except Exception as e:
+                secondary["sharded_iteration"] = {"error": repr(e)[:300]}
         # kernel time per rank: per-dispatch start / stop events (hipExtLaunchKernelGGL), median of five batches of 200
         out.per_dispatch = sorted(docp.time_cons_jac(x_full, c, vals, iters=200) for _ in range(5))[2]
         # algorithmic bytes of one launch: read the shard's x, write its c rows and Jacobian values:

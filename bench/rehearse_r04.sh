@@ -25,11 +25,14 @@ for f in ("r04_2rank_selflaunch", "r04_2rank_torchrun", "r04_2rank_halo"):
     print(f, "| value", round(d["value"]), "| ms/step", round(d["ms_per_step"], 4), "| x_mode", d["config"].get("x_mode"),
           "| check", d.get("sharded_iterate_check", {}).get("bit_identical_to_whole_iterate_on_every_rank"),
           "|", {k: round(d[k]["ms_per_step"], 4) for k in ("halo_allgather", "peer_in_place", "stitched_c", "ordered_step", "broadcast_x", "no_exchange") if k in d and "ms_per_step" in d[k]})
+    si = d.get("sharded_iteration", {})
+    print("    sharded_iteration |", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in si.items() if k != "what"})
     for k, b in d.get("strong", {}).items():
         if "value" not in b:
             print("   ", k, b); continue
         print("   ", k, "| evals/s", round(b["value"]), "| ms/step", round(b["ms_per_step"], 4), "| x_mode", b["x_mode"],
               "| per-rank us/frac", [(round(r["kernel_ms"] * 1e3, 2), round(r["frac"], 3)) for r in b["per_rank"]],
               "| stitched", round(b.get("stitched_c", {}).get("ms_per_step", -1), 4), "| ordered", round(b.get("ordered_step", {}).get("ms_per_step", -1), 4),
+              "| iteration", round(b.get("sharded_iteration", {}).get("ms_per_iteration", -1), 4),
               "| check", b.get("sharded_iterate_check", {}).get("bit_identical_to_whole_iterate_on_every_rank"))
 PY
