@@ -178,3 +178,30 @@ def test_csr_feeds_a_sparse_matvec(torch_cuda):
     fd = (d.cons(x + h * dirv) - d.cons(x - h * dirv)) / (2 * h)
     assert float((jd - fd).abs().max()) <= 1e-6 * max(1.0, float(fd.abs().max()))
     d.close()
+
+
+@pytest.mark.parametrize("prob,sch,N", [("goddard", "gauss_legendre_2", 10000), ("goddard_all", "trapeze", 1001),
+                                        ("double_integrator_path", "midpoint", 3000), ("quadrotor", "gauss_legendre_3", 300),
+                                        ("double_integrator_freet0tf", "euler_implicit", 5)])
+def test_whole_iteration_in_csr_order(torch_cuda, prob, sch, N):
+    """ctd_eval_all_dev_async (the horizontally fused iteration kernel) on a handle with value_order = CSR: its Jacobian values are
+    bit-identical to the single-purpose kernel's CSR values, which are the CSC handle's values under the host permutation; objective,
+    gradient, c and the Hessian values do not depend on the order."""
+    torch = torch_cuda
+    d, dc = ct.DOCP(prob, N, sch, pattern="structural", device=0, value_order="csr"), ct.DOCP(prob, N, sch, pattern="structural", device=0)
+    x = bench_inputs(describe(d, prob, sch), perturb=1e-2)
+    y = np.cos(0.41 * np.arange(d.dim_NLP_constraints))
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    new = lambda n: torch.full((n,), 777.25, dtype=torch.float64, device="cuda")      # noqa: E731
+    f, g, c, v, h = new(1), new(d.dim_NLP_variables), new(d.dim_NLP_constraints), new(d.nnzj), new(d.nnzh)
+    d.eval_all(xd, yd, 0.9, f, g, c, v, h, sync=True)
+    c1, v1 = d.cons_jac(xd)
+    assert torch.equal(c, c1) and torch.equal(v, v1)
+    fc, gc, cc, vc, hc = new(1), new(d.dim_NLP_variables), new(d.dim_NLP_constraints), new(d.nnzj), new(d.nnzh)
+    dc.eval_all(xd, yd, 0.9, fc, gc, cc, vc, hc, sync=True)
+    assert torch.equal(f, fc) and torch.equal(g, gc) and torch.equal(c, cc) and torch.equal(h, hc)
+    rows, cols = dc.jac_structure()
+    perm = torch.from_numpy(np.lexsort((cols, rows))).cuda()
+    assert torch.equal(v, vc[perm])
+    d.close()
+    dc.close()

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, prob, sch, q):
+def _worker(rank, world, port, N, prob, sch, q, order="csc"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -38,7 +38,7 @@ def _worker(rank, world, port, N, prob, sch, q):
         torch.cuda.set_device(0)
         o = OracleDOCP(prob, sch, N)
         x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
-        sh = ctdist.ShardedDOCP(lambda steps=None: ct.DOCP(prob, N, sch, device=0, steps=steps, pattern="structural"), N, world=world, rank=rank)
+        sh = ctdist.ShardedDOCP(lambda steps=None: ct.DOCP(prob, N, sch, device=0, steps=steps, pattern="structural", value_order=order), N, world=world, rank=rank)
         d = sh.docp
         # sharded iterate: own entries + the replicated variables, NaN everywhere else
         xs = np.full_like(x, np.nan)
@@ -55,6 +55,9 @@ def _worker(rank, world, port, N, prob, sch, q):
         torch.cuda.synchronize()
         o.set_pattern_mode(1)
         cref, vref = o.constraints(x), o.jac_coord(x)
+        if order == "csr":                  # the oracle's values are in the reference's CSC order
+            cp_, rv_ = o.jac_pattern()
+            vref = vref[np.lexsort((np.repeat(np.arange(len(cp_) - 1), np.diff(cp_)), rv_))]
         chk = {}
         chk['c'] = relerr(c.cpu().numpy(), cref) <= TOL                   # whole residual on every rank after stitching
         lo, hi = d.shard.vals_main_begin, d.shard.vals_main_end          # the rank's contiguous CSC range
@@ -158,13 +161,14 @@ def _worker(rank, world, port, N, prob, sch, q):
                                         (3000, "double_integrator_path", "midpoint"), (501, "quadrotor", "gauss_legendre_3"),
                                         (777, "goddard_all", "euler_implicit"),
                                         (20000, "goddard", "gauss_legendre_2")])      # (10 000 steps per rank: the lane-per-step Hessian kernel)
-def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
+@pytest.mark.parametrize("order", ["csc", "csr"])
+def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch, order):
     assert torch.cuda.is_available()
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, prob, sch, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, prob, sch, q, order)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
