@@ -31,6 +31,8 @@ CFGS = {"cfg2": ("goddard", "gauss_legendre_2", 10000), "cfg3": ("double_integra
         "cfg2_4M": ("goddard", "gauss_legendre_2", 1 << 22), "cfg4_4M": ("goddard", "gauss_legendre_3", 1 << 22),
         "di_gl2_4M": ("double_integrator_path", "gauss_legendre_2", 1 << 22), "gall_gl2_2M": ("goddard_all", "gauss_legendre_2", 1 << 21),
         "cfg3_8M": ("double_integrator_path", "midpoint", 1 << 23), "g_trap_4M": ("goddard", "trapeze", 1 << 22), "g_mid_4M": ("goddard", "midpoint", 1 << 22),
+        "g_eul_4M": ("goddard", "euler", 1 << 22), "g_euli_4M": ("goddard", "euler_implicit", 1 << 22), "di_eul_8M": ("double_integrator_path", "euler", 1 << 23),
+        "di_euli_8M": ("double_integrator_path", "euler_implicit", 1 << 23),
         "gall_mid_4M": ("goddard_all", "midpoint", 1 << 22), "di_mid_8M": ("double_integrator_freet0tf", "midpoint", 1 << 23), "ls_mid_8M": ("least_squares_with_constraint", "midpoint", 1 << 23),
         "di_gl3_4M": ("double_integrator_freet0tf", "gauss_legendre_3", 1 << 22)}
 

@@ -389,7 +389,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
     // (profiles/r03_phase_stamps_final.log: start percentiles 0.1 / 10.1 / 19.3 us).  A tile of up to 48 steps with the same R fixes
     // the number of rounds, the steps are spread evenly over them: 40 steps = 2001 tiles, 28.3 -> 26.9 us, optimized pattern
     // 20.3 -> 17.9; N = 200 000: 79.9 -> 74.3 (profiles/r03_experiments.md).  Only ever a LARGER tile than the rule's.
-    const bool long_mid = mo.L.sc == SC_MIDPOINT && mo.L.euler == 0 && mo.L.cs == 1;      // the midpoint scheme proper: long-grid rule only
+    const bool long_mid = mo.L.sc == SC_MIDPOINT && mo.L.cs == 1;      // midpoint and both Euler schemes (one point per step): long-grid rule only
     if (desc->device >= 0 && !h->rt && env_int("CTD_TILE", 0) <= 0 && env_int("CTD_ROUND_TILES", 1) && mo.nch_dyn <= 1 && (mo.L.sc == SC_IRK || long_mid) && h->tile >= 16) {
         DeviceGuard dgq(desc->device);
         if (dgq.err == hipSuccess) {
@@ -411,7 +411,7 @@ int32_t ctd_create(const ctd_desc* desc, ctd_handle** out) {
             // prologue latency.  Eight waves per workgroup and the largest tile whose records fit 64 KiB of LDS (two workgroups
             // per CU) amortise it: Goddard GL2, 4 194 304 steps 930 -> 795 us (0.59 -> 0.69 of 8 TB/s), GL3 1333 -> 1297,
             // double integrator + path GL2 508 -> 460, double integrator free t0 / tf GL3 915 -> 800, goddard_all GL2 (2 M steps,
-            // staged driver) 598 -> 556; the midpoint scheme (records up to 74 KiB): double integrator + path, 8 M steps 506 -> 421, Goddard 4 M 350 -> 283;
+            // staged driver) 598 -> 556; the midpoint scheme (records up to 74 KiB): double integrator + path, 8 M steps 506 -> 421, Goddard 4 M 350 -> 283, explicit / implicit Euler 335 -> 288 / 294, DI + path Euler 8 M 455 -> 367;
             // trapeze: flat, left alone (profiles/r04_tiles_long_grids.log; CTD_LONG_GRID=0: off; CTD_LONG_GRID_ROUNDS: the threshold, for tests)
             if (r0 > 0 && (ns + h->tile - 1) / h->tile >= env_int("CTD_LONG_GRID_ROUNDS", 8) * cap && maxb >= 512 && env_int("CTD_BLOCK", 0) <= 0 &&
                 env_int("CTD_LONG_GRID", 1)) {

@@ -183,11 +183,12 @@ def _long_grid_case(prob, sch, N, orders):
     o = OracleDOCP(prob, sch, N)
     x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
     ref = o.cons_jac_block(x, min(16, os.cpu_count() or 1))
-    assert ref is not None
+    if ref is None:                        # (implicit Euler has no block mode: the coloured passes)
+        ref = (o.constraints(x), o.jac_coord(x))
     for order in orders:
         d = ct.DOCP(prob, N, sch, device=0, value_order=order)
         li = d.launch_info()
-        assert li["block"] == 512 and li["steps_per_tile"] >= 64 and li["lds_bytes"] <= (74 if sch == "midpoint" else 64) * 1024, li
+        assert li["block"] == 512 and li["steps_per_tile"] >= 64 and li["lds_bytes"] <= (74 if sch in ("midpoint", "euler", "euler_implicit") else 64) * 1024, li
         c = torch.full((d.dim_NLP_constraints,), float("nan"), dtype=torch.float64, device="cuda")
         v = torch.full((d.nnzj,), float("nan"), dtype=torch.float64, device="cuda")
         d.cons_jac(torch.from_numpy(x).cuda(), c, v)
@@ -215,7 +216,8 @@ def test_long_grid_geometry_against_the_oracle():
 @pytest.mark.parametrize("prob,sch,log2n", [("goddard", "gauss_legendre_3", 17), ("double_integrator_freet0tf", "gauss_legendre_3", 17),
                                             ("goddard_all", "gauss_legendre_2", 17), ("double_integrator_path", "gauss_legendre_2", 17),
                                             ("goddard_all", "gauss_legendre_1", 17), ("double_integrator_path", "gauss_legendre_3", 17),
-                                            ("double_integrator_path", "midpoint", 19), ("goddard", "midpoint", 19), ("goddard_all", "midpoint", 19)])
+                                            ("double_integrator_path", "midpoint", 19), ("goddard", "midpoint", 19), ("goddard_all", "midpoint", 19),
+                                            ("goddard", "euler", 19), ("double_integrator_path", "euler_implicit", 18)])
 def test_long_grid_geometry_other_ocps(prob, sch, log2n, monkeypatch):
     """the same geometry forced on 2^17 / 2^19 steps (CTD_LONG_GRID_ROUNDS = 1: every grid of more than one round) for the other narrow
     OCPs, both drivers (direct: Goddard, double integrators; staged: goddard_all) and the midpoint scheme"""
