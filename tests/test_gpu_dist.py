@@ -161,8 +161,17 @@ def _worker(rank, world, port, N, prob, sch, q, order="csc"):
                                         (3000, "double_integrator_path", "midpoint"), (501, "quadrotor", "gauss_legendre_3"),
                                         (777, "goddard_all", "euler_implicit"),
                                         (20000, "goddard", "gauss_legendre_2")])      # (10 000 steps per rank: the lane-per-step Hessian kernel)
-@pytest.mark.parametrize("order", ["csc", "csr"])
-def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch, order):
+def test_two_ranks_one_gpu_sharded_iterate(N, prob, sch):
+    _two_ranks(N, prob, sch, "csc")
+
+
+@pytest.mark.parametrize("N,prob,sch", [(1001, "goddard_all", "trapeze"), (3000, "double_integrator_path", "midpoint"), (2000, "goddard", "gauss_legendre_2")])
+def test_two_ranks_one_gpu_sharded_iterate_csr_order(N, prob, sch):
+    """the same with the Jacobian values in CSR order (one value range per rank)"""
+    _two_ranks(N, prob, sch, "csr")
+
+
+def _two_ranks(N, prob, sch, order):
     assert torch.cuda.is_available()
     world = 2
     ctx = mp.get_context("spawn")
