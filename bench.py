@@ -533,7 +533,7 @@ def _main(real_stdout):
         # launch + one dependent chain; at 4 million steps the launch is 0.1 % of the kernel): what fraction of the 8 TB/s the
         # emission sustains.  (tests/test_gpu_max_sizes.py checks 2^24 steps -- 3.2e9 values -- bit for bit.)
         for prob, sch, n, order in (("goddard", "gauss_legendre_2", 1 << 22, "csc"), ("goddard", "gauss_legendre_2", 1 << 22, "csr"),
-                                    ("goddard", "gauss_legendre_3", 1 << 22, "csc")):
+                                    ("goddard", "gauss_legendre_3", 1 << 22, "csc"), ("double_integrator_path", "midpoint", 1 << 23, "csc")):
             try:
                 d2 = ct.DOCP(prob, n, sch, device=local_rank, stream="torch", value_order=order)
                 x2 = torch.from_numpy(bench_inputs(describe(d2, prob, sch), perturb=1e-3)).to(dev)
