@@ -1,0 +1,276 @@
+"""TEST INFRASTRUCTURE ONLY ("drive Ipopt ... or a small in-repo interior-point / SQP loop through the ABI").
+
+A compact primal-dual interior-point method of Ipopt's class (Waechter & Biegler 2006, restated from the paper, not from any code):
+log-barrier on the simple bounds, slacks for the two-sided constraint rows, Newton steps on the perturbed KKT conditions through
+ONE sparse symmetric-indefinite system per iteration, inertia-free regularisation by a curvature test (Chiang & Zavala 2016),
+fraction-to-the-boundary rule, an l1 merit function with Armijo backtracking, monotone barrier update, gradient-based scaling.
+
+It only ever sees an NLP through the five callbacks the engine serves -- obj, grad, cons, jac_coord (on jac_structure), hess_coord
+(on hess_structure, lower triangle, L = sigma f + y'c) -- plus bounds and an initial point, i.e. exactly what the reference hands
+to Ipopt through NLPModels (src/solve.jl).  `NLP.from_docp(d)` wraps a ctdirect DOCP (GPU callbacks through the C ABI, host
+pointers), `NLP.from_oracle(o)` the CPU oracle (for developing this file without a GPU)."""
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+class NLP:
+    def __init__(self, n, m, obj, grad, cons, jac, hess, xl, xu, cl, cu, x0, maximize=False):
+        self.n, self.m = n, m
+        sgn = -1.0 if maximize else 1.0
+        self.sgn = sgn
+        self.obj = lambda x: sgn * obj(x)
+        self.grad = lambda x: sgn * grad(x)
+        self.cons, self.jac = cons, jac
+        self.hess = lambda x, y, s: hess(x, y, sgn * s)
+        self.xl, self.xu, self.cl, self.cu, self.x0 = xl, xu, cl, cu, x0
+
+    @staticmethod
+    def from_docp(d, x0, ct):
+        n, m = d.dim_NLP_variables, d.dim_NLP_constraints
+        cl, cu = ct.constraints_bounds(d)
+        xl, xu = ct.variables_bounds(d)
+        jr, jc = d.jac_structure()
+        hr, hc = d.hess_structure()
+        offd = hr != hc
+
+        def jac(x):
+            return sp.csr_matrix((d.jac_coord(x), (jr - 1, jc - 1)), shape=(m, n))
+
+        def hess(x, y, s):
+            v = d.hess_coord(x, y, s)
+            return sp.coo_matrix((np.concatenate([v, v[offd]]), (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))),
+                                 shape=(n, n)).tocsr()
+        return NLP(n, m, d.obj, d.grad, d.cons, jac, hess, xl, xu, cl, cu, x0, maximize=bool(d.flags.max))
+
+    @staticmethod
+    def from_oracle(o, x0, maximize=False):
+        n, m = o.dim_NLP_variables, o.dim_NLP_constraints
+        xl, xu, cl, cu = o.bounds()
+        cp, rv = o.jac_pattern()
+        jcols = np.repeat(np.arange(n), np.diff(cp))
+        hp, hrv = o.hess_pattern()
+        hcols = np.repeat(np.arange(n), np.diff(hp))
+        offd = hrv != hcols
+
+        def jac(x):
+            return sp.csr_matrix((o.jac_coord(x), (rv, jcols)), shape=(m, n))
+
+        def hess(x, y, s):
+            v = o.hess_coord(x, y, s)
+            return sp.coo_matrix((np.concatenate([v, v[offd]]), (np.concatenate([hrv, hcols[offd]]), np.concatenate([hcols, hrv[offd]]))),
+                                 shape=(n, n)).tocsr()
+        return NLP(n, m, o.objective, o.gradient, o.constraints, jac, hess, xl, xu, cl, cu, x0, maximize=maximize)
+
+
+class Result:
+    pass
+
+
+def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e-6, time_limit=None, kappa_eps=10.0, dc0=0.0, mu_lin=0.2):
+    """returns Result(x, y, obj, status, iters, violation, kkt); status 0 = converged to tol, 1 = acceptable, 2 = iteration / time limit"""
+    t_start = time.time()
+    n, m = nlp.n, nlp.m
+    eq = nlp.cl == nlp.cu
+    ineq = ~eq
+    mi = int(ineq.sum())
+    # --- scaling (Ipopt's gradient-based rule, section 3.8): objective and every constraint row so that gradients at x0 are <= 100
+    x = np.clip(nlp.x0.astype(float).copy(), nlp.xl, nlp.xu)
+    g0 = nlp.grad(x)
+    sf = min(1.0, 100.0 / max(1e-300, np.max(np.abs(g0)))) if g0.size else 1.0
+    J0 = nlp.jac(x)
+    rown = np.asarray(abs(J0).max(axis=1).todense()).ravel() if m else np.zeros(0)
+    sc = np.minimum(1.0, 100.0 / np.maximum(rown, 1e-300))
+    Sc = sp.diags(sc)
+    # --- variables z = (x, s): s = slacks of the inequality rows; bounds, slightly relaxed (section 3.5)
+    zl = np.concatenate([nlp.xl, (sc * nlp.cl)[ineq]])
+    zu = np.concatenate([nlp.xu, (sc * nlp.cu)[ineq]])
+    hasl, hasu = np.isfinite(zl), np.isfinite(zu)
+    zl = np.where(hasl, zl - 1e-8 * np.maximum(1.0, np.abs(zl)), -np.inf)
+    zu = np.where(hasu, zu + 1e-8 * np.maximum(1.0, np.abs(zu)), np.inf)
+    nz = n + mi
+    ceq_target = np.where(eq, sc * nlp.cl, 0.0)
+
+    def push(z):      # initial point strictly inside the bounds (section 3.6)
+        k1 = k2 = 1e-2
+        pl = np.where(hasl, np.minimum(k1 * np.maximum(1.0, np.abs(zl)), k2 * np.where(hasu, zu - zl, np.inf)), 0.0)
+        pu = np.where(hasu, np.minimum(k1 * np.maximum(1.0, np.abs(zu)), k2 * np.where(hasl, zu - zl, np.inf)), 0.0)
+        z = np.where(hasl, np.maximum(z, zl + pl), z)
+        return np.where(hasu, np.minimum(z, zu - pu), z)
+
+    def cfun(xv):
+        return sc * nlp.cons(xv)
+
+    c_raw = cfun(x)
+    z = push(np.concatenate([x, c_raw[ineq]]))
+    lam = np.zeros(m)
+    vl = np.where(hasl, 1.0, 0.0)
+    vu = np.where(hasu, 1.0, 0.0)
+    mu = mu0
+    Aslack = sp.csr_matrix((-np.ones(mi), (np.where(ineq)[0], np.arange(mi))), shape=(m, mi)) if mi else sp.csr_matrix((m, 0))
+
+    def resid(z):
+        c = cfun(z[:n])
+        r = c - ceq_target
+        r[ineq] -= z[n:]
+        return r
+
+    def barrier(z, mu):
+        b = 0.0
+        if hasl.any():
+            b -= mu * np.sum(np.log(z[hasl] - zl[hasl]))
+        if hasu.any():
+            b -= mu * np.sum(np.log(zu[hasu] - z[hasu]))
+        return b
+
+    def phi(z, mu):
+        return sf * nlp.obj(z[:n]) + barrier(z, mu)
+
+    dw_last = 0.0
+    nu = 1.0
+    res = Result()
+    status = 2
+    it = 0
+    err0 = float("inf")
+    last_alpha = None
+    for it in range(max_iter):
+        xv = z[:n]
+        g = np.concatenate([sf * nlp.grad(xv), np.zeros(mi)])
+        J = Sc @ nlp.jac(xv)
+        A = sp.hstack([J, Aslack], format="csr") if mi else J
+        r = resid(z)
+        dl = np.where(hasl, z - zl, 1.0)
+        du = np.where(hasu, zu - z, 1.0)
+        dual_inf = g + A.T @ lam - vl + vu
+        sd = max(1.0, (np.abs(lam).sum() + np.abs(vl).sum() + np.abs(vu).sum()) / max(1, m + 2 * nz) / 100.0)
+        compl = lambda mu_: max(np.max(np.abs(dl * vl - mu_)[hasl], initial=0.0), np.max(np.abs(du * vu - mu_)[hasu], initial=0.0))
+        err0 = max(np.max(np.abs(dual_inf), initial=0.0) / sd, np.max(np.abs(r), initial=0.0), compl(0.0) / sd)
+        errmu = max(np.max(np.abs(dual_inf), initial=0.0) / sd, np.max(np.abs(r), initial=0.0), compl(mu) / sd)
+        if verbose and (it % verbose == 0):
+            print(f"it {it:4d} obj {nlp.sgn * nlp.obj(xv):.8f} inf_pr {np.max(np.abs(r), initial=0.0):.2e} inf_du {np.max(np.abs(dual_inf), initial=0.0):.2e} mu {mu:.1e} dw {dw_last:.1e} "
+                  f"sd {sd:.1e} |lam| {np.max(np.abs(lam), initial=0.0):.1e} |v| {max(np.max(vl, initial=0.0), np.max(vu, initial=0.0)):.1e} last alpha {last_alpha}")
+        if err0 <= tol:
+            status = 0
+            break
+        if time_limit is not None and time.time() - t_start > time_limit:
+            break
+        # barrier update (monotone, section 3.1, eq. 7)
+        if errmu <= kappa_eps * mu and mu > tol / 10.0:          # (one reduction per iteration: a Newton step at every barrier level)
+            mu = max(tol / 10.0, min(mu_lin * mu, mu ** 1.5))
+            nu = 1.0
+        tau = max(0.99, 1.0 - mu)
+        # Newton system on (dz, dlam) with the bound multipliers eliminated
+        Wx = nlp.hess(xv, lam * sc, sf)
+        W = sp.block_diag([Wx, sp.csr_matrix((mi, mi))], format="csr") if mi else Wx
+        sig = np.where(hasl, vl / dl, 0.0) + np.where(hasu, vu / du, 0.0)
+        gphi = g - np.where(hasl, mu / dl, 0.0) + np.where(hasu, mu / du, 0.0)
+        rhs = -np.concatenate([gphi + A.T @ lam, r])
+        dw = 0.0
+        dc = dc0
+        dz = dlam = None
+        lu = None
+        for attempt in range(40):
+            K = sp.bmat([[W + sp.diags(sig + dw), A.T], [A, -dc * sp.identity(m)]], format="csc")
+            try:
+                lu = spla.splu(K)
+                sol = lu.solve(rhs)
+                ok = bool(np.all(np.isfinite(sol)))
+            except RuntimeError:
+                ok = False
+                if dc == 0.0:
+                    dc = 1e-8 * mu ** 0.25
+            if ok:
+                dz, dlam = sol[:nz], sol[nz:]
+                curv = dz @ (W @ dz) + dz @ ((sig + dw) * dz)
+                # inertia-free test: positive curvature of the barrier Lagrangian along the step (on the null space of A up to the residual)
+                if curv >= 1e-10 * (dz @ dz):
+                    break
+            if dw == 0.0:
+                dw = 1e-4 if dw_last == 0.0 else max(1e-20, dw_last / 3.0)
+            else:
+                dw *= 100.0 if dw_last == 0.0 else 8.0
+            if dw > 1e40:
+                break
+        if dz is None:
+            status = 3
+            break
+        if dw > 0:
+            dw_last = dw
+        dvl = np.where(hasl, (mu - vl * dz) / dl - vl, 0.0)
+        dvu = np.where(hasu, (mu + vu * dz) / du - vu, 0.0)
+        # fraction to the boundary
+        def amax(v, dv, lim):
+            neg = dv < 0
+            return min(1.0, np.min(-lim * v[neg] / dv[neg], initial=1.0)) if neg.any() else 1.0
+        a_pri = min(amax(np.where(hasl, dl, 1.0), np.where(hasl, dz, 0.0), tau), amax(np.where(hasu, du, 1.0), np.where(hasu, -dz, 0.0), tau))
+        a_du = min(amax(np.where(hasl, vl, 1.0), dvl, tau), amax(np.where(hasu, vu, 1.0), dvu, tau))
+        # l1 merit function phi_mu + nu ||c||_1, penalty from the model decrease (Byrd, Hribar, Nocedal)
+        th = np.abs(r).sum()
+        curv = max(0.0, dz @ (W @ dz) + dz @ (sig * dz))
+        gd = gphi @ dz
+        if th > 1e-14:
+            nu_need = (gd + 0.5 * curv) / (0.9 * th)
+            if nu < nu_need:
+                nu = nu_need + 1.0
+        D = gd - nu * th
+        m0 = phi(z, mu) + nu * th
+        a = a_pri
+        accepted = False
+        for ls in range(40):
+            zt = z + a * dz
+            rt = resid(zt)
+            mt = phi(zt, mu) + nu * np.abs(rt).sum()
+            if np.isfinite(mt) and mt <= m0 + 1e-8 * a * D + 10 * np.finfo(float).eps * abs(m0):
+                accepted = True
+                break
+            if ls == 0 and np.abs(rt).sum() >= th and lu is not None:
+                # second-order correction (section 2.4): the full step was refused because the constraint violation grew (Maratos effect)
+                csoc = a * r + rt
+                for p_ in range(4):
+                    sol2 = lu.solve(-np.concatenate([gphi + A.T @ lam, csoc]))
+                    if not np.all(np.isfinite(sol2)):
+                        break
+                    d2 = sol2[:nz]
+                    a2 = min(amax(np.where(hasl, dl, 1.0), np.where(hasl, d2, 0.0), tau), amax(np.where(hasu, du, 1.0), np.where(hasu, -d2, 0.0), tau))
+                    z2 = z + a2 * d2
+                    r2 = resid(z2)
+                    m2 = phi(z2, mu) + nu * np.abs(r2).sum()
+                    if np.isfinite(m2) and m2 <= m0 + 1e-8 * a2 * D + 10 * np.finfo(float).eps * abs(m0):
+                        zt, a, dlam, accepted = z2, a2, sol2[nz:], True
+                        break
+                    if np.abs(r2).sum() > 0.99 * np.abs(rt).sum():
+                        break
+                    csoc = a2 * csoc + r2
+                    rt = r2
+                if accepted:
+                    break
+            a *= 0.5
+        if not accepted:
+            # no decrease along the Newton direction: take the tiny step anyway once, with more regularisation next time
+            dw_last = max(1e-4, dw_last * 10.0)
+            zt = z + a * dz
+        last_alpha = (round(a_pri, 4), round(a_du, 4), a, accepted)
+        z = zt
+        lam = lam + a * dlam
+        vl = vl + a_du * dvl
+        vu = vu + a_du * dvu
+        # keep the bound multipliers near mu / slack (section 3.2, eq. 16)
+        ks = 1e10
+        dl = np.where(hasl, z - zl, 1.0)
+        du = np.where(hasu, zu - z, 1.0)
+        vl = np.where(hasl, np.clip(vl, mu / (ks * dl), ks * mu / dl), 0.0)
+        vu = np.where(hasu, np.clip(vu, mu / (ks * du), ks * mu / du), 0.0)
+    xv = z[:n]
+    c = nlp.cons(xv)
+    res.x, res.y, res.iters = xv, lam * sc / sf, it
+    res.zl, res.zu = vl[:n] / sf, vu[:n] / sf          # bound multipliers of min sgn f:  grad + J'y - zl + zu = 0
+    res.obj = nlp.sgn * nlp.obj(xv)
+    res.violation = max(float(np.max(np.maximum(nlp.cl - c, 0.0), initial=0.0)), float(np.max(np.maximum(c - nlp.cu, 0.0), initial=0.0)),
+                        float(np.max(np.maximum(nlp.xl - xv, 0.0), initial=0.0)), float(np.max(np.maximum(xv - nlp.xu, 0.0), initial=0.0)))
+    if status == 2 and err0 <= acceptable_tol:
+        status = 1
+    res.status = status
+    res.kkt = float(err0)
+    return res
