@@ -15,6 +15,9 @@ jobs = [("cat", n, s) for n, s in (("beam", "midpoint"), ("fuller", "midpoint"),
                                    ("double_integrator_nobounds", "midpoint"), ("double_integrator_freet0tf", "midpoint"), ("electric_vehicle", "midpoint"),
                                    ("insurance", "trapeze"), ("space_shuttle", "trapeze"), ("goddard_all", "midpoint"), ("glider", "midpoint"), ("truck_trailer", "trapeze"))]
 jobs += [("pf", n, "midpoint") for n in ("algal_bacterial", "bioreactor_1day", "bioreactor_Ndays", "parametric", "swimmer", "goddard_all_f0f1")]
+if len(sys.argv) > 2 and sys.argv[2] == "hard":      # the ones the loop does not settle on the midpoint / trapeze grid: other schemes
+    jobs = [(k, n, s) for k, n in (("cat", "moonlander"), ("cat", "insurance"), ("cat", "space_shuttle"), ("cat", "truck_trailer"), ("pf", "bioreactor_1day"), ("pf", "swimmer"))
+            for s in ("trapeze", "midpoint", "gauss_legendre_2", "euler_implicit")]
 for kind, name, sch in jobs:
     try:
         prob, want, init = jit_defs.catalogue(name) if kind == "cat" else pf.folder(name)
