@@ -63,3 +63,26 @@ def test_interior_point_loop_on_the_default_grid(kind, name, scheme):
     scale = max(1.0, np.max(np.abs(r.y), initial=0.0), np.max(r.zl, initial=0.0), np.max(r.zu, initial=0.0))
     assert np.max(np.abs(res), initial=0.0) <= 1e-6 * scale
     d.close()
+
+
+def test_north_star_transcription_solved_end_to_end():
+    """The 10 000-step Goddard transcription BASELINE.json's north_star names (trapeze: 40 005 variables, 30 004 constraints, 270 028
+    Jacobian and 300 024 Hessian entries) solved by the in-repo interior-point loop through the GPU callbacks: 21 iterations, a few seconds,
+    of which the callbacks -- ~165 calls through the host-pointer entry points, PCIe both ways -- are a few tenths of a second; the rest is
+    the host's sparse LU (a bordered factorisation: the free final time makes one dense row / column).  The CPU oracle needs about two
+    minutes PER ITERATION for the same callbacks (profiles/r04_experiments.md section 7c)."""
+    import time
+    import ctdirect_jl_amd as ct
+    import ipm
+    d = ct.DOCP("goddard", 10000, "trapeze", pattern="structural", device=0)
+    lv, uv = ct.variables_bounds(d)
+    nlp = ipm.NLP.from_docp(d, np.clip(ct.initial_guess(d, "problem"), lv, uv), ct)
+    t0 = time.time()
+    with np.errstate(all="ignore"):
+        r = ipm.solve(nlp, max_iter=200, time_limit=300)
+    el, cb = time.time() - t0, sum(nlp.seconds.values())
+    print(f"goddard/trapeze N=10000: objective {r.obj:.7f}, {r.iters} iterations, {el:.1f} s total, {cb:.2f} s inside the callbacks {nlp.calls}")
+    assert r.status == 0 and r.violation <= 1e-6
+    assert abs(r.obj - 1.01257) <= 1e-3 * 1.01257          # (barrier shift mu x number of active bounds: 3e-5 at this size)
+    assert cb <= 0.5 * el
+    d.close()
