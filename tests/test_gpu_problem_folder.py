@@ -127,13 +127,14 @@ def _solve(name, scheme, N, maxiter=600, x0=None):
 
 
 @pytest.mark.parametrize("name, scheme, N, maxiter", [
-    ("algal_bacterial", "midpoint", 200, 1500),                               # catalogued 5.45 (archive: 5.4522 for every method)
+    # (algal_bacterial -- catalogued 5.45, archive 5.4522 -- and bioreactor_Ndays are solved on the reference's 250-step grid by the in-repo
+    #  interior-point loop, tests/test_gpu_solve_ipm.py: 5.4526 / 19.0793; scipy's trust-constr took 30 s for 5.4023 on 200 steps)
     ("bioreactor_1day", "midpoint", 100, 1500),                               # 0.614134
     ("parametric", "midpoint", 60, 800),                                      # -0.336
     ("goddard_all_f0f1", "midpoint", 60, 2000),                               # 1.01257 (the same optimum as goddard_all)
 ])
 # (swimmer, catalogued 0.984273: scipy's trust-constr ends 1.0 % off on the 100-step midpoint grid (0.99418) and CONVERGES to other KKT points
-#  on finer grids (N = 150: 0.9168, N = 200: 0.9098, N = 250 warm-started: 0.9383 -- several local solutions); bioreactor_Ndays (T = 300) does not converge either: recorded in
+#  on finer grids (N = 150: 0.9168, N = 200: 0.9098, N = 250 warm-started: 0.9383 -- several local solutions); bioreactor_Ndays (T = 300) does not converge with scipy: recorded in
 #  profiles/r04_experiments.md section 7, not asserted.  action / schlogl have no catalogued objective.)
 def test_folder_catalogued_objective(name, scheme, N, maxiter):
     obj, want, viol, res = _solve(name, scheme, N, maxiter=maxiter)
