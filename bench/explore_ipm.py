@@ -15,6 +15,8 @@ jobs = [("cat", n, s) for n, s in (("beam", "midpoint"), ("fuller", "midpoint"),
                                    ("double_integrator_nobounds", "midpoint"), ("double_integrator_freet0tf", "midpoint"), ("electric_vehicle", "midpoint"),
                                    ("insurance", "trapeze"), ("space_shuttle", "trapeze"), ("goddard_all", "midpoint"), ("glider", "midpoint"), ("truck_trailer", "trapeze"))]
 jobs += [("pf", n, "midpoint") for n in ("algal_bacterial", "bioreactor_1day", "bioreactor_Ndays", "parametric", "swimmer", "goddard_all_f0f1")]
+if len(sys.argv) > 2 and sys.argv[2] == "gl2":        # every problem on the stagewise Gauss-Legendre 2 grid
+    jobs = [(k, n, "gauss_legendre_2") for k, n, _ in jobs]
 if len(sys.argv) > 2 and sys.argv[2] == "hard":      # the ones the loop does not settle on the midpoint / trapeze grid: other schemes
     jobs = [("cat", "moonlander", "gauss_legendre_2"), ("cat", "moonlander", "trapeze"), ("cat", "insurance", "midpoint"), ("cat", "insurance", "gauss_legendre_2"),
             ("cat", "space_shuttle", "midpoint"), ("cat", "space_shuttle", "gauss_legendre_2"), ("pf", "bioreactor_1day", "trapeze"), ("pf", "bioreactor_1day", "gauss_legendre_2"),
@@ -26,7 +28,7 @@ for kind, name, sch in jobs:
         lv, uv = ct.variables_bounds(d)
         x0 = np.clip(ct.initial_guess(d, init), lv, uv)
         t0 = time.time()
-        r = ipm.solve(ipm.NLP.from_docp(d, x0, ct), max_iter=600, time_limit=(40 if len(sys.argv) > 2 else 60))
+        r = ipm.solve_auto(ipm.NLP.from_docp(d, x0, ct), max_iter=600, time_limit=30)
         rel = abs(r.obj - want) / abs(want) if want else float("nan")
         print(f"{name:28s} {sch:9s} N={N} obj {r.obj:.6f} catalogued {want} rel {rel:.1e} status {r.status} iters {r.iters} violation {r.violation:.1e} kkt {r.kkt:.1e} {time.time() - t0:.1f} s", flush=True)
         d.close()

@@ -9,13 +9,13 @@ import ctdirect_jl_amd as ct
 import ipm
 np.seterr(all='ignore')
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-for sch in ("trapeze", "midpoint"):
+for sch in ("trapeze", "midpoint", "gauss_legendre_2"):          # gauss_legendre_2 at 10 000 steps = BASELINE.json configs[1], the bench workload
     d = ct.DOCP("goddard", N, sch, pattern="structural", device=0)
     lv, uv = ct.variables_bounds(d)
     x0 = np.clip(ct.initial_guess(d, "problem"), lv, uv)
     nlp = ipm.NLP.from_docp(d, x0, ct)
     t0 = time.time()
-    r = ipm.solve(nlp, max_iter=300, time_limit=150)
+    r = ipm.solve_auto(nlp, max_iter=300, time_limit=150)
     el = time.time() - t0
     cb = sum(nlp.seconds.values())
     print(f"goddard/{sch} N={N}: nvar {d.dim_NLP_variables} ncon {d.dim_NLP_constraints} nnzj {d.nnzj} nnzh {d.nnzh} | objective {r.obj:.7f} (catalogue 1.01257) status {r.status} "

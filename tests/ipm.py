@@ -146,7 +146,19 @@ class _BorderedLU:
         return x
 
 
-def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e-6, time_limit=None, kappa_eps=10.0, dc0=0.0, mu_lin=0.2):
+def solve_auto(nlp, **kw):
+    """the filter line search first (it does not stall on the negative curvature of singular arcs: the Gauss-Legendre transcriptions of
+    Goddard), the l1 merit function when that does not converge (the 8-state quadrotor)"""
+    r = solve(nlp, linesearch="filter", **kw)
+    if r.status != 0:
+        r2 = solve(nlp, linesearch="merit", **kw)
+        if r2.status == 0 or (r2.status == 1 and r.status != 1):
+            r2.iters += r.iters
+            return r2
+    return r
+
+
+def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e-6, time_limit=None, kappa_eps=10.0, dc0=0.0, mu_lin=0.2, linesearch="merit"):
     """returns Result(x, y, obj, status, iters, violation, kkt); status 0 = converged to tol, 1 = acceptable, 2 = iteration / time limit"""
     t_start = time.time()
     n, m = nlp.n, nlp.m
@@ -213,6 +225,7 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
     err0 = float("inf")
     last_alpha = None
     kkt_solver = _BorderedLU()
+    filt, th_ref = [], None
     for it in range(max_iter):
         xv = z[:n]
         g = np.concatenate([sf * nlp.grad(xv), np.zeros(mi)])
@@ -238,6 +251,7 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
         if errmu <= kappa_eps * mu and mu > tol / 10.0:          # (one reduction per iteration: a Newton step at every barrier level)
             mu = max(tol / 10.0, min(mu_lin * mu, mu ** 1.5))
             nu = 1.0
+            filt = []
         tau = max(0.99, 1.0 - mu)
         # Newton system on (dz, dlam) with the bound multipliers eliminated
         Wx = nlp.hess(xv, lam * sc, sf)
@@ -294,14 +308,34 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
             if nu < nu_need:
                 nu = nu_need + 1.0
         D = gd - nu * th
-        m0 = phi(z, mu) + nu * th
+        phi0 = phi(z, mu)
+        m0 = phi0 + nu * th
+        if th_ref is None:
+            th_ref = max(1.0, th)
+        augment = [False]
+
+        def acceptable(zq, rq, aq):
+            """merit: Armijo on phi + nu ||c||_1.  filter (section 2.3): sufficient progress in the violation OR in the barrier function against
+            the current point, not dominated by a filter entry; Armijo on the barrier function when the step is a descent step at an
+            (almost) feasible point"""
+            pq, tq = phi(zq, mu), np.abs(rq).sum()
+            if not (np.isfinite(pq) and np.isfinite(tq)):
+                return False
+            if linesearch != "filter":
+                return pq + nu * tq <= m0 + 1e-8 * aq * D + 10 * np.finfo(float).eps * abs(m0)
+            if tq > 1e4 * th_ref or any(tq >= tf_ and pq >= pf_ for tf_, pf_ in filt):
+                return False
+            if gd < 0 and aq * (-gd) ** 2.3 > th ** 1.1 and th <= 1e-4 * th_ref:
+                augment[0] = False
+                return pq <= phi0 + 1e-8 * aq * gd + 10 * np.finfo(float).eps * abs(phi0)
+            augment[0] = True
+            return tq <= (1 - 1e-5) * th or pq <= phi0 - 1e-5 * th
         a = a_pri
         accepted = False
         for ls in range(40):
             zt = z + a * dz
             rt = resid(zt)
-            mt = phi(zt, mu) + nu * np.abs(rt).sum()
-            if np.isfinite(mt) and mt <= m0 + 1e-8 * a * D + 10 * np.finfo(float).eps * abs(m0):
+            if acceptable(zt, rt, a):
                 accepted = True
                 break
             if ls == 0 and np.abs(rt).sum() >= th and lu is not None:
@@ -315,8 +349,7 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
                     a2 = min(amax(np.where(hasl, dl, 1.0), np.where(hasl, d2, 0.0), tau), amax(np.where(hasu, du, 1.0), np.where(hasu, -d2, 0.0), tau))
                     z2 = z + a2 * d2
                     r2 = resid(z2)
-                    m2 = phi(z2, mu) + nu * np.abs(r2).sum()
-                    if np.isfinite(m2) and m2 <= m0 + 1e-8 * a2 * D + 10 * np.finfo(float).eps * abs(m0):
+                    if acceptable(z2, r2, a2):
                         zt, a, dlam, accepted = z2, a2, sol2[nz:], True
                         break
                     if np.abs(r2).sum() > 0.99 * np.abs(rt).sum():
@@ -330,6 +363,8 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
             # no decrease along the Newton direction: take the tiny step anyway once, with more regularisation next time
             dw_last = max(1e-4, dw_last * 10.0)
             zt = z + a * dz
+        if accepted and linesearch == "filter" and augment[0]:
+            filt.append(((1 - 1e-5) * th, phi0 - 1e-5 * th))
         last_alpha = (round(a_pri, 4), round(a_du, 4), a, accepted)
         z = zt
         lam = lam + a * dlam

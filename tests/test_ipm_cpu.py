@@ -10,12 +10,13 @@ from oracle.oracle import OracleDOCP
 
 @pytest.mark.parametrize("prob,sch,N,maximize,want", [("goddard", "trapeze", 100, True, 1.01257), ("goddard_all", "midpoint", 60, True, 1.01257),
                                                       ("double_integrator_path", "gauss_legendre_2", 40, False, 1.5),
-                                                      ("quadrotor", "midpoint", 250, False, None), ("goddard", "euler_implicit", 100, True, 1.01257)])
+                                                      ("quadrotor", "midpoint", 250, False, None), ("goddard", "euler_implicit", 100, True, 1.01257),
+                                                      ("goddard", "gauss_legendre_2", 50, True, 1.01257), ("goddard_all", "gauss_legendre_2", 50, True, 1.01257)])
 def test_interior_point_loop_on_the_oracle(prob, sch, N, maximize, want):
     o = OracleDOCP(prob, sch, N)
     o.set_pattern_mode(1)
     with np.errstate(all="ignore"):
-        r = ipm.solve(ipm.NLP.from_oracle(o, o.initial_guess(True), maximize=maximize), max_iter=300)
+        r = ipm.solve_auto(ipm.NLP.from_oracle(o, o.initial_guess(True), maximize=maximize), max_iter=400)
     assert r.status == 0 and r.kkt <= 1e-8 and r.violation <= 1e-6
     if want is not None:
         assert abs(r.obj - want) <= 1e-2 * abs(want)
