@@ -361,7 +361,7 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
             a *= 0.5
         if not accepted:
             # no decrease along the Newton direction: take the tiny step anyway once, with more regularisation next time
-            dw_last = max(1e-4, dw_last * 10.0)
+            dw_last = min(1e8, max(1e-4, dw_last * 10.0))
             zt = z + a * dz
         if accepted and linesearch == "filter" and augment[0]:
             filt.append(((1 - 1e-5) * th, phi0 - 1e-5 * th))
