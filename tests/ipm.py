@@ -270,6 +270,11 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
                 lu = kkt.factor(K)
                 sol = lu.solve(rhs)
                 ok = bool(np.all(np.isfinite(sol)))
+                if ok and np.max(np.abs(K @ sol - rhs)) > 1e-6 * max(1.0, np.max(np.abs(rhs))):
+                    ok = False                       # (numerically) singular: a rank-deficient Jacobian -- regularise the constraint block (section 3.1)
+                    if dc == 0.0:
+                        dc = 1e-8 * mu ** 0.25
+                        continue
             except (RuntimeError, np.linalg.LinAlgError):
                 ok = False
                 if dc == 0.0:
