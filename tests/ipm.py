@@ -39,7 +39,7 @@ class NLP:
         self.xl, self.xu, self.cl, self.cu, self.x0 = xl, xu, cl, cu, x0
 
     @staticmethod
-    def from_docp(d, x0, ct):
+    def from_docp(d, x0, ct, fused=False):
         n, m = d.dim_NLP_variables, d.dim_NLP_constraints
         cl, cu = ct.constraints_bounds(d)
         xl, xu = ct.variables_bounds(d)
@@ -54,7 +54,43 @@ class NLP:
             v = d.hess_coord(x, y, s)
             return sp.coo_matrix((np.concatenate([v, v[offd]]), (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))),
                                  shape=(n, n)).tocsr()
-        return NLP(n, m, d.obj, d.grad, d.cons, jac, hess, xl, xu, cl, cu, x0, maximize=bool(d.flags.max))
+        nlp = NLP(n, m, d.obj, d.grad, d.cons, jac, hess, xl, xu, cl, cu, x0, maximize=bool(d.flags.max))
+        if fused:
+            # ONE call of ctd_eval_all_dev_async per iteration (objective + gradient + constraints + Jacobian values + Hessian values at the
+            # iterate and its multipliers, two launches) instead of five host-pointer callbacks: `solve` announces the point with
+            # prepare(x, y, sigma); the callbacks at exactly that point are served from the device results, any other point (the line
+            # search's trial points) goes through the single callbacks as before
+            import torch
+            dev = torch.device("cuda", d.device)
+            buf = dict(x=torch.zeros(n, dtype=torch.float64, device=dev), y=torch.zeros(m, dtype=torch.float64, device=dev), f=torch.zeros(1, dtype=torch.float64, device=dev),
+                       g=torch.zeros(n, dtype=torch.float64, device=dev), c=torch.zeros(m, dtype=torch.float64, device=dev),
+                       v=torch.zeros(d.nnzj, dtype=torch.float64, device=dev), h=torch.zeros(d.nnzh, dtype=torch.float64, device=dev))
+            cache = {}
+            sgn = nlp.sgn
+            base = dict(obj=nlp.obj, grad=nlp.grad, cons=nlp.cons, jac=nlp.jac, hess=nlp.hess)
+
+            def prepare(x, y, sigma):
+                t0 = time.perf_counter()
+                buf["x"].copy_(torch.from_numpy(np.ascontiguousarray(x)))
+                buf["y"].copy_(torch.from_numpy(np.ascontiguousarray(y)))
+                d.eval_all(buf["x"], buf["y"], sgn * sigma, buf["f"], buf["g"], buf["c"], buf["v"], buf["h"], sync=True)
+                hv = buf["h"].cpu().numpy()
+                cache.clear()
+                cache.update(x=x.copy(), y=y.copy(), sigma=sigma, f=sgn * float(buf["f"][0]), g=sgn * buf["g"].cpu().numpy(), c=buf["c"].cpu().numpy(),
+                             J=sp.csr_matrix((buf["v"].cpu().numpy(), (jr - 1, jc - 1)), shape=(m, n)),
+                             H=sp.coo_matrix((np.concatenate([hv, hv[offd]]), (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))), shape=(n, n)).tocsr())
+                nlp.calls["eval_all"] = nlp.calls.get("eval_all", 0) + 1
+                nlp.seconds["eval_all"] = nlp.seconds.get("eval_all", 0.0) + time.perf_counter() - t0
+
+            def at(x):
+                return "x" in cache and np.array_equal(x, cache["x"])
+            nlp.prepare = prepare
+            nlp.obj = lambda x: cache["f"] if at(x) else base["obj"](x)
+            nlp.grad = lambda x: cache["g"] if at(x) else base["grad"](x)
+            nlp.cons = lambda x: cache["c"] if at(x) else base["cons"](x)
+            nlp.jac = lambda x: cache["J"] if at(x) else base["jac"](x)
+            nlp.hess = lambda x, y, s: cache["H"] if (at(x) and s == cache["sigma"] and np.array_equal(y, cache["y"])) else base["hess"](x, y, s)
+        return nlp
 
     @staticmethod
     def from_oracle(o, x0, maximize=False):
@@ -228,6 +264,8 @@ def solve(nlp, tol=1e-8, max_iter=500, mu0=0.1, verbose=False, acceptable_tol=1e
     filt, th_ref = [], None
     for it in range(max_iter):
         xv = z[:n]
+        if hasattr(nlp, "prepare"):
+            nlp.prepare(xv, lam * sc, sf)
         g = np.concatenate([sf * nlp.grad(xv), np.zeros(mi)])
         J = Sc @ nlp.jac(xv)
         A = sp.hstack([J, Aslack], format="csr") if mi else J

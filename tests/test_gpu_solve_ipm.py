@@ -91,3 +91,24 @@ def test_north_star_transcription_solved_end_to_end():
     assert abs(r.obj - 1.01257) <= 1e-3 * 1.01257          # (barrier shift mu x number of active bounds: 3e-5 at this size)
     assert cb <= 0.5 * el
     d.close()
+
+
+@pytest.mark.parametrize("name,scheme,N", [("goddard", "gauss_legendre_2", 250), ("goddard_all", "midpoint", 250), ("goddard", "trapeze", 10000)])
+def test_interior_point_loop_on_the_fused_iteration_call(name, scheme, N):
+    """the same loop with ONE ctd_eval_all_dev_async per iteration (objective, gradient, constraints, Jacobian and Hessian values at the
+    iterate and its multipliers in two launches, device buffers) instead of five host-pointer callbacks: same iterates, same solution"""
+    import ctdirect_jl_amd as ct
+    import ipm
+    d = ct.DOCP(name, N, scheme, pattern="structural", device=0)
+    lv, uv = ct.variables_bounds(d)
+    x0 = np.clip(ct.initial_guess(d, "problem"), lv, uv)
+    with np.errstate(all="ignore"):
+        a = ipm.solve(ipm.NLP.from_docp(d, x0, ct), max_iter=300, linesearch="filter")
+        nb = ipm.NLP.from_docp(d, x0, ct, fused=True)
+        b = ipm.solve(nb, max_iter=300, linesearch="filter")
+    print(f"{name}/{scheme} N={N}: {a.iters} / {b.iters} iterations, objective {a.obj:.9f} / {b.obj:.9f}; fused: {nb.calls}, {sum(nb.seconds.values()):.3f} s in callbacks")
+    assert a.status == 0 and b.status == 0
+    assert abs(a.obj - b.obj) <= 1e-7 * abs(a.obj) and abs(a.obj - 1.01257) <= 1e-3
+    # (one gradient and one Jacobian at the initial point, for the scaling; afterwards only the fused call and the line search's c / f)
+    assert nb.calls["eval_all"] == b.iters + 1 and "hess" not in nb.calls and nb.calls.get("jac", 0) <= 1 and nb.calls.get("grad", 0) <= 1
+    d.close()
