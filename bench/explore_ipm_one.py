@@ -13,5 +13,15 @@ prob, want, init = jit_defs.catalogue(name) if name in jit_defs.CATALOGUE else p
 d = ct.DOCP(prob, N, sch, pattern="structural", device=0)
 lv, uv = ct.variables_bounds(d)
 x0 = np.clip(ct.initial_guess(d, init), lv, uv)
-r = ipm.solve(ipm.NLP.from_docp(d, x0, ct), max_iter=400, time_limit=60, verbose=every, linesearch=ls)
-print("obj", r.obj, "want", want, "status", r.status, "iters", r.iters, "violation", r.violation, "kkt", r.kkt)
+base = ipm.NLP.from_docp(d, x0, ct)
+if len(sys.argv) > 6:                      # elastic mode with this penalty
+    el = ipm.elastic(base, float(sys.argv[6]))
+    r = ipm.solve(el, max_iter=int(sys.argv[7]) if len(sys.argv) > 7 else 600, time_limit=100, verbose=every, linesearch=ls)
+    nx = base.n
+    c = d.cons(r.x[:nx])
+    lc, uc = ct.constraints_bounds(d)
+    print("elastic: obj of the original", base.sgn * base.obj(r.x[:nx]), "want", want, "status", r.status, "iters", r.iters, "sum p+n", r.x[nx:].sum(),
+          "violation of the original", max(np.max(np.maximum(lc - c, 0)), np.max(np.maximum(c - uc, 0))), "kkt", r.kkt)
+else:
+    r = ipm.solve(base, max_iter=400, time_limit=60, verbose=every, linesearch=ls)
+    print("obj", r.obj, "want", want, "status", r.status, "iters", r.iters, "violation", r.violation, "kkt", r.kkt)

@@ -112,6 +112,52 @@ class NLP:
         return NLP(n, m, o.objective, o.gradient, o.constraints, jac, hess, xl, xu, cl, cu, x0, maximize=maximize)
 
 
+def elastic(nlp, rho=1e4):
+    """l1-elastic form of an NLP (what SNOPT calls elastic mode, Ipopt's restoration problem without the proximity term):
+        min  f(x) + rho sum(p + n)    s.t.  cl <= c(x) - p + n <= cu,   p, n >= 0
+    Every point has a feasible completion (p, n absorb the residual), so the interior-point loop never has to find a feasible point of
+    nonlinear equations from far away; for rho above the multipliers the solution has p = n = 0 and is the original problem's."""
+    n, m = nlp.n, nlp.m
+    E = sp.hstack([-sp.identity(m), sp.identity(m)], format="csr")
+    c0 = nlp.cons(np.clip(nlp.x0, nlp.xl, nlp.xu))
+    gap = np.where(c0 < nlp.cl, nlp.cl - c0, np.where(c0 > nlp.cu, c0 - nlp.cu, 0.0))
+    p0 = np.where(c0 > nlp.cu, gap, 0.0) + 1e-2
+    n0 = np.where(c0 < nlp.cl, gap, 0.0) + 1e-2
+    el = NLP(n + 2 * m, m,
+             obj=lambda z: nlp.obj(z[:n]) + rho * z[n:].sum(),
+             grad=lambda z: np.concatenate([nlp.grad(z[:n]), np.full(2 * m, rho)]),
+             cons=lambda z: nlp.cons(z[:n]) - z[n:n + m] + z[n + m:],
+             jac=lambda z: sp.hstack([nlp.jac(z[:n]), E], format="csr"),
+             hess=lambda z, y, s: sp.block_diag([nlp.hess(z[:n], y, s), sp.csr_matrix((2 * m, 2 * m))], format="csr"),
+             xl=np.concatenate([nlp.xl, np.zeros(2 * m)]), xu=np.concatenate([nlp.xu, np.full(2 * m, np.inf)]), cl=nlp.cl, cu=nlp.cu,
+             x0=np.concatenate([nlp.x0, p0, n0]))
+    el.sgn, el.inner = 1.0, nlp            # (nlp.obj / grad / hess already carry the sign of a maximisation)
+    return el
+
+
+def solve_elastic(nlp, rhos=(1e2, 1e4, 1e6), **kw):
+    """the interior-point loop on the elastic form, the penalty raised until the elastic variables vanish: returns the Result of the
+    ORIGINAL problem (x, y, objective, violation of the original constraints) + .rho, .elastic_sum"""
+    total = 0
+    last = None
+    for rho in rhos:
+        el = elastic(nlp, rho)
+        r = solve(el, **kw)
+        total += r.iters
+        x = r.x[:nlp.n]
+        c = nlp.cons(x)
+        viol = max(float(np.max(np.maximum(nlp.cl - c, 0.0), initial=0.0)), float(np.max(np.maximum(c - nlp.cu, 0.0), initial=0.0)))
+        out = Result()
+        out.x, out.y, out.zl, out.zu = x, r.y, r.zl[:nlp.n], r.zu[:nlp.n]
+        out.obj, out.violation, out.kkt, out.iters, out.rho = nlp.sgn * nlp.obj(x), viol, r.kkt, total, rho
+        out.elastic_sum = float(np.abs(r.x[nlp.n:]).sum())
+        out.status = 0 if (r.status == 0 and viol <= 1e-6) else 2
+        last = out
+        if out.status == 0:
+            break
+    return last
+
+
 class Result:
     pass
 

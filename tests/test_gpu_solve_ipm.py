@@ -112,3 +112,29 @@ def test_interior_point_loop_on_the_fused_iteration_call(name, scheme, N):
     # (one gradient and one Jacobian at the initial point, for the scaling; afterwards only the fused call and the line search's c / f)
     assert nb.calls["eval_all"] == b.iters + 1 and "hess" not in nb.calls and nb.calls.get("jac", 0) <= 1 and nb.calls.get("grad", 0) <= 1
     d.close()
+
+
+@pytest.mark.parametrize("kind,name,scheme,rho,iters", [("cat", "moonlander", "midpoint", 1e2, 600), ("pf", "bioreactor_1day", "midpoint", 1e4, 600),
+                                                        ("cat", "space_shuttle", "trapeze", 1e6, 1200), ("pf", "swimmer", "midpoint", 1e4, 2000)])
+def test_interior_point_loop_in_elastic_mode(kind, name, scheme, rho, iters):
+    """The four catalogued problems whose constraints the plain loop cannot satisfy from the problem file's initial guess (it has no
+    feasibility-restoration phase) in the l1-ELASTIC form  min f + rho sum(p + n),  cl <= c(x) - p + n <= cu,  p, n >= 0  (ipm.elastic):
+    every point has a feasible completion, and at the solution the elastic variables vanish -- on the reference's default 250-step grid:
+    moonlander 0.96182 (catalogued 0.962), bioreactor_1day 0.614111 (0.614134), space_shuttle 0.595692 (0.596554), and the swimmer
+    0.992069 (0.984273: 0.8 %, the one scipy's solvers left 1 - 8 % off).  rho: the penalty (above the constraint multipliers)."""
+    import ctdirect_jl_amd as ct
+    import ipm
+    import jit_defs
+    import problem_folder_defs as pf
+    prob, want, init = jit_defs.catalogue(name) if kind == "cat" else pf.folder(name)
+    d = ct.DOCP(prob, N_REF, scheme, pattern="structural", device=0)
+    lv, uv = ct.variables_bounds(d)
+    x0 = np.clip(ct.initial_guess(d, init), lv, uv)
+    with np.errstate(all="ignore"):
+        r = ipm.solve_elastic(ipm.NLP.from_docp(d, x0, ct), rhos=(rho,), max_iter=iters, time_limit=150, linesearch="filter")
+    print(f"{name}/{scheme} N={N_REF} elastic rho={rho:g}: objective {r.obj:.6f} (catalogue {want}), violation {r.violation:.1e}, KKT error {r.kkt:.1e}, "
+          f"{r.iters} iterations, sum of the elastic variables {r.elastic_sum:.1e}")
+    assert r.status == 0 and r.kkt <= 1e-8 and r.violation <= 1e-6
+    assert r.elastic_sum <= 1e-3
+    assert abs(r.obj - want) <= 1e-2 * abs(want)
+    d.close()
