@@ -9,10 +9,11 @@ Eighteen problems of test/ci/test_all_ocp.jl and of test/problems/ converge this
 them four that scipy's solvers did not settle on this grid or at all (double_integrator_freet0tf, insurance, bioreactor_Ndays,
 algal_bacterial on the archive's figure: 5.4530 against 5.4522 of test/archives/jump_ctdirect.md); plus the registry problems on the
 stagewise Gauss-Legendre grids, and BASELINE.json's own bench workload (Goddard, Gauss-Legendre 2, 10 000 steps) end to end
-(bench/solve_10k.py: 25 iterations, 8 s).  Not converged with this loop (600 iterations): moonlander, space_shuttle, truck_trailer,
-bioreactor_1day, swimmer -- the first two and bioreactor_1day are solved with scipy's solvers on coarser grids
-(tests/test_gpu_solve_catalogue.py, test_gpu_problem_folder.py), the last two are recorded as not met
-(profiles/r04_experiments.md section 7)."""
+(bench/solve_10k.py: 25 iterations, 8 s).  Four more -- moonlander, bioreactor_1day, space_shuttle and the swimmer (0.992069 against the
+catalogued 0.984273: the problem scipy's solvers left 1 - 8 % off) -- converge in the loop's ELASTIC mode (test_interior_point_loop_in_elastic_mode).
+That leaves ONE problem of the reference's catalogue and problem folder unsolved on the default grid: truck_trailer (the elastic form ends in
+a local minimum of the infeasibility, t_f at its lower bound; scipy on 50 steps: within 8 %, tests/test_gpu_solve_catalogue.py;
+profiles/r04_experiments.md section 7)."""
 import os
 import sys
 
