@@ -135,7 +135,8 @@ def _solve(name, scheme, N, maxiter=600, x0=None):
 ])
 # (swimmer, catalogued 0.984273: scipy's trust-constr ends 1.0 % off on the 100-step midpoint grid (0.99418) and CONVERGES to other KKT points
 #  on finer grids (N = 150: 0.9168, N = 200: 0.9098, N = 250 warm-started: 0.9383 -- several local solutions); bioreactor_Ndays (T = 300) does not converge with scipy: recorded in
-#  profiles/r04_experiments.md section 7, not asserted.  action / schlogl have no catalogued objective.)
+#  profiles/r04_experiments.md section 7.  Both ARE solved on the reference's 250-step grid by the in-repo interior-point loop (elastic mode for the
+#  swimmer: 0.992069), tests/test_gpu_solve_ipm.py.  action / schlogl have no catalogued objective.)
 def test_folder_catalogued_objective(name, scheme, N, maxiter):
     obj, want, viol, res = _solve(name, scheme, N, maxiter=maxiter)
     print(f"{name}/{scheme} N={N}: objective {obj:.6f} (catalogue {want}), violation {viol:.1e}, status {res.status}, nit {res.nit}")
