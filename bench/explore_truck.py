@@ -20,9 +20,9 @@ for N in (100, 250):
     lv, uv = ct.variables_bounds(d)
     x0 = np.clip(ct.initial_guess(d, warm), lv, uv)
     for mu0 in (1e-2, 1e-4):
-        for ls in ("filter", "merit"):
+        for ls in ("elastic1e3", "elastic1e5"):
             t1 = time.time()
-            r = ipm.solve(ipm.NLP.from_docp(d, x0, ct), max_iter=400, time_limit=40, mu0=mu0, linesearch=ls)
+            r = ipm.solve_elastic(ipm.NLP.from_docp(d, x0, ct), rhos=(float(ls[7:]),), max_iter=800, time_limit=40, mu0=mu0, linesearch="filter")
             print(f"ipm N={N} mu0={mu0:g} {ls}: obj {r.obj:.6f} (cat {want}) status {r.status} iters {r.iters} violation {r.violation:.1e} kkt {r.kkt:.1e} {time.time()-t1:.1f}s", flush=True)
             if r.status == 0:
                 sol = ct.unpack_solution(d, r.x)
