@@ -139,3 +139,25 @@ def test_interior_point_loop_in_elastic_mode(kind, name, scheme, rho, iters):
     assert r.elastic_sum <= 1e-3
     assert abs(r.obj - want) <= 1e-2 * abs(want)
     d.close()
+
+
+def test_solution_rebuild_from_the_interior_point_solution():
+    """test/ci/test_modeler_solver.jl:49-65 on its own terms: the min-energy double integrator on the reference's 250-step grid, solved by
+    the in-repo loop through the GPU callbacks, rebuilt with the reference's getter conventions (`unpack_solution`): state, control and
+    COSTATE (the multipliers of the state-equation rows, src/DOCP_data.jl:514-633) against the analytic extremal x = (0.75 t^2 - 0.25 t^3,
+    1.5 t - 0.75 t^2), u = 1.5 - 1.5 t, p = (3, 3 - 3 t), in norm at rtol 1e-2 as the reference does."""
+    import ctdirect_jl_amd as ct
+    import ipm
+    d = ct.DOCP("double_integrator_path", N_REF, "midpoint", pattern="structural", device=0)
+    lv, uv = ct.variables_bounds(d)
+    with np.errstate(all="ignore"):
+        r = ipm.solve_auto(ipm.NLP.from_docp(d, np.clip(ct.initial_guess(d), lv, uv), ct), max_iter=200)
+    assert r.status == 0 and abs(r.obj - 1.5) <= 1e-3
+    sol = ct.unpack_solution(d, r.x, r.y)
+    T = sol["T"]
+    X = np.stack([0.75 * T ** 2 - 0.25 * T ** 3, 1.5 * T - 0.75 * T ** 2], axis=1)
+    U = 1.5 - 1.5 * (T[:-1] + T[1:]) / 2
+    P = np.stack([np.full(N_REF, 3.0), 3.0 - 3.0 * T[1:]], axis=1)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)      # noqa: E731
+    assert rel(sol["X"], X) <= 1e-2 and rel(sol["U"][:-1, 0], U) <= 1e-2 and rel(sol["P"], P) <= 1e-2
+    d.close()

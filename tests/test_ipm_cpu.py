@@ -27,3 +27,13 @@ def test_interior_point_loop_on_the_oracle(prob, sch, N, maximize, want):
     g = (-1.0 if maximize else 1.0) * o.gradient(r.x)
     res = g + J.T @ r.y - r.zl + r.zu
     assert np.max(np.abs(res)) <= 1e-6 * max(1.0, np.max(np.abs(r.y)), np.max(r.zl), np.max(r.zu))
+
+
+def test_elastic_mode_on_the_oracle():
+    """ipm.elastic / solve_elastic: the l1-elastic form reaches the same solution with vanishing elastic variables"""
+    o = OracleDOCP("goddard", "trapeze", 100)
+    o.set_pattern_mode(1)
+    with np.errstate(all="ignore"):
+        r = ipm.solve_elastic(ipm.NLP.from_oracle(o, o.initial_guess(True), maximize=True), rhos=(1e4,), max_iter=300, linesearch="filter")
+    assert r.status == 0 and r.violation <= 1e-6 and r.elastic_sum <= 1e-3
+    assert abs(r.obj - 1.01257) <= 1e-3
