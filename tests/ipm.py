@@ -47,13 +47,24 @@ class NLP:
         hr, hc = d.hess_structure()
         offd = hr != hc
 
+        # the sparse structures are assembled ONCE (the patterns are fixed); a callback then only gathers the returned values into place
+        Jt = sp.csr_matrix((np.arange(1, len(jr) + 1, dtype=np.float64), (jr - 1, jc - 1)), shape=(m, n))
+        jperm = Jt.data.astype(np.int64) - 1
+        Ht = sp.coo_matrix((np.concatenate([np.arange(1, len(hr) + 1), np.arange(1, len(hr) + 1)[offd]]).astype(np.float64),
+                            (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))), shape=(n, n)).tocsr()
+        hperm = Ht.data.astype(np.int64) - 1
+
+        def jac_of(vals):
+            return sp.csr_matrix((vals[jperm], Jt.indices, Jt.indptr), shape=(m, n))
+
+        def hess_of(vals):
+            return sp.csr_matrix((vals[hperm], Ht.indices, Ht.indptr), shape=(n, n))
+
         def jac(x):
-            return sp.csr_matrix((d.jac_coord(x), (jr - 1, jc - 1)), shape=(m, n))
+            return jac_of(d.jac_coord(x))
 
         def hess(x, y, s):
-            v = d.hess_coord(x, y, s)
-            return sp.coo_matrix((np.concatenate([v, v[offd]]), (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))),
-                                 shape=(n, n)).tocsr()
+            return hess_of(d.hess_coord(x, y, s))
         nlp = NLP(n, m, d.obj, d.grad, d.cons, jac, hess, xl, xu, cl, cu, x0, maximize=bool(d.flags.max))
         if fused:
             # ONE call of ctd_eval_all_dev_async per iteration (objective + gradient + constraints + Jacobian values + Hessian values at the
@@ -77,8 +88,7 @@ class NLP:
                 hv = buf["h"].cpu().numpy()
                 cache.clear()
                 cache.update(x=x.copy(), y=y.copy(), sigma=sigma, f=sgn * float(buf["f"][0]), g=sgn * buf["g"].cpu().numpy(), c=buf["c"].cpu().numpy(),
-                             J=sp.csr_matrix((buf["v"].cpu().numpy(), (jr - 1, jc - 1)), shape=(m, n)),
-                             H=sp.coo_matrix((np.concatenate([hv, hv[offd]]), (np.concatenate([hr - 1, hc[offd] - 1]), np.concatenate([hc - 1, hr[offd] - 1]))), shape=(n, n)).tocsr())
+                             J=jac_of(buf["v"].cpu().numpy()), H=hess_of(hv))
                 nlp.calls["eval_all"] = nlp.calls.get("eval_all", 0) + 1
                 nlp.seconds["eval_all"] = nlp.seconds.get("eval_all", 0.0) + time.perf_counter() - t0
 
