@@ -237,3 +237,28 @@ def test_early_emission_knob_stays_bit_identical(monkeypatch):
                 c1, v1 = emu.cons_jac(ct.PROBLEMS[prob], ct.SCHEMES[sch], mode, 41, x, tile=8, nthr=320)
                 assert np.array_equal(c0, c1) and np.array_equal(v0, v1), (prob, sch, mode)
     monkeypatch.delenv("CTD_EMU_EARLY", raising=False)
+
+
+@pytest.mark.parametrize("prob,sch,tile", [("goddard", "gauss_legendre_2", 111), ("goddard", "gauss_legendre_3", 84), ("double_integrator_path", "midpoint", 254),
+                                           ("goddard", "midpoint", 199), ("goddard_all", "gauss_legendre_2", 85), ("goddard", "euler_implicit", 199),
+                                           ("double_integrator_freet0tf", "gauss_legendre_3", 112)])
+def test_emulated_long_grid_geometry(prob, sch, tile):
+    """The launch geometry `ctd_create` takes on grids of 8 rounds of resident workgroups and more (round 4: eight waves per workgroup, the
+    largest tile whose records fit 64 / 74 KiB -- the tile sizes of profiles/r04_tiles_long_grids.log), here in the serial emulator of the
+    same phase templates: 512 lanes, 84 - 254 steps per tile, a grid of several tiles with a ragged last one, both value orders, against
+    the oracle (GPU: tests/test_gpu_max_sizes.py)."""
+    from oracle.oracle import OracleDOCP
+    N = 2 * tile + 37
+    o = OracleDOCP(prob, sch, N)
+    o.set_pattern_mode(1)
+    x = bench_inputs(describe(o, prob, sch), perturb=1e-3)
+    cref, vref = o.constraints(x), o.jac_coord(x)
+    pid, sid = ct.PROBLEMS[prob], ct.SCHEMES[sch]
+    c, vals = emu.cons_jac(pid, sid, 1, N, x, tile=tile, nthr=512)
+    assert not np.any(c == 666.666) and not np.any(vals == 666.666)
+    assert relerr(c, cref) <= TOL and relerr(vals, vref) <= TOL
+    with emu.value_order(1):
+        c2, v2 = emu.cons_jac(pid, sid, 1, N, x, tile=tile, nthr=512)
+    cp, rv = o.jac_pattern()
+    cols = np.repeat(np.arange(len(cp) - 1), np.diff(cp))
+    assert np.array_equal(c2, c) and np.array_equal(v2, vals[np.lexsort((cols, rv))])
