@@ -116,7 +116,16 @@ def _worker(rank, world, port, N, prob, sch, q):
                                         (64, "double_integrator_path", "midpoint"), (9, "double_integrator_path", "midpoint"),
                                         (11, "goddard_all", "midpoint"), (8, "quadrotor", "trapeze"), (6, "goddard_all", "euler_implicit")])
 def test_stitch_constraints_world2_gloo(N, prob, sch):
-    world = 2
+    _run_world(2, N, prob, sch)
+
+
+@pytest.mark.parametrize("N,prob,sch", [(11, "goddard_all", "midpoint"), (10, "quadrotor", "trapeze"), (13, "goddard_all", "gauss_legendre_2")])
+def test_stitch_constraints_world3_gloo(N, prob, sch):
+    """three ranks: the middle one has a neighbour on both sides (halo of x from both, multipliers of the previous rank's last step), ragged split"""
+    _run_world(3, N, prob, sch)
+
+
+def _run_world(world, N, prob, sch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -128,7 +137,7 @@ def test_stitch_constraints_world2_gloo(N, prob, sch):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
-    assert all(tot == 3.0 for _, _, tot in res)
+    assert all(tot == world * (world + 1) / 2 for _, _, tot in res)
 
 
 def test_library_stitch_index_map_equals_the_python_stitcher():
